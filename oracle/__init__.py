@@ -1,0 +1,20 @@
+"""oracle/ -- TEST INFRASTRUCTURE ONLY (never imported by the product package).
+
+CPU restatement (numpy float64 / torch-CPU float32) of the reference hot path
+of henryxrl/Listening-to-Sound-of-Silence-for-Speech-Denoising, used as the
+parity checker for the HIP path.  Only `tests/`, `__graft_entry__.smoke()` and
+the `cpu_baseline` leg of `bench.py` may import it.
+
+Pinning status
+--------------
+* Networks, mask ops, bits->mask, add_signals: pinned against the *imported*
+  reference modules in the build container (tests/golden/make_goldens.py),
+  outputs committed under tests/golden/*.npz.
+* STFT/ISTFT arithmetic lives in third-party librosa==0.7.1
+  (reference requirements.txt:4) whose source is NOT under /root/reference and
+  is not installable here: **parity unpinned** against librosa itself.  The
+  restatement follows librosa 0.7.1's published algorithm (core/spectrum.py
+  stft/istft, filters.window_sumsquare) anchored on the reference call sites
+  (transform.py:174,193,199) and is cross-checked against torch.stft /
+  torch.istft in tests/test_oracle_frontend.py.
+"""
