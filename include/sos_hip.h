@@ -1,0 +1,136 @@
+/* sos_hip.h -- C ABI of libsos_hip.so, the MI355X (gfx950) hot path of the
+ * Listening-to-Sound-of-Silence speech-denoising pipeline.
+ *
+ * The reference is pure Python/PyTorch: it has no FFI or operator registry, so
+ * the drop-in seam is its Python module API.  Each entry point
+ * below is what the thin Python shims in
+ * listening-to-sound-of-silence-for-speech-denoising_amd/ bind through ctypes;
+ * the comment on each cites the reference function it replaces
+ * (paths relative to /root/reference, M1 = model_1_silent_interval_detection/
+ * audioonly_model, M2 = model_2_audio_denoising/audio_denoising_model).
+ *
+ * Conventions: every pointer is a DEVICE pointer unless said otherwise; no
+ * allocation and no synchronisation inside; work is enqueued on `stream`
+ * (a hipStream_t); return 0 on success, negative on error (message via
+ * sos_last_error()).  No C++ exceptions cross this boundary.
+ */
+#ifndef SOS_HIP_H
+#define SOS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sos_stream_t; /* hipStream_t */
+
+enum { SOS_OK = 0, SOS_EINVAL = -22, SOS_ELAUNCH = -5, SOS_ENOSPC = -28 };
+
+/* activation / padding / dtype codes */
+enum { SOS_ACT_NONE = 0, SOS_ACT_RELU = 1, SOS_ACT_PRELU = 2, SOS_ACT_SIGMOID = 3 };
+enum { SOS_PAD_ZERO = 0, SOS_PAD_REFLECT = 1 };
+enum { SOS_DT_BF16 = 0, SOS_DT_BF16X3 = 1, SOS_DT_F32 = 2 };
+
+int sos_abi_version(void);
+const char* sos_last_error(void);
+
+/* ---- a1  fast_stft: M1/transform.py:188-193 (librosa.stft(data,510,158,400),
+ * hann-periodic window centred in n_fft, center=True, reflect pad) fused with
+ * real_imag_expand (:10-17) and the caller's transpose to [2,F,T]
+ * (M2/dataset.py:255).  wave f32 [B][wave_stride], out f32 [B][2][n_fft/2+1][T],
+ * T = 1 + n_samples/hop.  window f32 [win_length], twiddle f32 [n_fft][2] (cos,sin). */
+int sos_stft_f32(const float* wave, int64_t batch, int64_t n_samples, int64_t wave_stride,
+                 const float* window, const float* twiddle, int n_fft, int hop, int win_length,
+                 float* out, int64_t n_frames, sos_stream_t stream);
+
+/* ---- a2  fast_istft: M1/transform.py:196-202 (librosa.istft(S,158,400)): irDFT,
+ * window, overlap-add, divide by window-sum-square, trim n_fft/2 both ends.
+ * spec f32 [B][2][F][T]; inv_wss f32 [n_fft + hop*(T-1)] = 1/wss where wss > tiny
+ * else 1; out f32 [B][out_stride], hop*(T-1) samples written. */
+int sos_istft_f32(const float* spec, int64_t batch, int64_t n_frames, const float* window,
+                  const float* twiddle, const float* inv_wss, int n_fft, int hop, int win_length,
+                  float* out, int64_t out_stride, sos_stream_t stream);
+
+/* ---- a4/a5  batch_fast_icRM_sigmoid: M1/transform.py:156-169 (and the numpy
+ * twin fast_icRM_sigmoid :141-153): M = (1/a)(log(c/(1-c+1e-8)+1e-10)+b), rec = M*Y
+ * (complex).  Y, crm, rec: f32 [B][2][plane]. */
+int sos_crm_apply_f32(const float* Y, const float* crm, float* rec, int64_t batch, int64_t plane,
+                      float a, float b, sos_stream_t stream);
+/* backward of the above w.r.t. crm (grad flows to the mask, M2/agent.py:186-189). */
+int sos_crm_apply_bwd_f32(const float* Y, const float* crm, const float* grad_rec, float* grad_crm,
+                          int64_t batch, int64_t plane, float a, sos_stream_t stream);
+/* ---- a3  fast_cRM_sigmoid: M1/transform.py:130-138 (generate_cRM :36-54 +
+ * cRM_sigmoid_compress :92-94).  clean, mix, out: f32 [B][2][plane]. */
+int sos_crm_target_f32(const float* clean, const float* mix, float* out, int64_t batch, int64_t plane,
+                       float a, float b, sos_stream_t stream);
+
+/* ---- a13/a15  convert_bitstreammask_to_audiomask: M2/tools.py:340-362 (=
+ * M1/tools.py:770-792, M2/predict.py:232-252) + `noise_sig = mixed*mask`
+ * (M2/predict.py:317).  bits u8 [B][n_frames] (1 = non-silent); mask f32
+ * [B][n_samples] (1 on silent samples); if sig != NULL, masked = sig*mask.
+ * Integer index rule evaluated in IEEE double exactly like the Python. */
+int sos_bits_to_mask(const uint8_t* bits, int64_t batch, int64_t n_frames, double ratio,
+                     int64_t n_samples, float* mask, const float* sig, float* masked,
+                     sos_stream_t stream);
+
+/* ---- a14  detector post-processing: M1/predict.py:117-119,
+ * bit = sigmoid(logit) >= 0.5 (1 = non-silent).  conf (optional) = sigmoid. */
+int sos_threshold_bits(const float* logits, int64_t n, float threshold, uint8_t* bits, float* conf,
+                       sos_stream_t stream);
+
+/* ---- layout glue at the module boundary: f32 NCHW [B][C][H][W] -> bf16 NHWC
+ * [B][H][W][cs] (channels >= C zero filled; SOS_DT_BF16X3 writes hi|hi|lo thirds
+ * of width cs/3). */
+int sos_pack_nchw_to_nhwc(const float* in, int64_t B, int C, int64_t H, int64_t W, void* out, int cs,
+                          int dtype, sos_stream_t stream);
+
+/* ---- a6,a8,a9 (+ a7/a10/a11 heads): Conv2d (zero or reflect pad, stride,
+ * dilation) / ConvTranspose2d phases / Linear, fused with folded BatchNorm or bias
+ * and ReLU / PReLU / Sigmoid -- M1/networks.py:28-51, M2/networks.py:28-51,97-149.
+ * Implicit GEMM on bf16 MFMA, fp32 accumulate. */
+typedef struct sos_conv_desc {
+    /* input activation, bf16 NHWC: element (b,h,w,c) at ((b*H + h)*W + w)*in_cs + c */
+    const void* in;
+    int32_t B, H, W;        /* physical input dims                                     */
+    int32_t in_cs;          /* channels stored per pixel (multiple of 8)               */
+    int32_t cin_off, cin;   /* contracted channel range [cin_off, cin_off+cin), cin%16==0 */
+    int32_t in_nseg;        /* number of such ranges (1, or 3 for the hi|hi|lo thirds)   */
+    int32_t in_seg_stride;  /* channel distance between consecutive ranges               */
+    const int32_t* w_gather;/* optional [Wl]: physical column of logical column (nearest resize) */
+    int32_t Wl;             /* logical input width (== W when w_gather == NULL)        */
+    /* weights, bf16 [kh*kw][cout_pad][in_nseg*cin], cout_pad % 32 == 0                */
+    const void* wgt;
+    int32_t kh, kw, cout, cout_pad;
+    int32_t stride, dil_h, dil_w, pad_top, pad_left, pad_mode;
+    /* output: pixel (b,ho,wo), channel co at out + b*sb + ho*sh + wo*sw + (c_off+co)*sc  */
+    int32_t Ho, Wo;
+    void* out;
+    int32_t out_dtype;      /* SOS_DT_*                                                */
+    int64_t out_sb, out_sh, out_sw, out_sc;
+    int32_t out_c_off;
+    int32_t cout_store;     /* channels [cout, cout_store) are written as zero          */
+    int64_t out_third;      /* SOS_DT_BF16X3: element distance between hi|hi|lo thirds  */
+    /* epilogue: y = act(acc*scale[co] + shift[co])                                     */
+    const float* scale;     /* [cout_pad]                                               */
+    const float* shift;     /* [cout_pad]                                               */
+    int32_t act;            /* SOS_ACT_*                                                */
+    const float* act_param; /* device scalar (PReLU slope) or NULL                      */
+} sos_conv_desc;
+
+int sos_conv2d_fwd(const sos_conv_desc* desc /* host pointer */, sos_stream_t stream);
+
+/* ---- a7/a11 recurrent part of nn.LSTM(bidirectional=True), gate order i,f,g,o
+ * (M1/networks.py:95,143-148; M2/networks.py:64,88).  The input projection
+ * x@W_ih^T + b_ih + b_hh is a sos_conv2d_fwd (1x1) producing xproj.
+ * xproj f32 [B][T][2][4H] (dir 0 fwd, 1 reverse); whh_t f32 [2][H][4H] (transposed
+ * W_hh); out_f32 (optional) [B][T][2H]; out_bf16 (optional) bf16 [B][T][out_cs]
+ * (+ thirds when dtype == SOS_DT_BF16X3). */
+int sos_lstm_bidir_fwd(const float* xproj, const float* whh_t, int64_t B, int64_t T, int H,
+                       float* out_f32, void* out_bf16, int out_cs, int out_dtype, int64_t out_third,
+                       sos_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOS_HIP_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of libsos_hip.so (C ABI declared in include/sos_hip.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsos_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+DT_BF16, DT_BF16X3, DT_F32 = 0, 1, 2
+
+
+class ConvDesc(C.Structure):
+    """struct sos_conv_desc (include/sos_hip.h)."""
+    _fields_ = [
+        ("in_", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("in_cs", C.c_int32), ("cin_off", C.c_int32), ("cin", C.c_int32),
+        ("in_nseg", C.c_int32), ("in_seg_stride", C.c_int32),
+        ("w_gather", C.c_void_p), ("Wl", C.c_int32),
+        ("wgt", C.c_void_p),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("cout", C.c_int32), ("cout_pad", C.c_int32),
+        ("stride", C.c_int32), ("dil_h", C.c_int32), ("dil_w", C.c_int32),
+        ("pad_top", C.c_int32), ("pad_left", C.c_int32), ("pad_mode", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("out", C.c_void_p), ("out_dtype", C.c_int32),
+        ("out_sb", C.c_int64), ("out_sh", C.c_int64), ("out_sw", C.c_int64), ("out_sc", C.c_int64),
+        ("out_c_off", C.c_int32), ("cout_store", C.c_int32), ("out_third", C.c_int64),
+        ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("act", C.c_int32), ("act_param", C.c_void_p),
+    ]
+
+
+_P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+
+# name -> argtypes, exactly the prototypes of include/sos_hip.h
+SIGNATURES = {
+    "sos_abi_version": [],
+    "sos_stft_f32": [_P, _L, _L, _L, _P, _P, _I, _I, _I, _P, _L, _P],
+    "sos_istft_f32": [_P, _L, _L, _P, _P, _P, _I, _I, _I, _P, _L, _P],
+    "sos_crm_apply_f32": [_P, _P, _P, _L, _L, _F, _F, _P],
+    "sos_crm_apply_bwd_f32": [_P, _P, _P, _P, _L, _L, _F, _P],
+    "sos_crm_target_f32": [_P, _P, _P, _L, _L, _F, _F, _P],
+    "sos_bits_to_mask": [_P, _L, _L, _D, _L, _P, _P, _P, _P],
+    "sos_threshold_bits": [_P, _L, _F, _P, _P, _P],
+    "sos_pack_nchw_to_nhwc": [_P, _L, _I, _L, _L, _P, _I, _I, _P],
+    "sos_conv2d_fwd": [C.POINTER(ConvDesc), _P],
+    "sos_lstm_bidir_fwd": [_P, _P, _L, _L, _I, _P, _P, _I, _I, _L, _P],
+}
+
+_lib = None
+
+
+def lib():
+    """Load libsos_hip.so or fail loudly (there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        h.sos_last_error.restype = C.c_char_p
+        h.sos_last_error.argtypes = []
+        _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().sos_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libsos_hip {what} failed (rc={rc}): {msg}")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("sos_amd: tensors must live on an MI355X (no CPU fallback); got device "
+                               f"{t.device}")
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

@@ -1,0 +1,107 @@
+"""Pieces shared by the detector and the denoiser mirrors: the zero-padded dilated
+Conv2d+BN+ReLU stack (Conv2dBlock M1/networks.py:28-51 == ConvBlock M2/networks.py:28-51),
+the BiLSTM head and nn.Linear, all executed by the HIP kernels."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import engine as E
+
+
+class Conv2dBlock(nn.Module):
+    """Parameter container with the reference's layout: block.0 = Conv2d(bias=False, zero pad
+    (k-1)//2*dil, dilation), block.1 = BatchNorm2d, block.2 = ReLU."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, dilation):
+        super().__init__()
+        pad = ((kernel_size[0] - 1) // 2 * dilation[0], (kernel_size[1] - 1) // 2 * dilation[1])
+        self.block = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, kernel_size, 1, pad, dilation, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU())
+
+    def forward(self, x):
+        raise RuntimeError("Conv2dBlock is executed by its parent network through libsos_hip")
+
+
+def make_encoder(kernel_sizes, dilations, nf, outf):
+    """make_audio_branch (M1/networks.py:120-128) / make_enc (M2/networks.py:72-80)."""
+    blocks = []
+    for i, (k, d) in enumerate(zip(kernel_sizes, dilations)):
+        blocks.append(Conv2dBlock(2 if i == 0 else nf, nf, k, d))
+    blocks.append(Conv2dBlock(nf, outf, (1, 1), (1, 1)))
+    return nn.Sequential(*blocks)
+
+
+def encoder_plan(enc, x3):
+    """Packed weights + folded eval BN for every block of an encoder stack."""
+    plan = []
+    for i, blk in enumerate(enc):
+        conv, bn = blk.block[0], blk.block[1]
+        cin_store = E.pad_to(conv.in_channels, 16)
+        w = E.pack_weight(conv.weight, cin_store, x3)
+        scale, shift = E.fold_bn(bn, w.shape[1])
+        plan.append(dict(w=w, scale=scale, shift=shift, kh=conv.kernel_size[0], kw=conv.kernel_size[1],
+                         dil=tuple(conv.dilation), pad=tuple(conv.padding), cout=conv.out_channels,
+                         cin_store=cin_store))
+    return plan
+
+
+def run_encoder(plan, a, feat, feat_row, feat_third, feat_c_off, x3, w_gather=None, T_out=None):
+    """Run blocks 0..n-2 NHWC->NHWC (ping-pong) and the final 1x1 block straight into the LSTM
+    feature matrix feat[b][t][c*F + f] (the reference's view(B,-1,T).permute(2,0,1),
+    M1/networks.py:132,142 / M2/networks.py:84-87), optionally through a nearest-resize column
+    gather (F.interpolate, M1/networks.py:133)."""
+    B, H, W = a.B, a.H, a.W
+    cur = a
+    bufs = [None, None]
+    for i, lp in enumerate(plan[:-1]):
+        dst = bufs[i & 1]
+        cs = E.pad_to(lp["cout"], 16)
+        if dst is None or dst.cs != cs:
+            dst = E.Act(B, H, W, cs, x3, a.t.device)
+            bufs[i & 1] = dst
+        E.conv_to_act(cur, 0, lp["cin_store"], lp["w"], lp["kh"], lp["kw"], lp["cout"], lp["scale"], lp["shift"],
+                      L.ACT_RELU, dst, cout_store=cs, dil=lp["dil"], pad=lp["pad"], Ho=H, Wo=W)
+        cur = dst
+    lp = plan[-1]
+    Wo = W if T_out is None else T_out
+    E.conv(cur, 0, lp["cin_store"], lp["w"], 1, 1, lp["cout"], lp["scale"], lp["shift"], L.ACT_RELU,
+           out=feat, out_dtype=L.DT_BF16X3 if x3 else L.DT_BF16, sb=Wo * feat_row, sh=1, sw=feat_row, sc=H,
+           c_off=feat_c_off, third=feat_third, Ho=H, Wo=Wo, w_gather=w_gather)
+
+
+def lstm_plan(lstm, cin_store, x3):
+    H = lstm.hidden_size
+    w_ih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse], dim=0).detach()
+    bias = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse]).detach()
+    w = E.pack_weight(w_ih[:, :, None, None], cin_store, x3)
+    whh_t = torch.stack([lstm.weight_hh_l0.detach().t(), lstm.weight_hh_l0_reverse.detach().t()]).float().contiguous()
+    return dict(w=w, scale=E.pad_vec(torch.ones(8 * H, device=w.device), w.shape[1], 1.0),
+                shift=E.pad_vec(bias, w.shape[1]), whh_t=whh_t, H=H, cin_store=cin_store)
+
+
+def run_lstm(lp, feat_dims, B, T, x3, device):
+    """Input projection (1x1 conv on MFMA) + recurrent kernel -> Act [B,1,T,pad16(2H)]."""
+    H = lp["H"]
+    xproj = torch.empty((B, T, 8 * H), dtype=torch.float32, device=device)
+    E.conv(None, 0, lp["cin_store"], lp["w"], 1, 1, 8 * H, lp["scale"], lp["shift"], L.ACT_NONE,
+           out=xproj, out_dtype=L.DT_F32, sb=T * 8 * H, sh=0, sw=8 * H, sc=1, Ho=1, Wo=T, in_dims=feat_dims)
+    h = E.Act(B, 1, T, E.pad_to(2 * H, 16), x3, device, zero=True)
+    E.lstm(xproj, lp["whh_t"], B, T, H, h)
+    return h
+
+
+def linear_plan(lin, cin_store, x3):
+    w = E.pack_weight(lin.weight[:, :, None, None], cin_store, x3)
+    return dict(w=w, scale=E.pad_vec(torch.ones(lin.out_features, device=w.device), w.shape[1], 1.0),
+                shift=E.pad_vec(lin.bias, w.shape[1]), cout=lin.out_features, cin_store=cin_store)
+
+
+def nearest_index(in_size, out_size, device):
+    """Source column of F.interpolate(mode='nearest'): min(floor(dst * float32(in/out)), in-1)
+    (ATen nearest_idx); int32 table on the device."""
+    scale = np.float32(in_size) / np.float32(out_size)
+    idx = np.minimum(np.floor(np.arange(out_size, dtype=np.float32) * scale).astype(np.int64), in_size - 1)
+    return torch.from_numpy(idx.astype(np.int32)).to(device)

@@ -1,0 +1,372 @@
+// frontend.hip -- STFT / ISTFT / complex-ratio-mask / bits->sample-mask kernels (gfx950).
+//
+// Reference semantics (paths relative to /root/reference, M1 = model_1_silent_interval_detection/
+// audioonly_model, M2 = model_2_audio_denoising/audio_denoising_model):
+//   fast_stft  M1/transform.py:188-193   fast_istft M1/transform.py:196-202
+//   batch_fast_icRM_sigmoid M1/transform.py:156-169   fast_cRM_sigmoid :130-138
+//   convert_bitstreammask_to_audiomask M2/tools.py:340-362
+#include "sos_common.h"
+
+// ------------------------------------------------------------------------------------ STFT
+// One workgroup = 16 consecutive frames of one clip, one thread per frequency bin.
+// The 16 windowed frames are staged once in LDS as xw[n][16] so the inner loop reads them with
+// four broadcast ds_read_b128 per sample; the n_fft-entry (cos,sin) table is LDS resident and is
+// walked with an incremental (f*n mod n_fft) index.  Output is written planar [B][2][F][T], i.e.
+// real_imag_expand + the dataset's transpose are fused into the store.
+#define STFT_FT 16
+
+__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wave, int64_t n_samples,
+                                                   int64_t wave_stride, const float* __restrict__ window,
+                                                   const float* __restrict__ twiddle, int n_fft, int hop,
+                                                   int win, float* __restrict__ out, int64_t T) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xw = (float*)smem;                                  // [win][STFT_FT]
+    float2* tw = (float2*)(smem + (size_t)win * STFT_FT * 4);  // [n_fft]
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.y;
+    const int64_t t0 = (int64_t)blockIdx.x * STFT_FT;
+    const int nbins = n_fft / 2 + 1;
+    const int lpad = (n_fft - win) / 2;
+    const float* wv = wave + b * wave_stride;
+
+    for (int k = tid; k < n_fft; k += 256) tw[k] = make_float2(twiddle[2 * k], twiddle[2 * k + 1]);
+    for (int idx = tid; idx < win * STFT_FT; idx += 256) {
+        const int tt = idx / win, n = idx - tt * win;
+        const int64_t t = t0 + tt;
+        float v = 0.f;
+        if (t < T) {
+            int64_t i = t * hop + n + lpad - n_fft / 2;       // index into the un-padded clip
+            if (i < 0) i = -i;
+            if (i >= n_samples) i = 2 * (n_samples - 1) - i;
+            v = wv[i] * window[n];
+        }
+        xw[n * STFT_FT + tt] = v;
+    }
+    __syncthreads();
+
+    for (int f = tid; f < nbins; f += 256) {
+        float re[STFT_FT], im[STFT_FT];
+#pragma unroll
+        for (int i = 0; i < STFT_FT; ++i) { re[i] = 0.f; im[i] = 0.f; }
+        int k = (int)(((int64_t)f * lpad) % n_fft);
+        for (int n = 0; n < win; ++n) {
+            const float2 cs = tw[k];
+            const float4* xv = (const float4*)(xw + n * STFT_FT);
+#pragma unroll
+            for (int q = 0; q < STFT_FT / 4; ++q) {
+                const float4 v = xv[q];
+                re[4 * q + 0] = fmaf(v.x, cs.x, re[4 * q + 0]); im[4 * q + 0] = fmaf(-v.x, cs.y, im[4 * q + 0]);
+                re[4 * q + 1] = fmaf(v.y, cs.x, re[4 * q + 1]); im[4 * q + 1] = fmaf(-v.y, cs.y, im[4 * q + 1]);
+                re[4 * q + 2] = fmaf(v.z, cs.x, re[4 * q + 2]); im[4 * q + 2] = fmaf(-v.z, cs.y, im[4 * q + 2]);
+                re[4 * q + 3] = fmaf(v.w, cs.x, re[4 * q + 3]); im[4 * q + 3] = fmaf(-v.w, cs.y, im[4 * q + 3]);
+            }
+            k += f;
+            if (k >= n_fft) k -= n_fft;
+        }
+        float* ore = out + ((b * 2 + 0) * nbins + f) * T + t0;
+        float* oim = out + ((b * 2 + 1) * nbins + f) * T + t0;
+#pragma unroll
+        for (int i = 0; i < STFT_FT; ++i) {
+            if (t0 + i < T) { ore[i] = re[i]; oim[i] = im[i]; }
+        }
+    }
+}
+
+extern "C" int sos_stft_f32(const float* wave, int64_t batch, int64_t n_samples, int64_t wave_stride,
+                            const float* window, const float* twiddle, int n_fft, int hop, int win_length,
+                            float* out, int64_t n_frames, sos_stream_t stream) {
+    if (!wave || !window || !twiddle || !out) { sos_set_error("sos_stft_f32: null pointer"); return SOS_EINVAL; }
+    if (n_fft < 2 || (n_fft & 1) || win_length > n_fft || hop < 1 || n_samples <= n_fft / 2 ||
+        n_frames != 1 + n_samples / hop || batch < 1 || batch > 65535) {
+        sos_set_error("sos_stft_f32: bad geometry n_fft=%d hop=%d win=%d n=%lld T=%lld", n_fft, hop, win_length,
+                      (long long)n_samples, (long long)n_frames);
+        return SOS_EINVAL;
+    }
+    const size_t lds = (size_t)win_length * STFT_FT * 4 + (size_t)n_fft * 8;
+    if (lds > 64 * 1024) { sos_set_error("sos_stft_f32: window too long for LDS staging"); return SOS_ENOSPC; }
+    dim3 grid((unsigned)((n_frames + STFT_FT - 1) / STFT_FT), (unsigned)batch);
+    hipLaunchKernelGGL(stft_kernel, grid, dim3(256), lds, (hipStream_t)stream, wave, n_samples, wave_stride,
+                       window, twiddle, n_fft, hop, win_length, out, n_frames);
+    return sos_check_launch("sos_stft_f32");
+}
+
+// ----------------------------------------------------------------------------------- ISTFT
+// One workgroup = 256 consecutive output samples of one clip, one thread per sample.  The <= 6
+// frames that overlap the tile are staged in LDS; each thread evaluates the inverse real DFT of
+// its (up to 3) contributing frames at its own in-frame position, applies the synthesis window,
+// sums (overlap-add), and multiplies by the precomputed 1/window-sum-square.  The centre trim is
+// folded into the indexing.
+#define ISTFT_MAXFR 6
+
+__global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ spec, int64_t T,
+                                                    const float* __restrict__ window,
+                                                    const float* __restrict__ twiddle,
+                                                    const float* __restrict__ inv_wss, int n_fft, int hop, int win,
+                                                    float* __restrict__ out, int64_t out_stride, int64_t n_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nbins = n_fft / 2 + 1;
+    float2* tw = (float2*)smem;                               // [n_fft]
+    float* sre = (float*)(smem + (size_t)n_fft * 8);          // [ISTFT_MAXFR][nbins]
+    float* sim = sre + ISTFT_MAXFR * nbins;
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.y;
+    const int64_t j0 = (int64_t)blockIdx.x * 256;
+    const int lpad = (n_fft - win) / 2;
+    const int half = n_fft / 2;
+    // frames overlapping [j0+half, j0+half+255]: n = p - t*hop in [lpad, lpad+win)
+    int64_t tlo = (j0 + half - lpad - win + 1 + hop - 1);
+    tlo = tlo <= 0 ? 0 : tlo / hop;
+    int64_t thi = (j0 + half + 255 - lpad) / hop;
+    if (thi > T - 1) thi = T - 1;
+    const int nfr = (int)(thi - tlo + 1);
+
+    for (int k = tid; k < n_fft; k += 256) tw[k] = make_float2(twiddle[2 * k], twiddle[2 * k + 1]);
+    for (int idx = tid; idx < ISTFT_MAXFR * nbins; idx += 256) {
+        const int fr = idx / nbins, f = idx - fr * nbins;
+        float r = 0.f, i = 0.f;
+        if (fr < nfr) {
+            r = spec[((b * 2 + 0) * nbins + f) * T + tlo + fr];
+            i = spec[((b * 2 + 1) * nbins + f) * T + tlo + fr];
+        }
+        sre[idx] = r;
+        sim[idx] = i;
+    }
+    __syncthreads();
+
+    const int64_t j = j0 + tid;
+    if (j >= n_out) return;
+    const int64_t p = j + half;
+    int64_t tmax = (p - lpad) / hop;
+    if (tmax > T - 1) tmax = T - 1;
+    float y = 0.f;
+    const float invn = 1.0f / (float)n_fft;
+    for (int s = 0; s < 3; ++s) {
+        const int64_t t = tmax - s;
+        if (t < 0 || t < tlo) break;
+        const int n = (int)(p - t * hop);
+        if (n >= lpad + win) break;           // earlier frames end even sooner
+        const int fr = (int)(t - tlo);
+        const float* fre = sre + fr * nbins;
+        const float* fim = sim + fr * nbins;
+        float acc = fre[0] + ((n & 1) ? -fre[nbins - 1] : fre[nbins - 1]);
+        float acc2 = 0.f;
+        int k = n;                            // (f*n) mod n_fft for f = 1
+        for (int f = 1; f < nbins - 1; ++f) {
+            const float2 cs = tw[k];
+            acc2 = fmaf(fre[f], cs.x, acc2);
+            acc2 = fmaf(-fim[f], cs.y, acc2);
+            k += n;
+            if (k >= n_fft) k -= n_fft;
+        }
+        y = fmaf(window[n - lpad], (acc + 2.f * acc2) * invn, y);
+    }
+    out[b * out_stride + j] = y * inv_wss[p];
+}
+
+extern "C" int sos_istft_f32(const float* spec, int64_t batch, int64_t n_frames, const float* window,
+                             const float* twiddle, const float* inv_wss, int n_fft, int hop, int win_length,
+                             float* out, int64_t out_stride, sos_stream_t stream) {
+    if (!spec || !window || !twiddle || !inv_wss || !out) { sos_set_error("sos_istft_f32: null pointer"); return SOS_EINVAL; }
+    const int64_t n_out = (int64_t)hop * (n_frames - 1);
+    if (n_fft < 2 || (n_fft & 1) || win_length > n_fft || hop < 1 || n_frames < 2 || batch < 1 || batch > 65535 ||
+        out_stride < n_out || (255 + win_length) / hop + 2 > ISTFT_MAXFR || (win_length + hop - 1) / hop > 3) {
+        sos_set_error("sos_istft_f32: bad geometry n_fft=%d hop=%d win=%d T=%lld", n_fft, hop, win_length,
+                      (long long)n_frames);
+        return SOS_EINVAL;
+    }
+    const int nbins = n_fft / 2 + 1;
+    const size_t lds = (size_t)n_fft * 8 + (size_t)ISTFT_MAXFR * nbins * 8;
+    dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)batch);
+    hipLaunchKernelGGL(istft_kernel, grid, dim3(256), lds, (hipStream_t)stream, spec, n_frames, window, twiddle,
+                       inv_wss, n_fft, hop, win_length, out, out_stride, n_out);
+    return sos_check_launch("sos_istft_f32");
+}
+
+// ------------------------------------------------------------------- complex ratio mask ops
+__device__ __forceinline__ float crm_recover(float c, float inv_a, float b) {
+    // 1/a * (log(c / (1 - c + 1e-8) + 1e-10) + b), same fp32 operation order as the torch code
+    return inv_a * (logf(c / (1.0f - c + 1e-8f) + 1e-10f) + b);
+}
+
+__global__ void crm_apply_kernel(const float* __restrict__ Y, const float* __restrict__ crm, float* __restrict__ rec,
+                                 int64_t total, int64_t plane, float inv_a, float b) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t bb = i / plane, r = i - bb * plane;
+        const int64_t o = bb * 2 * plane + r;
+        const float yr = Y[o], yi = Y[o + plane];
+        const float mr = crm_recover(crm[o], inv_a, b), mi = crm_recover(crm[o + plane], inv_a, b);
+        rec[o] = mr * yr - mi * yi;
+        rec[o + plane] = mr * yi + mi * yr;
+    }
+}
+
+__global__ void crm_apply_bwd_kernel(const float* __restrict__ Y, const float* __restrict__ crm,
+                                     const float* __restrict__ g, float* __restrict__ gc, int64_t total,
+                                     int64_t plane, float inv_a) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t bb = i / plane, r = i - bb * plane;
+        const int64_t o = bb * 2 * plane + r;
+        const float yr = Y[o], yi = Y[o + plane];
+        const float gr = g[o], gi = g[o + plane];
+        const float dmr = gr * yr + gi * yi;
+        const float dmi = gi * yr - gr * yi;
+        const float c0 = crm[o], c1 = crm[o + plane];
+        const float d0 = 1.0f - c0 + 1e-8f, d1 = 1.0f - c1 + 1e-8f;
+        // dM/dc = (1/a) * (1+1e-8) / (den^2 * (c/den + 1e-10))
+        gc[o] = dmr * inv_a * (1.0f + 1e-8f) / (d0 * d0 * (c0 / d0 + 1e-10f));
+        gc[o + plane] = dmi * inv_a * (1.0f + 1e-8f) / (d1 * d1 * (c1 / d1 + 1e-10f));
+    }
+}
+
+__global__ void crm_target_kernel(const float* __restrict__ S, const float* __restrict__ Y, float* __restrict__ out,
+                                  int64_t total, int64_t plane, float a, float b) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t bb = i / plane, r = i - bb * plane;
+        const int64_t o = bb * 2 * plane + r;
+        const float yr = Y[o], yi = Y[o + plane], sr = S[o], si = S[o + plane];
+        const float den = yr * yr + yi * yi + 1e-8f;
+        const float mr = (yr * sr + yi * si) / den;
+        const float mi = (yr * si - yi * sr) / den;
+        out[o] = 1.0f / (1.0f + expf(-a * mr + b));
+        out[o + plane] = 1.0f / (1.0f + expf(-a * mi + b));
+    }
+}
+
+static inline unsigned ew_grid(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+extern "C" int sos_crm_apply_f32(const float* Y, const float* crm, float* rec, int64_t batch, int64_t plane,
+                                 float a, float b, sos_stream_t stream) {
+    if (!Y || !crm || !rec || batch < 1 || plane < 1 || a == 0.f) { sos_set_error("sos_crm_apply_f32: bad args"); return SOS_EINVAL; }
+    const int64_t total = batch * plane;
+    hipLaunchKernelGGL(crm_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, Y, crm, rec, total,
+                       plane, 1.0f / a, b);
+    return sos_check_launch("sos_crm_apply_f32");
+}
+
+extern "C" int sos_crm_apply_bwd_f32(const float* Y, const float* crm, const float* grad_rec, float* grad_crm,
+                                     int64_t batch, int64_t plane, float a, sos_stream_t stream) {
+    if (!Y || !crm || !grad_rec || !grad_crm || batch < 1 || plane < 1 || a == 0.f) {
+        sos_set_error("sos_crm_apply_bwd_f32: bad args");
+        return SOS_EINVAL;
+    }
+    const int64_t total = batch * plane;
+    hipLaunchKernelGGL(crm_apply_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, Y, crm,
+                       grad_rec, grad_crm, total, plane, 1.0f / a);
+    return sos_check_launch("sos_crm_apply_bwd_f32");
+}
+
+extern "C" int sos_crm_target_f32(const float* clean, const float* mix, float* out, int64_t batch, int64_t plane,
+                                  float a, float b, sos_stream_t stream) {
+    if (!clean || !mix || !out || batch < 1 || plane < 1) { sos_set_error("sos_crm_target_f32: bad args"); return SOS_EINVAL; }
+    const int64_t total = batch * plane;
+    hipLaunchKernelGGL(crm_target_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, clean, mix, out,
+                       total, plane, a, b);
+    return sos_check_launch("sos_crm_target_f32");
+}
+
+// --------------------------------------------------------------------- bits -> sample mask
+// Pre-flip mask value of sample j: 1 if j lies in [int(i*r), int((i+1)*r - 1)) of a silent
+// frame i (bit 0), else 0.  All index arithmetic in IEEE double with explicit (un-fused)
+// multiply/add so it reproduces Python's float64 evaluation bit for bit.
+__device__ __forceinline__ int premask(const uint8_t* bits, int64_t n_frames, double ratio, int64_t j) {
+    int64_t i0 = (int64_t)((double)j / ratio);
+    for (int64_t i = i0 - 1; i <= i0 + 1; ++i) {
+        if (i < 0 || i >= n_frames) continue;
+        const int64_t lo = (int64_t)__dmul_rn((double)i, ratio);
+        const int64_t hi = (int64_t)__dadd_rn(__dmul_rn((double)(i + 1), ratio), -1.0);
+        if (j >= lo && j < hi) return bits[i] == 0 ? 1 : 0;
+    }
+    return 0;
+}
+
+__global__ void bits_to_mask_kernel(const uint8_t* __restrict__ bits, int64_t n_frames, double ratio,
+                                    int64_t n_samples, float* __restrict__ mask, const float* __restrict__ sig,
+                                    float* __restrict__ masked) {
+    const int64_t b = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_samples) return;
+    const uint8_t* bb = bits + b * n_frames;
+    const int v = premask(bb, n_frames, ratio, j);
+    // length of the ORIGINAL run containing j (capped): the reference flips every run shorter
+    // than 5 samples in one pass over the original runs (groupby never sees its own writes).
+    int len = 1;
+    for (int d = 1; d <= 4 && j - d >= 0; ++d) {
+        if (premask(bb, n_frames, ratio, j - d) != v) break;
+        ++len;
+    }
+    for (int d = 1; d <= 4 && j + d < n_samples && len < 5; ++d) {
+        if (premask(bb, n_frames, ratio, j + d) != v) break;
+        ++len;
+    }
+    const float m = (float)(len < 5 ? 1 - v : v);
+    mask[b * n_samples + j] = m;
+    if (masked) masked[b * n_samples + j] = sig[b * n_samples + j] * m;
+}
+
+extern "C" int sos_bits_to_mask(const uint8_t* bits, int64_t batch, int64_t n_frames, double ratio,
+                                int64_t n_samples, float* mask, const float* sig, float* masked,
+                                sos_stream_t stream) {
+    if (!bits || !mask || batch < 1 || batch > 65535 || n_frames < 1 || n_samples < 1 || !(ratio > 1.0) ||
+        (masked && !sig)) {
+        sos_set_error("sos_bits_to_mask: bad args");
+        return SOS_EINVAL;
+    }
+    dim3 grid((unsigned)((n_samples + 255) / 256), (unsigned)batch);
+    hipLaunchKernelGGL(bits_to_mask_kernel, grid, dim3(256), 0, (hipStream_t)stream, bits, n_frames, ratio,
+                       n_samples, mask, sig, masked);
+    return sos_check_launch("sos_bits_to_mask");
+}
+
+__global__ void threshold_kernel(const float* __restrict__ logits, int64_t n, float thr, uint8_t* __restrict__ bits,
+                                 float* __restrict__ conf) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = 1.0f / (1.0f + expf(-logits[i]));
+    bits[i] = s >= thr ? 1 : 0;
+    if (conf) conf[i] = s;
+}
+
+extern "C" int sos_threshold_bits(const float* logits, int64_t n, float threshold, uint8_t* bits, float* conf,
+                                  sos_stream_t stream) {
+    if (!logits || !bits || n < 1) { sos_set_error("sos_threshold_bits: bad args"); return SOS_EINVAL; }
+    hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits, n,
+                       threshold, bits, conf);
+    return sos_check_launch("sos_threshold_bits");
+}
+
+// ----------------------------------------------------------------- NCHW f32 -> NHWC bf16 pack
+__global__ void pack_kernel(const float* __restrict__ in, int C, int64_t HW, int64_t total, bf16_t* __restrict__ out,
+                            int cs, int x3) {
+    const int third = x3 ? cs / 3 : cs;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW, r = i - b * HW;
+        bf16_t* o = out + i * cs;
+        for (int c = 0; c < third; ++c) {
+            float v = c < C ? in[(b * C + c) * HW + r] : 0.f;
+            const bf16_t hi = f2bf(v);
+            o[c] = hi;
+            if (x3) {
+                o[c + third] = hi;
+                o[c + 2 * third] = f2bf(v - bf2f(hi));
+            }
+        }
+    }
+}
+
+extern "C" int sos_pack_nchw_to_nhwc(const float* in, int64_t B, int C, int64_t H, int64_t W, void* out, int cs,
+                                     int dtype, sos_stream_t stream) {
+    const int x3 = dtype == SOS_DT_BF16X3;
+    if (!in || !out || B < 1 || C < 1 || (dtype != SOS_DT_BF16 && !x3) || (x3 && cs % 3) || (x3 ? cs / 3 : cs) < C) {
+        sos_set_error("sos_pack_nchw_to_nhwc: bad args");
+        return SOS_EINVAL;
+    }
+    const int64_t total = B * H * W;
+    hipLaunchKernelGGL(pack_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, in, C, H * W, total,
+                       (bf16_t*)out, cs, x3);
+    return sos_check_launch("sos_pack_nchw_to_nhwc");
+}

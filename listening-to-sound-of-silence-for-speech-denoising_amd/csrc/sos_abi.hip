@@ -1,0 +1,24 @@
+// sos_abi.hip -- error plumbing shared by every entry point of libsos_hip.so.
+#include "sos_common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void sos_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int sos_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        sos_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return SOS_ELAUNCH;
+    }
+    return SOS_OK;
+}
+
+extern "C" int sos_abi_version(void) { return 1; }
+extern "C" const char* sos_last_error(void) { return g_err; }

@@ -1,0 +1,254 @@
+"""Mirror of M2/networks.py (model_2_audio_denoising/audio_denoising_model/networks.py):
+`get_network(config)` -> JointModel = InpaintNet (stage1) + ContextAggNet (stage2), same module
+tree / state_dict keys, forward executed by the HIP kernels."""
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import common_nets as CN
+from .. import engine as E
+
+
+def get_network(config):
+    """M2/networks.py:8-9; reads only config.kernel_sizes / config.dilations (:212)."""
+    return JointModel(config)
+
+
+class DownConvBlock(nn.Module):
+    """M2/networks.py:97-117: block.0 ReflectionPad2d, block.1 Conv2d(valid), block.2 BN, block.3 PReLU
+    (norm_fn=None -> conv has a bias and there is no BN; act=None -> no PReLU)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, dilation=1, norm_fn='bn', act='prelu'):
+        super().__init__()
+        pad = (kernel_size - 1) // 2 * dilation
+        block = [nn.ReflectionPad2d(pad),
+                 nn.Conv2d(in_channels, out_channels, kernel_size, stride, 0, dilation, bias=norm_fn is None)]
+        if norm_fn == 'bn':
+            block.append(nn.BatchNorm2d(out_channels))
+        if act == 'prelu':
+            block.append(nn.PReLU())
+        self.block = nn.Sequential(*block)
+
+    def forward(self, x):
+        raise RuntimeError("DownConvBlock is executed by InpaintNet through libsos_hip")
+
+
+class UpConvBlock(nn.Module):
+    """M2/networks.py:120-149 ('upconv'): block.0 ConvTranspose2d(k, stride, pad, output_padding=1)
+    -- the reference passes `dilation` in the output_padding slot (:130) --, block.1 BN, block.2 PReLU."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, dilation=1):
+        super().__init__()
+        pad = (kernel_size - 1) // 2 * dilation
+        self.block = nn.Sequential(
+            nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride, pad, dilation, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.PReLU())
+
+    def forward(self, x):
+        raise RuntimeError("UpConvBlock is executed by InpaintNet through libsos_hip")
+
+
+def _down_plan(blk, x3, in_perm=None):
+    conv = blk.block[1]
+    cin_store = E.pad_to(conv.in_channels, 16)
+    w = E.pack_weight(conv.weight, cin_store, x3, in_perm)
+    has_bn = len(blk.block) > 2 and isinstance(blk.block[2], nn.BatchNorm2d)
+    if has_bn:
+        scale, shift = E.fold_bn(blk.block[2], w.shape[1])
+    else:
+        scale = E.pad_vec(torch.ones(conv.out_channels, device=w.device), w.shape[1], 1.0)
+        shift = E.pad_vec(conv.bias, w.shape[1])
+    prelu = blk.block[-1] if isinstance(blk.block[-1], nn.PReLU) else None
+    k = conv.kernel_size[0]
+    return dict(w=w, scale=scale, shift=shift, k=k, stride=conv.stride[0], dil=conv.dilation[0],
+                pad=(k - 1) // 2 * conv.dilation[0], cout=conv.out_channels, cin_store=cin_store,
+                slope=prelu.weight.detach().float() if prelu is not None else None,
+                act=L.ACT_PRELU if prelu is not None else L.ACT_NONE)
+
+
+# ConvTranspose2d(k3,s2,p1,op1): output row 2i+ph gathers input rows i+u with kernel row a:
+#   ph=0: (u=0,a=1)        ph=1: (u=0,a=2), (u=1,a=0)        (same for columns)
+_PHASE_TAPS = {0: [1], 1: [2, 0]}
+
+
+def _up_plan(blk, x3):
+    ct, bn, prelu = blk.block[0], blk.block[1], blk.block[2]
+    assert ct.kernel_size == (3, 3) and ct.stride == (2, 2) and ct.padding == (1, 1) and ct.output_padding == (1, 1)
+    cin_store = E.pad_to(ct.in_channels, 16)
+    w = ct.weight.detach().float()                       # (Cin, Cout, 3, 3)
+    phases = {}
+    for ph in (0, 1):
+        for pw in (0, 1):
+            a, b = _PHASE_TAPS[ph], _PHASE_TAPS[pw]
+            sub = w[:, :, a][:, :, :, b].permute(1, 0, 2, 3).contiguous()   # (Cout, Cin, len(a), len(b))
+            phases[(ph, pw)] = E.pack_weight(sub, cin_store, x3)
+    cout_pad = E.pad_to(ct.out_channels, 32)
+    scale, shift = E.fold_bn(bn, cout_pad)
+    return dict(phases=phases, scale=scale, shift=shift, cout=ct.out_channels, cin_store=cin_store,
+                slope=prelu.weight.detach().float())
+
+
+def _run_down(lp, src, cin_off, dst, c_off, Ho, Wo):
+    E.conv_to_act(src, cin_off, lp["cin_store"], lp["w"], lp["k"], lp["k"], lp["cout"], lp["scale"], lp["shift"],
+                  lp["act"], dst, c_off=c_off, cout_store=lp["cout"], stride=lp["stride"], dil=(lp["dil"], lp["dil"]),
+                  pad=(lp["pad"], lp["pad"]), pad_mode=L.PAD_REFLECT, slope=lp["slope"], Ho=Ho, Wo=Wo)
+
+
+def _run_up(lp, src, dst, c_off):
+    """Four output-parity phases of the transposed conv, each a small stride-1 conv written to the
+    interleaved positions of `dst` (cropped to dst's size == the reference's nearest-resize fix-up
+    F.interpolate(out, skip.size()) which drops the surplus last row/column, M2/networks.py:199-203)."""
+    row = dst.nseg * dst.cs
+    for (ph, pw), w in lp["phases"].items():
+        Ho = min(src.H, (dst.H - ph + 1) // 2)
+        Wo = min(src.W, (dst.W - pw + 1) // 2)
+        if Ho <= 0 or Wo <= 0:
+            continue
+        E.conv(src, 0, lp["cin_store"], w, 1 + ph, 1 + pw, lp["cout"], lp["scale"], lp["shift"], L.ACT_PRELU,
+               out=dst.t, out_dtype=dst.dtype_code, sb=dst.H * dst.W * row, sh=2 * dst.W * row, sw=2 * row, sc=1,
+               c_off=c_off, cout_store=lp["cout"], third=dst.cs, slope=lp["slope"], Ho=Ho, Wo=Wo,
+               out_elem_offset=(ph * dst.W + pw) * row)
+
+
+class InpaintNet(nn.Module):
+    """M2/networks.py:152-205."""
+
+    def __init__(self):
+        super().__init__()
+        ch1, ch2, ch3 = 64, 128, 256
+        self.down1 = nn.Sequential(DownConvBlock(2, ch1, 5, 1))
+        self.down2 = nn.Sequential(DownConvBlock(ch1, ch2, 5, 2), DownConvBlock(ch2, ch2, 5, 1))
+        self.down3 = nn.Sequential(DownConvBlock(2, ch1, 5, 1))
+        self.down4 = nn.Sequential(DownConvBlock(ch1, ch2, 5, 2), DownConvBlock(ch2, ch2, 5, 1))
+        self.mid = nn.Sequential(
+            DownConvBlock(ch2 * 2, ch3, 3, 2),
+            DownConvBlock(ch3, ch3, 3, 1),
+            DownConvBlock(ch3, ch3, 3, 1, dilation=2),
+            DownConvBlock(ch3, ch3, 3, 1, dilation=4),
+            DownConvBlock(ch3, ch3, 3, 1, dilation=8),
+            DownConvBlock(ch3, ch3, 3, 1, dilation=16),
+            DownConvBlock(ch3, ch3, 3, 1),
+            DownConvBlock(ch3, ch3, 3, 1),
+            UpConvBlock(ch3, ch2, 3, 2))
+        self.up1 = nn.Sequential(DownConvBlock(ch2 * 2, ch2, 3, 1), UpConvBlock(ch2, ch1, 3, 2))
+        self.up2 = nn.Sequential(DownConvBlock(ch1 * 2, ch1, 3, 1), DownConvBlock(ch1, 2, 3, 1, norm_fn=None, act=None))
+
+    def build_plan(self, x3):
+        perm_up1 = list(range(128, 256)) + list(range(0, 128))   # buffer order [down4 | out] vs cat([out, down4])
+        return dict(
+            down1=_down_plan(self.down1[0], x3), down2_0=_down_plan(self.down2[0], x3),
+            down2_1=_down_plan(self.down2[1], x3), down3=_down_plan(self.down3[0], x3),
+            down4_0=_down_plan(self.down4[0], x3), down4_1=_down_plan(self.down4[1], x3),
+            mid=[_down_plan(self.mid[i], x3) for i in range(8)], mid8=_up_plan(self.mid[8], x3),
+            up1_0=_down_plan(self.up1[0], x3, perm_up1), up1_1=_up_plan(self.up1[1], x3),
+            up2_0=_down_plan(self.up2[0], x3), up2_1=_down_plan(self.up2[1], x3))
+
+    def run(self, plan, x, y, x3):
+        """forward(x, y) of M2/networks.py:192-205: x = noise-interval STFT, y = mixed STFT,
+        both f32 (B,2,F,T); returns f32 (B,2,F,T)."""
+        dev = x.device
+        B, _, H, W = x.shape
+        H1, W1 = (H + 1) // 2, (W + 1) // 2          # after the 5x5 stride-2 reflect-padded convs
+        H2, W2 = (H1 + 1) // 2, (W1 + 1) // 2        # after the 3x3 stride-2 one
+        ax, ay = E.pack_input(x, x3), E.pack_input(y, x3)
+        d1 = E.Act(B, H, W, 64, x3, dev)
+        U2 = E.Act(B, H, W, 128, x3, dev)            # [up1.1 out | down3]
+        X = E.Act(B, H1, W1, 384, x3, dev)           # [down2 | down4 | mid.8 out]
+        t128 = E.Act(B, H1, W1, 128, x3, dev)
+        _run_down(plan["down1"], ax, 0, d1, 0, H, W)
+        _run_down(plan["down2_0"], d1, 0, t128, 0, H1, W1)
+        _run_down(plan["down2_1"], t128, 0, X, 0, H1, W1)
+        _run_down(plan["down3"], ay, 0, U2, 64, H, W)
+        _run_down(plan["down4_0"], U2, 64, t128, 0, H1, W1)
+        _run_down(plan["down4_1"], t128, 0, X, 128, H1, W1)
+        m = [E.Act(B, H2, W2, 256, x3, dev), E.Act(B, H2, W2, 256, x3, dev)]
+        _run_down(plan["mid"][0], X, 0, m[0], 0, H2, W2)
+        for i in range(1, 8):
+            _run_down(plan["mid"][i], m[(i - 1) & 1], 0, m[i & 1], 0, H2, W2)
+        _run_up(plan["mid8"], m[1], X, 256)
+        _run_down(plan["up1_0"], X, 128, t128, 0, H1, W1)
+        _run_up(plan["up1_1"], t128, U2, 0)
+        _run_down(plan["up2_0"], U2, 0, d1, 0, H, W)
+        lp = plan["up2_1"]
+        out = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
+        E.conv(d1, 0, lp["cin_store"], lp["w"], 3, 3, 2, lp["scale"], lp["shift"], L.ACT_NONE, out=out,
+               out_dtype=L.DT_F32, sb=2 * H * W, sh=W, sw=1, sc=H * W, pad=(1, 1), pad_mode=L.PAD_REFLECT, Ho=H, Wo=W)
+        return out
+
+    def forward(self, x, y):
+        raise RuntimeError("call InpaintNet through JointModel (libsos_hip path)")
+
+
+class ContextAggNet(nn.Module):
+    """M2/networks.py:54-94."""
+
+    def __init__(self, kernel_sizes, dilations, freq_bins=256, nf=96):
+        super().__init__()
+        self.encoder_x = CN.make_encoder(kernel_sizes, dilations, nf, 8)
+        self.encoder_n = CN.make_encoder(kernel_sizes, dilations, nf // 2, 4)
+        self.lstm = nn.LSTM(input_size=8 * freq_bins + 4 * freq_bins, hidden_size=200, bidirectional=True)
+        self.fc = nn.Sequential(nn.Linear(400, 600), nn.ReLU(True), nn.Linear(600, 600), nn.ReLU(True),
+                                nn.Linear(600, freq_bins * 2), nn.Sigmoid())
+        self.freq_bins = freq_bins
+
+    def build_plan(self, x3):
+        return dict(enc_x=CN.encoder_plan(self.encoder_x, x3), enc_n=CN.encoder_plan(self.encoder_n, x3),
+                    lstm=CN.lstm_plan(self.lstm, 12 * self.freq_bins, x3),
+                    fc0=CN.linear_plan(self.fc[0], 400, x3), fc2=CN.linear_plan(self.fc[2], E.pad_to(600, 16), x3),
+                    fc4=CN.linear_plan(self.fc[4], E.pad_to(600, 16), x3))
+
+    def run(self, plan, x, n, x3):
+        """forward(x, n) of M2/networks.py:82-94 -> sigmoid mask f32 (B,2,F,T)."""
+        dev = x.device
+        B, _, F, T = x.shape
+        nseg = 3 if x3 else 1
+        nfeat = 12 * F
+        feat = torch.empty((B, T, nseg * nfeat), dtype=torch.bfloat16, device=dev)
+        CN.run_encoder(plan["enc_x"], E.pack_input(x, x3), feat, nseg * nfeat, nfeat, 0, x3)
+        CN.run_encoder(plan["enc_n"], E.pack_input(n, x3), feat, nseg * nfeat, nfeat, 8, x3)
+        h = CN.run_lstm(plan["lstm"], (feat, B, 1, T, nfeat, nseg), B, T, x3, dev)
+        f0, f2, f4 = plan["fc0"], plan["fc2"], plan["fc4"]
+        a0 = E.Act(B, 1, T, E.pad_to(600, 16), x3, dev)
+        a1 = E.Act(B, 1, T, E.pad_to(600, 16), x3, dev)
+        E.conv_to_act(h, 0, f0["cin_store"], f0["w"], 1, 1, 600, f0["scale"], f0["shift"], L.ACT_RELU, a0,
+                      cout_store=a0.cs, Ho=1, Wo=T)
+        E.conv_to_act(a0, 0, f2["cin_store"], f2["w"], 1, 1, 600, f2["scale"], f2["shift"], L.ACT_RELU, a1,
+                      cout_store=a1.cs, Ho=1, Wo=T)
+        out = torch.empty((B, 2, F, T), dtype=torch.float32, device=dev)
+        # fc output index c*F+f of pixel (b,t) lands at out[b, c, f, t]  (permute(0,2,1).view, :92)
+        E.conv(a1, 0, f4["cin_store"], f4["w"], 1, 1, 2 * F, f4["scale"], f4["shift"], L.ACT_SIGMOID, out=out,
+               out_dtype=L.DT_F32, sb=2 * F * T, sh=0, sw=1, sc=T, Ho=1, Wo=T)
+        return out
+
+    def forward(self, x, n):
+        raise RuntimeError("call ContextAggNet through JointModel (libsos_hip path)")
+
+
+class JointModel(nn.Module):
+    """M2/networks.py:208-217: n_pred = stage1(n, x); out = stage2(x, n_pred); returns both."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.stage1 = InpaintNet()
+        self.stage2 = ContextAggNet(config.kernel_sizes, config.dilations)
+        self._cache = E.PlanCache()
+
+    def _build_plan(self):
+        x3 = E.is_x3()
+        return dict(x3=x3, s1=self.stage1.build_plan(x3), s2=self.stage2.build_plan(x3))
+
+    def forward(self, x, n):
+        L.require_cuda(x, n)
+        if self.training:
+            raise NotImplementedError("JointModel: the training-mode (batch-statistics) path is not built yet; "
+                                      "call .eval() for inference")
+        if x.dim() != 4 or x.shape[1] != 2 or x.shape != n.shape:
+            raise ValueError(f"expected two (B, 2, F, T) inputs, got {tuple(x.shape)} and {tuple(n.shape)}")
+        plan = self._cache.get(self, self._build_plan)
+        x3 = plan["x3"]
+        x = x.contiguous().float()
+        n = n.contiguous().float()
+        n_pred = self.stage1.run(plan["s1"], n, x, x3)
+        out = self.stage2.run(plan["s2"], x, n_pred, x3)
+        return n_pred, out

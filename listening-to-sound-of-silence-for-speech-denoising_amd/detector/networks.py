@@ -1,0 +1,64 @@
+"""Mirror of M1/networks.py (model_1_silent_interval_detection/audioonly_model/networks.py):
+`get_network()` -> AudioVisualNet with the reference's module tree / state_dict keys
+ and `forward(s, v_num_frames=60)` executed by the HIP kernels."""
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import common_nets as CN
+from .. import engine as E
+
+
+def get_network():
+    """M1/networks.py:8-9."""
+    return AudioVisualNet()
+
+
+class AudioVisualNet(nn.Module):
+    """M1/networks.py:80-155 (audio-only: the video branch is commented out in the reference)."""
+
+    def __init__(self, freq_bins=256, time_bins=178, nf=96):
+        super().__init__()
+        audio_kernel_sizes = [(1, 7), (7, 1)] + [(5, 5)] * 9
+        audio_dilations = [(1, 1), (1, 1), (1, 1), (2, 1), (4, 1), (8, 1), (16, 1), (32, 1), (1, 1), (2, 2), (4, 4)]
+        self.encoder_audio = CN.make_encoder(audio_kernel_sizes, audio_dilations, nf=48, outf=8)
+        self.lstm = nn.LSTM(input_size=8 * freq_bins, hidden_size=100, bidirectional=True)
+        self.fc1 = nn.Sequential(nn.Linear(200, 100), nn.ReLU(True), nn.Linear(100, 1))
+        self.freq_bins = freq_bins
+        self._cache = E.PlanCache()
+
+    def _build_plan(self):
+        x3 = E.is_x3()
+        return dict(x3=x3,
+                    enc=CN.encoder_plan(self.encoder_audio, x3),
+                    lstm=CN.lstm_plan(self.lstm, 8 * self.freq_bins, x3),
+                    fc0=CN.linear_plan(self.fc1[0], E.pad_to(200, 16), x3),
+                    fc2=CN.linear_plan(self.fc1[2], E.pad_to(100, 16), x3))
+
+    def forward(self, s, v_num_frames=60):
+        L.require_cuda(s)
+        if self.training:
+            raise NotImplementedError("AudioVisualNet: the training-mode (batch-statistics) path is not built yet; "
+                                      "call .eval() for inference")
+        if s.dim() != 4 or s.shape[1] != 2 or s.shape[2] != self.freq_bins:
+            raise ValueError(f"expected (B, 2, {self.freq_bins}, T) input, got {tuple(s.shape)}")
+        plan = self._cache.get(self, self._build_plan)
+        x3 = plan["x3"]
+        dev = s.device
+        B, _, F, T = s.shape
+        n = int(v_num_frames)
+        a = E.pack_input(s, x3)
+        nseg = 3 if x3 else 1
+        nfeat = 8 * F
+        feat = torch.empty((B, n, nseg * nfeat), dtype=torch.bfloat16, device=dev)
+        gather = CN.nearest_index(T, n, dev)
+        CN.run_encoder(plan["enc"], a, feat, nseg * nfeat, nfeat, 0, x3, w_gather=gather, T_out=n)
+        h = CN.run_lstm(plan["lstm"], (feat, B, 1, n, nfeat, nseg), B, n, x3, dev)
+        f0, f2 = plan["fc0"], plan["fc2"]
+        m = E.Act(B, 1, n, E.pad_to(f0["cout"], 16), x3, dev)
+        E.conv_to_act(h, 0, f0["cin_store"], f0["w"], 1, 1, f0["cout"], f0["scale"], f0["shift"], L.ACT_RELU, m,
+                      cout_store=m.cs, Ho=1, Wo=n)
+        out = torch.empty((B, n), dtype=torch.float32, device=dev)
+        E.conv(m, 0, f2["cin_store"], f2["w"], 1, 1, 1, f2["scale"], f2["shift"], L.ACT_NONE, out=out,
+               out_dtype=L.DT_F32, sb=n, sh=0, sw=1, sc=1, Ho=1, Wo=n)
+        return out

@@ -1,0 +1,150 @@
+"""Host-side glue between the nn.Module mirrors and the C ABI: activation buffers, weight
+packing, descriptor filling.  Plumbing only -- all arithmetic on activations happens in the HIP
+kernels (include/sos_hip.h)."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import get_precision
+
+BN_EPS = 1e-5
+
+
+def pad_to(x, m):
+    return (x + m - 1) // m * m
+
+
+class Act:
+    """bf16 NHWC activation buffer [B, H, W, nseg*cs]; nseg = 3 (hi|hi|lo thirds) in bf16x3
+    mode.  `cs` is the per-third channel capacity (multiple of 16)."""
+
+    def __init__(self, B, H, W, cs, x3, device, zero=False):
+        self.B, self.H, self.W, self.cs, self.x3 = B, H, W, cs, x3
+        self.nseg = 3 if x3 else 1
+        alloc = torch.zeros if zero else torch.empty
+        self.t = alloc((B, H, W, self.nseg * cs), dtype=torch.bfloat16, device=device)
+
+    @property
+    def dtype_code(self):
+        return L.DT_BF16X3 if self.x3 else L.DT_BF16
+
+
+def is_x3():
+    return get_precision() == "bf16x3"
+
+
+def pack_input(x, x3=None):
+    """f32 NCHW module input -> Act with cs = 16 (sos_pack_nchw_to_nhwc)."""
+    L.require_cuda(x)
+    x3 = is_x3() if x3 is None else x3
+    x = x.contiguous().float()
+    B, Cc, H, W = x.shape
+    a = Act(B, H, W, pad_to(Cc, 16), x3, x.device)
+    L.check(L.lib().sos_pack_nchw_to_nhwc(L.ptr(x), B, Cc, H, W, L.ptr(a.t), a.nseg * a.cs, a.dtype_code,
+                                          L.stream_ptr()), "sos_pack_nchw_to_nhwc")
+    return a
+
+
+def pack_weight(w, cin_store, x3, in_perm=None):
+    """Conv weight (O, I, kh, kw) f32 -> bf16 [kh*kw][O_pad][nseg*cin_store].  In bf16x3 mode the
+    K axis is [w_hi | w_lo | w_hi], matching activations stored [x_hi | x_hi | x_lo], so one MFMA
+    pass computes x_hi*w_hi + x_hi*w_lo + x_lo*w_hi.  `in_perm` reorders input channels (concat
+    buffers whose parts are stored in a different order than torch.cat's)."""
+    O, I, kh, kw = w.shape
+    w = w.detach().float()
+    if in_perm is not None:
+        w = w[:, in_perm]
+    wp = w.permute(2, 3, 0, 1).reshape(kh * kw, O, I)
+    Op = pad_to(O, 32)
+    full = torch.zeros((kh * kw, Op, cin_store), dtype=torch.float32, device=w.device)
+    full[:, :O, :I] = wp
+    hi = full.to(torch.bfloat16)
+    if not x3:
+        return hi.contiguous()
+    lo = (full - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo, hi], dim=2).contiguous()
+
+
+def pad_vec(v, n, fill=0.0):
+    out = torch.full((n,), fill, dtype=torch.float32, device=v.device)
+    out[:v.numel()] = v.detach().float().reshape(-1)
+    return out
+
+
+def fold_bn(bn, cout_pad):
+    """Eval-mode BatchNorm2d as per-channel scale/shift for the conv epilogue."""
+    scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    return pad_vec(scale, cout_pad, 1.0), pad_vec(shift, cout_pad, 0.0)
+
+
+def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dtype, sb, sh, sw, sc,
+         Ho, Wo, c_off=0, cout_store=None, third=0, stride=1, dil=(1, 1), pad=(0, 0), pad_mode=L.PAD_ZERO,
+         slope=None, w_gather=None, out_elem_offset=0, in_dims=None):
+    """Fill a sos_conv_desc and enqueue sos_conv2d_fwd.  `src` is an Act (or a (tensor,B,H,W,cs,nseg)
+    view described by in_dims)."""
+    d = L.ConvDesc()
+    if in_dims is None:
+        t, B, H, W, cs, nseg = src.t, src.B, src.H, src.W, src.cs, src.nseg
+    else:
+        t, B, H, W, cs, nseg = in_dims
+    d.in_ = t.data_ptr()
+    d.B, d.H, d.W = B, H, W
+    d.in_cs = nseg * cs
+    d.cin_off, d.cin, d.in_nseg, d.in_seg_stride = cin_off, cin, nseg, cs
+    if w_gather is not None:
+        d.w_gather = w_gather.data_ptr()
+        d.Wl = w_gather.numel()
+    else:
+        d.w_gather = None
+        d.Wl = W
+    d.wgt = wgt.data_ptr()
+    d.kh, d.kw, d.cout, d.cout_pad = kh, kw, cout, wgt.shape[1]
+    d.stride, d.dil_h, d.dil_w = stride, dil[0], dil[1]
+    d.pad_top, d.pad_left, d.pad_mode = pad[0], pad[1], pad_mode
+    d.Ho, d.Wo = Ho, Wo
+    esize = 4 if out_dtype == L.DT_F32 else 2
+    d.out = out.data_ptr() + out_elem_offset * esize
+    d.out_dtype = out_dtype
+    d.out_sb, d.out_sh, d.out_sw, d.out_sc = sb, sh, sw, sc
+    d.out_c_off = c_off
+    d.cout_store = cout if cout_store is None else cout_store
+    d.out_third = third
+    d.scale, d.shift = scale.data_ptr(), shift.data_ptr()
+    d.act = act
+    d.act_param = slope.data_ptr() if slope is not None else None
+    L.check(L.lib().sos_conv2d_fwd(C.byref(d), L.stream_ptr()), "sos_conv2d_fwd")
+
+
+def conv_to_act(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, dst, c_off=0, cout_store=None, **kw_):
+    """Conv whose output is (a channel slice of) a dense NHWC Act."""
+    row = dst.nseg * dst.cs
+    conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, out=dst.t, out_dtype=dst.dtype_code,
+         sb=dst.H * dst.W * row, sh=dst.W * row, sw=row, sc=1, c_off=c_off,
+         cout_store=cout if cout_store is None else cout_store, third=dst.cs, **kw_)
+
+
+def lstm(xproj, whh_t, B, T, H, out_act):
+    """Recurrent part (sos_lstm_bidir_fwd); out_act: Act [B,1,T,cs>=2H] pre-zeroed."""
+    L.check(L.lib().sos_lstm_bidir_fwd(L.ptr(xproj), L.ptr(whh_t), B, T, H, None, L.ptr(out_act.t),
+                                       out_act.nseg * out_act.cs, out_act.dtype_code, out_act.cs,
+                                       L.stream_ptr()), "sos_lstm_bidir_fwd")
+
+
+class PlanCache:
+    """Packed weights keyed by the parameters' in-place version counters (optimizer steps and
+    load_state_dict bump them), the device and the precision mode."""
+
+    def __init__(self):
+        self.key = None
+        self.plan = None
+
+    def get(self, module, build):
+        ts = list(module.parameters()) + list(module.buffers())
+        key = (get_precision(), str(ts[0].device), tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts))
+        if key != self.key:
+            with torch.no_grad():
+                self.plan = build()
+            self.key = key
+        return self.plan

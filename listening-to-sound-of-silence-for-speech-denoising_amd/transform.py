@@ -1,0 +1,178 @@
+"""Mirror of the reference `transform.py` (M1/transform.py == M2/transform.py) on HIP kernels.
+
+Same public names and argument meaning: N_FFT/HOP_LENGTH/WIN_LENGTH (:6-8), fast_stft (:188-193),
+fast_istft (:196-202), batch_fast_icRM_sigmoid (:156-169, differentiable), fast_icRM_sigmoid
+(:141-153), fast_cRM_sigmoid (:130-138), real_imag_expand/shrink (:10-33).  numpy in -> numpy out
+like the reference; the `*_batch` functions are the device-resident forms the pipeline uses.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+N_FFT = 510
+HOP_LENGTH = 158
+WIN_LENGTH = 400
+
+_tables = {}
+
+
+def _front_tables(device, n_fft, win_length):
+    """hann (periodic, scipy get_window fftbins=True) and the (cos,sin) twiddle table."""
+    key = ("fe", str(device), n_fft, win_length)
+    if key not in _tables:
+        n = np.arange(win_length, dtype=np.float64)
+        window = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)
+        k = np.arange(n_fft, dtype=np.float64)
+        tw = np.stack([np.cos(2.0 * np.pi * k / n_fft), np.sin(2.0 * np.pi * k / n_fft)], axis=1)
+        _tables[key] = (torch.from_numpy(window.astype(np.float32)).to(device),
+                        torch.from_numpy(tw.astype(np.float32)).to(device).contiguous())
+    return _tables[key]
+
+
+def _inv_wss(device, n_frames, n_fft, hop, win_length):
+    """1 / window-sum-square (librosa filters.window_sumsquare), 1 where wss <= tiny."""
+    key = ("wss", str(device), n_frames, n_fft, hop, win_length)
+    if key not in _tables:
+        n = np.arange(win_length, dtype=np.float64)
+        w = np.zeros(n_fft)
+        lpad = (n_fft - win_length) // 2
+        w[lpad:lpad + win_length] = (0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)) ** 2
+        total = n_fft + hop * (n_frames - 1)
+        x = np.zeros(total)
+        for i in range(n_frames):
+            x[i * hop:i * hop + n_fft] += w
+        inv = np.ones(total)
+        nz = x > np.finfo(np.float32).tiny
+        inv[nz] = 1.0 / x[nz]
+        _tables[key] = torch.from_numpy(inv.astype(np.float32)).to(device)
+    return _tables[key]
+
+
+def stft_batch(wave, n_fft=N_FFT, hop_length=HOP_LENGTH, win_length=WIN_LENGTH):
+    """wave f32 (B, N) on the GPU -> (B, 2, n_fft//2+1, 1+N//hop) f32 (a1, fused with the
+    [F,T,2] -> [2,F,T] transpose of M2/dataset.py:255)."""
+    L.require_cuda(wave)
+    if wave.dim() != 2 or wave.dtype != torch.float32:
+        raise ValueError("stft_batch expects a float32 (B, N) tensor")
+    wave = wave.contiguous()
+    B, N = wave.shape
+    T = 1 + N // hop_length
+    window, tw = _front_tables(wave.device, n_fft, win_length)
+    out = torch.empty((B, 2, n_fft // 2 + 1, T), dtype=torch.float32, device=wave.device)
+    L.check(L.lib().sos_stft_f32(L.ptr(wave), B, N, N, L.ptr(window), L.ptr(tw), n_fft, hop_length, win_length,
+                                 L.ptr(out), T, L.stream_ptr()), "sos_stft_f32")
+    return out
+
+
+def istft_batch(spec, hop_length=HOP_LENGTH, win_length=WIN_LENGTH):
+    """spec f32 (B, 2, F, T) on the GPU -> (B, hop*(T-1)) f32 (a2)."""
+    L.require_cuda(spec)
+    if spec.dim() != 4 or spec.shape[1] != 2 or spec.dtype != torch.float32:
+        raise ValueError("istft_batch expects a float32 (B, 2, F, T) tensor")
+    spec = spec.contiguous()
+    B, _, F, T = spec.shape
+    n_fft = 2 * (F - 1)
+    window, tw = _front_tables(spec.device, n_fft, win_length)
+    inv = _inv_wss(spec.device, T, n_fft, hop_length, win_length)
+    n_out = hop_length * (T - 1)
+    out = torch.empty((B, n_out), dtype=torch.float32, device=spec.device)
+    L.check(L.lib().sos_istft_f32(L.ptr(spec), B, T, L.ptr(window), L.ptr(tw), L.ptr(inv), n_fft, hop_length,
+                                  win_length, L.ptr(out), n_out, L.stream_ptr()), "sos_istft_f32")
+    return out
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("sos_amd.transform needs an MI355X: there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def real_imag_expand(c_data, dim='new'):
+    """M1/transform.py:10-22 (pure layout glue on host arrays)."""
+    if dim == 'new':
+        return np.stack([np.real(c_data), np.imag(c_data)], axis=-1).astype(np.float64)
+    if dim == 'same':
+        D = np.zeros((c_data.shape[0], c_data.shape[1] * 2))
+        D[:, ::2] = np.real(c_data)
+        D[:, 1::2] = np.imag(c_data)
+        return D
+
+
+def real_imag_shrink(F, dim='new'):
+    """M1/transform.py:25-33."""
+    if dim == 'new':
+        return F[:, :, 0] + F[:, :, 1] * 1j
+    if dim == 'same':
+        return F[:, ::2] + F[:, 1::2] * 1j
+
+
+def fast_stft(data, power=False, n_fft=N_FFT, hop_length=HOP_LENGTH, win_length=WIN_LENGTH):
+    """M1/transform.py:188-193: 1-D waveform -> ndarray [F, T, 2]."""
+    if power:
+        raise NotImplementedError("power-law front-end (transform.py:178-185) is unused by the reference callers")
+    w = torch.as_tensor(np.asarray(data, dtype=np.float32), device=_device()).reshape(1, -1)
+    S = stft_batch(w, n_fft, hop_length, win_length)[0]          # (2, F, T)
+    return S.permute(1, 2, 0).cpu().numpy().astype(np.float64)
+
+
+def fast_istft(F, power=False, hop_length=HOP_LENGTH, win_length=WIN_LENGTH):
+    """M1/transform.py:196-202: [F, T, 2] -> 1-D float32 of length hop*(T-1)."""
+    if power:
+        raise NotImplementedError("power-law front-end (transform.py:178-185) is unused by the reference callers")
+    S = torch.as_tensor(np.asarray(F, dtype=np.float32), device=_device()).permute(2, 0, 1).unsqueeze(0)
+    return istft_batch(S, hop_length, win_length)[0].cpu().numpy()
+
+
+class _CrmApply(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Y, crm, a, b):
+        L.require_cuda(Y, crm)
+        Yc, cc = Y.contiguous().float(), crm.contiguous().float()
+        B = Yc.shape[0]
+        plane = Yc[0, 0].numel()
+        rec = torch.empty_like(Yc)
+        L.check(L.lib().sos_crm_apply_f32(L.ptr(Yc), L.ptr(cc), L.ptr(rec), B, plane, float(a), float(b),
+                                          L.stream_ptr()), "sos_crm_apply_f32")
+        ctx.save_for_backward(Yc, cc)
+        ctx.a = float(a)
+        return rec
+
+    @staticmethod
+    def backward(ctx, g):
+        Yc, cc = ctx.saved_tensors
+        g = g.contiguous().float()
+        gc = torch.empty_like(cc)
+        L.check(L.lib().sos_crm_apply_bwd_f32(L.ptr(Yc), L.ptr(cc), L.ptr(g), L.ptr(gc), Yc.shape[0],
+                                              Yc[0, 0].numel(), ctx.a, L.stream_ptr()), "sos_crm_apply_bwd_f32")
+        return None, gc, None, None
+
+
+def batch_fast_icRM_sigmoid(Y, crm, a=0.1, b=0):
+    """M1/transform.py:156-169: Y, crm (B, 2, F, T) -> rec (B, 2, F, T); grad flows to crm."""
+    if Y.dim() != 4 or Y.shape[1] != 2 or Y.shape != crm.shape:
+        raise ValueError("batch_fast_icRM_sigmoid expects two (B, 2, F, T) tensors")
+    return _CrmApply.apply(Y, crm, a, b)
+
+
+def fast_icRM_sigmoid(Y, crm):
+    """M1/transform.py:141-153: numpy [F, T, 2] x2 -> [F, T, 2]."""
+    dev = _device()
+    Yt = torch.as_tensor(np.asarray(Y, dtype=np.float32), device=dev).permute(2, 0, 1).unsqueeze(0)
+    ct = torch.as_tensor(np.asarray(crm, dtype=np.float32), device=dev).permute(2, 0, 1).unsqueeze(0)
+    with torch.no_grad():
+        rec = batch_fast_icRM_sigmoid(Yt, ct)
+    return rec[0].permute(1, 2, 0).cpu().numpy().astype(np.float64)
+
+
+def fast_cRM_sigmoid(Fclean, Fmix):
+    """M1/transform.py:130-138: target mask sigma(0.1 * S conj(Y) / (abs(Y)^2 + 1e-8))."""
+    dev = _device()
+    S = torch.as_tensor(np.asarray(Fclean, dtype=np.float32), device=dev).permute(2, 0, 1).unsqueeze(0).contiguous()
+    Y = torch.as_tensor(np.asarray(Fmix, dtype=np.float32), device=dev).permute(2, 0, 1).unsqueeze(0).contiguous()
+    out = torch.empty_like(S)
+    L.check(L.lib().sos_crm_target_f32(L.ptr(S), L.ptr(Y), L.ptr(out), 1, S[0, 0].numel(), 0.1, 0.0,
+                                       L.stream_ptr()), "sos_crm_target_f32")
+    return out[0].permute(1, 2, 0).cpu().numpy().astype(np.float64)

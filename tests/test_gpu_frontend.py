@@ -1,0 +1,114 @@
+"""HIP front-end kernels (through the C ABI) vs the oracle and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend as ofe
+from util import rel_err, hashed
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stft_golden(golden):
+    from sos_amd import transform as T
+    g = golden("frontend")
+    for i in range(3):
+        S = T.fast_stft(g[f"wave{i}"])
+        assert S.shape == g[f"stft{i}"].shape and S.dtype == np.float64
+        assert rel_err(S, g[f"stft{i}"]) < 1e-5          # north_star: spectrograms within 1e-3 rel
+
+
+def test_stft_batch_matches_oracle_full_size():
+    from sos_amd import transform as T
+    B, N = 64, 28000
+    w = (hashed(7, (B, N)) * 0.3).astype(np.float32)
+    S = T.stft_batch(torch.from_numpy(w).cuda())
+    assert tuple(S.shape) == (B, 2, 256, 178)
+    for b in (0, 17, 63):
+        ref = ofe.fast_stft(w[b]).transpose(2, 0, 1)
+        assert rel_err(S[b].cpu().numpy(), ref) < 1e-5
+
+
+def test_istft_golden_and_roundtrip(golden):
+    from sos_amd import transform as T
+    g = golden("frontend")
+    for i in range(3):
+        y = T.fast_istft(g[f"stft{i}"])
+        assert y.shape == g[f"istft{i}"].shape           # hop*(T-1): 27 966 for a 28 000-sample clip
+        assert rel_err(y, g[f"istft{i}"]) < 1e-5
+    y = T.fast_istft(g["rand_spec"])
+    assert rel_err(y, g["rand_spec_istft"]) < 1e-5
+    # size-independent property at BASELINE batch: istft(stft(x)) == x on the common length
+    B, N = 64, 28000
+    w = torch.from_numpy((hashed(8, (B, N)) * 0.3).astype(np.float32)).cuda()
+    r = T.istft_batch(T.stft_batch(w))
+    assert tuple(r.shape) == (B, 158 * 177)
+    assert float((r - w[:, :r.shape[1]]).abs().max()) < 2e-5
+
+
+def test_stft_linearity():
+    from sos_amd import transform as T
+    a = torch.from_numpy(hashed(9, (2, 9000)).astype(np.float32)).cuda()
+    b = torch.from_numpy(hashed(10, (2, 9000)).astype(np.float32)).cuda()
+    lhs = T.stft_batch(a + 2 * b)
+    rhs = T.stft_batch(a) + 2 * T.stft_batch(b)
+    assert float((lhs - rhs).abs().max()) < 1e-3 * float(rhs.abs().max())
+
+
+def test_mask_ops_golden(golden):
+    from sos_amd import transform as T
+    g = golden("maskops")
+    Y = torch.from_numpy(g["Y"]).cuda()
+    crm = torch.from_numpy(g["crm"]).cuda()
+    rec = T.batch_fast_icRM_sigmoid(Y, crm)
+    assert rel_err(rec.cpu().numpy(), g["rec"]) < 1e-5
+    Y1 = g["Y"][0].transpose(1, 2, 0)
+    c1 = g["crm"][0].transpose(1, 2, 0)
+    assert rel_err(T.fast_icRM_sigmoid(Y1, c1), g["rec1"]) < 1e-5
+    assert rel_err(T.fast_cRM_sigmoid(g["S1"], Y1.astype(np.float64)), g["tgt"]) < 1e-5
+
+
+def test_mask_apply_backward_matches_autograd():
+    from sos_amd import transform as T
+    from oracle import nets as onet
+    Y = torch.from_numpy(hashed(11, (2, 2, 16, 12), 2.0).astype(np.float32))
+    crm = torch.from_numpy((0.5 + 0.45 * hashed(12, (2, 2, 16, 12))).astype(np.float32))
+    gout = torch.from_numpy(hashed(13, (2, 2, 16, 12)).astype(np.float32))
+    c_ref = crm.clone().requires_grad_(True)
+    onet.mask_apply(Y, c_ref).backward(gout)
+    c_gpu = crm.cuda().requires_grad_(True)
+    T.batch_fast_icRM_sigmoid(Y.cuda(), c_gpu).backward(gout.cuda())
+    assert rel_err(c_gpu.grad.cpu().numpy(), c_ref.grad.numpy()) < 1e-5
+
+
+def test_bits_to_mask_bit_exact(golden):
+    from sos_amd import tools
+    g = golden("bitmask")
+    for i in range(20):
+        n = int(g[f"n{i}"])
+        bits = "".join(str(int(b)) for b in g[f"bits{i}"])
+        m = tools.convert_bitstreammask_to_audiomask(np.zeros(n, np.float32), float(g[f"ratio{i}"]), bits)
+        want = np.unpackbits(g[f"mask{i}"])[:n]
+        assert m.dtype == np.float32 and np.array_equal(m.astype(np.uint8), want), i
+    with pytest.raises(RuntimeError):
+        tools.convert_bitstreammask_to_audiomask(np.zeros(100, np.float32), 466.6, "012")
+
+
+def test_bits_to_mask_batch_and_masked_signal():
+    from sos_amd import tools
+    B, nfr, n = 64, 60, 28000
+    bits = (hashed(14, (B, nfr)) > -0.4).astype(np.uint8)
+    sig = hashed(15, (B, n)).astype(np.float32)
+    mask, masked = tools.bits_to_mask_batch(torch.from_numpy(bits).cuda(), 14000 / 30.0, n, torch.from_numpy(sig).cuda())
+    for b in (0, 31, 63):
+        want = ofe.convert_bitstreammask_to_audiomask(sig[b], 14000 / 30.0, list(bits[b]))
+        assert np.array_equal(mask[b].cpu().numpy(), want)
+        assert np.array_equal(masked[b].cpu().numpy(), sig[b] * want)
+
+
+def test_threshold_bits():
+    from sos_amd import tools
+    lg = torch.tensor([[-3.0, -1e-3, 0.0, 1e-3, 2.0]], device="cuda")
+    bits, conf = tools.threshold_bits(lg)
+    assert bits.cpu().tolist() == [[0, 0, 1, 1, 1]]
+    assert rel_err(conf.cpu().numpy(), torch.sigmoid(lg.cpu()).numpy()) < 1e-6

@@ -1,0 +1,69 @@
+"""HIP networks (through the reference-shaped module API) vs the oracle / reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+import sos_amd
+from oracle import nets as onet
+from util import rel_err, silent_gate, spec_input
+
+pytestmark = pytest.mark.gpu
+
+# tolerance on ||a-b||_inf / ||b||_inf per tensor: bf16x3 carries ~16 mantissa bits end to end
+# (north_star bar 1e-3); plain bf16 carries 8 and is checked against its own, looser bound.
+TOL = {"bf16x3": 1e-3, "bf16": 6e-2}
+
+
+def _nets():
+    from sos_amd.detector import networks as dnet
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.common import MyConfig
+    det = dnet.get_network()
+    det.load_state_dict(onet.closed_form_state(onet.detector_spec(), seed=1), strict=True)
+    jm = jnet.get_network(MyConfig())
+    jm.load_state_dict(onet.closed_form_state(onet.joint_spec(), seed=2), strict=True)
+    return det.cuda().eval(), jm.cuda().eval()
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_eval_forward_matches_reference_goldens(golden, precision):
+    g = golden("networks")
+    sos_amd.set_precision(precision)
+    try:
+        det, jm = _nets()
+        for tag, B, T, nfr in (("a", 1, 178, 60), ("b", 2, 89, 30)):
+            x = spec_input(100 + B, B, T).cuda()
+            n = silent_gate(spec_input(100 + B, B, T)).cuda()
+            with torch.no_grad():
+                lo = det(s=x, v_num_frames=nfr)
+                n_pred, out = jm(x, n)
+            assert tuple(lo.shape) == (B, nfr) and tuple(out.shape) == (B, 2, 256, T)
+            errs = (rel_err(lo.cpu(), g[f"det_logits_{tag}"]), rel_err(n_pred.cpu(), g[f"n_pred_{tag}"]),
+                    rel_err(out.cpu(), g[f"mask_{tag}"]))
+            print(precision, tag, "rel err logits/n_pred/mask:", errs)
+            assert max(errs) < TOL[precision], errs
+    finally:
+        sos_amd.set_precision("bf16")
+
+
+def test_variable_length_shapes():
+    """Whole-file inference (M1/predict.py, M2/predict.py) runs arbitrary T; odd sizes exercise the
+    crop that stands in for the reference's nearest-resize fix-ups."""
+    det, jm = _nets()
+    sos_amd.set_precision("bf16x3")
+    try:
+        sd1 = onet.closed_form_state(onet.detector_spec(), seed=1)
+        sd2 = onet.closed_form_state(onet.joint_spec(), seed=2)
+        for T, nfr in ((101, 33), (134, 47)):
+            x = spec_input(500 + T, 1, T)
+            n = silent_gate(x)
+            with torch.no_grad():
+                lo = det(x.cuda(), nfr)
+                n_pred, out = jm(x.cuda(), n.cuda())
+                lo_o = onet.detector_forward(sd1, x, nfr)
+                np_o, out_o = onet.joint_forward(sd2, x, n)
+            errs = (rel_err(lo.cpu(), lo_o), rel_err(n_pred.cpu(), np_o), rel_err(out.cpu(), out_o))
+            print("T", T, errs)
+            assert max(errs) < 1e-3, errs
+    finally:
+        sos_amd.set_precision("bf16")
