@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the Listening-to-Sound-of-Silence hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched with
+torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+
+A "step" is one pass of the hot path over one batch of synthetic 2 s clips resident in HBM:
+  --mode infer : STFT -> detector -> bits->mask -> STFT(noise) -> JointModel -> mask apply -> ISTFT
+Each rank processes its own batch (independent utterances, no data-path collective): weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_SAMPLES = 28000             # 2 s @ 14 kHz: the reference-true geometry
+GFLOP_PER_UTT_INFER = 446.5
+
+
+def cpu_baseline(n_clips=4):
+    """Oracle (CPU restatement, torch fp32 + numpy) inference of the same pipeline on host cores."""
+    from oracle import frontend as ofe
+    from oracle import nets as onet
+    from sos_amd.dataset import synth_batch
+    cores = max(1, min(os.cpu_count() or 1, 128))
+    torch.set_num_threads(cores)
+    sd1 = onet.closed_form_state(onet.detector_spec(), seed=1)
+    sd2 = onet.closed_form_state(onet.joint_spec(), seed=2)
+    raw = synth_batch(0, n_clips)
+
+    def run(waves):
+        S = torch.from_numpy(np.stack([ofe.fast_stft(w).transpose(2, 0, 1) for w in waves]).astype(np.float32))
+        with torch.no_grad():
+            lo = onet.detector_forward(sd1, S, 60)
+            bits = (torch.sigmoid(lo) >= 0.5).numpy().astype(np.uint8)
+            noise = [w * ofe.convert_bitstreammask_to_audiomask(w, 14000 / 30.0, list(b)) for w, b in zip(waves, bits)]
+            Sn = torch.from_numpy(np.stack([ofe.fast_stft(w).transpose(2, 0, 1) for w in noise]).astype(np.float32))
+            n_pred, crm = onet.joint_forward(sd2, S, Sn)
+        rec = onet.mask_apply(S, crm)
+        return [ofe.fast_istft(r.permute(1, 2, 0).numpy()) for r in rec]
+
+    run(raw["mixed"][:1])                  # warm-up
+    t0 = time.time()
+    run(raw["mixed"])
+    dt = time.time() - t0
+    return {"value": n_clips / dt, "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": f"{n_clips} clips of 2 s (28000 samples), full inference pipeline, torch-CPU fp32, one batch, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
+    ap.add_argument("--mode", default="infer", choices=["infer"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import sos_amd
+    from sos_amd import engine, pipeline
+    from sos_amd.common import MyConfig
+    from sos_amd.dataset import synth_batch
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+
+    sos_amd.set_precision("bf16")
+    torch.manual_seed(0)
+    det = dnet.get_network().cuda().eval()
+    jm = jnet.get_network(MyConfig()).cuda().eval()
+    B = args.batch
+    base = synth_batch(1000 * rank, min(B, 8))["mixed"]
+    mixed = torch.from_numpy(np.tile(base, ((B + len(base) - 1) // len(base), 1))[:B]).cuda().contiguous()
+
+    def step():
+        return pipeline.denoise(det, jm, mixed)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up; the first pass also finds the dominant kernel launch signature
+    engine.PROFILER = engine.LaunchProfiler()
+    for _ in range(max(1, args.warmup)):
+        step()
+    summ = engine.PROFILER.summary()
+    dom = max(summ, key=lambda k: summ[k]["total_ms"])
+    engine.PROFILER = engine.LaunchProfiler(only=dom)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = engine.PROFILER.summary()[dom]
+    engine.PROFILER = None
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        ach = prof["flops"] / (prof["avg_ms"] * 1e-3) / 1e12
+        line = {
+            "metric": "utterances/sec (2 s clips), inference pipeline STFT->detector->mask->denoiser->ISTFT",
+            "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"inference, batch={B} clips/GPU of 2 s @14 kHz (28000 samples, STFT 510/158/400 -> 2x256x178), "
+                                   "detector + two-stage denoiser, random-init weights (manual_seed 0)",
+                       "clips_per_gpu": B, "n_samples": N_SAMPLES,
+                       "realtime_factor": value * N_SAMPLES / 14000.0,
+                       "end_to_end_tflops": value * GFLOP_PER_UTT_INFER / 1e3 / world},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel": "conv_mfma_kernel " + str(dom), "launches": prof["launches"],
+                         "avg_ms": prof["avg_ms"], "flops_per_launch": prof["flops"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

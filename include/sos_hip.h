@@ -120,6 +120,14 @@ typedef struct sos_conv_desc {
 
 int sos_conv2d_fwd(const sos_conv_desc* desc /* host pointer */, sos_stream_t stream);
 
+/* One-time autotune for the SHAPE of `desc` (not its pointers): runs the `max_candidates` most
+ * promising tilings `iters` times each, timed with HIP events on `stream` (this call
+ * SYNCHRONISES -- keep it out of graph capture and timed regions), and caches the winner for
+ * every later sos_conv2d_fwd of the same shape.  *best_ms (optional) = winning time, or -1 if
+ * the shape was already tuned. */
+int sos_conv2d_tune(const sos_conv_desc* desc, int max_candidates, int iters, float* best_ms,
+                    sos_stream_t stream);
+
 /* ---- a7/a11 recurrent part of nn.LSTM(bidirectional=True), gate order i,f,g,o
  * (M1/networks.py:95,143-148; M2/networks.py:64,88).  The input projection
  * x@W_ih^T + b_ih + b_hh is a sos_conv2d_fwd (1x1) producing xproj.

@@ -45,6 +45,7 @@ SIGNATURES = {
     "sos_threshold_bits": [_P, _L, _F, _P, _P, _P],
     "sos_pack_nchw_to_nhwc": [_P, _L, _I, _L, _L, _P, _I, _I, _P],
     "sos_conv2d_fwd": [C.POINTER(ConvDesc), _P],
+    "sos_conv2d_tune": [C.POINTER(ConvDesc), _I, _I, C.POINTER(C.c_float), _P],
     "sos_lstm_bidir_fwd": [_P, _P, _L, _L, _I, _P, _P, _I, _I, _L, _P],
 }
 
@@ -59,6 +60,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+        import torch  # noqa: F401  -- load torch's bundled HIP runtime FIRST so libsos_hip binds to the same one
         h = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError if the symbol is not exported

@@ -18,6 +18,11 @@
 // (folded BN scale/shift or bias, ReLU / PReLU / Sigmoid).  LDS rows are padded by 16 B so the
 // 16-lane ds_read_b128 groups hit distinct banks.
 #include "sos_common.h"
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <vector>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -42,10 +47,57 @@ struct ConvParams {
     int npix;               // NC*PH*PW
     int tiles_h, tiles_w, ngw;
     int nblk;               // grid.x
+    int dbg;                // SOS_CONV_DBG ablation mask (0 in production)
 };
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* p) {
     return __builtin_bit_cast(bf16x8, *(const uint4*)p);
+}
+
+// Stage the input patch of one channel chunk: CPR lanes per pixel, 16 B per lane.  Batches of PU
+// pixels per thread: all PU global loads are issued before the first LDS store, so a batch costs
+// one memory latency instead of PU of them.
+template <int CPR, int PSTRIDE, bool GATHER>
+__device__ __forceinline__ void stage_patch(const ConvParams& p, char* patch, int tid, long long in_b,
+                                            long long cbase, int hin0, int win0, int rw0) {
+    constexpr int PU = 8;
+    constexpr int PPP = 256 / CPR;               // pixels per pass of the workgroup
+    const int pl = tid / CPR, cl = tid - pl * CPR;
+    const bool lane_on = pl < PPP;
+    const bool reflect = p.pad_mode == SOS_PAD_REFLECT;
+    const bf16_t* src0 = p.in + cbase + cl * 8;
+    // pixel index advances by PPP per step: walk (column c, combined row rr = cls*PH + r) with carries
+    const int dq = PPP / p.PW, dr = PPP - dq * p.PW;
+    int c0 = pl % p.PW, rr0 = pl / p.PW;
+    for (int pix0 = pl; pix0 < p.npix; pix0 += PPP * PU) {
+        uint4 v[PU];
+        bool okv[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const bool inside = pix0 + PPP * u < p.npix;
+            const int c = inside ? c0 : 0, rr = inside ? rr0 : 0;
+            int r = rr, cls = 0;
+            if (p.NC > 1) { cls = rr / p.PH; r = rr - cls * p.PH; }
+            int h = hin0 + r * p.dh;
+            int w = win0 + cls * p.stride + c * p.dw;
+            bool ok = (rw0 + cls) < p.dw || cls == 0;
+            const int hr = reflect_index(h, p.H), wr = reflect_index(w, p.Wl);
+            ok = ok && (reflect || (h >= 0 && h < p.H && w >= 0 && w < p.Wl));
+            h = reflect ? hr : min(max(h, 0), p.H - 1);      // always a legal address: load, then select
+            w = reflect ? wr : min(max(w, 0), p.Wl - 1);
+            if (GATHER) w = p.wgather[w];
+            okv[u] = ok;
+            v[u] = *(const uint4*)(src0 + (in_b + (long long)h * p.W + w) * p.in_cs);
+            c0 += dr; rr0 += dq;
+            if (c0 >= p.PW) { c0 -= p.PW; ++rr0; }
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int pix = pix0 + PPP * u;
+            if (lane_on && pix < p.npix)
+                *(uint4*)(patch + pix * PSTRIDE + cl * 16) = okv[u] ? v[u] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
 }
 
 template <int NT, int KS>
@@ -57,11 +109,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     constexpr int BROWS = NT * 32;
     constexpr int BPIECES = BROWS * CPR;
     constexpr int NBREG = (BPIECES + 255) / 256;
+    constexpr int BBYTES = BROWS * BSTRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
-    char* bbuf[2];
-    bbuf[0] = smem + (size_t)p.npix * PSTRIDE;
-    bbuf[1] = bbuf[0] + BROWS * BSTRIDE;
+    const int boff0 = p.npix * PSTRIDE;          // weight slab buffers follow the patch
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -103,6 +154,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     }
     const int bfrag_off = l31 * BSTRIDE + lhi * 16;
 
+    // ---- weight-slab staging: the piece each thread moves is tap invariant
+    int bsrc[NBREG], bdst[NBREG];
+    {
+        const int rmax = p.cout_pad - 1 - n0;   // rows past cout_pad are never stored: clamp, no branch
+#pragma unroll
+        for (int u = 0; u < NBREG; ++u) {
+            const int idx = min(tid + u * 256, BPIECES - 1);
+            const int row = idx / CPR, q = idx - row * CPR;
+            bsrc[u] = min(row, rmax) * p.ktot + q * 8;
+            bdst[u] = row * BSTRIDE + q * 16;
+        }
+    }
+    const long long tap_stride = (long long)p.cout_pad * p.ktot;
+
     f32x16 acc[2][NT];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -116,94 +181,111 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 
     for (int cc = 0; cc < p.nchunks; ++cc) {
         __syncthreads();   // everyone is done reading the previous chunk's patch / weight buffers
-        // ---- stage the input patch of this channel chunk: 16 lanes per pixel, 16 B per lane
-        {
-            const int cl = tid & 15;
+        // ---- stage the input patch of this channel chunk: CPR lanes per pixel, 16 B per lane.
+        // Batches of PU pixels per thread: all PU global loads are issued before the first LDS
+        // store, so a batch costs one memory latency instead of PU of them.
+        if (!(p.dbg & 1)) {
             const long long cbase = (long long)p.cin_off + (long long)(cc / p.cps) * p.seg_stride + (long long)(cc % p.cps) * KC;
-            for (int pix = tid >> 4; pix < p.npix; pix += 16) {
-                const int c = pix % p.PW;
-                const int rr = pix / p.PW;
-                const int r = rr % p.PH;
-                const int cls = rr / p.PH;
-                int h = hin0 + r * p.dh;
-                int w = win0 + cls * p.stride + c * p.dw;
-                bool ok = (rw0 + cls) < p.dw || cls == 0;
-                if (p.pad_mode == SOS_PAD_REFLECT) {
-                    h = reflect_index(h, p.H);
-                    w = reflect_index(w, p.Wl);
-                } else {
-                    ok = ok && h >= 0 && h < p.H && w >= 0 && w < p.Wl;
-                }
-                if (ok && p.wgather) w = p.wgather[w];
-                const bf16_t* src = p.in + ((in_b + (long long)h * p.W + w) * p.in_cs + cbase);
-                char* dst = patch + (size_t)pix * PSTRIDE;
-                for (int q = cl; q < CPR; q += 16) {
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (ok) v = *(const uint4*)(src + q * 8);
-                    *(uint4*)(dst + q * 16) = v;
-                }
-            }
+            // (uniform) specialisations keep the optional column-gather load and the reflect
+            // arithmetic out of the common loop: a data-dependent load inside it would force a
+            // vmcnt(0) per pixel and serialise the whole batch.
+            if (p.wgather) stage_patch<CPR, PSTRIDE, true>(p, patch, tid, in_b, cbase, hin0, win0, rw0);
+            else stage_patch<CPR, PSTRIDE, false>(p, patch, tid, in_b, cbase, hin0, win0, rw0);
         }
         // ---- weight slab of tap 0 straight into buffer 0
         {
             const bf16_t* wsrc = p.wgt + ((long long)n0 * p.ktot + (long long)cc * KC);
-            for (int idx = tid; idx < BPIECES; idx += 256) {
-                const int row = idx / CPR, q = idx - row * CPR;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (n0 + row < p.cout_pad) v = *(const uint4*)(wsrc + (long long)row * p.ktot + q * 8);
-                *(uint4*)(bbuf[0] + row * BSTRIDE + q * 16) = v;
+#pragma unroll
+            for (int u = 0; u < NBREG; ++u) {
+                const uint4 v = *(const uint4*)(wsrc + bsrc[u]);
+                if ((u + 1) * 256 <= BPIECES || tid + u * 256 < BPIECES) *(uint4*)(smem + boff0 + bdst[u]) = v;
             }
         }
         __syncthreads();
 
+        // Fragment pipeline: operands of k-step kk+1 are read from LDS while the MFMAs of kk run;
+        // the pixel operand of the NEXT tap's first k-step is read before the barrier (the patch
+        // does not change inside a chunk), only the weight operand has to wait for it.
+        bf16x8 af[2][2], wfr[2][NT], anext[2];
+        anext[0] = lds_frag(patch + abase[0]);
+        anext[1] = lds_frag(patch + abase[1]);
         int ta = 0, tb = 0;   // tap row / col
-        for (int tap = 0; tap < ntaps; ++tap) {
+        const bf16_t* wtap = p.wgt + ((long long)n0 * p.ktot + (long long)cc * KC);
+        for (int tap = 0; tap < ((p.dbg & 2) ? 0 : ntaps); ++tap) {
             const int cur = tap & 1;
-            // prefetch the next tap's weight slab into registers (lands while the MFMAs run)
-            uint4 breg[NBREG];
-            const bool more = tap + 1 < ntaps;
-            if (more) {
-                const bf16_t* wsrc = p.wgt + (((long long)(tap + 1) * p.cout_pad + n0) * p.ktot + (long long)cc * KC);
+            // prefetch the next tap's weight slab into registers (lands while the MFMAs run).  The
+            // loads are unconditional (last tap re-reads itself) so that breg stays in VGPRs: a
+            // conditionally-defined array is demoted to scratch and the loads become synchronous.
+            // (named scalars, not an array: with the scheduling barriers below an array is left in
+            // scratch memory, which makes the "prefetch" synchronous)
+            uint4 br0, br1, br2, br3, br4, br5, br6, br7;
+            if (tap + 1 < ntaps) wtap += tap_stride;
+#define SOS_BLOAD(i) if constexpr (NBREG > i) { if (!(p.dbg & 8)) br##i = *(const uint4*)(wtap + bsrc[i]); else br##i = make_uint4(0,0,0,0); }
+            SOS_BLOAD(0) SOS_BLOAD(1) SOS_BLOAD(2) SOS_BLOAD(3) SOS_BLOAD(4) SOS_BLOAD(5) SOS_BLOAD(6) SOS_BLOAD(7)
+#undef SOS_BLOAD
+            // hipcc otherwise sinks these loads to the end of the tap (right before their use) and
+            // hoists every ds_read to just before its MFMA; pin the software pipeline explicitly.
+            __builtin_amdgcn_sched_barrier(0);
+
+            const char* ap0 = patch + abase[0] + (ta * p.PW + tb) * PSTRIDE;
+            const char* ap1 = patch + abase[1] + (ta * p.PW + tb) * PSTRIDE;
+            int tan = ta, tbn = tb + 1;
+            if (tbn == p.kw) { tbn = 0; ++tan; }
+            if (tap + 1 == ntaps) { tan = ta; tbn = tb; }
+            const int toffn = (tan * p.PW + tbn) * PSTRIDE;
+            const char* bp = smem + boff0 + cur * BBYTES + bfrag_off;
+            af[0][0] = anext[0];
+            af[0][1] = anext[1];
 #pragma unroll
-                for (int u = 0; u < NBREG; ++u) {
-                    const int idx = tid + u * 256;
-                    const int row = idx / CPR, q = idx - row * CPR;
-                    breg[u] = make_uint4(0u, 0u, 0u, 0u);
-                    if (idx < BPIECES && n0 + row < p.cout_pad)
-                        breg[u] = *(const uint4*)(wsrc + (long long)row * p.ktot + q * 8);
-                }
-            }
-            const int toff = (ta * p.PW + tb) * PSTRIDE;
-            const char* a0p = patch + abase[0] + toff;
-            const char* a1p = patch + abase[1] + toff;
-            const char* bp = bbuf[cur] + bfrag_off;
+            for (int nt = 0; nt < NT; ++nt) wfr[0][nt] = lds_frag(bp + nt * 32 * BSTRIDE);
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
-                const bf16x8 a0 = lds_frag(a0p + kk * 32);
-                const bf16x8 a1 = lds_frag(a1p + kk * 32);
+                const int cb = kk & 1, nb = cb ^ 1;
+                if (p.dbg & 32) {
+                    af[nb][0] = af[cb][0]; af[nb][1] = af[cb][1];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) wfr[nb][nt] = wfr[cb][nt];
+                } else if (kk + 1 < KS) {
+                    af[nb][0] = lds_frag(ap0 + (kk + 1) * 32);
+                    af[nb][1] = lds_frag(ap1 + (kk + 1) * 32);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) wfr[nb][nt] = lds_frag(bp + nt * 32 * BSTRIDE + (kk + 1) * 32);
+                } else {
+                    anext[0] = lds_frag(patch + abase[0] + toffn);
+                    anext[1] = lds_frag(patch + abase[1] + toffn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const bf16x8 wf = lds_frag(bp + nt * 32 * BSTRIDE + kk * 32);
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, a0, acc[0][nt], 0, 0, 0);
-                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, a1, acc[1][nt], 0, 0, 0);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[cb][nt], af[cb][0], acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[cb][nt], af[cb][1], acc[1][nt], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (more) {
-#pragma unroll
-                for (int u = 0; u < NBREG; ++u) {
-                    const int idx = tid + u * 256;
-                    const int row = idx / CPR, q = idx - row * CPR;
-                    if (idx < BPIECES) *(uint4*)(bbuf[cur ^ 1] + row * BSTRIDE + q * 16) = breg[u];
-                }
-            }
-            __syncthreads();
-            if (++tb == p.kw) { tb = 0; ++ta; }
+#define SOS_BSTORE(i)                                                                      \
+    if constexpr (NBREG > i) {                                                               \
+        if (!(p.dbg & 8) && ((i + 1) * 256 <= BPIECES || tid + i * 256 < BPIECES))          \
+            *(uint4*)(smem + boff0 + (cur ^ 1) * BBYTES + bdst[i]) = br##i;                  \
+    }
+            SOS_BSTORE(0) SOS_BSTORE(1) SOS_BSTORE(2) SOS_BSTORE(3) SOS_BSTORE(4) SOS_BSTORE(5) SOS_BSTORE(6) SOS_BSTORE(7)
+#undef SOS_BSTORE
+            if (!(p.dbg & 16)) __syncthreads();
+            ta = tan; tb = tbn;
         }
     }
 
     // ---- fused epilogue.  Accumulator layout of v_mfma_f32_32x32x*: column = lane&31 (pixel),
     // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (output channel within the 32-row tile).
     const float slope = (p.act == SOS_ACT_PRELU && p.slope) ? p.slope[0] : 0.f;
+    if (p.dbg & 4) return;
+    const bool staged = p.out_dtype != SOS_DT_F32 && p.sc == 1;
+    const bool x3 = p.out_dtype == SOS_DT_BF16X3;
+    constexpr int OROW = NT * 64 + 16;           // bytes per staged output pixel row
+    char* ost_hi = smem;
+    char* ost_lo = smem + 256 * OROW;
+    int mrow[2];
+    long long obase[2];
+    bool pix_ok[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = wave * 64 + mt * 32 + l31;
@@ -212,63 +294,104 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         const int cls = m >> (p.logTW + p.logTH);
         const int ho = ho_base + i * p.dh;
         const int wo = wo_base + cls + j * p.dw;
-        const bool pix_ok = ho < p.Ho && wo < p.Wo && (cls == 0 || rw0 + cls < p.dw);
-        if (!pix_ok) continue;
-        const long long obase = (long long)b * p.sb + (long long)ho * p.sh + (long long)wo * p.sw;
+        mrow[mt] = m * OROW;
+        pix_ok[mt] = ho < p.Ho && wo < p.Wo && (cls == 0 || rw0 + cls < p.dw);
+        obase[mt] = (long long)b * p.sb + (long long)ho * p.sh + (long long)wo * p.sw;
+    }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = n0 + nt * 32 + g * 8 + lhi * 4;   // 4 consecutive channels co..co+3
-                if (co >= p.cout_store) continue;
+        for (int g = 0; g < 4; ++g) {
+            const int col = nt * 32 + g * 8 + lhi * 4;
+            const int co = n0 + col;                          // 4 consecutive channels co..co+3
+            if (co >= p.cout_store) continue;
+            const float4 sc4 = *(const float4*)(p.scale + co);
+            const float4 sh4 = *(const float4*)(p.shift + co);
+            const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+            const float shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int c = co + e;
-                    float y = 0.f;
-                    if (c < p.cout) {
-                        y = fmaf(acc[mt][nt][g * 4 + e], p.scale[c], p.shift[c]);
-                        if (p.act == SOS_ACT_RELU) y = fmaxf(y, 0.f);
-                        else if (p.act == SOS_ACT_PRELU) y = y >= 0.f ? y : slope * y;
-                        else if (p.act == SOS_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
-                    }
-                    v[e] = y;
+                    float y = fmaf(acc[mt][nt][g * 4 + e], scv[e], shv[e]);
+                    if (p.act == SOS_ACT_RELU) y = fmaxf(y, 0.f);
+                    else if (p.act == SOS_ACT_PRELU) y = y >= 0.f ? y : slope * y;
+                    else if (p.act == SOS_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
+                    v[e] = (co + e < p.cout) ? y : 0.f;
                 }
-                const long long o = obase + (long long)(p.c_off + co) * p.sc;
                 if (p.out_dtype == SOS_DT_F32) {
+                    if (!pix_ok[mt]) continue;
                     float* op = (float*)p.out;
+                    const long long o = obase[mt] + (long long)(p.c_off + co) * p.sc;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (co + e < p.cout_store) op[o + e * p.sc] = v[e];
+                    continue;
+                }
+                bf16_t hi[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hi[e] = f2bf(v[e]);
+                if (staged) {
+                    // transpose through LDS so that global stores are whole 16-byte channel runs
+                    *(uint2*)(ost_hi + mrow[mt] + col * 2) =
+                        make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
+                    if (x3) {
+                        bf16_t lo[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) lo[e] = f2bf(v[e] - bf2f(hi[e]));
+                        *(uint2*)(ost_lo + mrow[mt] + col * 2) =
+                            make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+                    }
                 } else {
+                    if (!pix_ok[mt]) continue;
                     bf16_t* op = (bf16_t*)p.out;
-                    bf16_t hi[4], lo[4];
+                    const long long o = obase[mt] + (long long)(p.c_off + co) * p.sc;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        hi[e] = f2bf(v[e]);
-                        lo[e] = f2bf(v[e] - bf2f(hi[e]));
-                    }
-                    if (p.sc == 1 && co + 3 < p.cout_store) {
-                        const uint2 hv = make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16),
-                                                    (unsigned)hi[2] | ((unsigned)hi[3] << 16));
-                        *(uint2*)(op + o) = hv;
-                        if (p.out_dtype == SOS_DT_BF16X3) {
-                            *(uint2*)(op + o + p.third) = hv;
-                            *(uint2*)(op + o + 2 * p.third) = make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16),
-                                                                          (unsigned)lo[2] | ((unsigned)lo[3] << 16));
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (co + e >= p.cout_store) continue;
-                            op[o + e * p.sc] = hi[e];
-                            if (p.out_dtype == SOS_DT_BF16X3) {
-                                op[o + e * p.sc + p.third] = hi[e];
-                                op[o + e * p.sc + 2 * p.third] = lo[e];
-                            }
+                        if (co + e >= p.cout_store) continue;
+                        op[o + e * p.sc] = hi[e];
+                        if (x3) {
+                            op[o + e * p.sc + p.third] = hi[e];
+                            op[o + e * p.sc + 2 * p.third] = f2bf(v[e] - bf2f(hi[e]));
                         }
                     }
                 }
+            }
+        }
+    }
+    if (!staged) return;
+    __syncthreads();
+    // ---- cooperative store: consecutive lanes write consecutive 16-byte pieces of a pixel's
+    // channel run (and consecutive pixels of a tile row are adjacent in memory when dil_w == 1).
+    constexpr int PPX = NT * 4;                  // 16-byte pieces per pixel
+    bf16_t* op = (bf16_t*)p.out + (long long)b * p.sb + p.c_off + n0;
+    const int ish = (int)p.sh, isw = (int)p.sw, ith = (int)p.third;
+#pragma unroll 4
+    for (int idx = tid; idx < 256 * PPX; idx += 256) {
+        const int m = idx / PPX, q = idx - m * PPX;
+        const int co = n0 + q * 8;
+        if (co >= p.cout_store) continue;
+        const int j = m & (TW - 1);
+        const int i = (m >> p.logTW) & (TH - 1);
+        const int cls = m >> (p.logTW + p.logTH);
+        const int ho = ho_base + i * p.dh;
+        const int wo = wo_base + cls + j * p.dw;
+        if (!(ho < p.Ho && wo < p.Wo && (cls == 0 || rw0 + cls < p.dw))) continue;
+        const int o = ho * ish + wo * isw + q * 8;
+        const uint4 hv = *(const uint4*)(ost_hi + m * OROW + q * 16);
+        if (co + 8 <= p.cout_store) {
+            *(uint4*)(op + o) = hv;
+            if (x3) {
+                *(uint4*)(op + o + ith) = hv;
+                *(uint4*)(op + o + 2 * ith) = *(const uint4*)(ost_lo + m * OROW + q * 16);
+            }
+        } else {
+            const bf16_t* hs = (const bf16_t*)(ost_hi + m * OROW + q * 16);
+            const bf16_t* ls = (const bf16_t*)(ost_lo + m * OROW + q * 16);
+            for (int e = 0; co + e < p.cout_store; ++e) {
+                op[o + e] = hs[e];
+                if (x3) { op[o + e + ith] = hs[e]; op[o + e + 2 * ith] = ls[e]; }
             }
         }
     }
@@ -315,52 +438,29 @@ static size_t lds_bytes(int npix, int nt, int ks) {
     return (size_t)npix * row + 2 * (size_t)nt * 32 * row;
 }
 
-static int pick_ks(int cin, int npix, int nt) {
-    static const int cand[] = {8, 6, 5, 4, 3, 2, 1};
-    const int k16 = cin / 16;
-    for (int c : cand)
-        if (k16 % c == 0 && lds_bytes(npix, nt, c) <= LDS_LIMIT) return c;
-    return 0;
-}
+// One tiling choice: NC residue classes x (1<<lth) x (1<<ltw) pixels, 16*ks channels per chunk.
+struct ConvCfg {
+    int NC, lth, ltw, ks;
+    double cost;
+};
 
-extern "C" int sos_conv2d_fwd(const sos_conv_desc* d, sos_stream_t stream) {
-    if (!d || !d->in || !d->wgt || !d->out || !d->scale || !d->shift) {
-        sos_set_error("sos_conv2d_fwd: null pointer");
-        return SOS_EINVAL;
-    }
-    if (d->cin < 16 || d->cin % 16 || d->in_cs % 8 || d->cin_off % 8 || d->cout_pad % 32 || d->cout > d->cout_pad ||
-        d->cout < 1 || d->kh < 1 || d->kw < 1 || d->stride < 1 || d->dil_h < 1 || d->dil_w < 1 ||
-        (d->stride > 1 && (d->dil_h > 1 || d->dil_w > 1)) || d->B < 1 || d->Ho < 1 || d->Wo < 1 ||
-        d->in_nseg < 1 || d->in_seg_stride % 8 || d->cin_off + (d->in_nseg - 1) * d->in_seg_stride + d->cin > d->in_cs || d->cout_store < d->cout || d->out_dtype < 0 || d->out_dtype > 2 ||
-        (d->w_gather == nullptr && d->Wl != d->W)) {
-        sos_set_error("sos_conv2d_fwd: bad descriptor (cin=%d in_cs=%d cin_off=%d cout=%d/%d k=%dx%d s=%d d=%dx%d)",
-                      d->cin, d->in_cs, d->cin_off, d->cout, d->cout_pad, d->kh, d->kw, d->stride, d->dil_h, d->dil_w);
-        return SOS_EINVAL;
-    }
-    if (d->pad_mode == SOS_PAD_REFLECT && (d->pad_top >= d->H || d->pad_left >= d->Wl)) {
-        sos_set_error("sos_conv2d_fwd: reflect pad %d/%d needs a larger input (%dx%d)", d->pad_top, d->pad_left, d->H, d->Wl);
-        return SOS_EINVAL;
-    }
-    ConvParams p;
-    p.in = (const bf16_t*)d->in; p.wgt = (const bf16_t*)d->wgt; p.out = d->out;
-    p.scale = d->scale; p.shift = d->shift; p.slope = d->act_param; p.wgather = d->w_gather;
-    p.B = d->B; p.H = d->H; p.W = d->W; p.Wl = d->Wl; p.in_cs = d->in_cs; p.cin_off = d->cin_off; p.cin = d->cin;
-    p.kh = d->kh; p.kw = d->kw; p.cout = d->cout; p.cout_pad = d->cout_pad; p.cout_store = d->cout_store;
-    p.stride = d->stride; p.dh = d->dil_h; p.dw = d->dil_w; p.pad_t = d->pad_top; p.pad_l = d->pad_left;
-    p.pad_mode = d->pad_mode; p.Ho = d->Ho; p.Wo = d->Wo; p.out_dtype = d->out_dtype; p.c_off = d->out_c_off;
-    p.act = d->act; p.sb = d->out_sb; p.sh = d->out_sh; p.sw = d->out_sw; p.sc = d->out_sc; p.third = d->out_third;
-
-    // output-channel tiles per block: as many as fit, balanced over the n-blocks
+static int nt_for(const sos_conv_desc* d) {
+    // output-channel tiles per block: as many as fit (<= 4), balanced over the n-blocks
     const int ntiles = d->cout_pad / 32;
     const int nby = (ntiles + 3) / 4;
-    const int nt = (ntiles + nby - 1) / nby;
+    return (ntiles + nby - 1) / nby;
+}
 
-    // ---- choose the pixel tile (NC classes x TH x TW = 256) by a cost model: MFMA work wasted on
-    // out-of-range pixels versus patch traffic (halo amplification).
+// Enumerate every legal tiling with a cost estimate: MFMA work wasted on out-of-range pixels,
+// patch traffic (halo amplification), per-chunk overheads, and a bonus when two workgroups fit a
+// CU's LDS (their load / epilogue phases then overlap each other's MFMA phase).
+static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
+    std::vector<ConvCfg> out;
+    const int nt = nt_for(d);
     const int Hc = (d->Ho + d->dil_h - 1) / d->dil_h, Wc = (d->Wo + d->dil_w - 1) / d->dil_w;
     const int taps = d->kh * d->kw;
-    double best = 1e300;
-    int bNC = 0, bTH = 0, bTW = 0, bKS = 0;
+    static const int kscand[] = {8, 6, 5, 4, 3, 2, 1};
+    const int k16 = d->cin / 16;
     for (int lnc = 0; lnc <= 8; ++lnc) {
         const int NC = 1 << lnc;
         if (NC > 1 && (d->stride > 1 || NC > d->dil_w)) break;
@@ -369,24 +469,79 @@ extern "C" int sos_conv2d_fwd(const sos_conv_desc* d, sos_stream_t stream) {
             const int TH = 1 << lth, TW = 1 << ltw;
             const int PH = (TH - 1) * d->stride + d->kh, PW = (TW - 1) * d->stride + d->kw;
             const int npix = NC * PH * PW;
-            const int ks = pick_ks(d->cin, npix, nt);
-            if (!ks) continue;
             const long long th = (Hc + TH - 1) / TH, tw = (Wc + TW - 1) / TW, ngw = (d->dil_w + NC - 1) / NC;
             const double blocks = (double)th * tw * ngw * d->dil_h;
-            // per block: MFMA time ~ 256*taps ; patch load ~ 3*npix ; per-chunk sync/latency overhead
-            const double cost = blocks * (256.0 * taps + 3.0 * npix + 64.0 * (d->in_nseg * d->cin / (16 * ks)) * (1 + taps / 4.0));
-            if (cost < best) { best = cost; bNC = NC; bTH = lth; bTW = ltw; bKS = ks; }
+            for (int ks : kscand) {
+                if (k16 % ks) continue;
+                const size_t lds = lds_bytes(npix, nt, ks);
+                if (lds > LDS_LIMIT) continue;
+                const int nchunks = d->in_nseg * k16 / ks;
+                double per_block = 256.0 * taps * nchunks * ks + 3.0 * npix * nchunks * ks + 40.0 * nchunks * (6 + taps);
+                if (lds > LDS_LIMIT / 2) per_block *= 1.3;     // a lone workgroup per CU hides nothing
+                out.push_back({NC, lth, ltw, ks, blocks * per_block});
+            }
         }
     }
-    if (!bKS) {
-        sos_set_error("sos_conv2d_fwd: no tile fits LDS (cin=%d k=%dx%d)", d->cin, d->kh, d->kw);
-        return SOS_ENOSPC;
+    std::sort(out.begin(), out.end(), [](const ConvCfg& a, const ConvCfg& b) { return a.cost < b.cost; });
+    return out;
+}
+
+struct ShapeKey {
+    int v[18];
+    bool operator<(const ShapeKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
+};
+
+static ShapeKey shape_key(const sos_conv_desc* d) {
+    ShapeKey k;
+    const int vals[18] = {d->B, d->H, d->W, d->Wl, d->cin, d->in_nseg, d->cout_pad, d->kh, d->kw, d->stride, d->dil_h,
+                          d->dil_w, d->Ho, d->Wo, d->out_dtype, d->out_sc == 1 ? 1 : 0, d->pad_mode, d->w_gather ? 1 : 0};
+    memcpy(k.v, vals, sizeof(vals));
+    return k;
+}
+
+static std::map<ShapeKey, ConvCfg>& tuned_cache() {
+    static std::map<ShapeKey, ConvCfg> m;
+    return m;
+}
+
+static int validate(const sos_conv_desc* d) {
+    if (!d || !d->in || !d->wgt || !d->out || !d->scale || !d->shift) {
+        sos_set_error("sos_conv2d_fwd: null pointer");
+        return SOS_EINVAL;
     }
-    p.NC = bNC; p.logTH = bTH; p.logTW = bTW;
-    const int TH = 1 << bTH, TW = 1 << bTW;
+    if (d->cin < 16 || d->cin % 16 || d->in_cs % 8 || d->cin_off % 8 || d->cout_pad % 32 || d->cout > d->cout_pad ||
+        d->cout < 1 || d->kh < 1 || d->kw < 1 || d->stride < 1 || d->dil_h < 1 || d->dil_w < 1 ||
+        (d->stride > 1 && (d->dil_h > 1 || d->dil_w > 1)) || d->B < 1 || d->Ho < 1 || d->Wo < 1 ||
+        d->in_nseg < 1 || d->in_seg_stride % 8 || d->cin_off + (d->in_nseg - 1) * d->in_seg_stride + d->cin > d->in_cs ||
+        d->cout_store < d->cout || d->out_dtype < 0 || d->out_dtype > 2 || (d->w_gather == nullptr && d->Wl != d->W)) {
+        sos_set_error("sos_conv2d_fwd: bad descriptor (cin=%d in_cs=%d cin_off=%d cout=%d/%d k=%dx%d s=%d d=%dx%d)",
+                      d->cin, d->in_cs, d->cin_off, d->cout, d->cout_pad, d->kh, d->kw, d->stride, d->dil_h, d->dil_w);
+        return SOS_EINVAL;
+    }
+    if (d->pad_mode == SOS_PAD_REFLECT && (d->pad_top >= d->H || d->pad_left >= d->Wl)) {
+        sos_set_error("sos_conv2d_fwd: reflect pad %d/%d needs a larger input (%dx%d)", d->pad_top, d->pad_left, d->H, d->Wl);
+        return SOS_EINVAL;
+    }
+    return SOS_OK;
+}
+
+static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
+    ConvParams p;
+    p.in = (const bf16_t*)d->in; p.wgt = (const bf16_t*)d->wgt; p.out = d->out;
+    p.scale = d->scale; p.shift = d->shift; p.slope = d->act_param; p.wgather = d->w_gather;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Wl = d->Wl; p.in_cs = d->in_cs; p.cin_off = d->cin_off; p.cin = d->cin;
+    p.kh = d->kh; p.kw = d->kw; p.cout = d->cout; p.cout_pad = d->cout_pad; p.cout_store = d->cout_store;
+    p.stride = d->stride; p.dh = d->dil_h; p.dw = d->dil_w; p.pad_t = d->pad_top; p.pad_l = d->pad_left;
+    p.pad_mode = d->pad_mode; p.Ho = d->Ho; p.Wo = d->Wo; p.out_dtype = d->out_dtype; p.c_off = d->out_c_off;
+    p.act = d->act; p.sb = d->out_sb; p.sh = d->out_sh; p.sw = d->out_sw; p.sc = d->out_sc; p.third = d->out_third;
+    const int nt = nt_for(d);
+    const int nby = (d->cout_pad / 32 + nt - 1) / nt;
+    const int Hc = (d->Ho + d->dil_h - 1) / d->dil_h, Wc = (d->Wo + d->dil_w - 1) / d->dil_w;
+    p.NC = c.NC; p.logTH = c.lth; p.logTW = c.ltw;
+    const int TH = 1 << c.lth, TW = 1 << c.ltw;
     p.PH = (TH - 1) * d->stride + d->kh; p.PW = (TW - 1) * d->stride + d->kw;
     p.npix = p.NC * p.PH * p.PW;
-    p.cps = d->cin / (16 * bKS);
+    p.cps = d->cin / (16 * c.ks);
     p.nchunks = p.cps * d->in_nseg;
     p.ktot = d->cin * d->in_nseg;
     p.seg_stride = d->in_seg_stride;
@@ -394,15 +549,75 @@ extern "C" int sos_conv2d_fwd(const sos_conv_desc* d, sos_stream_t stream) {
     const long long nblk = (long long)d->B * d->dil_h * p.tiles_h * p.ngw * p.tiles_w;
     if (nblk > 0x7fffffffLL) { sos_set_error("sos_conv2d_fwd: grid too large"); return SOS_EINVAL; }
     p.nblk = (int)nblk;
+    { const char* e = getenv("SOS_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
     dim3 grid((unsigned)nblk, (unsigned)nby);
-    const size_t lds = lds_bytes(p.npix, nt, bKS);
-    hipStream_t s = (hipStream_t)stream;
+    size_t lds = lds_bytes(p.npix, nt, c.ks);
+    if (d->out_dtype != SOS_DT_F32 && d->out_sc == 1) {
+        const size_t stage = (size_t)256 * (nt * 64 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1);
+        if (stage > lds) lds = stage;
+    }
     switch (nt) {
-        case 1: return launch_ks<1>(bKS, p, grid, lds, s);
-        case 2: return launch_ks<2>(bKS, p, grid, lds, s);
-        case 3: return launch_ks<3>(bKS, p, grid, lds, s);
-        case 4: return launch_ks<4>(bKS, p, grid, lds, s);
+        case 1: return launch_ks<1>(c.ks, p, grid, lds, s);
+        case 2: return launch_ks<2>(c.ks, p, grid, lds, s);
+        case 3: return launch_ks<3>(c.ks, p, grid, lds, s);
+        case 4: return launch_ks<4>(c.ks, p, grid, lds, s);
     }
     sos_set_error("sos_conv2d_fwd: internal: nt=%d", nt);
     return SOS_EINVAL;
+}
+
+extern "C" int sos_conv2d_fwd(const sos_conv_desc* d, sos_stream_t stream) {
+    int rc = validate(d);
+    if (rc) return rc;
+    auto& cache = tuned_cache();
+    auto it = cache.find(shape_key(d));
+    if (it != cache.end()) return launch_cfg(d, it->second, (hipStream_t)stream);
+    std::vector<ConvCfg> cfgs = enumerate_cfgs(d);
+    if (cfgs.empty()) {
+        sos_set_error("sos_conv2d_fwd: no tile fits LDS (cin=%d k=%dx%d)", d->cin, d->kh, d->kw);
+        return SOS_ENOSPC;
+    }
+    return launch_cfg(d, cfgs[0], (hipStream_t)stream);
+}
+
+// Measure the best few tilings of this descriptor's shape on the device (HIP events on `stream`,
+// synchronises!) and remember the winner for later sos_conv2d_fwd calls of the same shape.
+// Call outside of graph capture / timed regions.  Returns 0 and, if non-NULL, the winning time.
+extern "C" int sos_conv2d_tune(const sos_conv_desc* d, int max_candidates, int iters, float* best_ms,
+                               sos_stream_t stream) {
+    int rc = validate(d);
+    if (rc) return rc;
+    auto& cache = tuned_cache();
+    const ShapeKey key = shape_key(d);
+    if (cache.count(key)) { if (best_ms) *best_ms = -1.f; return SOS_OK; }
+    std::vector<ConvCfg> cfgs = enumerate_cfgs(d);
+    if (cfgs.empty()) { sos_set_error("sos_conv2d_tune: no tile fits LDS"); return SOS_ENOSPC; }
+    if (max_candidates < 1) max_candidates = 1;
+    if (iters < 1) iters = 1;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        sos_set_error("sos_conv2d_tune: hipEventCreate failed");
+        return SOS_ELAUNCH;
+    }
+    float best = 1e30f;
+    int besti = 0;
+    const int n = std::min<int>((int)cfgs.size(), max_candidates);
+    for (int i = 0; i < n; ++i) {
+        if ((rc = launch_cfg(d, cfgs[i], s))) break;           // warm-up
+        (void)hipEventRecord(e0, s);
+        for (int k = 0; k < iters && !rc; ++k) rc = launch_cfg(d, cfgs[i], s);
+        (void)hipEventRecord(e1, s);
+        if (rc || hipEventSynchronize(e1) != hipSuccess) { if (!rc) rc = SOS_ELAUNCH; break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        ms /= iters;
+        if (ms < best) { best = ms; besti = i; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    cache[key] = cfgs[besti];
+    if (best_ms) *best_ms = best;
+    return SOS_OK;
 }

@@ -13,82 +13,93 @@
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Thread layout: thread = (gate q, group of 4 consecutive hidden units) -> one 16-byte W_hh^T load
+// per k feeds 4 units x NB clips; the four gate pre-activations of a unit meet in LDS, then the
+// first H threads do the cell update (cell state lives in LDS, [j][NB]).
 __global__ __launch_bounds__(256) void lstm_kernel(const float* __restrict__ xproj, const float* __restrict__ whh_t,
                                                    int B, int T, int H, float* __restrict__ out_f32,
                                                    bf16_t* __restrict__ out_bf16, int out_cs, int x3,
                                                    long long third) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* hbuf = (float*)smem;                      // [2][H][LSTM_NB]
-    const int j = threadIdx.x;
+    float* hbuf = (float*)smem;                           // [2][H][NB]
+    float* gbuf = hbuf + 2 * H * LSTM_NB;                 // [4H][NB] gate pre-activations
+    float* cbuf = gbuf + 4 * H * LSTM_NB;                 // [H][NB] cell state
+    const int tid = threadIdx.x;
     const int dir = blockIdx.y;
     const int b0 = blockIdx.x * LSTM_NB;
     const int G = 4 * H;
-    const float* W = whh_t + (size_t)dir * H * G;    // [k][4H]
-    float c[LSTM_NB], hreg[LSTM_NB];
-#pragma unroll
-    for (int n = 0; n < LSTM_NB; ++n) { c[n] = 0.f; hreg[n] = 0.f; }
-    for (int idx = threadIdx.x; idx < 2 * H * LSTM_NB; idx += blockDim.x) hbuf[idx] = 0.f;
+    const float* W = whh_t + (size_t)dir * H * G;         // [k][4H]
+    const int nact = G >> 2;                               // active threads (4 gate columns each)
+    const int col0 = tid * 4;                              // first gate column of this thread
+    for (int idx = tid; idx < 2 * H * LSTM_NB + 4 * H * LSTM_NB + H * LSTM_NB; idx += blockDim.x) hbuf[idx] = 0.f;
     __syncthreads();
 
     for (int step = 0; step < T; ++step) {
         const int t = dir == 0 ? step : T - 1 - step;
         const float* hcur = hbuf + (size_t)(step & 1) * H * LSTM_NB;
         float* hnext = hbuf + (size_t)((step + 1) & 1) * H * LSTM_NB;
-        if (j < H) {
+        if (tid < nact) {
             float g[4][LSTM_NB];
 #pragma unroll
             for (int n = 0; n < LSTM_NB; ++n) {
                 const int b = b0 + n;
-                if (b < B) {
-                    const float* xp = xproj + (((size_t)b * T + t) * 2 + dir) * G;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g[q][n] = xp[q * H + j];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g[q][n] = 0.f;
-                }
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b < B) x = *(const float4*)(xproj + (((size_t)b * T + t) * 2 + dir) * G + col0);
+                g[0][n] = x.x; g[1][n] = x.y; g[2][n] = x.z; g[3][n] = x.w;
             }
-#pragma unroll 4
+            const float* wp = W + col0;
+#pragma unroll 8
             for (int k = 0; k < H; ++k) {
-                const float w0 = W[(size_t)k * G + j];
-                const float w1 = W[(size_t)k * G + H + j];
-                const float w2 = W[(size_t)k * G + 2 * H + j];
-                const float w3 = W[(size_t)k * G + 3 * H + j];
+                const float4 w = *(const float4*)(wp + (size_t)k * G);
                 const float4 ha = *(const float4*)(hcur + k * LSTM_NB);
                 const float4 hb = *(const float4*)(hcur + k * LSTM_NB + 4);
                 const float hv[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
 #pragma unroll
                 for (int n = 0; n < LSTM_NB; ++n) {
-                    g[0][n] = fmaf(w0, hv[n], g[0][n]);
-                    g[1][n] = fmaf(w1, hv[n], g[1][n]);
-                    g[2][n] = fmaf(w2, hv[n], g[2][n]);
-                    g[3][n] = fmaf(w3, hv[n], g[3][n]);
+                    g[0][n] = fmaf(w.x, hv[n], g[0][n]);
+                    g[1][n] = fmaf(w.y, hv[n], g[1][n]);
+                    g[2][n] = fmaf(w.z, hv[n], g[2][n]);
+                    g[3][n] = fmaf(w.w, hv[n], g[3][n]);
                 }
             }
 #pragma unroll
-            for (int n = 0; n < LSTM_NB; ++n) {
-                const float ig = sigmoidf_(g[0][n]), fg = sigmoidf_(g[1][n]);
-                const float gg = tanhf(g[2][n]), og = sigmoidf_(g[3][n]);
-                c[n] = fg * c[n] + ig * gg;
-                hreg[n] = og * tanhf(c[n]);
+            for (int e = 0; e < 4; ++e) {
+                *(float4*)(gbuf + (col0 + e) * LSTM_NB) = make_float4(g[e][0], g[e][1], g[e][2], g[e][3]);
+                *(float4*)(gbuf + (col0 + e) * LSTM_NB + 4) = make_float4(g[e][4], g[e][5], g[e][6], g[e][7]);
             }
-            float4 o0 = make_float4(hreg[0], hreg[1], hreg[2], hreg[3]);
-            float4 o1 = make_float4(hreg[4], hreg[5], hreg[6], hreg[7]);
-            *(float4*)(hnext + j * LSTM_NB) = o0;
-            *(float4*)(hnext + j * LSTM_NB + 4) = o1;
+        }
+        __syncthreads();
+        // cell update: thread (j, half) handles 4 clips of hidden unit j
+        for (int idx = tid; idx < 2 * H; idx += blockDim.x) {
+            const int j = idx >> 1, n0 = (idx & 1) * 4;
+            const float4 gi = *(const float4*)(gbuf + (0 * H + j) * LSTM_NB + n0);
+            const float4 gf = *(const float4*)(gbuf + (1 * H + j) * LSTM_NB + n0);
+            const float4 gg = *(const float4*)(gbuf + (2 * H + j) * LSTM_NB + n0);
+            const float4 go = *(const float4*)(gbuf + (3 * H + j) * LSTM_NB + n0);
+            float4 c4 = *(const float4*)(cbuf + j * LSTM_NB + n0);
+            const float iv[4] = {gi.x, gi.y, gi.z, gi.w}, fv[4] = {gf.x, gf.y, gf.z, gf.w};
+            const float gv[4] = {gg.x, gg.y, gg.z, gg.w}, ov[4] = {go.x, go.y, go.z, go.w};
+            float cv[4] = {c4.x, c4.y, c4.z, c4.w}, hv[4];
 #pragma unroll
-            for (int n = 0; n < LSTM_NB; ++n) {
-                const int b = b0 + n;
+            for (int e = 0; e < 4; ++e) {
+                cv[e] = sigmoidf_(fv[e]) * cv[e] + sigmoidf_(iv[e]) * tanhf(gv[e]);
+                hv[e] = sigmoidf_(ov[e]) * tanhf(cv[e]);
+            }
+            *(float4*)(cbuf + j * LSTM_NB + n0) = make_float4(cv[0], cv[1], cv[2], cv[3]);
+            *(float4*)(hnext + j * LSTM_NB + n0) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int b = b0 + n0 + e;
                 if (b >= B) continue;
                 const size_t row = (size_t)b * T + t;
-                if (out_f32) out_f32[row * (2 * H) + dir * H + j] = hreg[n];
+                if (out_f32) out_f32[row * (2 * H) + dir * H + j] = hv[e];
                 if (out_bf16) {
                     bf16_t* o = out_bf16 + row * out_cs + dir * H + j;
-                    const bf16_t hi = f2bf(hreg[n]);
+                    const bf16_t hi = f2bf(hv[e]);
                     o[0] = hi;
                     if (x3) {
                         o[third] = hi;
-                        o[2 * third] = f2bf(hreg[n] - bf2f(hi));
+                        o[2 * third] = f2bf(hv[e] - bf2f(hi));
                     }
                 }
             }
@@ -100,13 +111,13 @@ __global__ __launch_bounds__(256) void lstm_kernel(const float* __restrict__ xpr
 extern "C" int sos_lstm_bidir_fwd(const float* xproj, const float* whh_t, int64_t B, int64_t T, int H,
                                   float* out_f32, void* out_bf16, int out_cs, int out_dtype, int64_t out_third,
                                   sos_stream_t stream) {
-    if (!xproj || !whh_t || (!out_f32 && !out_bf16) || B < 1 || T < 1 || H < 1 || H > 256 || (H & 3) ||
+    if (!xproj || !whh_t || (!out_f32 && !out_bf16) || B < 1 || T < 1 || H < 4 || H > 256 || (H & 3) ||
         (out_bf16 && out_cs < 2 * H) || (out_dtype != SOS_DT_BF16 && out_dtype != SOS_DT_BF16X3)) {
         sos_set_error("sos_lstm_bidir_fwd: bad args (B=%lld T=%lld H=%d)", (long long)B, (long long)T, H);
         return SOS_EINVAL;
     }
     dim3 grid((unsigned)((B + LSTM_NB - 1) / LSTM_NB), 2);
-    const size_t lds = (size_t)2 * H * LSTM_NB * sizeof(float);
+    const size_t lds = (size_t)(2 + 4 + 1) * H * LSTM_NB * sizeof(float);
     hipLaunchKernelGGL(lstm_kernel, grid, dim3(256), lds, (hipStream_t)stream, xproj, whh_t, (int)B, (int)T, H,
                        out_f32, (bf16_t*)out_bf16, out_cs, out_dtype == SOS_DT_BF16X3 ? 1 : 0,
                        (long long)out_third);

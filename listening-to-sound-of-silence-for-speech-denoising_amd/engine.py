@@ -11,6 +11,40 @@ from . import get_precision
 BN_EPS = 1e-5
 
 
+class LaunchProfiler:
+    """Optional HIP-event bracket around conv launches on the stream they are enqueued on
+    (bench.py's roofline leg).  `only` restricts recording to one launch signature."""
+
+    def __init__(self, only=None):
+        self.only = only
+        self.records = {}      # signature -> [flops_per_launch, [(start, end), ...]]
+
+    def bracket(self, sig, flops):
+        if self.only is not None and sig != self.only:
+            return None
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.setdefault(sig, [flops, []])[1].append((s, e))
+        s.record()
+        return e
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for sig, (flops, evs) in self.records.items():
+            ms = [s.elapsed_time(e) for s, e in evs]
+            out[sig] = dict(flops=flops, launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms))
+        return out
+
+
+PROFILER = None
+
+# Autotune conv tilings the first time a launch shape is seen (sos_conv2d_tune synchronises, so it
+# is skipped while a stream capture is in progress).  SOS_CONV_TUNE=0 disables it.
+import os as _os
+AUTOTUNE = _os.environ.get("SOS_CONV_TUNE", "1") != "0"
+_tuned = set()
+
+
 def pad_to(x, m):
     return (x + m - 1) // m * m
 
@@ -114,7 +148,19 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
     d.scale, d.shift = scale.data_ptr(), shift.data_ptr()
     d.act = act
     d.act_param = slope.data_ptr() if slope is not None else None
+    if AUTOTUNE:
+        key = (B, H, W, d.Wl, cin, d.in_nseg, d.cout_pad, kh, kw, stride, dil, Ho, Wo, out_dtype, sc == 1, pad_mode,
+               w_gather is not None)
+        if key not in _tuned and not torch.cuda.is_current_stream_capturing():
+            L.check(L.lib().sos_conv2d_tune(C.byref(d), 8, 3, None, L.stream_ptr()), "sos_conv2d_tune")
+            _tuned.add(key)
+    end = None
+    if PROFILER is not None:
+        sig = ("conv", kh, kw, dil[0], dil[1], stride, d.in_nseg * cin, cout, B, Ho, Wo)
+        end = PROFILER.bracket(sig, 2.0 * B * Ho * Wo * cout * d.in_nseg * cin * kh * kw)
     L.check(L.lib().sos_conv2d_fwd(C.byref(d), L.stream_ptr()), "sos_conv2d_fwd")
+    if end is not None:
+        end.record()
 
 
 def conv_to_act(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, dst, c_off=0, cout_store=None, **kw_):

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of sos_conv2d_fwd on the model's layer shapes (B=64): TFLOP/s per shape."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from sos_amd import _lib as L  # noqa: E402
+from sos_amd import engine as E  # noqa: E402
+
+SHAPES = [
+    # name, H, W, cin, cout, k, dil, stride, pad_mode
+    ("ctx96 d1x1", 256, 178, 96, 96, (5, 5), (1, 1), 1, 0),
+    ("ctx96 d2x1", 256, 178, 96, 96, (5, 5), (2, 1), 1, 0),
+    ("ctx96 d8x1", 256, 178, 96, 96, (5, 5), (8, 1), 1, 0),
+    ("ctx96 d32x1", 256, 178, 96, 96, (5, 5), (32, 1), 1, 0),
+    ("ctx96 d4x4", 256, 178, 96, 96, (5, 5), (4, 4), 1, 0),
+    ("ctx96 d16x16", 256, 178, 96, 96, (5, 5), (16, 16), 1, 0),
+    ("ctx96 d32x32", 256, 178, 96, 96, (5, 5), (32, 32), 1, 0),
+    ("ctx96 7x1", 256, 178, 96, 96, (7, 1), (1, 1), 1, 0),
+    ("ctx48 d1x1", 256, 178, 48, 48, (5, 5), (1, 1), 1, 0),
+    ("ctx48 d32x32", 256, 178, 48, 48, (5, 5), (32, 32), 1, 0),
+    ("inp 128->128 5x5", 128, 89, 128, 128, (5, 5), (1, 1), 1, 1),
+    ("inp 64->128 5x5 s2", 256, 178, 64, 128, (5, 5), (1, 1), 2, 1),
+    ("inp 256->256 3x3 d1", 64, 45, 256, 256, (3, 3), (1, 1), 1, 1),
+    ("inp 256->256 3x3 d16", 64, 45, 256, 256, (3, 3), (16, 16), 1, 1),
+    ("inp 256->128 3x3", 128, 89, 256, 128, (3, 3), (1, 1), 1, 1),
+    ("inp 128->64 3x3", 256, 178, 128, 64, (3, 3), (1, 1), 1, 1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--warm", type=float, default=0.3)
+    a = ap.parse_args()
+    B = a.batch
+    dev = torch.device("cuda")
+    for name, H, W, cin, cout, k, dil, stride, pm in SHAPES:
+        if a.only and a.only not in name:
+            continue
+        src = E.Act(B, H, W, cin, False, dev)
+        if os.environ.get('SOS_BENCH_ZERO'):
+            src.t.zero_()
+        else:
+            src.t.normal_()
+        Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+        dst = E.Act(B, Ho, Wo, E.pad_to(cout, 16), False, dev)
+        w = E.pack_weight(torch.randn(cout, cin, k[0], k[1], device=dev) * (0.0 if os.environ.get('SOS_BENCH_ZERO') else 0.05), cin, False)
+        scale = torch.ones(w.shape[1], device=dev)
+        shift = torch.zeros(w.shape[1], device=dev)
+        pad = ((k[0] - 1) // 2 * dil[0], (k[1] - 1) // 2 * dil[1])
+
+        def run():
+            E.conv_to_act(src, 0, cin, w, k[0], k[1], cout, scale, shift, L.ACT_RELU, dst, cout_store=dst.cs,
+                          stride=stride, dil=dil, pad=pad, pad_mode=pm, Ho=Ho, Wo=Wo)
+        import time
+        t_end = time.time() + a.warm
+        run()
+        torch.cuda.synchronize()
+        while time.time() < t_end:      # let the clocks ramp: the box idles in a low-power state
+            for _ in range(10):
+                run()
+            torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(a.iters):
+            run()
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / a.iters
+        fl = 2.0 * B * Ho * Wo * cout * cin * k[0] * k[1]
+        print(f"{name:24s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s  ({100 * fl / ms / 1e9 / 2500:.1f}% of 2.5 PF)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
