@@ -138,6 +138,60 @@ int sos_lstm_bidir_fwd(const float* xproj, const float* whh_t, int64_t B, int64_
                        float* out_f32, void* out_bf16, int out_cs, int out_dtype, int64_t out_third,
                        sos_stream_t stream);
 
+/* ---------------------------------------------------------------- training-mode kernels
+ * A `sos_view` describes a channel slice of a bf16 NHWC activation: element (pix, c) lives at
+ * ptr[pix*row + c_off + c]; with x3 != 0 the value is hi + lo, hi at that address (and again at
+ * +third), lo at +2*third.  C <= 256. */
+typedef struct sos_view {
+    void* ptr;
+    int64_t npix;
+    int32_t row, c_off, C, x3;
+    int64_t third;
+} sos_view;
+
+/* ---- BatchNorm2d(train) of Conv2dBlock/ConvBlock/DownConvBlock/UpConvBlock (M1/networks.py:38-39,
+ * M2/networks.py:38-39,107-108,137-138): batch statistics over all pixels of the raw conv output.
+ * Stage 1 writes deterministic per-workgroup partial sums (no atomics): partial f32 [nblk][2][C],
+ * nblk = sos_bn_stats_blocks(npix). */
+int sos_bn_stats_blocks(int64_t npix);
+int sos_bn_stats(const sos_view* x, float* partial, sos_stream_t stream);
+/* Stage 2: mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale (for the apply
+ * pass), save_mean / save_invstd (for backward); running stats updated with momentum and the
+ * UNBIASED variance, num_batches_tracked += 1 (torch semantics).  gamma/beta may be NULL (=1/0). */
+int sos_bn_finalize(const float* partial, int nblk, int C, int64_t count, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* scale, float* shift, float* save_mean, float* save_invstd, sos_stream_t stream);
+/* y = act(x*scale + shift).  Dense form: y is a sos_view with the same npix.  Feature form
+ * (feat_H > 0): the reference's view(B,-1,T).permute(2,0,1) (+ optional nearest-resize column
+ * gather): pixel (b,h,w'), channel c is written to y.ptr[(b*feat_Wo + w')*y.row + (y.c_off + c)*feat_H + h]
+ * reading source column w = gather ? gather[w'] : w' of a [B][feat_H][feat_W] pixel grid. */
+int sos_bn_act_apply(const sos_view* x, const float* scale, const float* shift, int act, const float* slope,
+                     const sos_view* y, int feat_H, int feat_W, int feat_Wo, const int32_t* gather,
+                     sos_stream_t stream);
+
+/* ---- weight gradient of Conv2d / ConvTranspose2d / Linear (autograd of F.conv2d etc. behind
+ * loss.backward(), M1/agent.py:106-111, M2/agent.py:101-106):
+ *   dw[m][n][a][b] (+)= scale * sum_p G[p][m] * X[p*stride + (a,b)*dil - pad][n]
+ * G ("tile side"): bf16 NHWC [B][Hg][Wg][g_cs], channels [g_off, g_off+M); X ("patch side"): bf16
+ * NHWC [B][Hx][Wx][x_cs], channels [x_off, x_off+N).  Conv: G = grad of the raw conv output,
+ * X = layer input.  ConvTranspose2d(k3,s2,p1): G = layer input, X = output grad, stride 2 ->
+ * result is in the (Cin, Cout, kh, kw) layout.  partial: fp32 workspace of
+ * sos_wgrad_workspace_bytes(); dw fp32 [M][N][kh][kw]. */
+typedef struct sos_wgrad_desc {
+    const void* g;
+    int32_t B, Hg, Wg, g_cs, g_off;
+    const void* x;
+    int32_t Hx, Wx, x_cs, x_off;
+    int32_t M, N, kh, kw, stride, dil_h, dil_w, pad_top, pad_left, pad_mode;
+    int32_t ksplit;         /* pixel-range split (parallelism); partial sums reduced deterministically */
+    float* partial;
+    float* dw;
+    int32_t accumulate;     /* 0: dw = result, 1: dw += result */
+    float scale;
+} sos_wgrad_desc;
+int64_t sos_wgrad_workspace_bytes(const sos_wgrad_desc* desc);
+int sos_conv2d_wgrad(const sos_wgrad_desc* desc, sos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

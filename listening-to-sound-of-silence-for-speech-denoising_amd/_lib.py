@@ -31,6 +31,22 @@ class ConvDesc(C.Structure):
     ]
 
 
+class View(C.Structure):
+    """struct sos_view."""
+    _fields_ = [("ptr", C.c_void_p), ("npix", C.c_int64), ("row", C.c_int32), ("c_off", C.c_int32),
+                ("C", C.c_int32), ("x3", C.c_int32), ("third", C.c_int64)]
+
+
+class WgradDesc(C.Structure):
+    """struct sos_wgrad_desc."""
+    _fields_ = [("g", C.c_void_p), ("B", C.c_int32), ("Hg", C.c_int32), ("Wg", C.c_int32), ("g_cs", C.c_int32),
+                ("g_off", C.c_int32), ("x", C.c_void_p), ("Hx", C.c_int32), ("Wx", C.c_int32), ("x_cs", C.c_int32),
+                ("x_off", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("stride", C.c_int32), ("dil_h", C.c_int32), ("dil_w", C.c_int32), ("pad_top", C.c_int32),
+                ("pad_left", C.c_int32), ("pad_mode", C.c_int32), ("ksplit", C.c_int32), ("partial", C.c_void_p),
+                ("dw", C.c_void_p), ("accumulate", C.c_int32), ("scale", C.c_float)]
+
+
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 
 # name -> argtypes, exactly the prototypes of include/sos_hip.h
@@ -47,6 +63,12 @@ SIGNATURES = {
     "sos_conv2d_fwd": [C.POINTER(ConvDesc), _P],
     "sos_conv2d_tune": [C.POINTER(ConvDesc), _I, _I, C.POINTER(C.c_float), _P],
     "sos_lstm_bidir_fwd": [_P, _P, _L, _L, _I, _P, _P, _I, _I, _L, _P],
+    "sos_bn_stats_blocks": [_L],
+    "sos_bn_stats": [C.POINTER(View), _P, _P],
+    "sos_bn_finalize": [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sos_bn_act_apply": [C.POINTER(View), _P, _P, _I, _P, C.POINTER(View), _I, _I, _I, _P, _P],
+    "sos_wgrad_workspace_bytes": [C.POINTER(WgradDesc)],
+    "sos_conv2d_wgrad": [C.POINTER(WgradDesc), _P],
 }
 
 _lib = None
@@ -65,7 +87,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
-            fn.restype = C.c_int
+            fn.restype = C.c_int64 if name == "sos_wgrad_workspace_bytes" else C.c_int
         h.sos_last_error.restype = C.c_char_p
         h.sos_last_error.argtypes = []
         _lib = h

@@ -1,0 +1,271 @@
+// wgrad.hip -- weight gradient of Conv2d / ConvTranspose2d / Linear on bf16 MFMA (gfx950).
+//
+// Backward of the conv blocks of M1/networks.py:28-51 and M2/networks.py:28-51,97-149 with
+// respect to their weights (autograd of F.conv2d / F.conv_transpose2d / F.linear in the reference's
+// `loss.backward()`, M1/agent.py:106-111, M2/agent.py:101-106):
+//     dW[m][n][a][b] = sum over pixels p of  G[p][m] * X[p*stride + (a,b)*dil - pad][n]
+// For a conv, G = grad of the raw conv output (m = cout) and X = the layer input (n = cin); for the
+// transposed conv the roles swap (G = layer input, X = output grad, stride 2) and the result is
+// already in ConvTranspose2d's (Cin, Cout, kh, kw) layout.
+//
+// The contraction runs over PIXELS while activations are stored channel-contiguous (NHWC), so the
+// MFMA operands (8 consecutive k per lane) are produced by gfx950's LDS transpose read
+// ds_read_b64_tr_b16 straight from the pixel-major LDS images -- tap shifts are whole-row address
+// offsets, so no alignment problem and no explicit transpose pass.  One workgroup owns 32 rows (m) x
+// up to NTB*32 columns (n) x all taps of dW in registers (<= 16 accumulator tiles per wave) and
+// walks a slice of the pixels (split-K); partial sums go to a [ksplit][taps][M][N] fp32 buffer
+// that a deterministic reduce kernel folds into the OIHW gradient (no atomics).
+#include "sos_common.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define WG_MAXT 16            // accumulator tiles per wave
+#define WG_TH 8               // pixel tile: 8 x 32 (strided coordinates), 256 pixels per k-step
+#define WG_TW 32
+
+struct WgParams {
+    const bf16_t* g;          // [B][Hg][Wg][g_cs]   (tile side, m channels)
+    const bf16_t* x;          // [B][Hx][Wx][x_cs]   (patch side, n channels)
+    float* partial;           // [ksplit][taps][Mp][Np]
+    int B, Hg, Wg, g_cs, g_off, Hx, Wx, x_cs, x_off;
+    int M, N, Mp, Np;         // logical / padded-to-32 dims
+    int kh, kw, stride, dh, dw, pad_t, pad_l, pad_mode;
+    int NTB;                  // n-tiles (of 32) per workgroup
+    int tiles_h, tiles_w;     // pixel tiles per (image, residue class)
+    int steps_per_split, nsteps, ksplit;
+    int PH, PW, npix;
+};
+
+__device__ __forceinline__ uint2 lds_tr(unsigned addr) {
+    uint2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+
+template <int NTB>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgParams p) {
+    constexpr int XC = NTB * 32;                // patch channels held in LDS
+    constexpr int XSTRIDE = XC * 2 + 16;        // bytes per patch pixel (padded)
+    constexpr int GSTRIDE = 32 * 2 + 16;        // bytes per tile pixel of G (32 channels)
+    constexpr int XCPR = XC / 8;                // 16-byte pieces per patch pixel
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* gimg = smem;                                   // [256][GSTRIDE]
+    char* ximg = smem + 256 * GSTRIDE;                   // [npix][XSTRIDE]
+    const unsigned gbase = (unsigned)(uintptr_t)gimg, xbase = (unsigned)(uintptr_t)ximg;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x, mt = blockIdx.y, ng = blockIdx.z;
+    const int m0 = mt * 32, n0 = ng * XC;
+    const int taps = p.kh * p.kw;
+    const int ntl = taps * NTB;                          // 32x32 output tiles of this workgroup
+    // per-lane geometry of the transpose read: 16-lane group g4, in-group lane s
+    const int g4 = lane >> 4, s = lane & 15;
+    const int chan_off = (16 * (g4 & 1) + 4 * (s & 3)) * 2;      // byte offset of the 4-channel run
+    const int krow = 8 * (g4 >> 1) + (s >> 2);                   // pixel (k) row inside a 16-pixel k-step; +4 for 2nd read
+
+    f32x16 acc[WG_MAXT];
+#pragma unroll
+    for (int t = 0; t < WG_MAXT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const int step0 = split * p.steps_per_split;
+    const int step1 = min(step0 + p.steps_per_split, p.nsteps);
+    for (int step = step0; step < step1; ++step) {
+        // step -> (b, rh, rw, ti, tj)
+        int t = step;
+        const int tj = t % p.tiles_w; t /= p.tiles_w;
+        const int ti = t % p.tiles_h; t /= p.tiles_h;
+        const int rw = t % p.dw; t /= p.dw;
+        const int rh = t % p.dh; t /= p.dh;
+        const int b = t;
+        const int ho_base = rh + ti * WG_TH * p.dh, wo_base = rw + tj * WG_TW * p.dw;
+        const int hin0 = ho_base * p.stride - p.pad_t, win0 = wo_base * p.stride - p.pad_l;
+        __syncthreads();
+        // ---- stage G tile: 256 pixels x 32 channels (4 pieces of 16 B per pixel)
+        {
+            const int pl = tid >> 2, q = tid & 3;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = pl + 64 * u;
+                const int i = m / WG_TW, j = m - i * WG_TW;
+                const int h = ho_base + i * p.dh, w = wo_base + j * p.dw;
+                // channels past M inside a stored 8-run are zero padding of the producer
+                const int ch = m0 + q * 8;
+                const bool ok = h < p.Hg && w < p.Wg && ch < p.M && p.g_off + ch + 8 <= p.g_cs;
+                const int hc = min(h, p.Hg - 1), wc = min(w, p.Wg - 1);
+                const int cc = min(p.g_off + ch, p.g_cs - 8);
+                uint4 v = *(const uint4*)(p.g + (((long long)b * p.Hg + hc) * p.Wg + wc) * p.g_cs + cc);
+                if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+                *(uint4*)(gimg + m * GSTRIDE + q * 16) = v;
+            }
+        }
+        // ---- stage X patch: npix pixels x XC channels
+        {
+            constexpr int PPP = 256 / XCPR;
+            const int pl = tid / XCPR, cl = tid - pl * XCPR;
+            const bool reflect = p.pad_mode == SOS_PAD_REFLECT;
+            for (int pix0 = pl; pix0 < p.npix; pix0 += PPP * 4) {
+                uint4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pix = min(pix0 + PPP * u, p.npix - 1);
+                    const int c = pix % p.PW, r = pix / p.PW;
+                    int h = hin0 + r * p.dh, w = win0 + c * p.dw;
+                    bool ok = reflect || (h >= 0 && h < p.Hx && w >= 0 && w < p.Wx);
+                    h = reflect ? reflect_index(h, p.Hx) : min(max(h, 0), p.Hx - 1);
+                    w = reflect ? reflect_index(w, p.Wx) : min(max(w, 0), p.Wx - 1);
+                    const int ch = n0 + cl * 8;
+                    ok = ok && ch < p.N && p.x_off + ch + 8 <= p.x_cs;
+                    const int cc = min(p.x_off + ch, p.x_cs - 8);
+                    v[u] = *(const uint4*)(p.x + (((long long)b * p.Hx + h) * p.Wx + w) * p.x_cs + cc);
+                    if (!ok) v[u] = make_uint4(0u, 0u, 0u, 0u);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pix = pix0 + PPP * u;
+                    if (pl < PPP && pix < p.npix) *(uint4*)(ximg + pix * XSTRIDE + cl * 16) = v[u];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 16 k-steps of 16 pixels; every wave walks its own list of (tap, n-tile) output tiles
+#pragma unroll 1
+        for (int ks = 0; ks < 16; ++ks) {
+            // pixel of this lane's transpose-read rows: k = ks*16 + krow (+4): tile row i = k/32, col j = k%32
+            const int k0 = ks * 16 + krow;
+            const int i0 = k0 >> 5, j0 = k0 & 31;          // both reads stay in the same tile row (k0+4 < next 32)
+            const unsigned ga = gbase + k0 * GSTRIDE + chan_off;
+            uint2 a0 = lds_tr(ga), a1 = lds_tr(ga + 4 * GSTRIDE);
+            const unsigned xa = xbase + ((i0 * p.stride) * p.PW + j0 * p.stride) * XSTRIDE + chan_off;
+            const unsigned xstep4 = 4 * p.stride * XSTRIDE;
+            // the wait names its registers so that every consumer is ordered behind it
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");
+            const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+#pragma unroll
+            for (int tg = 0; tg < WG_MAXT / 4; ++tg) {
+                if (wave + 16 * tg >= ntl) break;              // wave-uniform
+                uint2 b0[4], b1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tl = min(wave + 4 * (4 * tg + u), ntl - 1);
+                    const int tap = tl / NTB, nt = tl - tap * NTB;
+                    const int ta = tap / p.kw, tb = tap - ta * p.kw;
+                    const unsigned xo = xa + (ta * p.PW + tb) * XSTRIDE + nt * 64;
+                    b0[u] = lds_tr(xo);
+                    b1[u] = lds_tr(xo + xstep4);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2]), "+v"(b0[3]), "+v"(b1[3])
+                             :: "memory");
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (wave + 4 * (4 * tg + u) < ntl) {
+                        const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(b0[u].x, b0[u].y, b1[u].x, b1[u].y));
+                        acc[4 * tg + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[4 * tg + u], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- write this split's partial tiles: D[row = m][col = n], row = (reg&3)+8*(reg>>2)+4*(lane>>5), col = lane&31
+    float* out = p.partial + (size_t)split * taps * p.Mp * p.Np;
+#pragma unroll
+    for (int tt = 0; tt < WG_MAXT; ++tt) {
+        const int tl = wave + 4 * tt;
+        if (tl >= ntl) continue;
+        const int tap = tl / NTB, nt = tl - tap * NTB;
+        const int n = n0 + nt * 32 + (lane & 31);
+        if (n >= p.Np) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            out[((size_t)tap * p.Mp + m) * p.Np + n] = acc[tt][r];
+        }
+    }
+}
+
+// dW[m][n][tap] (+)= sum over splits of partial[s][tap][m][n]; also used for 1x1 / Linear weights.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int ksplit, int taps, int M, int N, int Mp,
+                                    int Np, float* __restrict__ dw, int accumulate, float scale) {
+    const long long total = (long long)M * N * taps;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        const long long r = i / taps;
+        const int n = (int)(r % N), m = (int)(r / N);
+        float acc = 0.f;
+        for (int s = 0; s < ksplit; ++s) acc += partial[(((size_t)s * taps + tap) * Mp + m) * Np + n];
+        acc *= scale;
+        dw[i] = accumulate ? dw[i] + acc : acc;
+    }
+}
+
+extern "C" int64_t sos_wgrad_workspace_bytes(const sos_wgrad_desc* d) {
+    if (!d) return -1;
+    const int64_t Mp = (d->M + 31) / 32 * 32, Np = (d->N + 31) / 32 * 32;
+    return (int64_t)d->ksplit * d->kh * d->kw * Mp * Np * 4;
+}
+
+extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
+    if (!d || !d->g || !d->x || !d->partial || !d->dw) { sos_set_error("sos_conv2d_wgrad: null pointer"); return SOS_EINVAL; }
+    if (d->M < 1 || d->N < 1 || d->g_cs % 8 || d->x_cs % 8 || d->g_off % 8 || d->x_off % 8 || d->kh < 1 || d->kw < 1 ||
+        d->stride < 1 || d->dil_h < 1 || d->dil_w < 1 || (d->stride > 1 && (d->dil_h > 1 || d->dil_w > 1)) ||
+        d->ksplit < 1 || d->B < 1) {
+        sos_set_error("sos_conv2d_wgrad: bad descriptor");
+        return SOS_EINVAL;
+    }
+    WgParams p;
+    p.g = (const bf16_t*)d->g; p.x = (const bf16_t*)d->x; p.partial = d->partial;
+    p.B = d->B; p.Hg = d->Hg; p.Wg = d->Wg; p.g_cs = d->g_cs; p.g_off = d->g_off;
+    p.Hx = d->Hx; p.Wx = d->Wx; p.x_cs = d->x_cs; p.x_off = d->x_off;
+    p.M = d->M; p.N = d->N; p.Mp = (d->M + 31) / 32 * 32; p.Np = (d->N + 31) / 32 * 32;
+    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.dh = d->dil_h; p.dw = d->dil_w;
+    p.pad_t = d->pad_top; p.pad_l = d->pad_left; p.pad_mode = d->pad_mode;
+    const int taps = d->kh * d->kw;
+    int ntb = WG_MAXT * 4 / taps;                 // tiles per workgroup <= 64
+    if (ntb > 4) ntb = 4;
+    if (ntb < 1) ntb = 1;
+    if (ntb == 3) ntb = 2;
+    const int ntiles_n = p.Np / 32;
+    if (ntb > ntiles_n) ntb = ntiles_n >= 4 ? 4 : (ntiles_n >= 2 ? 2 : 1);
+    if (taps * ntb > WG_MAXT * 4) { sos_set_error("sos_conv2d_wgrad: kernel with %d taps not supported", taps); return SOS_ENOSPC; }
+    p.NTB = ntb;
+    const int Hc = (d->Hg + d->dil_h - 1) / d->dil_h, Wc = (d->Wg + d->dil_w - 1) / d->dil_w;
+    p.tiles_h = (Hc + WG_TH - 1) / WG_TH; p.tiles_w = (Wc + WG_TW - 1) / WG_TW;
+    p.nsteps = d->B * d->dil_h * d->dil_w * p.tiles_h * p.tiles_w;
+    p.ksplit = d->ksplit;
+    p.steps_per_split = (p.nsteps + d->ksplit - 1) / d->ksplit;
+    p.PH = (WG_TH - 1) * d->stride + d->kh; p.PW = (WG_TW - 1) * d->stride + d->kw;
+    p.npix = p.PH * p.PW;
+    size_t lds = (size_t)256 * (32 * 2 + 16) + (size_t)p.npix * (ntb * 64 + 16);
+    while (lds > 160 * 1024 && ntb > 1) {          // strided layers: fewer patch channels per workgroup
+        ntb >>= 1;
+        p.NTB = ntb;
+        lds = (size_t)256 * (32 * 2 + 16) + (size_t)p.npix * (ntb * 64 + 16);
+    }
+    if (lds > 160 * 1024) { sos_set_error("sos_conv2d_wgrad: patch does not fit LDS (%zu B)", lds); return SOS_ENOSPC; }
+    dim3 grid((unsigned)d->ksplit, (unsigned)(p.Mp / 32), (unsigned)((ntiles_n + ntb - 1) / ntb));
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr[5] = {false, false, false, false, false};
+#define SOS_WG_LAUNCH(NTBV)                                                                                         \
+    {                                                                                                               \
+        if (!attr[NTBV]) {                                                                                          \
+            (void)hipFuncSetAttribute((const void*)wgrad_kernel<NTBV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr[NTBV] = true;                                                                                      \
+        }                                                                                                           \
+        hipLaunchKernelGGL(wgrad_kernel<NTBV>, grid, dim3(256), lds, s, p);                                         \
+    }
+    if (ntb == 1) SOS_WG_LAUNCH(1) else if (ntb == 2) SOS_WG_LAUNCH(2) else SOS_WG_LAUNCH(4)
+#undef SOS_WG_LAUNCH
+    int rc = sos_check_launch("sos_conv2d_wgrad");
+    if (rc) return rc;
+    const long long total = (long long)d->M * d->N * taps;
+    long long gb = (total + 255) / 256;
+    if (gb > 4096) gb = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, d->partial, d->ksplit, taps, d->M, d->N,
+                       p.Mp, p.Np, d->dw, d->accumulate, d->scale);
+    return sos_check_launch("sos_conv2d_wgrad(reduce)");
+}

@@ -194,3 +194,88 @@ class PlanCache:
                 self.plan = build()
             self.key = key
         return self.plan
+
+
+# --------------------------------------------------------------------------- training helpers
+def view(act, c_off=0, C=None, third_index=None):
+    """sos_view of a channel slice of an Act.  third_index selects ONE third of a bf16x3 buffer as
+    a plain bf16 view (used by the three-pass wgrad)."""
+    v = L.View()
+    v.ptr = act.t.data_ptr()
+    v.npix = act.B * act.H * act.W
+    v.row = act.nseg * act.cs
+    v.C = act.cs if C is None else C
+    if third_index is None:
+        v.c_off, v.x3, v.third = c_off, 1 if act.x3 else 0, act.cs
+    else:
+        v.c_off, v.x3, v.third = c_off + third_index * act.cs, 0, 0
+    return v
+
+
+def bn_train(raw, c_off, Cn, bn, act, slope, dst, dst_c_off=0, feat=None):
+    """Training-mode BatchNorm (+activation) of the raw conv output `raw[:, c_off:c_off+C]`:
+    stats -> finalize (updates bn.running_* in place like torch) -> apply into `dst`.
+    Returns the saved tensors for backward."""
+    dev = raw.t.device
+    xv = view(raw, c_off, Cn)
+    nblk = L.lib().sos_bn_stats_blocks(xv.npix)
+    partial = torch.empty((nblk, 2, Cn), dtype=torch.float32, device=dev)
+    L.check(L.lib().sos_bn_stats(C.byref(xv), L.ptr(partial), L.stream_ptr()), "sos_bn_stats")
+    scale = torch.empty(Cn, dtype=torch.float32, device=dev)
+    shift = torch.empty_like(scale)
+    mean = torch.empty_like(scale)
+    invstd = torch.empty_like(scale)
+    L.check(L.lib().sos_bn_finalize(L.ptr(partial), nblk, Cn, xv.npix, L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps),
+                                    float(bn.momentum), L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                                    L.ptr(bn.num_batches_tracked), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd),
+                                    L.stream_ptr()), "sos_bn_finalize")
+    bn_apply(xv, scale, shift, act, slope, dst, dst_c_off, Cn, feat)
+    return dict(scale=scale, shift=shift, mean=mean, invstd=invstd)
+
+
+def bn_apply(xv, scale, shift, act, slope, dst, dst_c_off, C, feat=None):
+    import ctypes
+    if feat is None:
+        yv = view(dst, dst_c_off, C)
+        L.check(L.lib().sos_bn_act_apply(ctypes.byref(xv), L.ptr(scale), L.ptr(shift), act, L.ptr(slope), ctypes.byref(yv),
+                                         0, 0, 0, None, L.stream_ptr()), "sos_bn_act_apply")
+    else:
+        # feat = dict(t=feature tensor, row, third, c_off, H, W, Wo, gather, x3)
+        yv = L.View()
+        yv.ptr, yv.npix, yv.row, yv.c_off, yv.C = feat["t"].data_ptr(), 1, feat["row"], feat["c_off"], C
+        yv.x3, yv.third = (1 if feat["x3"] else 0), feat["third"]
+        L.check(L.lib().sos_bn_act_apply(ctypes.byref(xv), L.ptr(scale), L.ptr(shift), act, L.ptr(slope), ctypes.byref(yv),
+                                         feat["H"], feat["W"], feat["Wo"], L.ptr(feat.get("gather")), L.stream_ptr()),
+                "sos_bn_act_apply(feat)")
+
+
+_wg_ws = {}
+
+
+def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0, 0), pad_mode=L.PAD_ZERO,
+          accumulate=False, scale=1.0):
+    """dw[m][n][a][b] (+)= scale * sum_p G[p][m] X[p*stride + (a,b)*dil - pad][n] (sos_conv2d_wgrad).
+    g, x: Act.  In bf16x3 mode the product (g_hi+g_lo)(x_hi+x_lo) is taken as hi*hi + hi*lo + lo*hi
+    with three accumulating passes over the thirds."""
+    import ctypes
+    dev = g.t.device
+    passes = [(0, 0)] if not g.x3 else [(0, 0), (0, 2), (2, 0)]
+    first = True
+    for gt, xt in passes:
+        d = L.WgradDesc()
+        d.g, d.B, d.Hg, d.Wg, d.g_cs, d.g_off = g.t.data_ptr(), g.B, g.H, g.W, g.nseg * g.cs, g_off + gt * g.cs
+        d.x, d.Hx, d.Wx, d.x_cs, d.x_off = x.t.data_ptr(), x.H, x.W, x.nseg * x.cs, x_off + xt * x.cs
+        d.M, d.N, d.kh, d.kw, d.stride, d.dil_h, d.dil_w = M, N, kh, kw, stride, dil[0], dil[1]
+        d.pad_top, d.pad_left, d.pad_mode = pad[0], pad[1], pad_mode
+        npix = g.B * g.H * g.W
+        d.ksplit = max(1, min(256, npix // 2048))
+        need = L.lib().sos_wgrad_workspace_bytes(ctypes.byref(d))
+        key = str(dev)
+        if key not in _wg_ws or _wg_ws[key].numel() * 4 < need:
+            _wg_ws[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+        d.partial = _wg_ws[key].data_ptr()
+        d.dw = dw.data_ptr()
+        d.accumulate = 1 if (accumulate or not first) else 0
+        d.scale = scale
+        L.check(L.lib().sos_conv2d_wgrad(ctypes.byref(d), L.stream_ptr()), "sos_conv2d_wgrad")
+        first = False

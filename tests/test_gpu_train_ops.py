@@ -1,0 +1,114 @@
+"""Training-mode HIP kernels (BatchNorm statistics/apply, weight gradient) vs torch-CPU fp32."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import hashed, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _act_from_nchw(x, x3, cs=None):
+    """f32 NCHW (cpu) -> engine.Act on the GPU (+ the values it actually holds, as f32 NCHW)."""
+    from sos_amd import engine as E
+    B, Cc, H, W = x.shape
+    cs = E.pad_to(Cc, 16) if cs is None else cs
+    a = E.Act(B, H, W, cs, x3, torch.device("cuda"), zero=True)
+    xh = x.to(torch.bfloat16)
+    nhwc = torch.zeros(B, H, W, cs, dtype=torch.bfloat16)
+    nhwc[..., :Cc] = xh.permute(0, 2, 3, 1)
+    held = xh.float()
+    if x3:
+        lo = (x - xh.float()).to(torch.bfloat16)
+        nl = torch.zeros_like(nhwc)
+        nl[..., :Cc] = lo.permute(0, 2, 3, 1)
+        a.t.copy_(torch.cat([nhwc, nhwc, nl], dim=3).cuda())
+        held = held + lo.float()
+    else:
+        a.t.copy_(nhwc.cuda())
+    return a, held
+
+
+def _act_to_nchw(a, Cc):
+    t = a.t.float().cpu()
+    v = t[..., :Cc]
+    if a.x3:
+        v = v + t[..., 2 * a.cs:2 * a.cs + Cc]
+    return v.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("x3", [False, True])
+def test_bn_train_stats_and_apply(x3):
+    from sos_amd import engine as E, _lib as L
+    B, Cc, H, W = 3, 48, 20, 13
+    x = torch.from_numpy(hashed(31, (B, Cc, H, W), 2.0).astype(np.float32)) + 0.3
+    raw, held = _act_from_nchw(x, x3)
+    bn = torch.nn.BatchNorm2d(Cc)
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(1 + 0.2 * hashed(32, (Cc,)).astype(np.float32)))
+        bn.bias.copy_(torch.from_numpy(0.1 * hashed(33, (Cc,)).astype(np.float32)))
+    ref = torch.nn.BatchNorm2d(Cc)
+    ref.load_state_dict(bn.state_dict())
+    bn = bn.cuda().train()
+    dst = E.Act(B, H, W, 48, x3, torch.device("cuda"), zero=True)
+    saved = E.bn_train(raw, 0, Cc, bn, L.ACT_RELU, None, dst)
+    ref.train()
+    want = torch.relu(ref(held))
+    tol = 2e-5 if x3 else 1e-2
+    assert rel_err(_act_to_nchw(dst, Cc), want) < tol
+    assert rel_err(bn.running_mean.cpu(), ref.running_mean) < 1e-5
+    assert rel_err(bn.running_var.cpu(), ref.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == 1
+    assert rel_err(saved["mean"].cpu(), held.mean(dim=(0, 2, 3))) < 1e-5
+    assert rel_err(saved["invstd"].cpu(), torch.rsqrt(held.var(dim=(0, 2, 3), unbiased=False) + 1e-5)) < 1e-5
+
+
+CASES = [
+    # name, Cout(M), Cin(N), k, stride, dil, pad, pad_mode, H, W
+    ("5x5 dil(2,1) zero", 48, 96, (5, 5), 1, (2, 1), (4, 2), "zeros", 20, 40),
+    ("5x5 dil(8,8) zero", 96, 48, (5, 5), 1, (8, 8), (16, 16), "zeros", 33, 35),
+    ("7x1 zero", 48, 48, (7, 1), 1, (1, 1), (3, 0), "zeros", 18, 21),
+    ("3x3 s2 reflect", 64, 128, (3, 3), 2, (1, 1), (1, 1), "reflect", 17, 23),
+    ("5x5 s2 reflect", 128, 64, (5, 5), 2, (1, 1), (2, 2), "reflect", 18, 41),
+    ("1x1 linear", 100, 200, (1, 1), 1, (1, 1), (0, 0), "zeros", 1, 77),
+    ("3x3 narrow", 2, 64, (3, 3), 1, (1, 1), (1, 1), "reflect", 12, 19),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("x3", [False, True])
+def test_conv_weight_grad(case, x3):
+    from sos_amd import engine as E, _lib as L
+    _, M, N, k, stride, dil, pad, pmode, H, W = case
+    B = 2
+    x = torch.from_numpy(hashed(41, (B, N, H, W)).astype(np.float32))
+    xa, xheld = _act_from_nchw(x, x3)
+    xp = F.pad(xheld, (pad[1], pad[1], pad[0], pad[0]), mode="reflect") if pmode == "reflect" else xheld
+    w = torch.zeros(M, N, k[0], k[1], requires_grad=True)
+    y = F.conv2d(xp, w, None, stride, (0, 0) if pmode == "reflect" else pad, dil)
+    g = torch.from_numpy(hashed(42, tuple(y.shape)).astype(np.float32))
+    ga, gheld = _act_from_nchw(g, x3)
+    y.backward(gheld)
+    dw = torch.empty(M, N, k[0], k[1], dtype=torch.float32, device="cuda")
+    E.wgrad(ga, 0, M, xa, 0, N, k[0], k[1], dw, stride=stride, dil=dil, pad=pad,
+            pad_mode=L.PAD_REFLECT if pmode == "reflect" else L.PAD_ZERO)
+    err = rel_err(dw.cpu(), w.grad)
+    print(case[0], "x3" if x3 else "bf16", "wgrad rel err", err)
+    assert err < (2e-4 if x3 else 2e-5 + 1e-3)
+
+
+def test_conv_transpose_weight_grad():
+    """ConvTranspose2d(k3,s2,p1,output_padding=1): roles swap (G = layer input, X = output grad)."""
+    from sos_amd import engine as E, _lib as L
+    B, Cin, Cout, H, W = 2, 64, 32, 9, 11
+    x = torch.from_numpy(hashed(43, (B, Cin, H, W)).astype(np.float32))
+    xa, xheld = _act_from_nchw(x, False)
+    w = torch.zeros(Cin, Cout, 3, 3, requires_grad=True)
+    y = F.conv_transpose2d(xheld, w, None, 2, 1, 1)
+    g = torch.from_numpy(hashed(44, tuple(y.shape)).astype(np.float32))
+    ga, gheld = _act_from_nchw(g, False)
+    y.backward(gheld)
+    dw = torch.empty(Cin, Cout, 3, 3, dtype=torch.float32, device="cuda")
+    E.wgrad(xa, 0, Cin, ga, 0, Cout, 3, 3, dw, stride=2, pad=(1, 1))
+    assert rel_err(dw.cpu(), w.grad) < 1e-3

@@ -21,7 +21,13 @@ def silent_gate(x):
     return x * torch.from_numpy(g)[None, None, None, :]
 
 
+def _np(a):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.asarray(a, dtype=np.float64)
+
+
 def rel_err(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    a = _np(a)
+    b = _np(b)
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
