@@ -116,6 +116,8 @@ typedef struct sos_conv_desc {
     const float* shift;     /* [cout_pad]                                               */
     int32_t act;            /* SOS_ACT_*                                                */
     const float* act_param; /* device scalar (PReLU slope) or NULL                      */
+    int32_t accumulate;     /* 1: add to the existing bf16 output (dense NHWC outputs only): gradient
+                               fan-in of skip connections in the backward pass            */
 } sos_conv_desc;
 
 int sos_conv2d_fwd(const sos_conv_desc* desc /* host pointer */, sos_stream_t stream);
@@ -136,7 +138,8 @@ int sos_conv2d_tune(const sos_conv_desc* desc, int max_candidates, int iters, fl
  * (+ thirds when dtype == SOS_DT_BF16X3). */
 int sos_lstm_bidir_fwd(const float* xproj, const float* whh_t, int64_t B, int64_t T, int H,
                        float* out_f32, void* out_bf16, int out_cs, int out_dtype, int64_t out_third,
-                       sos_stream_t stream);
+                       float* save_gates /* optional f32 [B][T][2][4H] post-activation i,f,g,o */,
+                       float* save_c /* optional f32 [B][T][2][H] */, sos_stream_t stream);
 
 /* ---------------------------------------------------------------- training-mode kernels
  * A `sos_view` describes a channel slice of a bf16 NHWC activation: element (pix, c) lives at
@@ -191,6 +194,39 @@ typedef struct sos_wgrad_desc {
 } sos_wgrad_desc;
 int64_t sos_wgrad_workspace_bytes(const sos_wgrad_desc* desc);
 int sos_conv2d_wgrad(const sos_wgrad_desc* desc, sos_stream_t stream);
+
+/* ---- backward of the BatchNorm(+activation) / bias(+activation) tail of a conv block (autograd of
+ * nn.BatchNorm2d + ReLU/PReLU in train mode).  dy: grad of the block output; x: raw conv output;
+ * scale/shift/mean/invstd: from sos_bn_finalize (mean == invstd == NULL: no BatchNorm);
+ * partial: f32 [sos_bn_stats_blocks(npix)][3][C]; coef: f32 [3][C] scratch.  Writes dgamma, dbeta
+ * (or the bias gradient), dslope[0] (PReLU) and dx = grad of the raw conv output. */
+int sos_bn_bwd(const sos_view* dy, const sos_view* x, const float* scale, const float* shift, const float* mean,
+               const float* invstd, const float* gamma, int act, const float* slope, float* partial, float* coef,
+               float* dgamma, float* dbeta, float* dslope, const sos_view* dx, sos_stream_t stream);
+/* dz = dy * act'(y) from the stored OUTPUT y (Linear+ReLU / Linear+Sigmoid heads). */
+int sos_act_bwd_from_y(const sos_view* dy, const sos_view* y, int act, const sos_view* dz, sos_stream_t stream);
+/* f32 strided gradient (x sigmoid'(y) if act == SOS_ACT_SIGMOID) -> bf16 rows: element (o,t,c) read at
+ * g[o*so + t*st + c*sc], written to row o*inner+t, channel c of `out`. */
+int sos_pack_grad_f32(const float* g, const float* y, int act, int64_t outer, int64_t inner, int C, int64_t so,
+                      int64_t st, int64_t sc, const sos_view* out, sos_stream_t stream);
+/* gradient of the LSTM feature matrix back to NHWC (inverse of the feature form of sos_bn_act_apply):
+ * out[b][h][w][c] = sum_{i in [lo[w],hi[w])} feat[b][i][(feat.c_off+c)*H + h]  (lo/hi NULL: i == w). */
+int sos_feat_to_nhwc(const sos_view* feat, int B, int H, int W, int Wo, const int32_t* lo, const int32_t* hi,
+                     const sos_view* out, sos_stream_t stream);
+/* ---- BPTT of the recurrent part of nn.LSTM (autograd of M1/networks.py:148, M2/networks.py:88).
+ * dh_out: bf16 grad of the LSTM output [B][T][dh_cs]; gates/csave from the forward; whh f32
+ * [2][4H][H]; dgates f32 [B][T][2][4H] (gate pre-activation grads; dW_ih, dW_hh, bias and input
+ * grads are GEMMs over it). */
+int sos_lstm_bidir_bwd(const void* dh_out, int dh_cs, int dh_dtype, int64_t dh_third, const float* gates,
+                       const float* csave, const float* whh, int64_t B, int64_t T, int H, float* dgates,
+                       sos_stream_t stream);
+/* ---- losses (M2/agent.py:174,188-189; M1/agent.py:187,202) and optimizer (M1/agent.py:177). */
+int sos_mse_loss(const float* a, const float* b, int64_t n, float upstream, float* loss, float* grad, float* partial,
+                 sos_stream_t stream);
+int sos_bce_logits_loss(const float* x, const float* y, int64_t n, float upstream, float* loss, float* grad,
+                        float* partial, sos_stream_t stream);
+int sos_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int64_t step, float grad_scale, sos_stream_t stream);
 
 #ifdef __cplusplus
 }

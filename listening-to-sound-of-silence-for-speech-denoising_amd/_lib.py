@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
         ("out_sb", C.c_int64), ("out_sh", C.c_int64), ("out_sw", C.c_int64), ("out_sc", C.c_int64),
         ("out_c_off", C.c_int32), ("cout_store", C.c_int32), ("out_third", C.c_int64),
         ("scale", C.c_void_p), ("shift", C.c_void_p),
-        ("act", C.c_int32), ("act_param", C.c_void_p),
+        ("act", C.c_int32), ("act_param", C.c_void_p), ("accumulate", C.c_int32),
     ]
 
 
@@ -62,7 +62,15 @@ SIGNATURES = {
     "sos_pack_nchw_to_nhwc": [_P, _L, _I, _L, _L, _P, _I, _I, _P],
     "sos_conv2d_fwd": [C.POINTER(ConvDesc), _P],
     "sos_conv2d_tune": [C.POINTER(ConvDesc), _I, _I, C.POINTER(C.c_float), _P],
-    "sos_lstm_bidir_fwd": [_P, _P, _L, _L, _I, _P, _P, _I, _I, _L, _P],
+    "sos_lstm_bidir_fwd": [_P, _P, _L, _L, _I, _P, _P, _I, _I, _L, _P, _P, _P],
+    "sos_bn_bwd": [C.POINTER(View), C.POINTER(View), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(View), _P],
+    "sos_act_bwd_from_y": [C.POINTER(View), C.POINTER(View), _I, C.POINTER(View), _P],
+    "sos_pack_grad_f32": [_P, _P, _I, _L, _L, _I, _L, _L, _L, C.POINTER(View), _P],
+    "sos_feat_to_nhwc": [C.POINTER(View), _I, _I, _I, _I, _P, _P, C.POINTER(View), _P],
+    "sos_lstm_bidir_bwd": [_P, _I, _I, _L, _P, _P, _P, _L, _L, _I, _P, _P],
+    "sos_mse_loss": [_P, _P, _L, _F, _P, _P, _P, _P],
+    "sos_bce_logits_loss": [_P, _P, _L, _F, _P, _P, _P, _P],
+    "sos_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P],
     "sos_bn_stats_blocks": [_L],
     "sos_bn_stats": [C.POINTER(View), _P, _P],
     "sos_bn_finalize": [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],

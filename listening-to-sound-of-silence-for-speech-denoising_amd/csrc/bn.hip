@@ -24,7 +24,7 @@ static inline View to_view(const sos_view* v) {
 }
 
 static int check_view(const sos_view* v, const char* what) {
-    if (!v || !v->ptr || v->npix < 1 || v->C < 1 || v->C > 256 || v->row % 8 || v->c_off % 8 || (v->x3 && v->third % 8)) {
+    if (!v || !v->ptr || v->npix < 1 || v->C < 1 || v->C > 2048 || v->row % 8 || v->c_off % 8 || (v->x3 && v->third % 8)) {
         sos_set_error("%s: bad view", what);
         return SOS_EINVAL;
     }
@@ -80,7 +80,7 @@ extern "C" int sos_bn_stats_blocks(int64_t npix) {
 // thread = (pixel lane, 8-channel group); per-thread sums, then an LDS tree over the pixel lanes.
 __global__ __launch_bounds__(256) void bn_stats_kernel(View x, float* __restrict__ partial) {
     __shared__ float red[256 * 16];
-    const int CG = (x.C + 7) / 8;
+    const int CG = (x.C + 7) / 8;           // <= 256 (C <= 2048)
     const int PL = 256 / CG;
     const int tid = threadIdx.x;
     const int cg = tid % CG, pl = tid / CG;
@@ -240,4 +240,267 @@ extern "C" int sos_bn_act_apply(const sos_view* x, const float* scale, const flo
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, to_view(x), scale,
                        shift, act, slope, to_view(y));
     return sos_check_launch("sos_bn_act_apply");
+}
+
+
+// ------------------------------------------------------------------------- BatchNorm backward
+// dz = dy * act'(z), z = x*scale + shift (x = raw conv output); xhat = (x - mean) * invstd.
+//   reduce  : S1 = sum dz, S2 = sum dz*xhat, S3 = sum_{z<0} dy*z (PReLU slope gradient)
+//   finalize: dgamma = S2, dbeta = S1, dslope = sum_c S3;  dx = a*dz + b*xhat + c with
+//             a = gamma*invstd, b = -a*S2/N, c = -a*S1/N
+//   apply   : writes dx (grad of the raw conv output) as bf16 / bf16x3.
+// With mean == NULL the layer has no BatchNorm (bias + activation only): dx = dz, S1 = dbias.
+__device__ __forceinline__ float act_grad(float z, int act, float slope) {
+    if (act == SOS_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == SOS_ACT_PRELU) return z >= 0.f ? 1.f : slope;
+    if (act == SOS_ACT_SIGMOID) { const float y = 1.0f / (1.0f + expf(-z)); return y * (1.f - y); }
+    return 1.f;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(View dy, View x, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int act,
+                                                            const float* __restrict__ slope_p,
+                                                            float* __restrict__ partial) {
+    __shared__ float red[256 * 24];
+    const int CG = (x.C + 7) / 8;
+    const int PL = 256 / CG;
+    const int tid = threadIdx.x;
+    const int cg = tid % CG, pl = tid / CG;
+    const float slope = slope_p ? slope_p[0] : 0.f;
+    float s1[8], s2[8], s3[8], sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s1[i] = s2[i] = s3[i] = 0.f;
+        const int c = min(cg * 8 + i, x.C - 1);
+        sc[i] = scale[c]; sh[i] = shift[c];
+        mu[i] = mean ? mean[c] : 0.f; is[i] = invstd ? invstd[c] : 1.f;
+    }
+    if (pl < PL) {
+        for (long long pix = (long long)blockIdx.x * PL + pl; pix < x.npix; pix += (long long)gridDim.x * PL) {
+            float fx[8], fg[8];
+            load8(x, pix, cg * 8, fx);
+            load8(dy, pix, cg * 8, fg);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float z = fmaf(fx[i], sc[i], sh[i]);
+                const float dz = fg[i] * act_grad(z, act, slope);
+                s1[i] += dz;
+                s2[i] = fmaf(dz, (fx[i] - mu[i]) * is[i], s2[i]);
+                if (z < 0.f) s3[i] = fmaf(fg[i], z, s3[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[tid * 24 + i] = s1[i]; red[tid * 24 + 8 + i] = s2[i]; red[tid * 24 + 16 + i] = s3[i]; }
+    __syncthreads();
+    for (int o = tid; o < 3 * x.C; o += 256) {
+        const int which = o / x.C, c = o - which * x.C;
+        const int g = c >> 3, e = c & 7;
+        float acc = 0.f;
+        for (int l = 0; l < PL; ++l) acc += red[(l * CG + g) * 24 + which * 8 + e];
+        partial[((size_t)blockIdx.x * 3 + which) * x.C + c] = acc;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dslope,
+                                       float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc) {
+    __shared__ double s3sum[256];
+    const int tid = threadIdx.x;
+    double my3 = 0.0;
+    for (int c = tid; c < C; c += blockDim.x) {
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+            s1 += (double)partial[((size_t)b * 3 + 0) * C + c];
+            s2 += (double)partial[((size_t)b * 3 + 1) * C + c];
+            s3 += (double)partial[((size_t)b * 3 + 2) * C + c];
+        }
+        my3 += s3;
+        if (dgamma) dgamma[c] = (float)s2;
+        if (dbeta) dbeta[c] = (float)s1;
+        if (invstd) {
+            const double a = (double)(gamma ? gamma[c] : 1.f) * (double)invstd[c];
+            ca[c] = (float)a;
+            cb[c] = (float)(-a * s2 / count);
+            cc[c] = (float)(-a * s1 / count);
+        } else {
+            ca[c] = 1.f; cb[c] = 0.f; cc[c] = 0.f;
+        }
+    }
+    s3sum[tid] = my3;
+    __syncthreads();
+    if (tid == 0 && dslope) {
+        double t = 0.0;
+        for (int i = 0; i < (int)blockDim.x; ++i) t += s3sum[i];
+        dslope[0] = (float)t;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View x, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, int act,
+                                                           const float* __restrict__ slope_p,
+                                                           const float* __restrict__ ca, const float* __restrict__ cb,
+                                                           const float* __restrict__ cc, View dx) {
+    const int CG = (x.C + 7) / 8;
+    const float slope = slope_p ? slope_p[0] : 0.f;
+    const long long total = x.npix * CG;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pix = i / CG;
+        const int cg = (int)(i - pix * CG);
+        float fx[8], fg[8], o[8];
+        load8(x, pix, cg * 8, fx);
+        load8(dy, pix, cg * 8, fg);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cg * 8 + e;
+            if (c < x.C) {
+                const float z = fmaf(fx[e], scale[c], shift[c]);
+                const float dz = fg[e] * act_grad(z, act, slope);
+                const float xh = mean ? (fx[e] - mean[c]) * invstd[c] : 0.f;
+                o[e] = fmaf(ca[c], dz, fmaf(cb[c], xh, cc[c]));
+            } else {
+                o[e] = 0.f;
+            }
+        }
+        store8(dx, pix, cg * 8, o);
+    }
+}
+
+extern "C" int sos_bn_bwd(const sos_view* dy, const sos_view* x, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, const float* gamma, int act, const float* slope,
+                          float* partial, float* coef /* [3][C] */, float* dgamma, float* dbeta, float* dslope,
+                          const sos_view* dx, sos_stream_t stream) {
+    int rc = check_view(dy, "sos_bn_bwd");
+    if (!rc) rc = check_view(x, "sos_bn_bwd");
+    if (!rc) rc = check_view(dx, "sos_bn_bwd");
+    if (rc) return rc;
+    if (!scale || !shift || !partial || !coef || dy->npix != x->npix || dx->npix != x->npix || dy->C < x->C || dx->C < x->C ||
+        (mean == nullptr) != (invstd == nullptr)) {
+        sos_set_error("sos_bn_bwd: bad args");
+        return SOS_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = sos_bn_stats_blocks(x->npix);
+    const int C = x->C;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, s, to_view(dy), to_view(x), scale, shift, mean,
+                       invstd, act, slope, partial);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nblk, C, (double)x->npix, gamma, invstd,
+                       dgamma, dbeta, dslope, coef, coef + C, coef + 2 * C);
+    const long long total = x->npix * ((C + 7) / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, to_view(dy), to_view(x), scale, shift,
+                       mean, invstd, act, slope, coef, coef + C, coef + 2 * C, to_view(dx));
+    return sos_check_launch("sos_bn_bwd");
+}
+
+// dz = dy * act'(y) for layers whose pre-activation is not kept (nn.Linear + ReLU / Sigmoid heads):
+// ReLU: y > 0, Sigmoid: y(1-y).
+__global__ __launch_bounds__(256) void act_bwd_from_y_kernel(View dy, View y, int act, View dz) {
+    const int CG = (y.C + 7) / 8;
+    const long long total = y.npix * CG;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pix = i / CG;
+        const int cg = (int)(i - pix * CG);
+        float fy[8], fg[8], o[8];
+        load8(y, pix, cg * 8, fy);
+        load8(dy, pix, cg * 8, fg);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float d = fg[e];
+            if (act == SOS_ACT_RELU) d = fy[e] > 0.f ? d : 0.f;
+            else if (act == SOS_ACT_SIGMOID) d = d * fy[e] * (1.f - fy[e]);
+            o[e] = (cg * 8 + e < y.C) ? d : 0.f;
+        }
+        store8(dz, pix, cg * 8, o);
+    }
+}
+
+extern "C" int sos_act_bwd_from_y(const sos_view* dy, const sos_view* y, int act, const sos_view* dz,
+                                  sos_stream_t stream) {
+    int rc = check_view(dy, "sos_act_bwd_from_y");
+    if (!rc) rc = check_view(y, "sos_act_bwd_from_y");
+    if (!rc) rc = check_view(dz, "sos_act_bwd_from_y");
+    if (rc) return rc;
+    if (dy->npix != y->npix || dz->npix != y->npix) { sos_set_error("sos_act_bwd_from_y: view mismatch"); return SOS_EINVAL; }
+    const long long total = y->npix * ((y->C + 7) / 8);
+    hipLaunchKernelGGL(act_bwd_from_y_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, to_view(dy),
+                       to_view(y), act, to_view(dz));
+    return sos_check_launch("sos_act_bwd_from_y");
+}
+
+// f32 strided gradient (+ optional sigmoid' from the f32 output y) -> bf16 / bf16x3 rows.
+// element (outer o, inner t, channel c) is read at g[o*so + t*st + c*sc] and written to
+// out row (o*inner + t), channel c.
+__global__ __launch_bounds__(256) void pack_grad_kernel(const float* __restrict__ g, const float* __restrict__ y, int act,
+                                                        long long outer, long long inner, int C, long long so,
+                                                        long long st, long long sc, View out) {
+    const long long total = outer * inner * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        // t fastest so that reads along the (usually unit-stride) inner axis coalesce
+        const long long t = i % inner;
+        const long long r = i / inner;
+        const int c = (int)(r % C);
+        const long long o = r / C;
+        const long long src = o * so + t * st + c * sc;
+        float v = g[src];
+        if (act == SOS_ACT_SIGMOID) { const float yy = y[src]; v *= yy * (1.f - yy); }
+        bf16_t* dst = out.ptr + (o * inner + t) * out.row + out.c_off + c;
+        const bf16_t hi = f2bf(v);
+        dst[0] = hi;
+        if (out.x3) { dst[out.third] = hi; dst[2 * out.third] = f2bf(v - bf2f(hi)); }
+    }
+}
+
+extern "C" int sos_pack_grad_f32(const float* g, const float* y, int act, int64_t outer, int64_t inner, int C,
+                                 int64_t so, int64_t st, int64_t sc, const sos_view* out, sos_stream_t stream) {
+    if (!g || !out || !out->ptr || outer < 1 || inner < 1 || C < 1 || (act == SOS_ACT_SIGMOID && !y)) {
+        sos_set_error("sos_pack_grad_f32: bad args");
+        return SOS_EINVAL;
+    }
+    const long long total = outer * inner * C;
+    hipLaunchKernelGGL(pack_grad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g, y, act, outer, inner, C,
+                       so, st, sc, to_view(out));
+    return sos_check_launch("sos_pack_grad_f32");
+}
+
+// gradient of the feature form back to NHWC: dy[b][h][w][c] = sum_{i in [lo[w], hi[w])} dfeat[b][i][(c_off+c)*H + h]
+// (lo/hi NULL: identity, i == w).  Inverse of sos_bn_act_apply's feature write (+ nearest-resize gather).
+__global__ __launch_bounds__(256) void feat_to_nhwc_kernel(View f, int H, int W, int Wo, const int* __restrict__ lo,
+                                                           const int* __restrict__ hi, View out, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int h = (int)(i % H);
+        const long long r = i / H;
+        const int w = (int)(r % W);
+        const long long b = r / W;
+        const int i0 = lo ? lo[w] : w, i1 = hi ? hi[w] : w + 1;
+        const long long pix = (b * H + h) * W + w;
+        for (int c = 0; c < out.C; ++c) {
+            float acc = 0.f;
+            for (int k = i0; k < i1; ++k) {
+                const bf16_t* p = f.ptr + (b * Wo + k) * f.row + (long long)(f.c_off + c) * H + h;
+                acc += bf2f(p[0]);
+                if (f.x3) acc += bf2f(p[2 * f.third]);
+            }
+            bf16_t* d = out.ptr + pix * out.row + out.c_off + c;
+            const bf16_t hv = f2bf(acc);
+            d[0] = hv;
+            if (out.x3) { d[out.third] = hv; d[2 * out.third] = f2bf(acc - bf2f(hv)); }
+        }
+    }
+}
+
+extern "C" int sos_feat_to_nhwc(const sos_view* feat, int B, int H, int W, int Wo, const int32_t* lo, const int32_t* hi,
+                                const sos_view* out, sos_stream_t stream) {
+    if (!feat || !feat->ptr || !out || !out->ptr || B < 1 || H < 1 || W < 1 || Wo < 1 || (lo == nullptr) != (hi == nullptr)) {
+        sos_set_error("sos_feat_to_nhwc: bad args");
+        return SOS_EINVAL;
+    }
+    const long long total = (long long)B * W * H;
+    hipLaunchKernelGGL(feat_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, to_view(feat), H, W, Wo,
+                       lo, hi, to_view(out), total);
+    return sos_check_launch("sos_feat_to_nhwc");
 }

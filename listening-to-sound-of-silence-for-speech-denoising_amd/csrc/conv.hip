@@ -39,7 +39,7 @@ struct ConvParams {
     int kh, kw, cout, cout_pad, cout_store;
     int stride, dh, dw, pad_t, pad_l, pad_mode;
     int Ho, Wo;
-    int out_dtype, c_off, act;
+    int out_dtype, c_off, act, accum;
     long long sb, sh, sw, sc, third;
     // tiling
     int NC, logTH, logTW, PH, PW;
@@ -379,12 +379,35 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         const int wo = wo_base + cls + j * p.dw;
         if (!(ho < p.Ho && wo < p.Wo && (cls == 0 || rw0 + cls < p.dw))) continue;
         const int o = ho * ish + wo * isw + q * 8;
-        const uint4 hv = *(const uint4*)(ost_hi + m * OROW + q * 16);
+        uint4 hv = *(const uint4*)(ost_hi + m * OROW + q * 16);
         if (co + 8 <= p.cout_store) {
+            uint4 lv = make_uint4(0u, 0u, 0u, 0u);
+            if (x3) lv = *(const uint4*)(ost_lo + m * OROW + q * 16);
+            if (p.accum) {
+                // gradient fan-in: new = old + this, re-split into hi (+ lo)
+                const uint4 oh = *(const uint4*)(op + o);
+                uint4 ol = make_uint4(0u, 0u, 0u, 0u);
+                if (x3) ol = *(const uint4*)(op + o + 2 * ith);
+                const unsigned nh[4] = {hv.x, hv.y, hv.z, hv.w}, nl[4] = {lv.x, lv.y, lv.z, lv.w};
+                const unsigned ph[4] = {oh.x, oh.y, oh.z, oh.w}, pl[4] = {ol.x, ol.y, ol.z, ol.w};
+                unsigned rh[4], rl[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = __uint_as_float(nh[e] << 16) + __uint_as_float(nl[e] << 16) +
+                                     __uint_as_float(ph[e] << 16) + __uint_as_float(pl[e] << 16);
+                    const float a1 = __uint_as_float(nh[e] & 0xffff0000u) + __uint_as_float(nl[e] & 0xffff0000u) +
+                                     __uint_as_float(ph[e] & 0xffff0000u) + __uint_as_float(pl[e] & 0xffff0000u);
+                    const bf16_t h0 = f2bf(a0), h1 = f2bf(a1);
+                    rh[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    rl[e] = (unsigned)f2bf(a0 - bf2f(h0)) | ((unsigned)f2bf(a1 - bf2f(h1)) << 16);
+                }
+                hv = make_uint4(rh[0], rh[1], rh[2], rh[3]);
+                lv = make_uint4(rl[0], rl[1], rl[2], rl[3]);
+            }
             *(uint4*)(op + o) = hv;
             if (x3) {
                 *(uint4*)(op + o + ith) = hv;
-                *(uint4*)(op + o + 2 * ith) = *(const uint4*)(ost_lo + m * OROW + q * 16);
+                *(uint4*)(op + o + 2 * ith) = lv;
             }
         } else {
             const bf16_t* hs = (const bf16_t*)(ost_hi + m * OROW + q * 16);
@@ -533,7 +556,7 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     p.kh = d->kh; p.kw = d->kw; p.cout = d->cout; p.cout_pad = d->cout_pad; p.cout_store = d->cout_store;
     p.stride = d->stride; p.dh = d->dil_h; p.dw = d->dil_w; p.pad_t = d->pad_top; p.pad_l = d->pad_left;
     p.pad_mode = d->pad_mode; p.Ho = d->Ho; p.Wo = d->Wo; p.out_dtype = d->out_dtype; p.c_off = d->out_c_off;
-    p.act = d->act; p.sb = d->out_sb; p.sh = d->out_sh; p.sw = d->out_sw; p.sc = d->out_sc; p.third = d->out_third;
+    p.act = d->act; p.accum = d->accumulate; p.sb = d->out_sb; p.sh = d->out_sh; p.sw = d->out_sw; p.sc = d->out_sc; p.third = d->out_third;
     const int nt = nt_for(d);
     const int nby = (d->cout_pad / 32 + nt - 1) / nt;
     const int Hc = (d->Ho + d->dil_h - 1) / d->dil_h, Wc = (d->Wo + d->dil_w - 1) / d->dil_w;
@@ -569,15 +592,20 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
 extern "C" int sos_conv2d_fwd(const sos_conv_desc* d, sos_stream_t stream) {
     int rc = validate(d);
     if (rc) return rc;
+    // SOS_CONV_FORCE_CFG=k (testing): use the k-th candidate tiling (mod count) instead of the tuned one
+    static const char* force = getenv("SOS_CONV_FORCE_CFG");
     auto& cache = tuned_cache();
-    auto it = cache.find(shape_key(d));
-    if (it != cache.end()) return launch_cfg(d, it->second, (hipStream_t)stream);
+    if (!force) {
+        auto it = cache.find(shape_key(d));
+        if (it != cache.end()) return launch_cfg(d, it->second, (hipStream_t)stream);
+    }
     std::vector<ConvCfg> cfgs = enumerate_cfgs(d);
     if (cfgs.empty()) {
         sos_set_error("sos_conv2d_fwd: no tile fits LDS (cin=%d k=%dx%d)", d->cin, d->kh, d->kw);
         return SOS_ENOSPC;
     }
-    return launch_cfg(d, cfgs[0], (hipStream_t)stream);
+    const size_t pick = force ? (size_t)atol(force) % cfgs.size() : 0;
+    return launch_cfg(d, cfgs[pick], (hipStream_t)stream);
 }
 
 // Measure the best few tilings of this descriptor's shape on the device (HIP events on `stream`,

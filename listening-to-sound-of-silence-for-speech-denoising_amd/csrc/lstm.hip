@@ -19,7 +19,8 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 __global__ __launch_bounds__(256) void lstm_kernel(const float* __restrict__ xproj, const float* __restrict__ whh_t,
                                                    int B, int T, int H, float* __restrict__ out_f32,
                                                    bf16_t* __restrict__ out_bf16, int out_cs, int x3,
-                                                   long long third) {
+                                                   long long third, float* __restrict__ save_gates,
+                                                   float* __restrict__ save_c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* hbuf = (float*)smem;                           // [2][H][NB]
     float* gbuf = hbuf + 2 * H * LSTM_NB;                 // [4H][NB] gate pre-activations
@@ -82,8 +83,15 @@ __global__ __launch_bounds__(256) void lstm_kernel(const float* __restrict__ xpr
             float cv[4] = {c4.x, c4.y, c4.z, c4.w}, hv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                cv[e] = sigmoidf_(fv[e]) * cv[e] + sigmoidf_(iv[e]) * tanhf(gv[e]);
-                hv[e] = sigmoidf_(ov[e]) * tanhf(cv[e]);
+                const float ig = sigmoidf_(iv[e]), fg = sigmoidf_(fv[e]), gt = tanhf(gv[e]), og = sigmoidf_(ov[e]);
+                cv[e] = fg * cv[e] + ig * gt;
+                hv[e] = og * tanhf(cv[e]);
+                const int bb = b0 + n0 + e;
+                if (save_gates && bb < B) {
+                    float* sg = save_gates + (((size_t)bb * T + t) * 2 + dir) * G;
+                    sg[j] = ig; sg[H + j] = fg; sg[2 * H + j] = gt; sg[3 * H + j] = og;
+                    save_c[(((size_t)bb * T + t) * 2 + dir) * H + j] = cv[e];
+                }
             }
             *(float4*)(cbuf + j * LSTM_NB + n0) = make_float4(cv[0], cv[1], cv[2], cv[3]);
             *(float4*)(hnext + j * LSTM_NB + n0) = make_float4(hv[0], hv[1], hv[2], hv[3]);
@@ -110,9 +118,10 @@ __global__ __launch_bounds__(256) void lstm_kernel(const float* __restrict__ xpr
 
 extern "C" int sos_lstm_bidir_fwd(const float* xproj, const float* whh_t, int64_t B, int64_t T, int H,
                                   float* out_f32, void* out_bf16, int out_cs, int out_dtype, int64_t out_third,
-                                  sos_stream_t stream) {
+                                  float* save_gates, float* save_c, sos_stream_t stream) {
     if (!xproj || !whh_t || (!out_f32 && !out_bf16) || B < 1 || T < 1 || H < 4 || H > 256 || (H & 3) ||
-        (out_bf16 && out_cs < 2 * H) || (out_dtype != SOS_DT_BF16 && out_dtype != SOS_DT_BF16X3)) {
+        (out_bf16 && out_cs < 2 * H) || (out_dtype != SOS_DT_BF16 && out_dtype != SOS_DT_BF16X3) ||
+        ((save_gates == nullptr) != (save_c == nullptr))) {
         sos_set_error("sos_lstm_bidir_fwd: bad args (B=%lld T=%lld H=%d)", (long long)B, (long long)T, H);
         return SOS_EINVAL;
     }
@@ -120,6 +129,127 @@ extern "C" int sos_lstm_bidir_fwd(const float* xproj, const float* whh_t, int64_
     const size_t lds = (size_t)(2 + 4 + 1) * H * LSTM_NB * sizeof(float);
     hipLaunchKernelGGL(lstm_kernel, grid, dim3(256), lds, (hipStream_t)stream, xproj, whh_t, (int)B, (int)T, H,
                        out_f32, (bf16_t*)out_bf16, out_cs, out_dtype == SOS_DT_BF16X3 ? 1 : 0,
-                       (long long)out_third);
+                       (long long)out_third, save_gates, save_c);
     return sos_check_launch("sos_lstm_bidir_fwd");
+}
+
+// ------------------------------------------------------------------------ backward through time
+// One workgroup per (direction, NB clips) walks the steps in reverse.  Per step:
+//   A) per (hidden unit, clip): dh = dh_out + dh_rec, dc = dc_rec + dh*o*(1-tanh(c)^2); gate
+//      pre-activation grads di,df,dg,do -> LDS [4H][NB] and global dgates (fp32 [B][T][2][4H]);
+//      dc_rec = dc*f.
+//   B) dh_rec[k] = sum_r W_hh[r][k] * dgate[r]: thread = (4 consecutive k, slice of rows); the
+//      slices meet in LDS.  W_hh ([4H][H], the layout torch stores) streams from L2.
+// dW_ih, dW_hh, the bias gradient and dx are GEMMs over dgates done by the wgrad / conv kernels.
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_t* __restrict__ dh_out, int dh_cs, int dh_x3,
+                                                       long long dh_third, const float* __restrict__ gates,
+                                                       const float* __restrict__ csave, const float* __restrict__ whh,
+                                                       int B, int T, int H, float* __restrict__ dgates) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int G = 4 * H;
+    float* dgl = (float*)smem;                 // [4H][NB]
+    float* dhr = dgl + G * LSTM_NB;            // [H][NB]  recurrent dh
+    float* dcr = dhr + H * LSTM_NB;            // [H][NB]  recurrent dc
+    float* part = dcr + H * LSTM_NB;           // [RS][H][NB] partial dh_rec
+    const int tid = threadIdx.x;
+    const int dir = blockIdx.y;
+    const int b0 = blockIdx.x * LSTM_NB;
+    const float* W = whh + (size_t)dir * G * H;   // [4H][H]
+    const int KG = H >> 2;                         // groups of 4 consecutive k
+    const int RS = 256 / KG;                       // row slices
+    const int rows_per = (G + RS - 1) / RS;
+    for (int idx = tid; idx < 2 * H * LSTM_NB; idx += 256) dhr[idx] = 0.f;   // dhr and dcr are adjacent
+    __syncthreads();
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? T - 1 - step : step;     // reverse of the forward order
+        const int tprev = dir == 0 ? t - 1 : t + 1;       // time index the forward pass came from
+        for (int idx = tid; idx < H * LSTM_NB; idx += 256) {
+            const int j = idx / LSTM_NB, n = idx - j * LSTM_NB;
+            const int b = b0 + n;
+            float di = 0.f, df = 0.f, dg = 0.f, dov = 0.f, dcn = 0.f;
+            if (b < B) {
+                const size_t row = (size_t)b * T + t;
+                const bf16_t* dp = dh_out + row * dh_cs + dir * H + j;
+                float dh = bf2f(dp[0]);
+                if (dh_x3) dh += bf2f(dp[2 * dh_third]);
+                dh += dhr[idx];
+                const float* gp = gates + (row * 2 + dir) * G;
+                const float ig = gp[j], fg = gp[H + j], gt = gp[2 * H + j], og = gp[3 * H + j];
+                const float c = csave[(row * 2 + dir) * H + j];
+                const float cprev = (tprev >= 0 && tprev < T) ? csave[(((size_t)b * T + tprev) * 2 + dir) * H + j] : 0.f;
+                const float tc = tanhf(c);
+                const float dc = dcr[idx] + dh * og * (1.f - tc * tc);
+                di = dc * gt * ig * (1.f - ig);
+                df = dc * cprev * fg * (1.f - fg);
+                dg = dc * ig * (1.f - gt * gt);
+                dov = dh * tc * og * (1.f - og);
+                dcn = dc * fg;
+                float* dgp = dgates + (row * 2 + dir) * G;
+                dgp[j] = di; dgp[H + j] = df; dgp[2 * H + j] = dg; dgp[3 * H + j] = dov;
+            }
+            dcr[idx] = dcn;
+            dgl[(0 * H + j) * LSTM_NB + n] = di;
+            dgl[(1 * H + j) * LSTM_NB + n] = df;
+            dgl[(2 * H + j) * LSTM_NB + n] = dg;
+            dgl[(3 * H + j) * LSTM_NB + n] = dov;
+        }
+        __syncthreads();
+        {
+            const int kg = tid % KG, rs = tid / KG;
+            if (rs < RS) {
+                float acc[4][LSTM_NB];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int n = 0; n < LSTM_NB; ++n) acc[e][n] = 0.f;
+                const int r0 = rs * rows_per, r1 = min(r0 + rows_per, G);
+#pragma unroll 4
+                for (int r = r0; r < r1; ++r) {
+                    const float4 w = *(const float4*)(W + (size_t)r * H + kg * 4);
+                    const float4 da = *(const float4*)(dgl + r * LSTM_NB);
+                    const float4 db = *(const float4*)(dgl + r * LSTM_NB + 4);
+                    const float dv[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+#pragma unroll
+                    for (int n = 0; n < LSTM_NB; ++n) {
+                        acc[0][n] = fmaf(w.x, dv[n], acc[0][n]);
+                        acc[1][n] = fmaf(w.y, dv[n], acc[1][n]);
+                        acc[2][n] = fmaf(w.z, dv[n], acc[2][n]);
+                        acc[3][n] = fmaf(w.w, dv[n], acc[3][n]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float* pp = part + ((size_t)rs * H + kg * 4 + e) * LSTM_NB;
+                    *(float4*)pp = make_float4(acc[e][0], acc[e][1], acc[e][2], acc[e][3]);
+                    *(float4*)(pp + 4) = make_float4(acc[e][4], acc[e][5], acc[e][6], acc[e][7]);
+                }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < H * LSTM_NB; idx += 256) {
+            float s = 0.f;
+            for (int rs = 0; rs < RS; ++rs) s += part[(size_t)rs * H * LSTM_NB + idx];
+            dhr[idx] = s;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int sos_lstm_bidir_bwd(const void* dh_out, int dh_cs, int dh_dtype, int64_t dh_third, const float* gates,
+                                  const float* csave, const float* whh, int64_t B, int64_t T, int H, float* dgates,
+                                  sos_stream_t stream) {
+    if (!dh_out || !gates || !csave || !whh || !dgates || B < 1 || T < 1 || H < 4 || H > 256 || (H & 3) || dh_cs < 2 * H ||
+        (dh_dtype != SOS_DT_BF16 && dh_dtype != SOS_DT_BF16X3)) {
+        sos_set_error("sos_lstm_bidir_bwd: bad args");
+        return SOS_EINVAL;
+    }
+    const int KG = H >> 2, RS = 256 / KG;
+    const size_t lds = (size_t)(4 + 1 + 1 + RS) * H * LSTM_NB * sizeof(float);
+    if (lds > 160 * 1024) { sos_set_error("sos_lstm_bidir_bwd: LDS"); return SOS_ENOSPC; }
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    dim3 grid((unsigned)((B + LSTM_NB - 1) / LSTM_NB), 2);
+    hipLaunchKernelGGL(lstm_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dh_out, dh_cs,
+                       dh_dtype == SOS_DT_BF16X3 ? 1 : 0, (long long)dh_third, gates, csave, whh, (int)B, (int)T, H, dgates);
+    return sos_check_launch("sos_lstm_bidir_bwd");
 }

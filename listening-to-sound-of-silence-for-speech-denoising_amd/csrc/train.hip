@@ -1,0 +1,108 @@
+// train.hip -- fused losses and optimizer step (gfx950, HBM-bound elementwise kernels).
+//
+// Reference: M2/agent.py:174,188-189 (nn.MSELoss on (n_pred, full_noise) and (rec, clean)),
+// M1/agent.py:187,202 (nn.BCEWithLogitsLoss), M1/agent.py:177 / M2/agent.py:167 (optim.Adam,
+// lr 1e-3, betas (0.9, 0.999), eps 1e-8).  Each loss kernel produces the scalar loss (two-stage,
+// deterministic) and the gradient w.r.t. its first argument in one pass.
+#include "sos_common.h"
+
+#define LOSS_BLOCKS 1024
+
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                  float gscale, float* __restrict__ grad, float* __restrict__ partial) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = a[i] - b[i];
+        acc = fmaf(d, d, acc);
+        if (grad) grad[i] = gscale * d;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ x, const float* __restrict__ y, long long n,
+                                                  float gscale, float* __restrict__ grad, float* __restrict__ partial) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float xv = x[i], yv = y[i];
+        acc += fmaxf(xv, 0.f) - xv * yv + log1pf(expf(-fabsf(xv)));
+        if (grad) grad[i] = gscale * (1.0f / (1.0f + expf(-xv)) - yv);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void loss_finalize_kernel(const float* __restrict__ partial, int nblk, double inv_n, float* __restrict__ loss) {
+    double s = 0.0;
+    for (int i = 0; i < nblk; ++i) s += (double)partial[i];
+    loss[0] = (float)(s * inv_n);
+}
+
+static int loss_blocks(long long n) {
+    long long b = (n + 255) / 256;
+    if (b > LOSS_BLOCKS) b = LOSS_BLOCKS;
+    return (int)(b < 1 ? 1 : b);
+}
+
+/* mean((a-b)^2) -> loss[0]; grad (optional) = upstream * 2(a-b)/n.  partial: f32 [1024]. */
+extern "C" int sos_mse_loss(const float* a, const float* b, int64_t n, float upstream, float* loss, float* grad,
+                            float* partial, sos_stream_t stream) {
+    if (!a || !b || !loss || !partial || n < 1) { sos_set_error("sos_mse_loss: bad args"); return SOS_EINVAL; }
+    const int nb = loss_blocks(n);
+    hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, (long long)n,
+                       upstream * 2.0f / (float)n, grad, partial);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, partial, nb, 1.0 / (double)n, loss);
+    return sos_check_launch("sos_mse_loss");
+}
+
+/* mean(max(x,0) - x*y + log1p(exp(-|x|))) -> loss[0]; grad (optional) = upstream*(sigmoid(x)-y)/n. */
+extern "C" int sos_bce_logits_loss(const float* x, const float* y, int64_t n, float upstream, float* loss, float* grad,
+                                   float* partial, sos_stream_t stream) {
+    if (!x || !y || !loss || !partial || n < 1) { sos_set_error("sos_bce_logits_loss: bad args"); return SOS_EINVAL; }
+    const int nb = loss_blocks(n);
+    hipLaunchKernelGGL(bce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n, upstream / (float)n,
+                       grad, partial);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, partial, nb, 1.0 / (double)n, loss);
+    return sos_check_launch("sos_bce_logits_loss");
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float bc2_sqrt, float gscale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float gi = g[i] * gscale;
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+/* torch.optim.Adam (amsgrad=False) single-tensor update; step = 1-based step count after increment. */
+extern "C" int sos_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int64_t step, float grad_scale, sos_stream_t stream) {
+    if (!p || !g || !m || !v || n < 1 || step < 1) { sos_set_error("sos_adam_step: bad args"); return SOS_EINVAL; }
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2 = 1.0f - powf(beta2, (float)step);
+    long long gb = (n + 255) / 256;
+    if (gb > 2048) gb = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr,
+                       beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+    return sos_check_launch("sos_adam_step");
+}

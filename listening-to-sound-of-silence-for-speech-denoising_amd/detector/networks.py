@@ -7,11 +7,29 @@ import torch.nn as nn
 from .. import _lib as L
 from .. import common_nets as CN
 from .. import engine as E
+from .. import train_ops as TO
 
 
 def get_network():
     """M1/networks.py:8-9."""
     return AudioVisualNet()
+
+
+class _TrainFn(torch.autograd.Function):
+    """Training-mode forward (batch-statistics BN, running stats updated in place) with the
+    hand-written HIP backward; the parameters are passed so autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, net, s, n, *params):
+        out, tape = net._forward_train(s, n)
+        ctx.net, ctx.tape = net, tape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = ctx.net._backward(ctx.tape, g)
+        ctx.tape = None
+        return (None, None, None) + tuple(grads[name].reshape(p.shape) for name, p in ctx.net.named_parameters())
 
 
 class AudioVisualNet(nn.Module):
@@ -26,6 +44,7 @@ class AudioVisualNet(nn.Module):
         self.fc1 = nn.Sequential(nn.Linear(200, 100), nn.ReLU(True), nn.Linear(100, 1))
         self.freq_bins = freq_bins
         self._cache = E.PlanCache()
+        self._tcache = E.PlanCache()
 
     def _build_plan(self):
         x3 = E.is_x3()
@@ -35,13 +54,62 @@ class AudioVisualNet(nn.Module):
                     fc0=CN.linear_plan(self.fc1[0], E.pad_to(200, 16), x3),
                     fc2=CN.linear_plan(self.fc1[2], E.pad_to(100, 16), x3))
 
+    # ------------------------------------------------------------------ training path
+    def _build_train_plan(self):
+        x3 = E.is_x3()
+        return dict(x3=x3, enc=TO.encoder_train_plan(self.encoder_audio, x3),
+                    lstm=TO.lstm_train_plan(self.lstm, 8 * self.freq_bins, x3),
+                    fc0=TO.linear_train_plan(self.fc1[0], E.pad_to(200, 16), x3),
+                    fc2=TO.linear_train_plan(self.fc1[2], E.pad_to(100, 16), x3))
+
+    def _forward_train(self, s, n):
+        plan = self._tcache.get(self, self._build_train_plan)
+        x3 = plan["x3"]
+        dev = s.device
+        B, _, F, T = s.shape
+        nseg = 3 if x3 else 1
+        nfeat = 8 * F
+        a = E.pack_input(s, x3)
+        feat = torch.empty((B, n, nseg * nfeat), dtype=torch.bfloat16, device=dev)
+        gather = CN.nearest_index(T, n, dev)
+        fspec = dict(t=feat, row=nseg * nfeat, third=nfeat, c_off=0, H=F, W=T, Wo=n, gather=gather, x3=x3)
+        tape_enc = TO.encoder_forward_train(plan["enc"], a, fspec, x3)
+        h, tape_lstm = TO.lstm_forward_train(plan["lstm"], (feat, B, 1, n, nfeat, nseg), B, n, x3, dev)
+        f0, f2 = plan["fc0"], plan["fc2"]
+        m = E.Act(B, 1, n, E.pad_to(f0["cout"], 16), x3, dev, zero=True)
+        E.conv_to_act(h, 0, f0["cin_store"], f0["w"], 1, 1, f0["cout"], f0["scale"], f0["shift"], L.ACT_RELU, m,
+                      cout_store=m.cs, Ho=1, Wo=n)
+        out = torch.empty((B, n), dtype=torch.float32, device=dev)
+        E.conv(m, 0, f2["cin_store"], f2["w"], 1, 1, 1, f2["scale"], f2["shift"], L.ACT_NONE, out=out,
+               out_dtype=L.DT_F32, sb=n, sh=0, sw=1, sc=1, Ho=1, Wo=n)
+        tape = dict(plan=plan, enc=tape_enc, lstm=tape_lstm, h=h, m=m, gather=gather, dims=(B, F, T, n), x3=x3)
+        return out, tape
+
+    def _backward(self, tape, g):
+        plan, x3 = tape["plan"], tape["x3"]
+        B, F, T, n = tape["dims"]
+        dev = g.device
+        grads = {}
+        dz2 = E.Act(B, 1, n, 16, x3, dev, zero=True)
+        TO.pack_grad(g.contiguous().float(), None, L.ACT_NONE, B, n, 1, n, 1, 1, dz2)
+        d_m = TO.linear_backward(plan["fc2"], tape["m"], dz2, grads, "fc1.2", x3, dev)
+        dz0 = E.Act(B, 1, n, tape["m"].cs, x3, dev, zero=True)
+        TO.act_bwd_from_y(d_m, tape["m"], L.ACT_RELU, dz0, plan["fc0"]["cout"])
+        dh = TO.linear_backward(plan["fc0"], tape["h"], dz0, grads, "fc1.0", x3, dev)
+        dfeat = TO.lstm_backward(plan["lstm"], tape["lstm"], dh, grads, "lstm", B, n, x3, dev)
+        lo, hi = TO.gather_ranges(tape["gather"].cpu().numpy(), T)
+        nseg = 3 if x3 else 1
+        dy = TO.feat_grad_to_nhwc(dfeat, nseg * 8 * F, 8 * F, 0, 8, B, F, T, n, x3,
+                                  torch.from_numpy(lo).to(dev), torch.from_numpy(hi).to(dev))
+        TO.encoder_backward(plan["enc"], tape["enc"], dy, grads, "encoder_audio", x3)
+        return grads
+
     def forward(self, s, v_num_frames=60):
         L.require_cuda(s)
-        if self.training:
-            raise NotImplementedError("AudioVisualNet: the training-mode (batch-statistics) path is not built yet; "
-                                      "call .eval() for inference")
         if s.dim() != 4 or s.shape[1] != 2 or s.shape[2] != self.freq_bins:
             raise ValueError(f"expected (B, 2, {self.freq_bins}, T) input, got {tuple(s.shape)}")
+        if self.training:
+            return _TrainFn.apply(self, s.contiguous().float(), int(v_num_frames), *self.parameters())
         plan = self._cache.get(self, self._build_plan)
         x3 = plan["x3"]
         dev = s.device

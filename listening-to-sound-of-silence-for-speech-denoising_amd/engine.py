@@ -115,7 +115,7 @@ def fold_bn(bn, cout_pad):
 
 def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dtype, sb, sh, sw, sc,
          Ho, Wo, c_off=0, cout_store=None, third=0, stride=1, dil=(1, 1), pad=(0, 0), pad_mode=L.PAD_ZERO,
-         slope=None, w_gather=None, out_elem_offset=0, in_dims=None):
+         slope=None, w_gather=None, out_elem_offset=0, in_dims=None, accumulate=False):
     """Fill a sos_conv_desc and enqueue sos_conv2d_fwd.  `src` is an Act (or a (tensor,B,H,W,cs,nseg)
     view described by in_dims)."""
     d = L.ConvDesc()
@@ -148,6 +148,7 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
     d.scale, d.shift = scale.data_ptr(), shift.data_ptr()
     d.act = act
     d.act_param = slope.data_ptr() if slope is not None else None
+    d.accumulate = 1 if accumulate else 0
     if AUTOTUNE:
         key = (B, H, W, d.Wl, cin, d.in_nseg, d.cout_pad, kh, kw, stride, dil, Ho, Wo, out_dtype, sc == 1, pad_mode,
                w_gather is not None)
@@ -171,11 +172,11 @@ def conv_to_act(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, dst, c_
          cout_store=cout if cout_store is None else cout_store, third=dst.cs, **kw_)
 
 
-def lstm(xproj, whh_t, B, T, H, out_act):
+def lstm(xproj, whh_t, B, T, H, out_act, save_gates=None, save_c=None):
     """Recurrent part (sos_lstm_bidir_fwd); out_act: Act [B,1,T,cs>=2H] pre-zeroed."""
     L.check(L.lib().sos_lstm_bidir_fwd(L.ptr(xproj), L.ptr(whh_t), B, T, H, None, L.ptr(out_act.t),
                                        out_act.nseg * out_act.cs, out_act.dtype_code, out_act.cs,
-                                       L.stream_ptr()), "sos_lstm_bidir_fwd")
+                                       L.ptr(save_gates), L.ptr(save_c), L.stream_ptr()), "sos_lstm_bidir_fwd")
 
 
 class PlanCache:
