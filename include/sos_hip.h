@@ -228,6 +228,14 @@ int sos_bce_logits_loss(const float* x, const float* y, int64_t n, float upstrea
 int sos_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int64_t step, float grad_scale, sos_stream_t stream);
 
+/* backward of ReflectionPad2d(pad) (DownConvBlock, M2/networks.py:105): out (+)= fold of the padded-domain
+ * gradient `padded` ([B][H+2pad][W+2pad]) onto the [B][H][W] interior. */
+int sos_reflect_fold(const sos_view* padded, int H, int W, int pad, const sos_view* out, int accumulate,
+                     sos_stream_t stream);
+/* copy a channel slice between NHWC grids [B][Hs][Ws] -> [B][Hd][Wd]: overlap copied, rest of dst zeroed
+ * (the crop that stands in for F.interpolate(out, skip.size()) at M2/networks.py:199-203, and its backward). */
+int sos_copy_crop(const sos_view* src, int Hs, int Ws, const sos_view* dst, int Hd, int Wd, sos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,8 @@ SIGNATURES = {
     "sos_act_bwd_from_y": [C.POINTER(View), C.POINTER(View), _I, C.POINTER(View), _P],
     "sos_pack_grad_f32": [_P, _P, _I, _L, _L, _I, _L, _L, _L, C.POINTER(View), _P],
     "sos_feat_to_nhwc": [C.POINTER(View), _I, _I, _I, _I, _P, _P, C.POINTER(View), _P],
+    "sos_reflect_fold": [C.POINTER(View), _I, _I, _I, C.POINTER(View), _I, _P],
+    "sos_copy_crop": [C.POINTER(View), _I, _I, C.POINTER(View), _I, _I, _P],
     "sos_lstm_bidir_bwd": [_P, _I, _I, _L, _P, _P, _P, _L, _L, _I, _P, _P],
     "sos_mse_loss": [_P, _P, _L, _F, _P, _P, _P, _P],
     "sos_bce_logits_loss": [_P, _P, _L, _F, _P, _P, _P, _P],

@@ -504,3 +504,99 @@ extern "C" int sos_feat_to_nhwc(const sos_view* feat, int B, int H, int W, int W
                        lo, hi, to_view(out), total);
     return sos_check_launch("sos_feat_to_nhwc");
 }
+
+
+// ------------------------------------------------------------------- reflect-pad gradient fold
+// Backward of ReflectionPad2d(pad) (DownConvBlock, M2/networks.py:105): the gradient w.r.t. the
+// padded tensor [B][H+2p][W+2p] is folded back, every border cell adding to the interior cell it
+// mirrors.  out (+)= fold(padded).
+__global__ __launch_bounds__(256) void reflect_fold_kernel(View pd, int H, int W, int pad, View out, int accumulate,
+                                                           long long total) {
+    const int CG = (out.C + 7) / 8;
+    const int Wp = W + 2 * pad, Hp = H + 2 * pad;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cg = (int)(i % CG);
+        long long r = i / CG;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const long long b = r / H;
+        int us[3], vs[3], nu = 0, nv = 0;
+        us[nu++] = h + pad;
+        if (h >= 1 && h <= pad) us[nu++] = pad - h;
+        if (h >= H - 1 - pad && h <= H - 2) us[nu++] = 2 * (H - 1) - h + pad;
+        vs[nv++] = w + pad;
+        if (w >= 1 && w <= pad) vs[nv++] = pad - w;
+        if (w >= W - 1 - pad && w <= W - 2) vs[nv++] = 2 * (W - 1) - w + pad;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int a = 0; a < nu; ++a)
+            for (int c = 0; c < nv; ++c) {
+                float f[8];
+                load8(pd, (b * Hp + us[a]) * Wp + vs[c], cg * 8, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += f[e];
+            }
+        const long long opix = (b * H + h) * W + w;
+        if (accumulate) {
+            float f[8];
+            load8(out, opix, cg * 8, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += f[e];
+        }
+        store8(out, opix, cg * 8, acc);
+    }
+}
+
+extern "C" int sos_reflect_fold(const sos_view* padded, int H, int W, int pad, const sos_view* out, int accumulate,
+                                sos_stream_t stream) {
+    int rc = check_view(padded, "sos_reflect_fold");
+    if (!rc) rc = check_view(out, "sos_reflect_fold");
+    if (rc) return rc;
+    if (H < 1 || W < 1 || pad < 0 || pad >= H || pad >= W || out->npix % ((long long)H * W) ||
+        padded->npix != out->npix / ((long long)H * W) * (H + 2 * pad) * (W + 2 * pad) || padded->C < out->C) {
+        sos_set_error("sos_reflect_fold: bad geometry");
+        return SOS_EINVAL;
+    }
+    const long long total = out->npix * ((out->C + 7) / 8);
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, to_view(padded), H, W,
+                       pad, to_view(out), accumulate, total);
+    return sos_check_launch("sos_reflect_fold");
+}
+
+// copy a channel slice between two NHWC pixel grids of different size: the overlap
+// [min(Hs,Hd)] x [min(Ws,Wd)] is copied, the rest of dst is zero filled (crop of the
+// ConvTranspose2d output to the skip tensor's size in the forward pass, zero-pad back in backward).
+__global__ __launch_bounds__(256) void copy_crop_kernel(View src, int Hs, int Ws, View dst, int Hd, int Wd, long long total) {
+    const int CG = (dst.C + 7) / 8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cg = (int)(i % CG);
+        long long r = i / CG;
+        const int w = (int)(r % Wd); r /= Wd;
+        const int h = (int)(r % Hd);
+        const long long b = r / Hd;
+        float f[8];
+        if (h < Hs && w < Ws) {
+            load8(src, (b * Hs + h) * Ws + w, cg * 8, f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        }
+        store8(dst, (b * Hd + h) * Wd + w, cg * 8, f);
+    }
+}
+
+extern "C" int sos_copy_crop(const sos_view* src, int Hs, int Ws, const sos_view* dst, int Hd, int Wd, sos_stream_t stream) {
+    int rc = check_view(src, "sos_copy_crop");
+    if (!rc) rc = check_view(dst, "sos_copy_crop");
+    if (rc) return rc;
+    if (Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1 || src->npix % ((long long)Hs * Ws) || dst->npix % ((long long)Hd * Wd) ||
+        src->npix / ((long long)Hs * Ws) != dst->npix / ((long long)Hd * Wd) || src->C < dst->C) {
+        sos_set_error("sos_copy_crop: bad geometry");
+        return SOS_EINVAL;
+    }
+    const long long total = dst->npix * ((dst->C + 7) / 8);
+    hipLaunchKernelGGL(copy_crop_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, to_view(src), Hs, Ws,
+                       to_view(dst), Hd, Wd, total);
+    return sos_check_launch("sos_copy_crop");
+}

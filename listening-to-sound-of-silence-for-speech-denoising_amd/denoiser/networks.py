@@ -7,6 +7,7 @@ import torch.nn as nn
 from .. import _lib as L
 from .. import common_nets as CN
 from .. import engine as E
+from .. import train_ops as TO
 
 
 def get_network(config):
@@ -176,6 +177,75 @@ class InpaintNet(nn.Module):
                out_dtype=L.DT_F32, sb=2 * H * W, sh=W, sw=1, sc=H * W, pad=(1, 1), pad_mode=L.PAD_REFLECT, Ho=H, Wo=W)
         return out
 
+    # ------------------------------------------------------------------ training path
+    _LAYERS = ["down1.0", "down2.0", "down2.1", "down3.0", "down4.0", "down4.1"] + [f"mid.{i}" for i in range(8)]
+
+    def build_train_plan(self, x3):
+        perm_up1 = list(range(128, 256)) + list(range(0, 128))
+        P = TO.down_train_plan
+        return dict(down1=P(self.down1[0], x3), down2_0=P(self.down2[0], x3), down2_1=P(self.down2[1], x3),
+                    down3=P(self.down3[0], x3), down4_0=P(self.down4[0], x3), down4_1=P(self.down4[1], x3),
+                    mid=[P(self.mid[i], x3) for i in range(8)], mid8=TO.up_train_plan(self.mid[8], x3),
+                    up1_0=P(self.up1[0], x3, perm_up1), up1_1=TO.up_train_plan(self.up1[1], x3),
+                    up2_0=P(self.up2[0], x3), up2_1=_down_plan(self.up2[1], x3),
+                    up2_1_wd=E.pack_weight(self.up2[1].block[1].weight.detach().float().flip(2, 3).transpose(0, 1).contiguous(),
+                                           16, x3))
+
+    def forward_train(self, plan, x, y, x3):
+        dev = x.device
+        B, _, H, W = x.shape
+        H1, W1 = (H + 1) // 2, (W + 1) // 2
+        H2, W2 = (H1 + 1) // 2, (W1 + 1) // 2
+        ax, ay = E.pack_input(x, x3), E.pack_input(y, x3)
+        d1 = E.Act(B, H, W, 64, x3, dev)
+        U2 = E.Act(B, H, W, 128, x3, dev)
+        X = E.Act(B, H1, W1, 384, x3, dev)
+        ta, tb = E.Act(B, H1, W1, 128, x3, dev), E.Act(B, H1, W1, 128, x3, dev)
+        F_ = TO.down_forward_train
+        tape = []
+        tape.append(("down1.0", F_(plan["down1"], ax, 0, d1, 0, H, W, x3)))
+        tape.append(("down2.0", F_(plan["down2_0"], d1, 0, ta, 0, H1, W1, x3)))
+        tape.append(("down2.1", F_(plan["down2_1"], ta, 0, X, 0, H1, W1, x3)))
+        tape.append(("down3.0", F_(plan["down3"], ay, 0, U2, 64, H, W, x3)))
+        tape.append(("down4.0", F_(plan["down4_0"], U2, 64, tb, 0, H1, W1, x3)))
+        tape.append(("down4.1", F_(plan["down4_1"], tb, 0, X, 128, H1, W1, x3)))
+        prev, cin_off = X, 0
+        for i in range(8):
+            m = E.Act(B, H2, W2, 256, x3, dev)
+            tape.append((f"mid.{i}", F_(plan["mid"][i], prev, cin_off, m, 0, H2, W2, x3)))
+            prev = m
+        tape.append(("mid.8", TO.up_forward_train(plan["mid8"], prev, X, 256, x3)))
+        u128 = E.Act(B, H1, W1, 128, x3, dev)
+        tape.append(("up1.0", F_(plan["up1_0"], X, 128, u128, 0, H1, W1, x3)))
+        tape.append(("up1.1", TO.up_forward_train(plan["up1_1"], u128, U2, 0, x3)))
+        u64 = E.Act(B, H, W, 64, x3, dev)
+        tape.append(("up2.0", F_(plan["up2_0"], U2, 0, u64, 0, H, W, x3)))
+        lp = plan["up2_1"]
+        out = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
+        E.conv(u64, 0, lp["cin_store"], lp["w"], 3, 3, 2, lp["scale"], lp["shift"], L.ACT_NONE, out=out,
+               out_dtype=L.DT_F32, sb=2 * H * W, sh=W, sw=1, sc=H * W, pad=(1, 1), pad_mode=L.PAD_REFLECT, Ho=H, Wo=W)
+        return out, dict(layers=tape, u64=u64, packed=(ax, ay))
+
+    def backward(self, plan, tape, d_out, grads, x3, prefix="stage1"):
+        """d_out: Act [B,H,W,16] holding the gradient of the 2-channel output."""
+        dev = d_out.t.device
+        gb = TO.GradBufs(x3)
+        u64 = tape["u64"]
+        # up2.1: conv + bias, no BN / activation
+        grads[f"{prefix}.up2.1.block.1.bias"] = TO.colsum(d_out, 0, 2)
+        dw = torch.empty((2, 64, 3, 3), dtype=torch.float32, device=dev)
+        E.wgrad(d_out, 0, 2, u64, 0, 64, 3, 3, dw, pad=(1, 1), pad_mode=L.PAD_REFLECT)
+        grads[f"{prefix}.up2.1.block.1.weight"] = dw
+        last = dict(wd=plan["up2_1_wd"], pad=1, k=3, dil=1, stride=1, cin=64)
+        TO._reflect_dgrad(last, d_out, u64, 0, gb, x3)
+        no_src_grad = {"down1.0", "down3.0"}
+        for name, t in reversed(tape["layers"]):
+            full = f"{prefix}.{name}"
+            if t["kind"] == "up":
+                TO.up_backward(t, gb, grads, full, x3)
+            else:
+                TO.down_backward(t, gb, grads, full, x3, need_src_grad=name not in no_src_grad)
+
     def forward(self, x, y):
         raise RuntimeError("call InpaintNet through JointModel (libsos_hip path)")
 
@@ -221,8 +291,75 @@ class ContextAggNet(nn.Module):
                out_dtype=L.DT_F32, sb=2 * F * T, sh=0, sw=1, sc=T, Ho=1, Wo=T)
         return out
 
+    # ------------------------------------------------------------------ training path
+    def build_train_plan(self, x3):
+        return dict(enc_x=TO.encoder_train_plan(self.encoder_x, x3), enc_n=TO.encoder_train_plan(self.encoder_n, x3),
+                    lstm=TO.lstm_train_plan(self.lstm, 12 * self.freq_bins, x3),
+                    fc0=TO.linear_train_plan(self.fc[0], 400, x3), fc2=TO.linear_train_plan(self.fc[2], E.pad_to(600, 16), x3),
+                    fc4=TO.linear_train_plan(self.fc[4], E.pad_to(600, 16), x3))
+
+    def forward_train(self, plan, x, n, x3):
+        dev = x.device
+        B, _, F, T = x.shape
+        nseg = 3 if x3 else 1
+        nfeat = 12 * F
+        feat = torch.empty((B, T, nseg * nfeat), dtype=torch.bfloat16, device=dev)
+        fs = dict(t=feat, row=nseg * nfeat, third=nfeat, H=F, W=T, Wo=T, gather=None, x3=x3)
+        tx = TO.encoder_forward_train(plan["enc_x"], E.pack_input(x, x3), dict(fs, c_off=0), x3)
+        tn = TO.encoder_forward_train(plan["enc_n"], E.pack_input(n, x3), dict(fs, c_off=8), x3)
+        h, tl = TO.lstm_forward_train(plan["lstm"], (feat, B, 1, T, nfeat, nseg), B, T, x3, dev)
+        f0, f2, f4 = plan["fc0"], plan["fc2"], plan["fc4"]
+        a0 = E.Act(B, 1, T, E.pad_to(600, 16), x3, dev)
+        a1 = E.Act(B, 1, T, E.pad_to(600, 16), x3, dev)
+        E.conv_to_act(h, 0, f0["cin_store"], f0["w"], 1, 1, 600, f0["scale"], f0["shift"], L.ACT_RELU, a0,
+                      cout_store=a0.cs, Ho=1, Wo=T)
+        E.conv_to_act(a0, 0, f2["cin_store"], f2["w"], 1, 1, 600, f2["scale"], f2["shift"], L.ACT_RELU, a1,
+                      cout_store=a1.cs, Ho=1, Wo=T)
+        out = torch.empty((B, 2, F, T), dtype=torch.float32, device=dev)
+        E.conv(a1, 0, f4["cin_store"], f4["w"], 1, 1, 2 * F, f4["scale"], f4["shift"], L.ACT_SIGMOID, out=out,
+               out_dtype=L.DT_F32, sb=2 * F * T, sh=0, sw=1, sc=T, Ho=1, Wo=T)
+        return out, dict(tx=tx, tn=tn, tl=tl, h=h, a0=a0, a1=a1, out=out, dims=(B, F, T))
+
+    def backward(self, plan, tape, g_out, grads, x3, prefix="stage2"):
+        """g_out: f32 (B,2,F,T) gradient of the mask.  Returns the Act gradient of encoder_n's
+        2-channel input (the stage-1 prediction)."""
+        B, F, T = tape["dims"]
+        dev = g_out.device
+        nseg = 3 if x3 else 1
+        dz4 = E.Act(B, 1, T, 2 * F, x3, dev)
+        TO.pack_grad(g_out.contiguous().float(), tape["out"], L.ACT_SIGMOID, B, T, 2 * F, 2 * F * T, 1, T, dz4)
+        d_a1 = TO.linear_backward(plan["fc4"], tape["a1"], dz4, grads, f"{prefix}.fc.4", x3, dev)
+        dz2 = E.Act(B, 1, T, tape["a1"].cs, x3, dev, zero=True)
+        TO.act_bwd_from_y(d_a1, tape["a1"], L.ACT_RELU, dz2, 600)
+        d_a0 = TO.linear_backward(plan["fc2"], tape["a0"], dz2, grads, f"{prefix}.fc.2", x3, dev)
+        dz0 = E.Act(B, 1, T, tape["a0"].cs, x3, dev, zero=True)
+        TO.act_bwd_from_y(d_a0, tape["a0"], L.ACT_RELU, dz0, 600)
+        dh = TO.linear_backward(plan["fc0"], tape["h"], dz0, grads, f"{prefix}.fc.0", x3, dev)
+        dfeat = TO.lstm_backward(plan["lstm"], tape["tl"], dh, grads, f"{prefix}.lstm", B, T, x3, dev)
+        nfeat = 12 * F
+        dyx = TO.feat_grad_to_nhwc(dfeat, nseg * nfeat, nfeat, 0, 8, B, F, T, T, x3)
+        TO.encoder_backward(plan["enc_x"], tape["tx"], dyx, grads, f"{prefix}.encoder_x", x3)
+        dyn = TO.feat_grad_to_nhwc(dfeat, nseg * nfeat, nfeat, 8, 4, B, F, T, T, x3)
+        return TO.encoder_backward(plan["enc_n"], tape["tn"], dyn, grads, f"{prefix}.encoder_n", x3, need_input_grad=True)
+
     def forward(self, x, n):
         raise RuntimeError("call ContextAggNet through JointModel (libsos_hip path)")
+
+
+class _JointTrainFn(torch.autograd.Function):
+    """Training-mode forward of JointModel with the hand-written HIP backward (both outputs)."""
+
+    @staticmethod
+    def forward(ctx, net, x, n, *params):
+        (n_pred, out), tape = net._forward_train(x, n)
+        ctx.net, ctx.tape = net, tape
+        return n_pred, out
+
+    @staticmethod
+    def backward(ctx, g_npred, g_out):
+        grads = ctx.net._backward(ctx.tape, g_npred, g_out)
+        ctx.tape = None
+        return (None, None, None) + tuple(grads[name].reshape(p.shape) for name, p in ctx.net.named_parameters())
 
 
 class JointModel(nn.Module):
@@ -233,18 +370,43 @@ class JointModel(nn.Module):
         self.stage1 = InpaintNet()
         self.stage2 = ContextAggNet(config.kernel_sizes, config.dilations)
         self._cache = E.PlanCache()
+        self._tcache = E.PlanCache()
 
     def _build_plan(self):
         x3 = E.is_x3()
         return dict(x3=x3, s1=self.stage1.build_plan(x3), s2=self.stage2.build_plan(x3))
 
+    def _build_train_plan(self):
+        x3 = E.is_x3()
+        return dict(x3=x3, s1=self.stage1.build_train_plan(x3), s2=self.stage2.build_train_plan(x3))
+
+    def _forward_train(self, x, n):
+        plan = self._tcache.get(self, self._build_train_plan)
+        x3 = plan["x3"]
+        n_pred, t1 = self.stage1.forward_train(plan["s1"], n, x, x3)
+        out, t2 = self.stage2.forward_train(plan["s2"], x, n_pred, x3)
+        return (n_pred, out), dict(plan=plan, t1=t1, t2=t2, x3=x3)
+
+    def _backward(self, tape, g_npred, g_out):
+        plan, x3 = tape["plan"], tape["x3"]
+        grads = {}
+        dev = tape["t2"]["out"].device
+        B, F, T = tape["t2"]["dims"]
+        if g_out is None:
+            g_out = torch.zeros((B, 2, F, T), dtype=torch.float32, device=dev)
+        d_np = self.stage2.backward(plan["s2"], tape["t2"], g_out, grads, x3)          # Act [B,F,T,16]
+        if g_npred is not None:
+            direct = E.pack_input(g_npred.contiguous().float(), x3)                    # loss gradient on n_pred
+            TO.reflect_fold(direct, F, T, 0, d_np, 0, 2, accumulate=True)              # pad 0: plain add
+        self.stage1.backward(plan["s1"], tape["t1"], d_np, grads, x3)
+        return grads
+
     def forward(self, x, n):
         L.require_cuda(x, n)
-        if self.training:
-            raise NotImplementedError("JointModel: the training-mode (batch-statistics) path is not built yet; "
-                                      "call .eval() for inference")
         if x.dim() != 4 or x.shape[1] != 2 or x.shape != n.shape:
             raise ValueError(f"expected two (B, 2, F, T) inputs, got {tuple(x.shape)} and {tuple(n.shape)}")
+        if self.training:
+            return _JointTrainFn.apply(self, x.contiguous().float(), n.contiguous().float(), *self.parameters())
         plan = self._cache.get(self, self._build_plan)
         x3 = plan["x3"]
         x = x.contiguous().float()

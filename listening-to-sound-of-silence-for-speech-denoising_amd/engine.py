@@ -153,7 +153,17 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
         key = (B, H, W, d.Wl, cin, d.in_nseg, d.cout_pad, kh, kw, stride, dil, Ho, Wo, out_dtype, sc == 1, pad_mode,
                w_gather is not None)
         if key not in _tuned and not torch.cuda.is_current_stream_capturing():
-            L.check(L.lib().sos_conv2d_tune(C.byref(d), 8, 3, None, L.stream_ptr()), "sos_conv2d_tune")
+            if accumulate:
+                # the tuner launches the kernel many times: never let it accumulate into the real
+                # gradient buffer -- tune a non-accumulating copy of the descriptor on scratch output
+                scratch = torch.empty_like(out)
+                real_out = d.out
+                d.out = scratch.data_ptr() + out_elem_offset * esize
+                d.accumulate = 0
+                L.check(L.lib().sos_conv2d_tune(C.byref(d), 8, 3, None, L.stream_ptr()), "sos_conv2d_tune")
+                d.out, d.accumulate = real_out, 1
+            else:
+                L.check(L.lib().sos_conv2d_tune(C.byref(d), 8, 3, None, L.stream_ptr()), "sos_conv2d_tune")
             _tuned.add(key)
     end = None
     if PROFILER is not None:

@@ -242,3 +242,166 @@ def linear_backward(lp, a_in, dz, grads, prefix, x3, dev):
     E.conv_to_act(dz, 0, dz.cs, lp["wd"], 1, 1, lp["cin"], one, zero, L.ACT_NONE, d_in, cout_store=a_in.cs, Ho=1,
                   Wo=a_in.W)
     return d_in
+
+
+# ----------------------------------------------------------- InpaintNet blocks (M2/networks.py:97-205)
+def reflect_fold(padded, H, W, pad, dst, dst_off, C, accumulate=True):
+    pv, ov = E.view(padded, 0, C), E.view(dst, dst_off, C)
+    L.check(L.lib().sos_reflect_fold(ctypes.byref(pv), H, W, pad, ctypes.byref(ov), 1 if accumulate else 0, L.stream_ptr()),
+            "sos_reflect_fold")
+
+
+def copy_crop(src, src_off, dst, dst_off, C):
+    sv, dv = E.view(src, src_off, C), E.view(dst, dst_off, C)
+    L.check(L.lib().sos_copy_crop(ctypes.byref(sv), src.H, src.W, ctypes.byref(dv), dst.H, dst.W, L.stream_ptr()),
+            "sos_copy_crop")
+
+
+def down_train_plan(blk, x3, in_perm=None):
+    """DownConvBlock: block.0 ReflectionPad2d, block.1 Conv2d, [block.2 BN, block.3 PReLU]."""
+    import torch.nn as nn
+    conv = blk.block[1]
+    has_bn = len(blk.block) > 2 and isinstance(blk.block[2], nn.BatchNorm2d)
+    prelu = blk.block[-1] if isinstance(blk.block[-1], nn.PReLU) else None
+    k, s, d = conv.kernel_size[0], conv.stride[0], conv.dilation[0]
+    cin_store = E.pad_to(conv.in_channels, 16)
+    cout_cs = E.pad_to(conv.out_channels, 16)
+    w = conv.weight.detach().float()
+    wperm = w if in_perm is None else w[:, in_perm]
+    plan = dict(w=E.pack_weight(w, cin_store, x3, in_perm), conv=conv, bn=blk.block[2] if has_bn else None, prelu=prelu,
+                k=k, stride=s, dil=d, pad=(k - 1) // 2 * d, cout=conv.out_channels, cin=conv.in_channels,
+                cin_store=cin_store, in_perm=in_perm)
+    if s == 1:
+        plan["wd"] = E.pack_weight(wperm.flip(2, 3).transpose(0, 1).contiguous(), cout_cs, x3)
+    else:
+        assert s == 2 and d == 1
+        phases = {}
+        for ph in (0, 1):
+            for pw in (0, 1):
+                Mh, Mw = (k + 1 - ph) // 2, (k + 1 - pw) // 2
+                a = [ph + 2 * (Mh - 1 - t) for t in range(Mh)]
+                b = [pw + 2 * (Mw - 1 - t) for t in range(Mw)]
+                sub = wperm[:, :, a][:, :, :, b].transpose(0, 1).contiguous()        # (I, O, Mh, Mw)
+                phases[(ph, pw)] = (E.pack_weight(sub, cout_cs, x3), Mh, Mw)
+        plan["wd_phases"] = phases
+    return plan
+
+
+def up_train_plan(blk, x3):
+    """UpConvBlock: block.0 ConvTranspose2d(k3,s2,p1,op1), block.1 BN, block.2 PReLU."""
+    ct, bn, prelu = blk.block[0], blk.block[1], blk.block[2]
+    cin_store = E.pad_to(ct.in_channels, 16)
+    w = ct.weight.detach().float()                                                    # (Cin, Cout, 3, 3)
+    taps = {0: [1], 1: [2, 0]}
+    phases = {}
+    for ph in (0, 1):
+        for pw in (0, 1):
+            sub = w[:, :, taps[ph]][:, :, :, taps[pw]].permute(1, 0, 2, 3).contiguous()
+            phases[(ph, pw)] = E.pack_weight(sub, cin_store, x3)
+    # data gradient: d_in[hi] = sum_a d_raw[2hi - 1 + a] W[ci][co][a] -> stride-2 conv, weight (O=Cin, I=Cout)
+    wd = E.pack_weight(w, E.pad_to(ct.out_channels, 16), x3)
+    return dict(phases=phases, wd=wd, ct=ct, bn=bn, prelu=prelu, cout=ct.out_channels, cin=ct.in_channels,
+                cin_store=cin_store)
+
+
+def down_forward_train(lp, src, cin_off, dst, c_off, Ho, Wo, x3):
+    dev = src.t.device
+    cs = E.pad_to(lp["cout"], 16)
+    one, zero = ones_zeros(lp["w"].shape[1], dev)
+    raw = E.Act(src.B, Ho, Wo, cs, x3, dev)
+    E.conv_to_act(src, cin_off, lp["cin_store"], lp["w"], lp["k"], lp["k"], lp["cout"], one, zero, L.ACT_NONE, raw,
+                  cout_store=cs, stride=lp["stride"], dil=(lp["dil"], lp["dil"]), pad=(lp["pad"], lp["pad"]),
+                  pad_mode=L.PAD_REFLECT, Ho=Ho, Wo=Wo)
+    saved = E.bn_train(raw, 0, lp["cout"], lp["bn"], L.ACT_PRELU, lp["prelu"].weight, dst, c_off)
+    return dict(kind="down", lp=lp, src=src, cin_off=cin_off, dst=dst, c_off=c_off, raw=raw, saved=saved)
+
+
+def up_forward_train(lp, src, dst, c_off, x3):
+    dev = src.t.device
+    cs = E.pad_to(lp["cout"], 16)
+    raw = E.Act(src.B, 2 * src.H, 2 * src.W, cs, x3, dev, zero=cs > lp["cout"])
+    row = raw.nseg * raw.cs
+    for (ph, pw), w in lp["phases"].items():
+        one, zero = ones_zeros(w.shape[1], dev)
+        E.conv(src, 0, lp["cin_store"], w, 1 + ph, 1 + pw, lp["cout"], one, zero, L.ACT_NONE, out=raw.t,
+               out_dtype=raw.dtype_code, sb=raw.H * raw.W * row, sh=2 * raw.W * row, sw=2 * row, sc=1,
+               cout_store=lp["cout"], third=raw.cs, Ho=src.H, Wo=src.W, out_elem_offset=(ph * raw.W + pw) * row)
+    # batch statistics over the UNCROPPED output (the reference resizes after the block), then crop
+    yfull = E.Act(raw.B, raw.H, raw.W, cs, x3, dev, zero=cs > E.pad_to(lp["cout"], 8))
+    saved = E.bn_train(raw, 0, lp["cout"], lp["bn"], L.ACT_PRELU, lp["prelu"].weight, yfull, 0)
+    copy_crop(yfull, 0, dst, c_off, lp["cout"])
+    return dict(kind="up", lp=lp, src=src, dst=dst, c_off=c_off, raw=raw, saved=saved)
+
+
+class GradBufs:
+    """Zero-initialised gradient mirror of every activation buffer, created on first use; all
+    producers accumulate into it (skip connections fan in)."""
+
+    def __init__(self, x3):
+        self.x3, self.bufs = x3, {}
+
+    def of(self, act):
+        k = id(act)
+        if k not in self.bufs:
+            self.bufs[k] = E.Act(act.B, act.H, act.W, act.cs, self.x3, act.t.device, zero=True)
+        return self.bufs[k]
+
+
+def _reflect_dgrad(lp, d_raw, src, cin_off, gb, x3):
+    """Data gradient of ReflectionPad2d + (strided / dilated) valid conv: zero-padded full
+    correlation onto the padded domain, then fold the border back (accumulating into grad(src))."""
+    dev = d_raw.t.device
+    p, k, d = lp["pad"], lp["k"], lp["dil"]
+    H, W = src.H, src.W
+    cin_cs = E.pad_to(lp["cin"], 16)
+    dpad = E.Act(src.B, H + 2 * p, W + 2 * p, cin_cs, x3, dev, zero=lp["stride"] != 1)
+    if lp["stride"] == 1:
+        one, zero = ones_zeros(lp["wd"].shape[1], dev)
+        E.conv_to_act(d_raw, 0, d_raw.cs, lp["wd"], k, k, lp["cin"], one, zero, L.ACT_NONE, dpad, cout_store=cin_cs,
+                      dil=(d, d), pad=((k - 1) * d, (k - 1) * d), Ho=dpad.H, Wo=dpad.W)
+    else:
+        row = dpad.nseg * dpad.cs
+        for (ph, pw), (w, Mh, Mw) in lp["wd_phases"].items():
+            Ho, Wo = (dpad.H - ph + 1) // 2, (dpad.W - pw + 1) // 2
+            one, zero = ones_zeros(w.shape[1], dev)
+            E.conv(d_raw, 0, d_raw.cs, w, Mh, Mw, lp["cin"], one, zero, L.ACT_NONE, out=dpad.t, out_dtype=dpad.dtype_code,
+                   sb=dpad.H * dpad.W * row, sh=2 * dpad.W * row, sw=2 * row, sc=1, cout_store=cin_cs, third=dpad.cs,
+                   pad=(Mh - 1, Mw - 1), Ho=Ho, Wo=Wo, out_elem_offset=(ph * dpad.W + pw) * row)
+    reflect_fold(dpad, H, W, p, gb.of(src), cin_off, lp["cin"], accumulate=True)
+
+
+def down_backward(t, gb, grads, name, x3, need_src_grad=True):
+    lp, raw = t["lp"], t["raw"]
+    dev = raw.t.device
+    d_raw = E.Act(raw.B, raw.H, raw.W, raw.cs, x3, dev, zero=raw.cs > E.pad_to(lp["cout"], 8))
+    dgamma, dbeta, dslope = bn_bwd(gb.of(t["dst"]), t["c_off"], raw, 0, lp["cout"], t["saved"], lp["bn"].weight,
+                                   L.ACT_PRELU, lp["prelu"].weight, d_raw)
+    grads[f"{name}.block.2.weight"], grads[f"{name}.block.2.bias"], grads[f"{name}.block.3.weight"] = dgamma, dbeta, dslope
+    dw = torch.empty_like(lp["conv"].weight, dtype=torch.float32)
+    E.wgrad(d_raw, 0, lp["cout"], t["src"], t["cin_off"], lp["cin"], lp["k"], lp["k"], dw, stride=lp["stride"],
+            dil=(lp["dil"], lp["dil"]), pad=(lp["pad"], lp["pad"]), pad_mode=L.PAD_REFLECT)
+    if lp["in_perm"] is not None:           # dw is in the stored channel order; undo the concat permutation
+        inv = torch.empty(len(lp["in_perm"]), dtype=torch.long)
+        inv[torch.tensor(lp["in_perm"])] = torch.arange(len(lp["in_perm"]))
+        dw = dw[:, inv.to(dw.device)].contiguous()
+    grads[f"{name}.block.1.weight"] = dw
+    if need_src_grad:
+        _reflect_dgrad(lp, d_raw, t["src"], t["cin_off"], gb, x3)
+
+
+def up_backward(t, gb, grads, name, x3):
+    lp, raw, src = t["lp"], t["raw"], t["src"]
+    dev = raw.t.device
+    dy_full = E.Act(raw.B, raw.H, raw.W, raw.cs, x3, dev, zero=raw.cs > E.pad_to(lp["cout"], 8))
+    copy_crop(gb.of(t["dst"]), t["c_off"], dy_full, 0, lp["cout"])
+    d_raw = E.Act(raw.B, raw.H, raw.W, raw.cs, x3, dev, zero=raw.cs > E.pad_to(lp["cout"], 8))
+    dgamma, dbeta, dslope = bn_bwd(dy_full, 0, raw, 0, lp["cout"], t["saved"], lp["bn"].weight, L.ACT_PRELU,
+                                   lp["prelu"].weight, d_raw)
+    grads[f"{name}.block.1.weight"], grads[f"{name}.block.1.bias"], grads[f"{name}.block.2.weight"] = dgamma, dbeta, dslope
+    dw = torch.empty_like(lp["ct"].weight, dtype=torch.float32)                      # (Cin, Cout, 3, 3)
+    E.wgrad(src, 0, lp["cin"], d_raw, 0, lp["cout"], 3, 3, dw, stride=2, pad=(1, 1))
+    grads[f"{name}.block.0.weight"] = dw
+    gsrc = gb.of(src)
+    one, zero = ones_zeros(lp["wd"].shape[1], dev)
+    E.conv_to_act(d_raw, 0, d_raw.cs, lp["wd"], 3, 3, lp["cin"], one, zero, L.ACT_NONE, gsrc, cout_store=lp["cin"],
+                  stride=2, pad=(1, 1), Ho=src.H, Wo=src.W, accumulate=True)
