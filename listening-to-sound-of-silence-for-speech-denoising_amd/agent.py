@@ -1,0 +1,276 @@
+"""Trainer mirroring the reference `agent.py` (M1/agent.py:25-206, M2/agent.py:20-190) on the HIP
+kernels, one process per GPU.
+
+Kept from the reference: the loss definitions (BCEWithLogits for the detector, MSE(n_pred,
+full_noise) + MSE(rec, clean) summed for the denoiser), Adam(lr) + StepLR(step_size), the
+`{clock, model_state_dict, optimizer_state_dict, scheduler_state_dict}` checkpoint dict with
+un-prefixed state-dict keys, TrainClock's `{epoch, minibatch, step}`.
+
+Replaced: nn.DataParallel (single process, replicate/scatter/gather every step, gradients reduced
+to GPU 0) by data parallelism across processes -- each rank owns its batch shard and its own
+BatchNorm statistics (DataParallel semantics, no SyncBN) and the gradients are averaged with
+bucketed RCCL all-reduces launched while the hand-written backward pass is still running.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import transform
+from .engine import bump_version
+
+PHASE_TRAINING, PHASE_TESTING = "training", "testing"
+
+
+class TrainClock(object):
+    """M1/utils.py:8-34."""
+
+    def __init__(self):
+        self.epoch, self.minibatch, self.step = 1, 0, 0
+
+    def tick(self):
+        self.minibatch += 1
+        self.step += 1
+
+    def tock(self):
+        self.epoch += 1
+        self.minibatch = 0
+
+    def make_checkpoint(self):
+        return {"epoch": self.epoch, "minibatch": self.minibatch, "step": self.step}
+
+    def restore_checkpoint(self, clock_dict):
+        self.epoch, self.minibatch, self.step = clock_dict["epoch"], clock_dict["minibatch"], clock_dict["step"]
+
+
+# ------------------------------------------------------------------------------------ fused losses
+class _MSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        L.require_cuda(a, b)
+        a, b = a.contiguous().float(), b.contiguous().float()
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        grad = torch.empty_like(a)
+        partial = torch.empty(1024, dtype=torch.float32, device=a.device)
+        L.check(L.lib().sos_mse_loss(L.ptr(a), L.ptr(b), a.numel(), 1.0, L.ptr(loss), L.ptr(grad), L.ptr(partial),
+                                     L.stream_ptr()), "sos_mse_loss")
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+class _BCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        L.require_cuda(x, y)
+        x, y = x.contiguous().float(), y.contiguous().float()
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x)
+        partial = torch.empty(1024, dtype=torch.float32, device=x.device)
+        L.check(L.lib().sos_bce_logits_loss(L.ptr(x), L.ptr(y), x.numel(), 1.0, L.ptr(loss), L.ptr(grad), L.ptr(partial),
+                                            L.stream_ptr()), "sos_bce_logits_loss")
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+def mse_loss(a, b):
+    """nn.MSELoss() (mean), M2/agent.py:174."""
+    return _MSE.apply(a, b)
+
+
+def bce_with_logits_loss(x, y):
+    """nn.BCEWithLogitsLoss() (mean), M1/agent.py:187."""
+    return _BCE.apply(x, y)
+
+
+# ------------------------------------------------------------------------------------- optimizer
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam (amsgrad=False) semantics and state_dict layout, one sos_adam_step launch per
+    parameter tensor; `grad_scale` folds the 1/world_size of the data-parallel average into it."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.grad_scale = 1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.zeros((), dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad.contiguous()
+                L.require_cuda(p, g)
+                L.check(L.lib().sos_adam_step(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
+                                              float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                              float(group["weight_decay"]), int(st["step"]), float(self.grad_scale),
+                                              L.stream_ptr()), "sos_adam_step")
+                bump_version(p)     # raw-pointer write: invalidate the packed-weight caches keyed on _version
+        return None
+
+
+# ----------------------------------------------------------------------------- gradient all-reduce
+class GradBucketer:
+    """Flat ~`bucket_bytes` gradient buckets in the order the backward pass produces them; a bucket's
+    all-reduce (RCCL over xGMI with backend 'nccl'; gloo in CPU tests) starts as soon as its last
+    gradient has been written, overlapping the rest of the backward.  xGMI is point-to-point, so a
+    ring all-reduce is bound by one link: a few large buckets (25 MB) beat many small ones."""
+
+    def __init__(self, named_params, bucket_bytes=25 * 1024 * 1024, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.shapes = {n: p.shape for n, p in named_params}
+        self.params = dict(named_params)
+        self.bucket_bytes = bucket_bytes
+        self.reset()
+
+    def reset(self):
+        self.buckets, self.cur, self.cur_fill, self.handles, self.views = [], None, 0, [], {}
+
+    def _launch(self, flat, fill):
+        if self.world > 1:
+            self.handles.append(dist.all_reduce(flat[:fill], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def ready(self, name, g):
+        """Called by the backward pass when a parameter gradient is final; returns the bucket view that
+        now holds it."""
+        n = g.numel()
+        cap = max(self.bucket_bytes // 4, n)
+        if self.cur is None or self.cur_fill + n > self.cur.numel():
+            if self.cur is not None:
+                self._launch(self.cur, self.cur_fill)
+            self.cur = torch.empty(cap, dtype=torch.float32, device=g.device)
+            self.cur_fill = 0
+            self.buckets.append(self.cur)
+        v = self.cur[self.cur_fill:self.cur_fill + n]
+        v.copy_(g.reshape(-1))
+        self.cur_fill += n
+        self.views[name] = v.view(self.shapes[name])
+        return self.views[name]
+
+    def finalize(self):
+        """Flush the last bucket, wait for every all-reduce and point p.grad at the reduced views (the
+        1/world average is applied by the optimizer's grad_scale)."""
+        if self.cur is not None and self.cur_fill:
+            self._launch(self.cur, self.cur_fill)
+        for h in self.handles:
+            h.wait()
+        for name, v in self.views.items():
+            self.params[name].grad = v
+        self.reset_keep_views()
+
+    def reset_keep_views(self):
+        self.cur, self.cur_fill, self.handles, self.buckets, self.views = None, 0, [], [], {}
+
+
+class GradSink(dict):
+    """dict the backward pass fills; every insertion is routed through the bucketer."""
+
+    def __init__(self, bucketer):
+        super().__init__()
+        self.bucketer = bucketer
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, self.bucketer.ready(k, v) if self.bucketer is not None else v)
+
+
+# ------------------------------------------------------------------------------------------ agents
+class BaseAgent(object):
+    """M1/agent.py:25-150 without tensorboard / path plumbing."""
+
+    def __init__(self, net, lr=1e-3, lr_step_size=15, model_dir=None, device=None):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.net = net.to(self.device)
+        self.clock = TrainClock()
+        self.model_dir = model_dir
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        if self.world > 1:      # same initial weights and buffers on every rank (rank 0's, like DataParallel)
+            for t in list(self.net.parameters()) + list(self.net.buffers()):
+                dist.broadcast(t.data, src=0)
+        self.optimizer = FusedAdam(self.net.parameters(), lr)
+        self.optimizer.grad_scale = 1.0 / self.world
+        self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, lr_step_size)
+        self.bucketer = GradBucketer(list(self.net.named_parameters())) if self.world > 1 else None
+        self.net.grad_sink_factory = (lambda: GradSink(self.bucketer)) if self.bucketer is not None else None
+
+    # -- checkpoints: M1/agent.py:62-100
+    def save_ckpt(self, name=None):
+        path = os.path.join(self.model_dir, f"ckpt_epoch{self.clock.epoch}.pth" if name is None else f"{name}.pth")
+        torch.save({"clock": self.clock.make_checkpoint(),
+                    "model_state_dict": {k: v.detach().cpu() for k, v in self.net.state_dict().items()},
+                    "optimizer_state_dict": self.optimizer.state_dict(),
+                    "scheduler_state_dict": self.scheduler.state_dict()}, path)
+        return path
+
+    def load_ckpt(self, name=None):
+        name = name if name == "latest" else f"ckpt_epoch{name}"
+        path = os.path.join(self.model_dir, f"{name}.pth")
+        if not os.path.exists(path):
+            raise ValueError("Checkpoint {} not exists.".format(path))
+        ck = torch.load(path, map_location=self.device)
+        self.net.load_state_dict(ck["model_state_dict"])
+        self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        self.scheduler.load_state_dict(ck["scheduler_state_dict"])
+        self.clock.restore_checkpoint(ck["clock"])
+
+    # -- M1/agent.py:101-130
+    def update_network(self, loss_dict):
+        loss = sum(loss_dict.values())
+        self.optimizer.zero_grad(set_to_none=True)
+        if self.bucketer is not None:
+            self.bucketer.reset()
+        loss.backward()
+        if self.bucketer is not None:
+            self.bucketer.finalize()
+        self.optimizer.step()
+
+    def update_learning_rate(self):
+        self.scheduler.step()
+
+    def train_func(self, data):
+        self.net.train()
+        outputs, losses = self.forward(data)
+        self.update_network(losses)
+        return outputs, losses
+
+    def val_func(self, data):
+        self.net.eval()
+        with torch.no_grad():
+            return self.forward(data)
+
+
+class DetectorAgent(BaseAgent):
+    """MyAgent of M1/agent.py:153-206."""
+
+    def forward(self, data):
+        label = data["label"].to(self.device)
+        audio = data["audio"].to(self.device)
+        output = self.net(audio) if label.shape[1] == 60 else self.net(audio, label.shape[1])
+        return output, {"bce": bce_with_logits_loss(output, label)}
+
+
+class DenoiserAgent(BaseAgent):
+    """MyAgent of M2/agent.py:148-190."""
+
+    def forward(self, data):
+        mixed, noise = data["mixed"].to(self.device), data["noise"].to(self.device)
+        clean, full_noise = data["clean"].to(self.device), data["full_noise"].to(self.device)
+        pred_noise, outputs = self.net(mixed, noise)
+        rec = transform.batch_fast_icRM_sigmoid(mixed, outputs)
+        return (pred_noise, outputs), {"stage1": mse_loss(pred_noise, full_noise), "stage2": mse_loss(rec, clean)}

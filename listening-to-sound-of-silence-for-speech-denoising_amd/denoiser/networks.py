@@ -389,7 +389,8 @@ class JointModel(nn.Module):
 
     def _backward(self, tape, g_npred, g_out):
         plan, x3 = tape["plan"], tape["x3"]
-        grads = {}
+        factory = getattr(self, "grad_sink_factory", None)
+        grads = factory() if factory is not None else {}
         dev = tape["t2"]["out"].device
         B, F, T = tape["t2"]["dims"]
         if g_out is None:

@@ -89,7 +89,8 @@ class AudioVisualNet(nn.Module):
         plan, x3 = tape["plan"], tape["x3"]
         B, F, T, n = tape["dims"]
         dev = g.device
-        grads = {}
+        factory = getattr(self, "grad_sink_factory", None)
+        grads = factory() if factory is not None else {}
         dz2 = E.Act(B, 1, n, 16, x3, dev, zero=True)
         TO.pack_grad(g.contiguous().float(), None, L.ACT_NONE, B, n, 1, n, 1, 1, dz2)
         d_m = TO.linear_backward(plan["fc2"], tape["m"], dz2, grads, "fc1.2", x3, dev)

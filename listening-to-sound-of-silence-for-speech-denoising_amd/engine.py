@@ -240,8 +240,20 @@ def bn_train(raw, c_off, Cn, bn, act, slope, dst, dst_c_off=0, feat=None):
                                     float(bn.momentum), L.ptr(bn.running_mean), L.ptr(bn.running_var),
                                     L.ptr(bn.num_batches_tracked), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd),
                                     L.stream_ptr()), "sos_bn_finalize")
+    for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked):
+        bump_version(t)
     bn_apply(xv, scale, shift, act, slope, dst, dst_c_off, Cn, feat)
     return dict(scale=scale, shift=shift, mean=mean, invstd=invstd)
+
+
+def bump_version(t):
+    """Our kernels write parameters / buffers through raw pointers; tell torch (and the packed-weight
+    caches keyed on `_version`) that the tensor changed."""
+    try:
+        torch.autograd.graph.increment_version(t)
+    except AttributeError:       # older torch: a no-op in-place op does the same
+        with torch.no_grad():
+            t.add_(0)
 
 
 def bn_apply(xv, scale, shift, act, slope, dst, dst_c_off, C, feat=None):

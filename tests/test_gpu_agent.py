@@ -1,0 +1,96 @@
+"""Trainer semantics on the GPU: fused losses, Adam step vs torch.optim.Adam, checkpoint format."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as onet
+from util import hashed, rel_err, silent_gate, spec_input
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fused_losses_match_torch():
+    from sos_amd import agent
+    a = torch.from_numpy(hashed(61, (3, 2, 32, 20)).astype(np.float32)).cuda().requires_grad_(True)
+    b = torch.from_numpy(hashed(62, (3, 2, 32, 20)).astype(np.float32)).cuda()
+    l = agent.mse_loss(a, b)
+    (3.0 * l).backward()
+    ar = a.detach().cpu().requires_grad_(True)
+    lr = torch.nn.functional.mse_loss(ar, b.cpu())
+    (3.0 * lr).backward()
+    assert abs(float(l) - float(lr)) < 1e-6 and rel_err(a.grad, ar.grad) < 1e-6
+    x = torch.from_numpy(hashed(63, (4, 60), 3.0).astype(np.float32)).cuda().requires_grad_(True)
+    y = (torch.from_numpy(hashed(64, (4, 60))) > 0).float().cuda()
+    l = agent.bce_with_logits_loss(x, y)
+    l.backward()
+    xr = x.detach().cpu().requires_grad_(True)
+    lr = torch.nn.functional.binary_cross_entropy_with_logits(xr, y.cpu())
+    lr.backward()
+    assert abs(float(l) - float(lr)) < 1e-6 and rel_err(x.grad, xr.grad) < 1e-6
+
+
+def test_fused_adam_matches_torch_adam():
+    from sos_amd.agent import FusedAdam
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(17, 5)), torch.nn.Parameter(torch.randn(300))]
+    pr = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ps = [torch.nn.Parameter(p.detach().cuda()) for p in ps]
+    o1, o2 = FusedAdam(ps, lr=1e-3), torch.optim.Adam(pr, lr=1e-3)
+    for it in range(5):
+        for p, q in zip(ps, pr):
+            g = torch.randn(q.shape)
+            p.grad, q.grad = g.cuda(), g.clone()
+        v0 = ps[0]._version
+        o1.step()
+        o2.step()
+        assert ps[0]._version > v0                    # packed-weight caches see the update
+    for p, q in zip(ps, pr):
+        assert rel_err(p, q) < 1e-6
+    sd = o1.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and sd["param_groups"][0]["lr"] == 1e-3
+
+
+def test_agents_train_step_and_checkpoint(tmp_path):
+    import sos_amd
+    from sos_amd import agent
+    from sos_amd.common import MyConfig
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+    B, T = 2, 89
+    x = spec_input(100 + B, B, T)
+    batch2 = {"mixed": x, "noise": silent_gate(x), "clean": spec_input(300, B, T) * 0.5,
+              "full_noise": x - spec_input(300, B, T) * 0.5}
+    det = dnet.get_network()
+    det.load_state_dict(onet.closed_form_state(onet.detector_spec(), seed=1))
+    ag1 = agent.DetectorAgent(det, lr=1e-3, model_dir=str(tmp_path))
+    label = (torch.from_numpy(hashed(301, (B, 60))) > 0).float()
+    losses = [float(ag1.train_func({"label": label, "audio": x})[1]["bce"]) for _ in range(4)]
+    print("detector bce over 4 steps", losses)
+    assert losses[-1] < losses[0]                       # same batch: Adam must reduce the loss
+    jm = jnet.get_network(MyConfig())
+    jm.load_state_dict(onet.closed_form_state(onet.joint_spec(), seed=2))
+    ag2 = agent.DenoiserAgent(jm, lr=1e-3, model_dir=str(tmp_path))
+    tot = []
+    for _ in range(3):
+        _, ls = ag2.train_func(batch2)
+        tot.append(float(ls["stage1"]) + float(ls["stage2"]))
+    print("denoiser loss over 3 steps", tot)
+    assert tot[-1] < tot[0]
+    # eval after training uses the UPDATED weights and running statistics
+    (n_pred, out), ls = ag2.val_func(batch2)
+    assert torch.isfinite(out).all() and torch.isfinite(n_pred).all()
+    ag2.clock.tick()
+    path = ag2.save_ckpt()
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck.keys()) == {"clock", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict"}
+    assert list(ck["model_state_dict"].keys()) == [k for k, _, _ in onet.joint_spec()]
+    assert ck["clock"] == {"epoch": 1, "minibatch": 1, "step": 1}
+    jm2 = jnet.get_network(MyConfig())
+    ag3 = agent.DenoiserAgent(jm2, lr=1e-3, model_dir=str(tmp_path))
+    ag3.load_ckpt(1)
+    (n2, o2), _ = ag3.val_func(batch2)
+    assert torch.equal(o2, out) and torch.equal(n2, n_pred)
+    with pytest.raises(ValueError):
+        ag3.load_ckpt(99)
