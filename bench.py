@@ -5,8 +5,11 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
 
 A "step" is one pass of the hot path over one batch of synthetic 2 s clips resident in HBM:
-  --mode infer : STFT -> detector -> bits->mask -> STFT(noise) -> JointModel -> mask apply -> ISTFT
-Each rank processes its own batch (independent utterances, no data-path collective): weak scaling.
+  --mode train (default, BASELINE.json configs[1]): detector forward/backward/Adam (BCE) AND denoiser
+               forward/backward/Adam (MSE + MSE through the mask apply) on the same B clips, bf16;
+               for N > 1 the gradients are averaged with bucketed RCCL all-reduces overlapped with backward
+  --mode infer: STFT -> detector -> bits->mask -> STFT(noise) -> JointModel -> mask apply -> ISTFT
+Each rank processes its own batch (independent utterances): weak scaling.
 """
 import argparse
 import json
@@ -62,7 +65,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
-    ap.add_argument("--mode", default="infer", choices=["infer"])
+    ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -78,7 +81,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import sos_amd
-    from sos_amd import engine, pipeline
+    from sos_amd import agent, engine, pipeline, tools, transform
     from sos_amd.common import MyConfig
     from sos_amd.dataset import synth_batch
     from sos_amd.denoiser import networks as jnet
@@ -92,8 +95,26 @@ def main():
     base = synth_batch(1000 * rank, min(B, 8))["mixed"]
     mixed = torch.from_numpy(np.tile(base, ((B + len(base) - 1) // len(base), 1))[:B]).cuda().contiguous()
 
-    def step():
-        return pipeline.denoise(det, jm, mixed)
+    if args.mode == "train":
+        # batch dicts of the reference schema (M1/dataset.py:348-352, M2/dataset.py:311-320), resident in HBM
+        raw = synth_batch(1000 * rank, min(B, 8))
+        rep = (B + len(raw["mixed"]) - 1) // len(raw["mixed"])
+        tile = lambda a: torch.from_numpy(np.tile(a, (rep, 1))[:B]).cuda().contiguous()   # noqa: E731
+        clean, full_noise, bits = tile(raw["clean"]), tile(raw["full_noise"]), tile(raw["bits"])
+        mask, noise_sig = tools.bits_to_mask_batch(bits, 14000 / 30.0, N_SAMPLES, mixed)
+        S = transform.stft_batch(torch.cat([mixed, clean * (1 - mask), noise_sig, full_noise]))
+        batch_jm = {"mixed": S[:B].contiguous(), "clean": S[B:2 * B].contiguous(), "noise": S[2 * B:3 * B].contiguous(),
+                    "full_noise": S[3 * B:].contiguous()}
+        batch_det = {"audio": batch_jm["mixed"], "label": bits.float()}
+        ag_det = agent.DetectorAgent(det.train(), lr=1e-3)
+        ag_jm = agent.DenoiserAgent(jm.train(), lr=1e-3)
+
+        def step():
+            ag_det.train_func(batch_det)
+            ag_jm.train_func(batch_jm)
+    else:
+        def step():
+            return pipeline.denoise(det, jm, mixed)
 
     def barrier():
         if dist is not None:
@@ -124,19 +145,25 @@ def main():
     if rank == 0:
         value = world * B * args.steps / dt
         ach = prof["flops"] / (prof["avg_ms"] * 1e-3) / 1e12
+        train = args.mode == "train"
+        gflop = GFLOP_PER_UTT_INFER * (3.0 if train else 1.0)
         line = {
-            "metric": "utterances/sec (2 s clips), inference pipeline STFT->detector->mask->denoiser->ISTFT",
+            "metric": "utterances/sec (2 s clips), " + ("training step: detector + denoiser forward/backward/Adam" if train
+                                                         else "inference pipeline STFT->detector->mask->denoiser->ISTFT"),
             "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"inference, batch={B} clips/GPU of 2 s @14 kHz (28000 samples, STFT 510/158/400 -> 2x256x178), "
-                                   "detector + two-stage denoiser, random-init weights (manual_seed 0)",
-                       "clips_per_gpu": B, "n_samples": N_SAMPLES,
+            "config": {"workload": ("training (BASELINE configs[1])" if train else "inference") +
+                                   f", batch={B} clips/GPU of 2 s @14 kHz (28000 samples, STFT 510/158/400 -> 2x256x178), "
+                                   "detector + two-stage denoiser, random-init weights (manual_seed 0)"
+                                   + (", detector BCE + denoiser 2xMSE, Adam lr 1e-3, per-rank BatchNorm" if train else ""),
+                       "clips_per_gpu": B, "n_samples": N_SAMPLES, "mode": args.mode,
                        "realtime_factor": value * N_SAMPLES / 14000.0,
-                       "end_to_end_tflops": value * GFLOP_PER_UTT_INFER / 1e3 / world},
+                       "end_to_end_tflops": value * gflop / 1e3 / world},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                         "kernel": "conv_mfma_kernel " + str(dom), "launches": prof["launches"],
+                         "kernel": ("wgrad_kernel " if dom[0] == "wgrad" else "conv_mfma_kernel ") + str(dom),
+                         "launches": prof["launches"],
                          "avg_ms": prof["avg_ms"], "flops_per_launch": prof["flops"]},
         }
         if world == 1 and not args.no_cpu_baseline:

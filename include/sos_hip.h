@@ -129,6 +129,9 @@ int sos_conv2d_fwd(const sos_conv_desc* desc /* host pointer */, sos_stream_t st
  * the shape was already tuned. */
 int sos_conv2d_tune(const sos_conv_desc* desc, int max_candidates, int iters, float* best_ms,
                     sos_stream_t stream);
+/* Save / load the tuned-tiling cache (host text file).  load returns the number of entries read. */
+int sos_conv2d_tune_save(const char* path);
+int sos_conv2d_tune_load(const char* path);
 
 /* ---- a7/a11 recurrent part of nn.LSTM(bidirectional=True), gate order i,f,g,o
  * (M1/networks.py:95,143-148; M2/networks.py:64,88).  The input projection
@@ -198,7 +201,7 @@ int sos_conv2d_wgrad(const sos_wgrad_desc* desc, sos_stream_t stream);
 /* ---- backward of the BatchNorm(+activation) / bias(+activation) tail of a conv block (autograd of
  * nn.BatchNorm2d + ReLU/PReLU in train mode).  dy: grad of the block output; x: raw conv output;
  * scale/shift/mean/invstd: from sos_bn_finalize (mean == invstd == NULL: no BatchNorm);
- * partial: f32 [sos_bn_stats_blocks(npix)][3][C]; coef: f32 [3][C] scratch.  Writes dgamma, dbeta
+ * partial: f32 [sos_bn_stats_blocks(npix)][3][C]; coef: f32 [4][C] scratch.  Writes dgamma, dbeta
  * (or the bias gradient), dslope[0] (PReLU) and dx = grad of the raw conv output. */
 int sos_bn_bwd(const sos_view* dy, const sos_view* x, const float* scale, const float* shift, const float* mean,
                const float* invstd, const float* gamma, int act, const float* slope, float* partial, float* coef,

@@ -62,6 +62,8 @@ SIGNATURES = {
     "sos_pack_nchw_to_nhwc": [_P, _L, _I, _L, _L, _P, _I, _I, _P],
     "sos_conv2d_fwd": [C.POINTER(ConvDesc), _P],
     "sos_conv2d_tune": [C.POINTER(ConvDesc), _I, _I, C.POINTER(C.c_float), _P],
+    "sos_conv2d_tune_save": [C.c_char_p],
+    "sos_conv2d_tune_load": [C.c_char_p],
     "sos_lstm_bidir_fwd": [_P, _P, _L, _L, _I, _P, _P, _I, _I, _L, _P, _P, _P],
     "sos_bn_bwd": [C.POINTER(View), C.POINTER(View), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(View), _P],
     "sos_act_bwd_from_y": [C.POINTER(View), C.POINTER(View), _I, C.POINTER(View), _P],

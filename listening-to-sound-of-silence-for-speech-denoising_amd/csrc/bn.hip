@@ -117,19 +117,29 @@ extern "C" int sos_bn_stats(const sos_view* x, float* partial, sos_stream_t stre
     return sos_check_launch("sos_bn_stats");
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+// one workgroup per channel: 256 threads stride over the per-workgroup partial sums (fixed order ->
+// deterministic), double accumulation, LDS tree.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
                                    long long* __restrict__ nbt, float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) nbt[0] += 1;
-    if (c >= C) return;
+    __shared__ double rs[256], rq[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = tid; b < nblk; b += 256) {
         s += (double)partial[((size_t)b * 2 + 0) * C + c];
         q += (double)partial[((size_t)b * 2 + 1) * C + c];
     }
+    rs[tid] = s; rq[tid] = q;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) { rs[tid] += rs[tid + st]; rq[tid] += rq[tid + st]; }
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    if (c == 0 && nbt) nbt[0] += 1;
+    s = rs[0]; q = rq[0];
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -149,7 +159,7 @@ extern "C" int sos_bn_finalize(const float* partial, int nblk, int C, int64_t co
                                int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
                                float* save_invstd, sos_stream_t stream) {
     if (!partial || !scale || !shift || nblk < 1 || C < 1 || count < 1) { sos_set_error("sos_bn_finalize: bad args"); return SOS_EINVAL; }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, nblk, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
                        (double)count, gamma, beta, eps, momentum, running_mean, running_var,
                        (long long*)num_batches_tracked, scale, shift, save_mean, save_invstd);
     return sos_check_launch("sos_bn_finalize");
@@ -162,22 +172,28 @@ __device__ __forceinline__ float apply_act(float z, int act, float slope) {
     return z;
 }
 
+// Elementwise passes: a thread keeps ONE 8-channel group for its whole pixel walk, so the per-channel
+// coefficients are loaded once into registers (per-element scalar loads made these passes
+// issue-bound at ~1.3 TB/s).
 __global__ __launch_bounds__(256) void bn_apply_kernel(View x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int act,
                                                        const float* __restrict__ slope_p, View y) {
     const int CG = (x.C + 7) / 8;
+    const int PL = 256 / CG;
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+    if (pl >= PL) return;
     const float slope = slope_p ? slope_p[0] : 0.f;
-    const long long total = x.npix * CG;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long pix = i / CG;
-        const int cg = (int)(i - pix * CG);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = min(cg * 8 + e, x.C - 1);
+        sc[e] = scale[c]; sh[e] = shift[c];
+    }
+    for (long long pix = (long long)blockIdx.x * PL + pl; pix < x.npix; pix += (long long)gridDim.x * PL) {
         float f[8];
         load8(x, pix, cg * 8, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = cg * 8 + e;
-            f[e] = c < x.C ? apply_act(fmaf(f[e], scale[c], shift[c]), act, slope) : 0.f;
-        }
+        for (int e = 0; e < 8; ++e) f[e] = (cg * 8 + e < x.C) ? apply_act(fmaf(f[e], sc[e], sh[e]), act, slope) : 0.f;
         store8(y, pix, cg * 8, f);
     }
 }
@@ -236,9 +252,9 @@ extern "C" int sos_bn_act_apply(const sos_view* x, const float* scale, const flo
     rc = check_view(y, "sos_bn_act_apply");
     if (rc) return rc;
     if (y->npix != x->npix || y->C < x->C) { sos_set_error("sos_bn_act_apply: view mismatch"); return SOS_EINVAL; }
-    const long long total = x->npix * ((x->C + 7) / 8);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, to_view(x), scale,
-                       shift, act, slope, to_view(y));
+    const int PLh = 256 / ((x->C + 7) / 8);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for((x->npix + PLh - 1) / PLh * 256)), dim3(256), 0, (hipStream_t)stream,
+                       to_view(x), scale, shift, act, slope, to_view(y));
     return sos_check_launch("sos_bn_act_apply");
 }
 
@@ -304,39 +320,50 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(View dy, View x, con
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dslope,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ s3out,
                                        float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc) {
-    __shared__ double s3sum[256];
-    const int tid = threadIdx.x;
-    double my3 = 0.0;
-    for (int c = tid; c < C; c += blockDim.x) {
-        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        for (int b = 0; b < nblk; ++b) {
-            s1 += (double)partial[((size_t)b * 3 + 0) * C + c];
-            s2 += (double)partial[((size_t)b * 3 + 1) * C + c];
-            s3 += (double)partial[((size_t)b * 3 + 2) * C + c];
-        }
-        my3 += s3;
-        if (dgamma) dgamma[c] = (float)s2;
-        if (dbeta) dbeta[c] = (float)s1;
-        if (invstd) {
-            const double a = (double)(gamma ? gamma[c] : 1.f) * (double)invstd[c];
-            ca[c] = (float)a;
-            cb[c] = (float)(-a * s2 / count);
-            cc[c] = (float)(-a * s1 / count);
-        } else {
-            ca[c] = 1.f; cb[c] = 0.f; cc[c] = 0.f;
-        }
+    __shared__ double r1[256], r2[256], r3[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int b = tid; b < nblk; b += 256) {
+        s1 += (double)partial[((size_t)b * 3 + 0) * C + c];
+        s2 += (double)partial[((size_t)b * 3 + 1) * C + c];
+        s3 += (double)partial[((size_t)b * 3 + 2) * C + c];
     }
-    s3sum[tid] = my3;
+    r1[tid] = s1; r2[tid] = s2; r3[tid] = s3;
     __syncthreads();
-    if (tid == 0 && dslope) {
-        double t = 0.0;
-        for (int i = 0; i < (int)blockDim.x; ++i) t += s3sum[i];
-        dslope[0] = (float)t;
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) { r1[tid] += r1[tid + st]; r2[tid] += r2[tid + st]; r3[tid] += r3[tid + st]; }
+        __syncthreads();
     }
+    if (tid != 0) return;
+    s1 = r1[0]; s2 = r2[0]; s3 = r3[0];
+    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
+    if (s3out) s3out[c] = (float)s3;            // per-channel PReLU slope partials, summed by the next kernel
+    if (invstd) {
+        const double a = (double)(gamma ? gamma[c] : 1.f) * (double)invstd[c];
+        ca[c] = (float)a;
+        cb[c] = (float)(-a * s2 / count);
+        cc[c] = (float)(-a * s1 / count);
+    } else {
+        ca[c] = 1.f; cb[c] = 0.f; cc[c] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void slope_sum_kernel(const float* __restrict__ s3, int C, float* __restrict__ dslope) {
+    __shared__ double r[256];
+    double t = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) t += (double)s3[c];
+    r[threadIdx.x] = t;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) r[threadIdx.x] += r[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dslope[0] = (float)r[0];
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View x, const float* __restrict__ scale,
@@ -347,25 +374,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View x, cons
                                                            const float* __restrict__ ca, const float* __restrict__ cb,
                                                            const float* __restrict__ cc, View dx) {
     const int CG = (x.C + 7) / 8;
+    const int PL = 256 / CG;
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+    if (pl >= PL) return;
     const float slope = slope_p ? slope_p[0] : 0.f;
-    const long long total = x.npix * CG;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long pix = i / CG;
-        const int cg = (int)(i - pix * CG);
+    float sc[8], sh[8], mu[8], is[8], a[8], b[8], c0[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = min(cg * 8 + e, x.C - 1);
+        sc[e] = scale[c]; sh[e] = shift[c];
+        mu[e] = mean ? mean[c] : 0.f; is[e] = mean ? invstd[c] : 0.f;
+        a[e] = ca[c]; b[e] = cb[c]; c0[e] = cc[c];
+    }
+    for (long long pix = (long long)blockIdx.x * PL + pl; pix < x.npix; pix += (long long)gridDim.x * PL) {
         float fx[8], fg[8], o[8];
         load8(x, pix, cg * 8, fx);
         load8(dy, pix, cg * 8, fg);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int c = cg * 8 + e;
-            if (c < x.C) {
-                const float z = fmaf(fx[e], scale[c], shift[c]);
-                const float dz = fg[e] * act_grad(z, act, slope);
-                const float xh = mean ? (fx[e] - mean[c]) * invstd[c] : 0.f;
-                o[e] = fmaf(ca[c], dz, fmaf(cb[c], xh, cc[c]));
-            } else {
-                o[e] = 0.f;
-            }
+            const float z = fmaf(fx[e], sc[e], sh[e]);
+            const float dz = fg[e] * act_grad(z, act, slope);
+            const float xh = (fx[e] - mu[e]) * is[e];
+            o[e] = (cg * 8 + e < x.C) ? fmaf(a[e], dz, fmaf(b[e], xh, c0[e])) : 0.f;
         }
         store8(dx, pix, cg * 8, o);
     }
@@ -373,7 +403,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View x, cons
 
 extern "C" int sos_bn_bwd(const sos_view* dy, const sos_view* x, const float* scale, const float* shift,
                           const float* mean, const float* invstd, const float* gamma, int act, const float* slope,
-                          float* partial, float* coef /* [3][C] */, float* dgamma, float* dbeta, float* dslope,
+                          float* partial, float* coef /* [4][C] */, float* dgamma, float* dbeta, float* dslope,
                           const sos_view* dx, sos_stream_t stream) {
     int rc = check_view(dy, "sos_bn_bwd");
     if (!rc) rc = check_view(x, "sos_bn_bwd");
@@ -389,11 +419,15 @@ extern "C" int sos_bn_bwd(const sos_view* dy, const sos_view* x, const float* sc
     const int C = x->C;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, s, to_view(dy), to_view(x), scale, shift, mean,
                        invstd, act, slope, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nblk, C, (double)x->npix, gamma, invstd,
-                       dgamma, dbeta, dslope, coef, coef + C, coef + 2 * C);
-    const long long total = x->npix * ((C + 7) / 8);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, to_view(dy), to_view(x), scale, shift,
-                       mean, invstd, act, slope, coef, coef + C, coef + 2 * C, to_view(dx));
+    // partial[0 .. C) of block 0's S1 row is dead after the finalize read it: reuse the head of the
+    // (nblk*3*C) partial buffer?  No -- keep it simple: the slope partials go to the tail of `coef`
+    // (caller sizes coef as [4][C]).
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, partial, nblk, C, (double)x->npix, gamma, invstd,
+                       dgamma, dbeta, dslope ? coef + 3 * C : nullptr, coef, coef + C, coef + 2 * C);
+    if (dslope) hipLaunchKernelGGL(slope_sum_kernel, dim3(1), dim3(256), 0, s, coef + 3 * C, C, dslope);
+    const int PLh = 256 / ((C + 7) / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((x->npix + PLh - 1) / PLh * 256)), dim3(256), 0, s, to_view(dy),
+                       to_view(x), scale, shift, mean, invstd, act, slope, coef, coef + C, coef + 2 * C, to_view(dx));
     return sos_check_launch("sos_bn_bwd");
 }
 

@@ -649,3 +649,35 @@ extern "C" int sos_conv2d_tune(const sos_conv_desc* d, int max_candidates, int i
     if (best_ms) *best_ms = best;
     return SOS_OK;
 }
+
+// Persist / restore the tuned tilings (text file: 18 shape ints + 4 config ints per line) so that
+// profiling and benchmark runs do not have to repeat the tuning launches.
+extern "C" int sos_conv2d_tune_save(const char* path) {
+    FILE* f = fopen(path, "w");
+    if (!f) { sos_set_error("sos_conv2d_tune_save: cannot open %s", path); return SOS_EINVAL; }
+    for (const auto& kv : tuned_cache()) {
+        for (int i = 0; i < 18; ++i) fprintf(f, "%d ", kv.first.v[i]);
+        fprintf(f, "%d %d %d %d\n", kv.second.NC, kv.second.lth, kv.second.ltw, kv.second.ks);
+    }
+    fclose(f);
+    return SOS_OK;
+}
+
+extern "C" int sos_conv2d_tune_load(const char* path) {
+    FILE* f = fopen(path, "r");
+    if (!f) return 0;                    // nothing cached yet
+    int n = 0;
+    for (;;) {
+        ShapeKey k;
+        ConvCfg c;
+        bool ok = true;
+        for (int i = 0; i < 18 && ok; ++i) ok = fscanf(f, "%d", &k.v[i]) == 1;
+        if (!ok || fscanf(f, "%d %d %d %d", &c.NC, &c.lth, &c.ltw, &c.ks) != 4) break;
+        c.cost = 0;
+        if (c.NC < 1 || c.lth < 0 || c.ltw < 0 || c.lth + c.ltw > 8 || c.ks < 1 || c.ks > 8) continue;
+        tuned_cache()[k] = c;
+        ++n;
+    }
+    fclose(f);
+    return n;
+}

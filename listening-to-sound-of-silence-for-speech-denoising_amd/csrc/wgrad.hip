@@ -22,8 +22,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define WG_MAXT 16            // accumulator tiles per wave
-#define WG_TH 8               // pixel tile: 8 x 32 (strided coordinates), 256 pixels per k-step
-#define WG_TW 32
+// pixel tile: NC residue classes x TH x TW (dilation-strided coordinates, like the forward kernel),
+// 256 pixels per k-step
 
 struct WgParams {
     const bf16_t* g;          // [B][Hg][Wg][g_cs]   (tile side, m channels)
@@ -33,9 +33,9 @@ struct WgParams {
     int M, N, Mp, Np;         // logical / padded-to-32 dims
     int kh, kw, stride, dh, dw, pad_t, pad_l, pad_mode;
     int NTB;                  // n-tiles (of 32) per workgroup
-    int tiles_h, tiles_w;     // pixel tiles per (image, residue class)
+    int tiles_h, tiles_w, ngw; // pixel tiles per (image, residue class group)
     int steps_per_split, nsteps, ksplit;
-    int PH, PW, npix;
+    int NC, logTH, logTW, PH, PW, npix;
 };
 
 __device__ __forceinline__ uint2 lds_tr(unsigned addr) {
@@ -75,14 +75,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgParams p) {
     const int step0 = split * p.steps_per_split;
     const int step1 = min(step0 + p.steps_per_split, p.nsteps);
     for (int step = step0; step < step1; ++step) {
-        // step -> (b, rh, rw, ti, tj)
+        // step -> (b, rh, gw, ti, tj)
         int t = step;
         const int tj = t % p.tiles_w; t /= p.tiles_w;
         const int ti = t % p.tiles_h; t /= p.tiles_h;
-        const int rw = t % p.dw; t /= p.dw;
+        const int gw = t % p.ngw; t /= p.ngw;
         const int rh = t % p.dh; t /= p.dh;
         const int b = t;
-        const int ho_base = rh + ti * WG_TH * p.dh, wo_base = rw + tj * WG_TW * p.dw;
+        const int TH = 1 << p.logTH, TW = 1 << p.logTW;
+        const int rw0 = gw * p.NC;
+        const int ho_base = rh + ti * TH * p.dh, wo_base = rw0 + tj * TW * p.dw;
         const int hin0 = ho_base * p.stride - p.pad_t, win0 = wo_base * p.stride - p.pad_l;
         __syncthreads();
         // ---- stage G tile: 256 pixels x 32 channels (4 pieces of 16 B per pixel)
@@ -91,11 +93,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgParams p) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int m = pl + 64 * u;
-                const int i = m / WG_TW, j = m - i * WG_TW;
-                const int h = ho_base + i * p.dh, w = wo_base + j * p.dw;
+                const int j = m & (TW - 1), i = (m >> p.logTW) & (TH - 1), cls = m >> (p.logTW + p.logTH);
+                const int h = ho_base + i * p.dh, w = wo_base + cls + j * p.dw;
                 // channels past M inside a stored 8-run are zero padding of the producer
                 const int ch = m0 + q * 8;
-                const bool ok = h < p.Hg && w < p.Wg && ch < p.M && p.g_off + ch + 8 <= p.g_cs;
+                const bool ok = h < p.Hg && w < p.Wg && (cls == 0 || rw0 + cls < p.dw) && ch < p.M && p.g_off + ch + 8 <= p.g_cs;
                 const int hc = min(h, p.Hg - 1), wc = min(w, p.Wg - 1);
                 const int cc = min(p.g_off + ch, p.g_cs - 8);
                 uint4 v = *(const uint4*)(p.g + (((long long)b * p.Hg + hc) * p.Wg + wc) * p.g_cs + cc);
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgParams p) {
                 *(uint4*)(gimg + m * GSTRIDE + q * 16) = v;
             }
         }
-        // ---- stage X patch: npix pixels x XC channels
+        // ---- stage X patch: NC x PH x PW pixels x XC channels
         {
             constexpr int PPP = 256 / XCPR;
             const int pl = tid / XCPR, cl = tid - pl * XCPR;
@@ -113,8 +115,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgParams p) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int pix = min(pix0 + PPP * u, p.npix - 1);
-                    const int c = pix % p.PW, r = pix / p.PW;
-                    int h = hin0 + r * p.dh, w = win0 + c * p.dw;
+                    const int c = pix % p.PW, rr = pix / p.PW;
+                    const int r = rr % p.PH, cls = rr / p.PH;
+                    int h = hin0 + r * p.dh, w = win0 + cls * p.stride + c * p.dw;
                     bool ok = reflect || (h >= 0 && h < p.Hx && w >= 0 && w < p.Wx);
                     h = reflect ? reflect_index(h, p.Hx) : min(max(h, 0), p.Hx - 1);
                     w = reflect ? reflect_index(w, p.Wx) : min(max(w, 0), p.Wx - 1);
@@ -135,13 +138,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgParams p) {
         // ---- 16 k-steps of 16 pixels; every wave walks its own list of (tap, n-tile) output tiles
 #pragma unroll 1
         for (int ks = 0; ks < 16; ++ks) {
-            // pixel of this lane's transpose-read rows: k = ks*16 + krow (+4): tile row i = k/32, col j = k%32
-            const int k0 = ks * 16 + krow;
-            const int i0 = k0 >> 5, j0 = k0 & 31;          // both reads stay in the same tile row (k0+4 < next 32)
+            // pixels of this lane's two transpose-read rows: k = ks*16 + krow and k + 4 -> (cls, i, j)
+            const int k0 = ks * 16 + krow, k1 = k0 + 4;
             const unsigned ga = gbase + k0 * GSTRIDE + chan_off;
             uint2 a0 = lds_tr(ga), a1 = lds_tr(ga + 4 * GSTRIDE);
-            const unsigned xa = xbase + ((i0 * p.stride) * p.PW + j0 * p.stride) * XSTRIDE + chan_off;
-            const unsigned xstep4 = 4 * p.stride * XSTRIDE;
+            const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTH) - 1, lsh = p.logTW + p.logTH;
+            const int pp0 = (((k0 >> lsh) * p.PH + ((k0 >> p.logTW) & THm) * p.stride) * p.PW + (k0 & TWm) * p.stride);
+            const int pp1 = (((k1 >> lsh) * p.PH + ((k1 >> p.logTW) & THm) * p.stride) * p.PW + (k1 & TWm) * p.stride);
+            const unsigned xa = xbase + pp0 * XSTRIDE + chan_off;
+            const unsigned xstep4 = (unsigned)((pp1 - pp0) * XSTRIDE);
             // the wait names its registers so that every consumer is ordered behind it
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");
             const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
@@ -234,19 +239,41 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     if (taps * ntb > WG_MAXT * 4) { sos_set_error("sos_conv2d_wgrad: kernel with %d taps not supported", taps); return SOS_ENOSPC; }
     p.NTB = ntb;
     const int Hc = (d->Hg + d->dil_h - 1) / d->dil_h, Wc = (d->Wg + d->dil_w - 1) / d->dil_w;
-    p.tiles_h = (Hc + WG_TH - 1) / WG_TH; p.tiles_w = (Wc + WG_TW - 1) / WG_TW;
-    p.nsteps = d->B * d->dil_h * d->dil_w * p.tiles_h * p.tiles_w;
+    // pixel tile (NC x TH x TW = 256): fewest k-steps (best utilisation of the 256 lanes-worth of pixels)
+    // among the shapes whose patch fits LDS with the current channel tile; shrink the channel tile if none
+    size_t lds = 0;
+    for (;;) {
+        double best = 1e300;
+        int bnc = 0, bth = 0, btw = 0;
+        for (int lnc = 0; lnc <= 6; ++lnc) {
+            const int NC = 1 << lnc;
+            if (NC > 1 && (d->stride > 1 || NC > d->dil_w)) break;
+            for (int lth = 0; lth + lnc <= 8; ++lth) {
+                const int ltw = 8 - lnc - lth;
+                if (ltw < 2) continue;                      // a transpose-read quad (4 pixels) stays inside one tile row
+                const int TH = 1 << lth, TW = 1 << ltw;
+                const int PH = (TH - 1) * d->stride + d->kh, PW = (TW - 1) * d->stride + d->kw;
+                const size_t need = (size_t)256 * (32 * 2 + 16) + (size_t)NC * PH * PW * (ntb * 64 + 16);
+                if (need > 160 * 1024) continue;
+                const double steps = (double)((Hc + TH - 1) / TH) * ((Wc + TW - 1) / TW) * ((d->dil_w + NC - 1) / NC);
+                const double cost = steps * (256.0 * taps + 4.0 * NC * PH * PW);
+                if (cost < best) { best = cost; bnc = NC; bth = lth; btw = ltw; lds = need; }
+            }
+        }
+        if (bnc) { p.NC = bnc; p.logTH = bth; p.logTW = btw; break; }
+        if (ntb == 1) { sos_set_error("sos_conv2d_wgrad: patch does not fit LDS"); return SOS_ENOSPC; }
+        ntb >>= 1;
+    }
+    p.NTB = ntb;
+    {
+        const int TH = 1 << p.logTH, TW = 1 << p.logTW;
+        p.tiles_h = (Hc + TH - 1) / TH; p.tiles_w = (Wc + TW - 1) / TW; p.ngw = (d->dil_w + p.NC - 1) / p.NC;
+        p.PH = (TH - 1) * d->stride + d->kh; p.PW = (TW - 1) * d->stride + d->kw;
+        p.npix = p.NC * p.PH * p.PW;
+    }
+    p.nsteps = d->B * d->dil_h * p.ngw * p.tiles_h * p.tiles_w;
     p.ksplit = d->ksplit;
     p.steps_per_split = (p.nsteps + d->ksplit - 1) / d->ksplit;
-    p.PH = (WG_TH - 1) * d->stride + d->kh; p.PW = (WG_TW - 1) * d->stride + d->kw;
-    p.npix = p.PH * p.PW;
-    size_t lds = (size_t)256 * (32 * 2 + 16) + (size_t)p.npix * (ntb * 64 + 16);
-    while (lds > 160 * 1024 && ntb > 1) {          // strided layers: fewer patch channels per workgroup
-        ntb >>= 1;
-        p.NTB = ntb;
-        lds = (size_t)256 * (32 * 2 + 16) + (size_t)p.npix * (ntb * 64 + 16);
-    }
-    if (lds > 160 * 1024) { sos_set_error("sos_conv2d_wgrad: patch does not fit LDS (%zu B)", lds); return SOS_ENOSPC; }
     dim3 grid((unsigned)d->ksplit, (unsigned)(p.Mp / 32), (unsigned)((ntiles_n + ntb - 1) / ntb));
     hipStream_t s = (hipStream_t)stream;
     static bool attr[5] = {false, false, false, false, false};

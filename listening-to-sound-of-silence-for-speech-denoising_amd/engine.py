@@ -43,6 +43,22 @@ PROFILER = None
 import os as _os
 AUTOTUNE = _os.environ.get("SOS_CONV_TUNE", "1") != "0"
 _tuned = set()
+# SOS_CONV_TUNE_CACHE=<file>: tuned tilings are loaded from / saved to this file, so that a second
+# process (e.g. a rocprofv3 run) starts with the tuned configuration and launches no tuning kernels.
+_TUNE_CACHE = _os.environ.get("SOS_CONV_TUNE_CACHE")
+_cache_loaded = False
+
+
+def _load_tune_cache():
+    global _cache_loaded, AUTOTUNE
+    if _cache_loaded or not _TUNE_CACHE:
+        return
+    _cache_loaded = True
+    n = L.lib().sos_conv2d_tune_load(_TUNE_CACHE.encode())
+    if n > 0 and _os.environ.get("SOS_CONV_TUNE_FROZEN", "0") == "1":
+        AUTOTUNE = False                      # profile runs: use the cached tilings only
+    import atexit
+    atexit.register(lambda: L.lib().sos_conv2d_tune_save(_TUNE_CACHE.encode()))
 
 
 def pad_to(x, m):
@@ -149,6 +165,7 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
     d.act = act
     d.act_param = slope.data_ptr() if slope is not None else None
     d.accumulate = 1 if accumulate else 0
+    _load_tune_cache()
     if AUTOTUNE:
         key = (B, H, W, d.Wl, cin, d.in_nseg, d.cout_pad, kh, kw, stride, dil, Ho, Wo, out_dtype, sc == 1, pad_mode,
                w_gather is not None)
@@ -300,5 +317,11 @@ def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0,
         d.dw = dw.data_ptr()
         d.accumulate = 1 if (accumulate or not first) else 0
         d.scale = scale
+        end = None
+        if PROFILER is not None:
+            sig = ("wgrad", kh, kw, dil[0], dil[1], stride, M, N, g.B, g.H, g.W)
+            end = PROFILER.bracket(sig, 2.0 * g.B * g.H * g.W * M * N * kh * kw)
         L.check(L.lib().sos_conv2d_wgrad(ctypes.byref(d), L.stream_ptr()), "sos_conv2d_wgrad")
+        if end is not None:
+            end.record()
         first = False

@@ -50,7 +50,7 @@ def bn_bwd(dy, dy_off, raw, raw_off, C, saved, gamma, act, slope, dx, dx_off=0):
     dyv, xv, dxv = E.view(dy, dy_off, C), E.view(raw, raw_off, C), E.view(dx, dx_off, C)
     nblk = L.lib().sos_bn_stats_blocks(xv.npix)
     partial = torch.empty((nblk, 3, C), dtype=torch.float32, device=dev)
-    coef = torch.empty((3, C), dtype=torch.float32, device=dev)
+    coef = torch.empty((4, C), dtype=torch.float32, device=dev)
     dgamma = torch.empty(C, dtype=torch.float32, device=dev)
     dbeta = torch.empty(C, dtype=torch.float32, device=dev)
     dslope = torch.empty(1, dtype=torch.float32, device=dev) if slope is not None else None
