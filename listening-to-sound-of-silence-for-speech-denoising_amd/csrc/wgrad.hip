@@ -21,7 +21,10 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define WG_MAXT 16            // accumulator tiles per wave
+#define WG_MAXT 4             // accumulator tiles per wave (64 registers: two 8-wave workgroups per CU,
+                              // so one workgroup's operand staging overlaps the other's MFMAs)
+#define WG_WAVES 8            // waves per workgroup (512 threads)
+#define WG_THREADS (WG_WAVES * 64)
 // pixel tile: NC residue classes x TH x TW (dilation-strided coordinates, like the forward kernel),
 // 256 pixels per k-step
 
@@ -45,10 +48,12 @@ __device__ __forceinline__ uint2 lds_tr(unsigned addr) {
 }
 
 template <int NTB>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgParams p) {
+__global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     constexpr int XC = NTB * 32;                // patch channels held in LDS
-    constexpr int XSTRIDE = XC * 2 + 16;        // bytes per patch pixel (padded)
-    constexpr int GSTRIDE = 32 * 2 + 16;        // bytes per tile pixel of G (32 channels)
+    // Row pitches chosen for the ds_read_b64_tr_b16 access: a 32-lane half reads 4 pixel rows x 64 B;
+    // pitch/4 = 16 or 48 (mod 64) dwords puts the 4 rows on disjoint 16-bank windows (conflict free).
+    constexpr int XSTRIDE = NTB == 1 ? 64 : (NTB == 2 ? 192 : 320);   // bytes per patch pixel
+    constexpr int GSTRIDE = 64;                 // bytes per tile pixel of G (32 channels, no padding)
     constexpr int XCPR = XC / 8;                // 16-byte pieces per patch pixel
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* gimg = smem;                                   // [256][GSTRIDE]
@@ -74,105 +79,131 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgParams p) {
 
     const int step0 = split * p.steps_per_split;
     const int step1 = min(step0 + p.steps_per_split, p.nsteps);
-    for (int step = step0; step < step1; ++step) {
-        // step -> (b, rh, gw, ti, tj)
+    const int TH = 1 << p.logTH, TW = 1 << p.logTW;
+    const int TWm = TW - 1, THm = TH - 1, lsh = p.logTW + p.logTH;
+    const bool reflect = p.pad_mode == SOS_PAD_REFLECT;
+    constexpr int GPF = 1024 / WG_THREADS;        // G pieces per thread (256 px x 4 pieces)
+    constexpr int XPF = 8;                        // X pieces per thread fetched ahead (rest: synchronous)
+
+    // global -> register fetch of one k-step's operands (issued one step ahead: the loads land while
+    // the MFMAs of the current step run; the LDS images are rewritten after the step's barrier)
+    auto fetch = [&](int step, uint4 (&gq)[GPF], uint4 (&xq)[XPF], int first_piece, bool sync_rest) {
         int t = step;
         const int tj = t % p.tiles_w; t /= p.tiles_w;
         const int ti = t % p.tiles_h; t /= p.tiles_h;
         const int gw = t % p.ngw; t /= p.ngw;
         const int rh = t % p.dh; t /= p.dh;
         const int b = t;
-        const int TH = 1 << p.logTH, TW = 1 << p.logTW;
         const int rw0 = gw * p.NC;
         const int ho_base = rh + ti * TH * p.dh, wo_base = rw0 + tj * TW * p.dw;
         const int hin0 = ho_base * p.stride - p.pad_t, win0 = wo_base * p.stride - p.pad_l;
-        __syncthreads();
-        // ---- stage G tile: 256 pixels x 32 channels (4 pieces of 16 B per pixel)
-        {
-            const int pl = tid >> 2, q = tid & 3;
+        if (!sync_rest) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int m = pl + 64 * u;
-                const int j = m & (TW - 1), i = (m >> p.logTW) & (TH - 1), cls = m >> (p.logTW + p.logTH);
+            for (int u = 0; u < GPF; ++u) {
+                const int m = (tid >> 2) + (WG_THREADS / 4) * u, q = tid & 3;
+                const int j = m & TWm, i = (m >> p.logTW) & THm, cls = m >> lsh;
                 const int h = ho_base + i * p.dh, w = wo_base + cls + j * p.dw;
-                // channels past M inside a stored 8-run are zero padding of the producer
-                const int ch = m0 + q * 8;
+                const int ch = m0 + q * 8;      // channels past M inside a stored 8-run are the producer's zero padding
                 const bool ok = h < p.Hg && w < p.Wg && (cls == 0 || rw0 + cls < p.dw) && ch < p.M && p.g_off + ch + 8 <= p.g_cs;
                 const int hc = min(h, p.Hg - 1), wc = min(w, p.Wg - 1);
                 const int cc = min(p.g_off + ch, p.g_cs - 8);
                 uint4 v = *(const uint4*)(p.g + (((long long)b * p.Hg + hc) * p.Wg + wc) * p.g_cs + cc);
-                if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
-                *(uint4*)(gimg + m * GSTRIDE + q * 16) = v;
+                gq[u] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
             }
         }
-        // ---- stage X patch: NC x PH x PW pixels x XC channels
-        {
-            constexpr int PPP = 256 / XCPR;
-            const int pl = tid / XCPR, cl = tid - pl * XCPR;
-            const bool reflect = p.pad_mode == SOS_PAD_REFLECT;
-            for (int pix0 = pl; pix0 < p.npix; pix0 += PPP * 4) {
-                uint4 v[4];
+        const int npieces = p.npix * XCPR;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int pix = min(pix0 + PPP * u, p.npix - 1);
-                    const int c = pix % p.PW, rr = pix / p.PW;
-                    const int r = rr % p.PH, cls = rr / p.PH;
-                    int h = hin0 + r * p.dh, w = win0 + cls * p.stride + c * p.dw;
-                    bool ok = reflect || (h >= 0 && h < p.Hx && w >= 0 && w < p.Wx);
-                    h = reflect ? reflect_index(h, p.Hx) : min(max(h, 0), p.Hx - 1);
-                    w = reflect ? reflect_index(w, p.Wx) : min(max(w, 0), p.Wx - 1);
-                    const int ch = n0 + cl * 8;
-                    ok = ok && ch < p.N && p.x_off + ch + 8 <= p.x_cs;
-                    const int cc = min(p.x_off + ch, p.x_cs - 8);
-                    v[u] = *(const uint4*)(p.x + (((long long)b * p.Hx + h) * p.Wx + w) * p.x_cs + cc);
-                    if (!ok) v[u] = make_uint4(0u, 0u, 0u, 0u);
-                }
+        for (int u = 0; u < XPF; ++u) {
+            const int piece = first_piece + tid + WG_THREADS * u;
+            const int pc = min(piece, npieces - 1);
+            const int pix = pc / XCPR, cl = pc - pix * XCPR;
+            const int c = pix % p.PW, rr = pix / p.PW;
+            const int r = rr % p.PH, cls = rr / p.PH;
+            int h = hin0 + r * p.dh, w = win0 + cls * p.stride + c * p.dw;
+            bool ok = reflect || (h >= 0 && h < p.Hx && w >= 0 && w < p.Wx);
+            h = reflect ? reflect_index(h, p.Hx) : min(max(h, 0), p.Hx - 1);
+            w = reflect ? reflect_index(w, p.Wx) : min(max(w, 0), p.Wx - 1);
+            const int ch = n0 + cl * 8;
+            ok = ok && ch < p.N && p.x_off + ch + 8 <= p.x_cs;
+            const int cc = min(p.x_off + ch, p.x_cs - 8);
+            const uint4 v = *(const uint4*)(p.x + (((long long)b * p.Hx + h) * p.Wx + w) * p.x_cs + cc);
+            xq[u] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto put = [&](const uint4 (&gq)[GPF], const uint4 (&xq)[XPF], int first_piece, bool with_g) {
+        if (with_g) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int pix = pix0 + PPP * u;
-                    if (pl < PPP && pix < p.npix) *(uint4*)(ximg + pix * XSTRIDE + cl * 16) = v[u];
-                }
+            for (int u = 0; u < GPF; ++u) {
+                const int m = (tid >> 2) + (WG_THREADS / 4) * u, q = tid & 3;
+                *(uint4*)(gimg + m * GSTRIDE + q * 16) = gq[u];
             }
+        }
+        const int npieces = p.npix * XCPR;
+#pragma unroll
+        for (int u = 0; u < XPF; ++u) {
+            const int piece = first_piece + tid + WG_THREADS * u;
+            if (piece < npieces) {
+                const int pix = piece / XCPR, cl = piece - pix * XCPR;
+                *(uint4*)(ximg + pix * XSTRIDE + cl * 16) = xq[u];
+            }
+        }
+    };
+
+    for (int step = step0; step < step1; ++step) {
+        __syncthreads();                              // previous step's LDS reads are done
+        {
+            uint4 gq[GPF], xq[XPF];
+            fetch(step, gq, xq, 0, false);
+            put(gq, xq, 0, true);
+        }
+        // patches larger than XPF pieces per thread: the remainder is fetched synchronously
+        for (int fp = WG_THREADS * XPF; fp < p.npix * XCPR; fp += WG_THREADS * XPF) {
+            uint4 g2[GPF], x2[XPF];
+            fetch(step, g2, x2, fp, true);
+            put(g2, x2, fp, false);
         }
         __syncthreads();
         // ---- 16 k-steps of 16 pixels; every wave walks its own list of (tap, n-tile) output tiles
+        unsigned toff[1][4];
+#pragma unroll
+        for (int g = 0; g < 1; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tl = min(wave + WG_WAVES * (4 * g + u), ntl - 1);
+                const int tap = tl / NTB, nt = tl - tap * NTB;
+                const int ta = tap / p.kw, tb = tap - ta * p.kw;
+                toff[g][u] = (unsigned)((ta * p.PW + tb) * XSTRIDE + nt * 64);
+            }
 #pragma unroll 1
         for (int ks = 0; ks < 16; ++ks) {
-            // pixels of this lane's two transpose-read rows: k = ks*16 + krow and k + 4 -> (cls, i, j)
             const int k0 = ks * 16 + krow, k1 = k0 + 4;
             const unsigned ga = gbase + k0 * GSTRIDE + chan_off;
             uint2 a0 = lds_tr(ga), a1 = lds_tr(ga + 4 * GSTRIDE);
-            const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTH) - 1, lsh = p.logTW + p.logTH;
             const int pp0 = (((k0 >> lsh) * p.PH + ((k0 >> p.logTW) & THm) * p.stride) * p.PW + (k0 & TWm) * p.stride);
             const int pp1 = (((k1 >> lsh) * p.PH + ((k1 >> p.logTW) & THm) * p.stride) * p.PW + (k1 & TWm) * p.stride);
             const unsigned xa = xbase + pp0 * XSTRIDE + chan_off;
-            const unsigned xstep4 = (unsigned)((pp1 - pp0) * XSTRIDE);
-            // the wait names its registers so that every consumer is ordered behind it
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");
+            const unsigned xs = (unsigned)((pp1 - pp0) * XSTRIDE);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1));
             const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
 #pragma unroll
-            for (int tg = 0; tg < WG_MAXT / 4; ++tg) {
-                if (wave + 16 * tg >= ntl) break;              // wave-uniform
+            for (int g = 0; g < WG_MAXT / 4; ++g) {
+                if (wave + 4 * WG_WAVES * g >= ntl) break;          // wave-uniform
                 uint2 b0[4], b1[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int tl = min(wave + 4 * (4 * tg + u), ntl - 1);
-                    const int tap = tl / NTB, nt = tl - tap * NTB;
-                    const int ta = tap / p.kw, tb = tap - ta * p.kw;
-                    const unsigned xo = xa + (ta * p.PW + tb) * XSTRIDE + nt * 64;
-                    b0[u] = lds_tr(xo);
-                    b1[u] = lds_tr(xo + xstep4);
+                    b0[u] = lds_tr(xa + toff[g][u]);
+                    b1[u] = lds_tr(xa + toff[g][u] + xs);
                 }
+                // the wait names its registers so that every consumer is ordered behind it
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2]), "+v"(b0[3]), "+v"(b1[3])
-                             :: "memory");
+                             );
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (wave + 4 * (4 * tg + u) < ntl) {
+                for (int u = 0; u < 4; ++u)
+                    if (wave + WG_WAVES * (4 * g + u) < ntl) {
                         const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(b0[u].x, b0[u].y, b1[u].x, b1[u].y));
-                        acc[4 * tg + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[4 * tg + u], 0, 0, 0);
+                        acc[4 * g + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[4 * g + u], 0, 0, 0);
                     }
-                }
             }
         }
     }
@@ -180,7 +211,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgParams p) {
     float* out = p.partial + (size_t)split * taps * p.Mp * p.Np;
 #pragma unroll
     for (int tt = 0; tt < WG_MAXT; ++tt) {
-        const int tl = wave + 4 * tt;
+        const int tl = wave + WG_WAVES * tt;
         if (tl >= ntl) continue;
         const int tap = tl / NTB, nt = tl - tap * NTB;
         const int n = n0 + nt * 32 + (lane & 31);
@@ -230,13 +261,13 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.dh = d->dil_h; p.dw = d->dil_w;
     p.pad_t = d->pad_top; p.pad_l = d->pad_left; p.pad_mode = d->pad_mode;
     const int taps = d->kh * d->kw;
-    int ntb = WG_MAXT * 4 / taps;                 // tiles per workgroup <= 64
+    int ntb = WG_MAXT * WG_WAVES / taps;          // tiles per workgroup <= 64
     if (ntb > 4) ntb = 4;
     if (ntb < 1) ntb = 1;
     if (ntb == 3) ntb = 2;
     const int ntiles_n = p.Np / 32;
     if (ntb > ntiles_n) ntb = ntiles_n >= 4 ? 4 : (ntiles_n >= 2 ? 2 : 1);
-    if (taps * ntb > WG_MAXT * 4) { sos_set_error("sos_conv2d_wgrad: kernel with %d taps not supported", taps); return SOS_ENOSPC; }
+    if (taps * ntb > WG_MAXT * WG_WAVES) { sos_set_error("sos_conv2d_wgrad: kernel with %d taps not supported", taps); return SOS_ENOSPC; }
     p.NTB = ntb;
     const int Hc = (d->Hg + d->dil_h - 1) / d->dil_h, Wc = (d->Wg + d->dil_w - 1) / d->dil_w;
     // pixel tile (NC x TH x TW = 256): fewest k-steps (best utilisation of the 256 lanes-worth of pixels)
@@ -253,7 +284,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
                 if (ltw < 2) continue;                      // a transpose-read quad (4 pixels) stays inside one tile row
                 const int TH = 1 << lth, TW = 1 << ltw;
                 const int PH = (TH - 1) * d->stride + d->kh, PW = (TW - 1) * d->stride + d->kw;
-                const size_t need = (size_t)256 * (32 * 2 + 16) + (size_t)NC * PH * PW * (ntb * 64 + 16);
+                const size_t need = (size_t)256 * 64 + (size_t)NC * PH * PW * (ntb == 1 ? 64 : (ntb == 2 ? 192 : 320));
                 if (need > 160 * 1024) continue;
                 const double steps = (double)((Hc + TH - 1) / TH) * ((Wc + TW - 1) / TW) * ((d->dil_w + NC - 1) / NC);
                 const double cost = steps * (256.0 * taps + 4.0 * NC * PH * PW);
@@ -283,7 +314,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
             (void)hipFuncSetAttribute((const void*)wgrad_kernel<NTBV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr[NTBV] = true;                                                                                      \
         }                                                                                                           \
-        hipLaunchKernelGGL(wgrad_kernel<NTBV>, grid, dim3(256), lds, s, p);                                         \
+        hipLaunchKernelGGL(wgrad_kernel<NTBV>, grid, dim3(WG_THREADS), lds, s, p);                                         \
     }
     if (ntb == 1) SOS_WG_LAUNCH(1) else if (ntb == 2) SOS_WG_LAUNCH(2) else SOS_WG_LAUNCH(4)
 #undef SOS_WG_LAUNCH
