@@ -147,6 +147,15 @@ def main():
         ach = prof["flops"] / (prof["avg_ms"] * 1e-3) / 1e12
         train = args.mode == "train"
         gflop = GFLOP_PER_UTT_INFER * (3.0 if train else 1.0)
+        # HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs, FETCH_SIZE doubled per the gfx950 correction); null when the signature has no PMC record
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv96.json")))
+            if dom[0] == "conv" and tuple(dom[1:8]) == (5, 5, 1, 1, 1, 96, 96) and dom[8] == 64:
+                traffic = pmc["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         line = {
             "metric": "utterances/sec (2 s clips), " + ("training step: detector + denoiser forward/backward/Adam" if train
                                                          else "inference pipeline STFT->detector->mask->denoiser->ISTFT"),
@@ -161,7 +170,7 @@ def main():
                        "realtime_factor": value * N_SAMPLES / 14000.0,
                        "end_to_end_tflops": value * gflop / 1e3 / world},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "kernel": ("wgrad_kernel " if dom[0] == "wgrad" else "conv_mfma_kernel ") + str(dom),
                          "launches": prof["launches"],
                          "avg_ms": prof["avg_ms"], "flops_per_launch": prof["flops"]},
