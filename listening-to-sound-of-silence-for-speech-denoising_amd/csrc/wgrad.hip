@@ -21,12 +21,9 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define WG_MAXT 4             // accumulator tiles per wave (64 registers: two 8-wave workgroups per CU,
-                              // so one workgroup's operand staging overlaps the other's MFMAs)
-#define WG_WAVES 8            // waves per workgroup (512 threads)
+#define WG_WAVES 8            // waves per workgroup (512 threads, two per SIMD)
 #define WG_THREADS (WG_WAVES * 64)
-// pixel tile: NC residue classes x TH x TW (dilation-strided coordinates, like the forward kernel),
-// 256 pixels per k-step
+#define WG_PAIRS 4            // (tap, n-tile) pairs per wave; x MT m-tiles = accumulator tiles per wave
 
 struct WgParams {
     const bf16_t* g;          // [B][Hg][Wg][g_cs]   (tile side, m channels)
@@ -35,10 +32,12 @@ struct WgParams {
     int B, Hg, Wg, g_cs, g_off, Hx, Wx, x_cs, x_off;
     int M, N, Mp, Np;         // logical / padded-to-32 dims
     int kh, kw, stride, dh, dw, pad_t, pad_l, pad_mode;
-    int NTB;                  // n-tiles (of 32) per workgroup
     int tiles_h, tiles_w, ngw; // pixel tiles per (image, residue class group)
     int steps_per_split, nsteps, ksplit;
     int NC, logTH, logTW, PH, PW, npix;
+    int dbuf, ppk;            // LDS double buffering on/off; staging pieces per thread per k-step
+    int dbg;                  // SOS_WGRAD_DBG ablation mask (0 in production)
+    unsigned magic_pw, magic_ph; // ceil(2^32 / PW), ceil(2^32 / PH): exact division of small indices by mulhi
 };
 
 __device__ __forceinline__ uint2 lds_tr(unsigned addr) {
@@ -47,179 +46,200 @@ __device__ __forceinline__ uint2 lds_tr(unsigned addr) {
     return v;
 }
 
-template <int NTB>
+// Workgroup = MT m-tiles (32 rows of dW each) x NTB n-tiles x all taps, 8 waves.  Wave w owns the
+// (tap, n-tile) pairs {w, w+8, w+16, w+24} for ALL MT m-tiles, so every transposed X fragment feeds
+// MT MFMAs and every G fragment WG_PAIRS of them (LDS reads per MFMA ~1.2 instead of 2.5).
+// The operands of the NEXT pixel tile are fetched 1/16th per k-step into the other LDS buffer while
+// the MFMAs of the current tile run.
+template <int MT, int NTB>
 __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
-    constexpr int XC = NTB * 32;                // patch channels held in LDS
-    // Row pitches chosen for the ds_read_b64_tr_b16 access: a 32-lane half reads 4 pixel rows x 64 B;
-    // pitch/4 = 16 or 48 (mod 64) dwords puts the 4 rows on disjoint 16-bank windows (conflict free).
-    constexpr int XSTRIDE = NTB == 1 ? 64 : (NTB == 2 ? 192 : 320);   // bytes per patch pixel
-    constexpr int GSTRIDE = 64;                 // bytes per tile pixel of G (32 channels, no padding)
-    constexpr int XCPR = XC / 8;                // 16-byte pieces per patch pixel
+    constexpr int XC = NTB * 32, GC = MT * 32;
+    // Row pitches chosen for ds_read_b64_tr_b16: a 32-lane half reads 4 pixel rows x 64 B; pitch/4 = 16 or
+    // 48 (mod 64) dwords puts the 4 rows on disjoint 16-bank windows (conflict free).
+    constexpr int XSTRIDE = NTB == 1 ? 64 : (NTB == 2 ? 192 : 320);
+    constexpr int GSTRIDE = MT == 1 ? 64 : 192;
+    constexpr int XCPR = XC / 8, GCPR = GC / 8;          // 16-byte pieces per pixel
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* gimg = smem;                                   // [256][GSTRIDE]
-    char* ximg = smem + 256 * GSTRIDE;                   // [npix][XSTRIDE]
-    const unsigned gbase = (unsigned)(uintptr_t)gimg, xbase = (unsigned)(uintptr_t)ximg;
+    const int gbytes = 256 * GSTRIDE;
+    const int bufbytes = gbytes + p.npix * XSTRIDE;
+    const unsigned sbase = (unsigned)(uintptr_t)smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int split = blockIdx.x, mt = blockIdx.y, ng = blockIdx.z;
-    const int m0 = mt * 32, n0 = ng * XC;
+    const int split = blockIdx.x;
+    const int m0 = blockIdx.y * GC, n0 = blockIdx.z * XC;
     const int taps = p.kh * p.kw;
-    const int ntl = taps * NTB;                          // 32x32 output tiles of this workgroup
-    // per-lane geometry of the transpose read: 16-lane group g4, in-group lane s
+    const int npairs = taps * NTB;
     const int g4 = lane >> 4, s = lane & 15;
-    const int chan_off = (16 * (g4 & 1) + 4 * (s & 3)) * 2;      // byte offset of the 4-channel run
-    const int krow = 8 * (g4 >> 1) + (s >> 2);                   // pixel (k) row inside a 16-pixel k-step; +4 for 2nd read
-
-    f32x16 acc[WG_MAXT];
-#pragma unroll
-    for (int t = 0; t < WG_MAXT; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-
-    const int step0 = split * p.steps_per_split;
-    const int step1 = min(step0 + p.steps_per_split, p.nsteps);
+    const int chan_off = (16 * (g4 & 1) + 4 * (s & 3)) * 2;      // byte offset of this lane's 4-channel run
+    const int krow = 8 * (g4 >> 1) + (s >> 2);                   // pixel (k) inside a 16-pixel k-step; +4 for 2nd read
     const int TH = 1 << p.logTH, TW = 1 << p.logTW;
     const int TWm = TW - 1, THm = TH - 1, lsh = p.logTW + p.logTH;
     const bool reflect = p.pad_mode == SOS_PAD_REFLECT;
-    constexpr int GPF = 1024 / WG_THREADS;        // G pieces per thread (256 px x 4 pieces)
-    constexpr int XPF = 8;                        // X pieces per thread fetched ahead (rest: synchronous)
+    const int ngp = 256 * GCPR, npieces = ngp + p.npix * XCPR;
 
-    // global -> register fetch of one k-step's operands (issued one step ahead: the loads land while
-    // the MFMAs of the current step run; the LDS images are rewritten after the step's barrier)
-    auto fetch = [&](int step, uint4 (&gq)[GPF], uint4 (&xq)[XPF], int first_piece, bool sync_rest) {
+    f32x16 acc[MT][WG_PAIRS];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int t = 0; t < WG_PAIRS; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][t][e] = 0.f;
+
+    // per-wave offsets of its pairs inside the X image (tap shift + n-tile)
+    unsigned toff[WG_PAIRS];
+#pragma unroll
+    for (int u = 0; u < WG_PAIRS; ++u) {
+        const int pr = min(wave + WG_WAVES * u, npairs - 1);
+        const int tap = pr / NTB, nt = pr - tap * NTB;
+        const int ta = tap / p.kw, tb = tap - ta * p.kw;
+        toff[u] = (unsigned)((ta * p.PW + tb) * XSTRIDE + nt * 64);
+    }
+
+    // tile origin of pixel tile `step` (wave-uniform, computed once per tile)
+    struct Origin { int b, rw0, ho_base, wo_base, hin0, win0; };
+    auto origin_of = [&](int step) {
         int t = step;
         const int tj = t % p.tiles_w; t /= p.tiles_w;
         const int ti = t % p.tiles_h; t /= p.tiles_h;
         const int gw = t % p.ngw; t /= p.ngw;
         const int rh = t % p.dh; t /= p.dh;
-        const int b = t;
-        const int rw0 = gw * p.NC;
-        const int ho_base = rh + ti * TH * p.dh, wo_base = rw0 + tj * TW * p.dw;
-        const int hin0 = ho_base * p.stride - p.pad_t, win0 = wo_base * p.stride - p.pad_l;
-        if (!sync_rest) {
-#pragma unroll
-            for (int u = 0; u < GPF; ++u) {
-                const int m = (tid >> 2) + (WG_THREADS / 4) * u, q = tid & 3;
-                const int j = m & TWm, i = (m >> p.logTW) & THm, cls = m >> lsh;
-                const int h = ho_base + i * p.dh, w = wo_base + cls + j * p.dw;
-                const int ch = m0 + q * 8;      // channels past M inside a stored 8-run are the producer's zero padding
-                const bool ok = h < p.Hg && w < p.Wg && (cls == 0 || rw0 + cls < p.dw) && ch < p.M && p.g_off + ch + 8 <= p.g_cs;
-                const int hc = min(h, p.Hg - 1), wc = min(w, p.Wg - 1);
-                const int cc = min(p.g_off + ch, p.g_cs - 8);
-                uint4 v = *(const uint4*)(p.g + (((long long)b * p.Hg + hc) * p.Wg + wc) * p.g_cs + cc);
-                gq[u] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
-        const int npieces = p.npix * XCPR;
-#pragma unroll
-        for (int u = 0; u < XPF; ++u) {
-            const int piece = first_piece + tid + WG_THREADS * u;
-            const int pc = min(piece, npieces - 1);
+        Origin o;
+        o.b = t; o.rw0 = gw * p.NC;
+        o.ho_base = rh + ti * TH * p.dh; o.wo_base = o.rw0 + tj * TW * p.dw;
+        o.hin0 = o.ho_base * p.stride - p.pad_t; o.win0 = o.wo_base * p.stride - p.pad_l;
+        return o;
+    };
+    // one 16-byte staging piece of a pixel tile: value + LDS byte offset inside a buffer.  Index
+    // decoding uses shifts / constant divisors / mulhi magic numbers only (it runs once per k-step
+    // next to the MFMAs and must stay a handful of VALU instructions).
+    auto fetch_piece = [&](const Origin& o, int id, uint4& v, int& dst) {
+        const int idc = min(id, npieces - 1);
+        if (idc < ngp) {
+            const int m = idc / GCPR, q = idc - m * GCPR;
+            const int j = m & TWm, i = (m >> p.logTW) & THm, cls = m >> lsh;
+            const int h = o.ho_base + i * p.dh, w = o.wo_base + cls + j * p.dw;
+            const int ch = m0 + q * 8;          // channels past M inside a stored 8-run are the producer's zero padding
+            const bool ok = h < p.Hg && w < p.Wg && (cls == 0 || o.rw0 + cls < p.dw) && ch < p.M && p.g_off + ch + 8 <= p.g_cs;
+            const int hc = min(h, p.Hg - 1), wc = min(w, p.Wg - 1);
+            const int cc = min(p.g_off + ch, p.g_cs - 8);
+            const uint4 r = *(const uint4*)(p.g + (((long long)o.b * p.Hg + hc) * p.Wg + wc) * p.g_cs + cc);
+            v = ok ? r : make_uint4(0u, 0u, 0u, 0u);
+            dst = m * GSTRIDE + q * 16;
+        } else {
+            const int pc = idc - ngp;
             const int pix = pc / XCPR, cl = pc - pix * XCPR;
-            const int c = pix % p.PW, rr = pix / p.PW;
-            const int r = rr % p.PH, cls = rr / p.PH;
-            int h = hin0 + r * p.dh, w = win0 + cls * p.stride + c * p.dw;
+            const int rr = (int)__umulhi((unsigned)pix, p.magic_pw), c = pix - rr * p.PW;
+            const int cls = (int)__umulhi((unsigned)rr, p.magic_ph), r = rr - cls * p.PH;
+            int h = o.hin0 + r * p.dh, w = o.win0 + cls * p.stride + c * p.dw;
             bool ok = reflect || (h >= 0 && h < p.Hx && w >= 0 && w < p.Wx);
             h = reflect ? reflect_index(h, p.Hx) : min(max(h, 0), p.Hx - 1);
             w = reflect ? reflect_index(w, p.Wx) : min(max(w, 0), p.Wx - 1);
             const int ch = n0 + cl * 8;
             ok = ok && ch < p.N && p.x_off + ch + 8 <= p.x_cs;
             const int cc = min(p.x_off + ch, p.x_cs - 8);
-            const uint4 v = *(const uint4*)(p.x + (((long long)b * p.Hx + h) * p.Wx + w) * p.x_cs + cc);
-            xq[u] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 rv = *(const uint4*)(p.x + (((long long)o.b * p.Hx + h) * p.Wx + w) * p.x_cs + cc);
+            v = ok ? rv : make_uint4(0u, 0u, 0u, 0u);
+            dst = gbytes + pix * XSTRIDE + cl * 16;
         }
     };
-    auto put = [&](const uint4 (&gq)[GPF], const uint4 (&xq)[XPF], int first_piece, bool with_g) {
-        if (with_g) {
+    // stage a whole pixel tile synchronously into buffer `buf`
+    auto stage_all = [&](int step, int buf) {
+        const Origin o = origin_of(step);
+        for (int id0 = 0; id0 < npieces; id0 += WG_THREADS * 4) {
+            uint4 v[4];
+            int d[4];
 #pragma unroll
-            for (int u = 0; u < GPF; ++u) {
-                const int m = (tid >> 2) + (WG_THREADS / 4) * u, q = tid & 3;
-                *(uint4*)(gimg + m * GSTRIDE + q * 16) = gq[u];
-            }
-        }
-        const int npieces = p.npix * XCPR;
+            for (int u = 0; u < 4; ++u) fetch_piece(o, id0 + tid + WG_THREADS * u, v[u], d[u]);
 #pragma unroll
-        for (int u = 0; u < XPF; ++u) {
-            const int piece = first_piece + tid + WG_THREADS * u;
-            if (piece < npieces) {
-                const int pix = piece / XCPR, cl = piece - pix * XCPR;
-                *(uint4*)(ximg + pix * XSTRIDE + cl * 16) = xq[u];
-            }
+            for (int u = 0; u < 4; ++u)
+                if (id0 + tid + WG_THREADS * u < npieces) *(uint4*)(smem + buf * bufbytes + d[u]) = v[u];
         }
     };
 
+    const int step0 = split * p.steps_per_split;
+    const int step1 = min(step0 + p.steps_per_split, p.nsteps);
+    int cur = 0;
+    if (step0 < step1 && p.dbuf) stage_all(step0, 0);
     for (int step = step0; step < step1; ++step) {
-        __syncthreads();                              // previous step's LDS reads are done
-        {
-            uint4 gq[GPF], xq[XPF];
-            fetch(step, gq, xq, 0, false);
-            put(gq, xq, 0, true);
+        if (!p.dbuf) {
+            __syncthreads();                       // previous tile's LDS reads are done
+            stage_all(step, 0);
         }
-        // patches larger than XPF pieces per thread: the remainder is fetched synchronously
-        for (int fp = WG_THREADS * XPF; fp < p.npix * XCPR; fp += WG_THREADS * XPF) {
-            uint4 g2[GPF], x2[XPF];
-            fetch(step, g2, x2, fp, true);
-            put(g2, x2, fp, false);
-        }
-        __syncthreads();
-        // ---- 16 k-steps of 16 pixels; every wave walks its own list of (tap, n-tile) output tiles
-        unsigned toff[1][4];
-#pragma unroll
-        for (int g = 0; g < 1; ++g)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int tl = min(wave + WG_WAVES * (4 * g + u), ntl - 1);
-                const int tap = tl / NTB, nt = tl - tap * NTB;
-                const int ta = tap / p.kw, tb = tap - ta * p.kw;
-                toff[g][u] = (unsigned)((ta * p.PW + tb) * XSTRIDE + nt * 64);
-            }
+        __syncthreads();                           // tile `step` is complete in buffer `cur`
+        const bool more = p.dbuf && step + 1 < step1 && !(p.dbg & 1);
+        const Origin onext = origin_of(more ? step + 1 : step);
+        const unsigned gb = sbase + cur * bufbytes, xb = gb + gbytes;
 #pragma unroll 1
         for (int ks = 0; ks < 16; ++ks) {
+            // 1/16th of the next tile: global loads now, LDS stores after this k-step's MFMAs
+            uint4 pv[2];
+            int pd[2];
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (j < p.ppk) fetch_piece(onext, (ks * p.ppk + j) * WG_THREADS + tid, pv[j], pd[j]);
+            }
             const int k0 = ks * 16 + krow, k1 = k0 + 4;
-            const unsigned ga = gbase + k0 * GSTRIDE + chan_off;
-            uint2 a0 = lds_tr(ga), a1 = lds_tr(ga + 4 * GSTRIDE);
+            uint2 a0[MT], a1[MT];
+            const bool rd = !(p.dbg & 2) || ks == 0;
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const unsigned ga = gb + k0 * GSTRIDE + a * 64 + chan_off;
+                if (rd) { a0[a] = lds_tr(ga); a1[a] = lds_tr(ga + 4 * GSTRIDE); } else { a0[a] = make_uint2(ks, k0); a1[a] = a0[a]; }
+            }
             const int pp0 = (((k0 >> lsh) * p.PH + ((k0 >> p.logTW) & THm) * p.stride) * p.PW + (k0 & TWm) * p.stride);
             const int pp1 = (((k1 >> lsh) * p.PH + ((k1 >> p.logTW) & THm) * p.stride) * p.PW + (k1 & TWm) * p.stride);
-            const unsigned xa = xbase + pp0 * XSTRIDE + chan_off;
+            const unsigned xa = xb + pp0 * XSTRIDE + chan_off;
             const unsigned xs = (unsigned)((pp1 - pp0) * XSTRIDE);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1));
-            const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+            uint2 b0[WG_PAIRS], b1[WG_PAIRS];
 #pragma unroll
-            for (int g = 0; g < WG_MAXT / 4; ++g) {
-                if (wave + 4 * WG_WAVES * g >= ntl) break;          // wave-uniform
-                uint2 b0[4], b1[4];
+            for (int u = 0; u < WG_PAIRS; ++u) {
+                if (rd) { b0[u] = lds_tr(xa + toff[u]); b1[u] = lds_tr(xa + toff[u] + xs); } else { b0[u] = make_uint2(xa, u); b1[u] = b0[u]; }
+            }
+            // the waits name their registers so that every consumer is ordered behind them
+            if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a1[0]));
+            if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[1]), "+v"(a1[1]));
+            if constexpr (MT == 3)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[1]), "+v"(a1[1]), "+v"(a0[2]), "+v"(a1[2]));
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2]), "+v"(b0[3]), "+v"(b1[3]));
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    b0[u] = lds_tr(xa + toff[g][u]);
-                    b1[u] = lds_tr(xa + toff[g][u] + xs);
-                }
-                // the wait names its registers so that every consumer is ordered behind it
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2]), "+v"(b0[3]), "+v"(b1[3])
-                             );
+            for (int u = 0; u < WG_PAIRS; ++u) {
+                if (wave + WG_WAVES * u < npairs) {
+                    const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(b0[u].x, b0[u].y, b1[u].x, b1[u].y));
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (wave + WG_WAVES * (4 * g + u) < ntl) {
-                        const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(b0[u].x, b0[u].y, b1[u].x, b1[u].y));
-                        acc[4 * g + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[4 * g + u], 0, 0, 0);
+                    for (int a = 0; a < MT; ++a) {
+                        const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(a0[a].x, a0[a].y, a1[a].x, a1[a].y));
+                        acc[a][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[a][u], 0, 0, 0);
                     }
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (j < p.ppk && (ks * p.ppk + j) * WG_THREADS + tid < npieces)
+                        *(uint4*)(smem + (cur ^ 1) * bufbytes + pd[j]) = pv[j];
             }
         }
+        if (p.dbuf) cur ^= 1;
     }
     // ---- write this split's partial tiles: D[row = m][col = n], row = (reg&3)+8*(reg>>2)+4*(lane>>5), col = lane&31
     float* out = p.partial + (size_t)split * taps * p.Mp * p.Np;
 #pragma unroll
-    for (int tt = 0; tt < WG_MAXT; ++tt) {
-        const int tl = wave + WG_WAVES * tt;
-        if (tl >= ntl) continue;
-        const int tap = tl / NTB, nt = tl - tap * NTB;
+    for (int u = 0; u < WG_PAIRS; ++u) {
+        const int pr = wave + WG_WAVES * u;
+        if (pr >= npairs) continue;
+        const int tap = pr / NTB, nt = pr - tap * NTB;
         const int n = n0 + nt * 32 + (lane & 31);
         if (n >= p.Np) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            out[((size_t)tap * p.Mp + m) * p.Np + n] = acc[tt][r];
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.Mp) out[((size_t)tap * p.Mp + m) * p.Np + n] = acc[a][u][r];
+            }
         }
     }
 }
@@ -261,63 +281,81 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.dh = d->dil_h; p.dw = d->dil_w;
     p.pad_t = d->pad_top; p.pad_l = d->pad_left; p.pad_mode = d->pad_mode;
     const int taps = d->kh * d->kw;
-    int ntb = WG_MAXT * WG_WAVES / taps;          // tiles per workgroup <= 64
-    if (ntb > 4) ntb = 4;
-    if (ntb < 1) ntb = 1;
-    if (ntb == 3) ntb = 2;
-    const int ntiles_n = p.Np / 32;
+    if (taps > WG_WAVES * WG_PAIRS) { sos_set_error("sos_conv2d_wgrad: kernel with %d taps not supported", taps); return SOS_ENOSPC; }
+    int ntb = WG_WAVES * WG_PAIRS / taps;         // (tap, n-tile) pairs per workgroup <= 32
+    ntb = ntb >= 4 ? 4 : (ntb >= 2 ? 2 : 1);
+    const int ntiles_n = p.Np / 32, ntiles_m = p.Mp / 32;
     if (ntb > ntiles_n) ntb = ntiles_n >= 4 ? 4 : (ntiles_n >= 2 ? 2 : 1);
-    if (taps * ntb > WG_MAXT * WG_WAVES) { sos_set_error("sos_conv2d_wgrad: kernel with %d taps not supported", taps); return SOS_ENOSPC; }
-    p.NTB = ntb;
+    const int mgroups = (ntiles_m + 2) / 3;
+    const int mt = (ntiles_m + mgroups - 1) / mgroups;          // 1..3 m-tiles per workgroup, balanced
+    const int gstride = mt == 1 ? 64 : 192;
     const int Hc = (d->Hg + d->dil_h - 1) / d->dil_h, Wc = (d->Wg + d->dil_w - 1) / d->dil_w;
-    // pixel tile (NC x TH x TW = 256): fewest k-steps (best utilisation of the 256 lanes-worth of pixels)
-    // among the shapes whose patch fits LDS with the current channel tile; shrink the channel tile if none
+    // pixel tile (NC x TH x TW = 256): fewest k-steps among the shapes whose operands fit LDS (double
+    // buffered if possible); shrink the channel tile if none fits
     size_t lds = 0;
     for (;;) {
+        const int xstride = ntb == 1 ? 64 : (ntb == 2 ? 192 : 320);
         double best = 1e300;
-        int bnc = 0, bth = 0, btw = 0;
+        int bnc = 0, bth = 0, btw = 0, bdb = 0;
         for (int lnc = 0; lnc <= 6; ++lnc) {
             const int NC = 1 << lnc;
             if (NC > 1 && (d->stride > 1 || NC > d->dil_w)) break;
             for (int lth = 0; lth + lnc <= 8; ++lth) {
                 const int ltw = 8 - lnc - lth;
-                if (ltw < 2) continue;                      // a transpose-read quad (4 pixels) stays inside one tile row
+                if (ltw < 2) continue;
                 const int TH = 1 << lth, TW = 1 << ltw;
                 const int PH = (TH - 1) * d->stride + d->kh, PW = (TW - 1) * d->stride + d->kw;
-                const size_t need = (size_t)256 * 64 + (size_t)NC * PH * PW * (ntb == 1 ? 64 : (ntb == 2 ? 192 : 320));
-                if (need > 160 * 1024) continue;
+                const size_t one = (size_t)256 * gstride + (size_t)NC * PH * PW * xstride;
+                if (one > 160 * 1024) continue;
+                const int db = 2 * one <= 160 * 1024;
                 const double steps = (double)((Hc + TH - 1) / TH) * ((Wc + TW - 1) / TW) * ((d->dil_w + NC - 1) / NC);
-                const double cost = steps * (256.0 * taps + 4.0 * NC * PH * PW);
-                if (cost < best) { best = cost; bnc = NC; bth = lth; btw = ltw; lds = need; }
+                const double cost = steps * (256.0 * taps + (db ? 1.0 : 6.0) * NC * PH * PW);
+                if (cost < best) { best = cost; bnc = NC; bth = lth; btw = ltw; bdb = db; lds = db ? 2 * one : one; }
             }
         }
-        if (bnc) { p.NC = bnc; p.logTH = bth; p.logTW = btw; break; }
+        if (bnc) { p.NC = bnc; p.logTH = bth; p.logTW = btw; p.dbuf = bdb; break; }
         if (ntb == 1) { sos_set_error("sos_conv2d_wgrad: patch does not fit LDS"); return SOS_ENOSPC; }
         ntb >>= 1;
     }
-    p.NTB = ntb;
     {
         const int TH = 1 << p.logTH, TW = 1 << p.logTW;
         p.tiles_h = (Hc + TH - 1) / TH; p.tiles_w = (Wc + TW - 1) / TW; p.ngw = (d->dil_w + p.NC - 1) / p.NC;
         p.PH = (TH - 1) * d->stride + d->kh; p.PW = (TW - 1) * d->stride + d->kw;
         p.npix = p.NC * p.PH * p.PW;
     }
+    {
+        const int np = 256 * mt * 4 + p.npix * ntb * 4;
+        p.ppk = (np + WG_THREADS * 16 - 1) / (WG_THREADS * 16);
+        if (p.ppk > 2) { p.dbuf = 0; lds = (size_t)256 * gstride + (size_t)p.npix * (ntb == 1 ? 64 : (ntb == 2 ? 192 : 320)); }
+    }
+    { const char* e = getenv("SOS_WGRAD_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.magic_pw = (unsigned)((0x100000000ULL + p.PW - 1) / p.PW);
+    p.magic_ph = (unsigned)((0x100000000ULL + p.PH - 1) / p.PH);
     p.nsteps = d->B * d->dil_h * p.ngw * p.tiles_h * p.tiles_w;
     p.ksplit = d->ksplit;
     p.steps_per_split = (p.nsteps + d->ksplit - 1) / d->ksplit;
-    dim3 grid((unsigned)d->ksplit, (unsigned)(p.Mp / 32), (unsigned)((ntiles_n + ntb - 1) / ntb));
+    dim3 grid((unsigned)d->ksplit, (unsigned)mgroups, (unsigned)((ntiles_n + ntb - 1) / ntb));
     hipStream_t s = (hipStream_t)stream;
-    static bool attr[5] = {false, false, false, false, false};
-#define SOS_WG_LAUNCH(NTBV)                                                                                         \
-    {                                                                                                               \
-        if (!attr[NTBV]) {                                                                                          \
-            (void)hipFuncSetAttribute((const void*)wgrad_kernel<NTBV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr[NTBV] = true;                                                                                      \
-        }                                                                                                           \
-        hipLaunchKernelGGL(wgrad_kernel<NTBV>, grid, dim3(WG_THREADS), lds, s, p);                                         \
+    static bool attr_done = false;
+#define SOS_WG_CASE(MTV, NTBV)                                                                                       \
+    if (mt == MTV && ntb == NTBV) {                                                                                  \
+        hipLaunchKernelGGL((wgrad_kernel<MTV, NTBV>), grid, dim3(WG_THREADS), lds, s, p);                            \
     }
-    if (ntb == 1) SOS_WG_LAUNCH(1) else if (ntb == 2) SOS_WG_LAUNCH(2) else SOS_WG_LAUNCH(4)
-#undef SOS_WG_LAUNCH
+    if (!attr_done) {       // every instantiation may use the full 160 KB of LDS
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    SOS_WG_CASE(1, 1) SOS_WG_CASE(1, 2) SOS_WG_CASE(1, 4) SOS_WG_CASE(2, 1) SOS_WG_CASE(2, 2) SOS_WG_CASE(2, 4)
+    SOS_WG_CASE(3, 1) SOS_WG_CASE(3, 2) SOS_WG_CASE(3, 4)
+#undef SOS_WG_CASE
     int rc = sos_check_launch("sos_conv2d_wgrad");
     if (rc) return rc;
     const long long total = (long long)d->M * d->N * taps;
