@@ -35,48 +35,83 @@ struct WgParams {
     int tiles_h, tiles_w, ngw; // pixel tiles per (image, residue class group)
     int steps_per_split, nsteps, ksplit;
     int NC, logTH, logTW, PH, PW, npix;
-    int dbuf, ppk;            // LDS double buffering on/off; staging pieces per thread per k-step
+    int npixp;                // npix rounded up to 16 (one wave's DMA never straddles two sub-images)
+    int bufbytes;             // bytes of one LDS operand buffer (multiple of 1 KB)
+    int dbuf;                 // two operand buffers: the next tile is fetched while this one is multiplied
     int dbg;                  // SOS_WGRAD_DBG ablation mask (0 in production)
-    unsigned magic_pw, magic_ph; // ceil(2^32 / PW), ceil(2^32 / PH): exact division of small indices by mulhi
 };
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 __device__ __forceinline__ uint2 lds_tr(unsigned addr) {
     uint2 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
+__device__ __forceinline__ uint2 lds_read64(unsigned addr) {     // opaque to hipcc's LDS-DMA alias tracking
+    uint2 v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
 
 // Workgroup = MT m-tiles (32 rows of dW each) x NTB n-tiles x all taps, 8 waves.  Wave w owns the
 // (tap, n-tile) pairs {w, w+8, w+16, w+24} for ALL MT m-tiles, so every transposed X fragment feeds
-// MT MFMAs and every G fragment WG_PAIRS of them (LDS reads per MFMA ~1.2 instead of 2.5).
-// The operands of the NEXT pixel tile are fetched 1/16th per k-step into the other LDS buffer while
-// the MFMAs of the current tile run.
+// MT MFMAs and every G fragment WG_PAIRS of them.
+//
+// Operand staging is LDS-DMA (buffer_load_dwordx4 ... lds, no registers, no ds_write).  LDS images:
+//     G: [MT sub-images][256 pixels][32 channels]      X: [NTB sub-images][npixp patch pixels][32 channels]
+// Every sub-image has a 64-byte pixel pitch (conflict free for the transpose reads); a DMA "slot" is one
+// instruction per wave = 8 KB of consecutive LDS per workgroup.  The source offset of a pixel relative
+// to the tile origin is the same for every tile, so it is decoded ONCE per kernel into an LDS table
+// (byte offset, row | column << 16); per tile a lane's slot costs one table read, an add, two range
+// checks (out-of-range lanes get an offset beyond the buffer: the hardware writes zeros) and the DMA
+// issue.  With double buffering slot ks of the next tile is issued in k-step ks of the current one.
 template <int MT, int NTB>
 __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
-    constexpr int XC = NTB * 32, GC = MT * 32;
-    // Row pitches chosen for ds_read_b64_tr_b16: a 32-lane half reads 4 pixel rows x 64 B; pitch/4 = 16 or
-    // 48 (mod 64) dwords puts the 4 rows on disjoint 16-bank windows (conflict free).
-    constexpr int XSTRIDE = NTB == 1 ? 64 : (NTB == 2 ? 192 : 320);
-    constexpr int GSTRIDE = MT == 1 ? 64 : 192;
-    constexpr int XCPR = XC / 8, GCPR = GC / 8;          // 16-byte pieces per pixel
+#if __HIP_DEVICE_COMPILE__     // buffer-resource builtins exist in the device pass only; the host pass needs just the stub
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int gbytes = 256 * GSTRIDE;
-    const int bufbytes = gbytes + p.npix * XSTRIDE;
+    constexpr int gbytes = 256 * 64 * MT;
+    constexpr int ngp = 256 * 4 * MT;                             // 16-byte pieces of the G image
+    const int ximg = p.npixp * 64;                                // bytes of one X sub-image
+    const int n4 = p.npixp * 4;                                   // pieces of one X sub-image
+    const int npieces = ngp + NTB * n4;
+    const int nslots = (npieces + WG_THREADS - 1) / WG_THREADS;
     const unsigned sbase = (unsigned)(uintptr_t)smem;
+    const unsigned tab = sbase + (unsigned)p.bufbytes * (p.dbuf ? 2 : 1);   // [256 + npixp] x {rel, crd}
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x;
-    const int m0 = blockIdx.y * GC, n0 = blockIdx.z * XC;
+    const int m0 = blockIdx.y * (MT * 32), n0 = blockIdx.z * (NTB * 32);
     const int taps = p.kh * p.kw;
     const int npairs = taps * NTB;
-    const int g4 = lane >> 4, s = lane & 15;
-    const int chan_off = (16 * (g4 & 1) + 4 * (s & 3)) * 2;      // byte offset of this lane's 4-channel run
-    const int krow = 8 * (g4 >> 1) + (s >> 2);                   // pixel (k) inside a 16-pixel k-step; +4 for 2nd read
+    const int g4 = lane >> 4, s16 = lane & 15;
+    const int chan_off = (16 * (g4 & 1) + 4 * (s16 & 3)) * 2;    // byte offset of this lane's 4-channel run
+    const int krow = 8 * (g4 >> 1) + (s16 >> 2);                 // pixel (k) inside a 16-pixel k-step; +4 for 2nd read
     const int TH = 1 << p.logTH, TW = 1 << p.logTW;
     const int TWm = TW - 1, THm = TH - 1, lsh = p.logTW + p.logTH;
     const bool reflect = p.pad_mode == SOS_PAD_REFLECT;
-    const int ngp = 256 * GCPR, npieces = ngp + p.npix * XCPR;
+
+    // ---- tile-invariant pixel table
+    for (int e = tid; e < 256 + p.npixp; e += WG_THREADS) {
+        unsigned r = 0u, c = 0x7fff7fffu;                         // invalid: always out of range
+        if (e < 256) {
+            const int j = e & TWm, i = (e >> p.logTW) & THm, cls = e >> lsh;
+            const int hrel = i * p.dh, wrel = cls + j * p.dw;
+            r = (unsigned)((hrel * p.Wg + wrel) * p.g_cs * 2);
+            c = (unsigned)hrel | ((unsigned)wrel << 16);
+        } else if (e - 256 < p.npix) {
+            const int pix = e - 256;
+            const int rr = pix / p.PW, cc = pix - rr * p.PW;
+            const int cls = rr / p.PH, row = rr - cls * p.PH;
+            const int hrel = row * p.dh, wrel = cls * p.stride + cc * p.dw;
+            r = (unsigned)((hrel * p.Wx + wrel) * p.x_cs * 2);
+            c = (unsigned)hrel | ((unsigned)wrel << 16);
+        }
+        *(uint2*)(smem + (tab - sbase) + e * 8) = make_uint2(r, c);
+    }
+    // this lane's channel run inside a pixel's 64-byte sub-image row (same in every slot)
+    const int q8 = (lane & 3) * 8;
 
     f32x16 acc[MT][WG_PAIRS];
 #pragma unroll
@@ -86,124 +121,130 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][t][e] = 0.f;
 
-    // per-wave offsets of its pairs inside the X image (tap shift + n-tile)
+    // per-wave offsets of its pairs inside the X image (tap shift + n-tile sub-image)
     unsigned toff[WG_PAIRS];
 #pragma unroll
     for (int u = 0; u < WG_PAIRS; ++u) {
         const int pr = min(wave + WG_WAVES * u, npairs - 1);
         const int tap = pr / NTB, nt = pr - tap * NTB;
         const int ta = tap / p.kw, tb = tap - ta * p.kw;
-        toff[u] = (unsigned)((ta * p.PW + tb) * XSTRIDE + nt * 64);
+        toff[u] = (unsigned)((ta * p.PW + tb) * 64 + nt * ximg);
     }
 
-    // tile origin of pixel tile `step` (wave-uniform, computed once per tile)
-    struct Origin { int b, rw0, ho_base, wo_base, hin0, win0; };
+    // origin of pixel tile `step` (wave-uniform, once per tile)
+    struct TileOrg {
+        __amdgpu_buffer_rsrc_t rg, rx;
+        int gh0, gw0, xh0, xw0;
+        unsigned gorg, xorg;
+        bool xslow;
+    };
+    const unsigned gimg_bytes = (unsigned)p.Hg * p.Wg * p.g_cs * 2, ximg_bytes = (unsigned)p.Hx * p.Wx * p.x_cs * 2;
+    const int xspan_h = (p.PH - 1) * p.dh, xspan_w = (p.NC - 1) * p.stride + (p.PW - 1) * p.dw;
     auto origin_of = [&](int step) {
         int t = step;
         const int tj = t % p.tiles_w; t /= p.tiles_w;
         const int ti = t % p.tiles_h; t /= p.tiles_h;
         const int gw = t % p.ngw; t /= p.ngw;
         const int rh = t % p.dh; t /= p.dh;
-        Origin o;
-        o.b = t; o.rw0 = gw * p.NC;
-        o.ho_base = rh + ti * TH * p.dh; o.wo_base = o.rw0 + tj * TW * p.dw;
-        o.hin0 = o.ho_base * p.stride - p.pad_t; o.win0 = o.wo_base * p.stride - p.pad_l;
+        TileOrg o;
+        o.gh0 = rh + ti * TH * p.dh; o.gw0 = gw * p.NC + tj * TW * p.dw;
+        o.xh0 = o.gh0 * p.stride - p.pad_t; o.xw0 = o.gw0 * p.stride - p.pad_l;
+        o.gorg = (unsigned)((o.gh0 * p.Wg + o.gw0) * p.g_cs * 2);
+        o.xorg = (unsigned)((o.xh0 * p.Wx + o.xw0) * p.x_cs * 2);      // may be "negative": wraps, valid lanes land in range
+        o.xslow = reflect && (o.xh0 < 0 || o.xw0 < 0 || o.xh0 + xspan_h >= p.Hx || o.xw0 + xspan_w >= p.Wx);
+        o.rg = __builtin_amdgcn_make_buffer_rsrc((void*)(p.g + (size_t)t * p.Hg * p.Wg * p.g_cs), 0, gimg_bytes, 0x00020000);
+        o.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)t * p.Hx * p.Wx * p.x_cs), 0, ximg_bytes, 0x00020000);
         return o;
     };
-    // one 16-byte staging piece of a pixel tile: value + LDS byte offset inside a buffer.  Index
-    // decoding uses shifts / constant divisors / mulhi magic numbers only (it runs once per k-step
-    // next to the MFMAs and must stay a handful of VALU instructions).
-    auto fetch_piece = [&](const Origin& o, int id, uint4& v, int& dst) {
-        const int idc = min(id, npieces - 1);
-        if (idc < ngp) {
-            const int m = idc / GCPR, q = idc - m * GCPR;
-            const int j = m & TWm, i = (m >> p.logTW) & THm, cls = m >> lsh;
-            const int h = o.ho_base + i * p.dh, w = o.wo_base + cls + j * p.dw;
-            const int ch = m0 + q * 8;          // channels past M inside a stored 8-run are the producer's zero padding
-            const bool ok = h < p.Hg && w < p.Wg && (cls == 0 || o.rw0 + cls < p.dw) && ch < p.M && p.g_off + ch + 8 <= p.g_cs;
-            const int hc = min(h, p.Hg - 1), wc = min(w, p.Wg - 1);
-            const int cc = min(p.g_off + ch, p.g_cs - 8);
-            const uint4 r = *(const uint4*)(p.g + (((long long)o.b * p.Hg + hc) * p.Wg + wc) * p.g_cs + cc);
-            v = ok ? r : make_uint4(0u, 0u, 0u, 0u);
-            dst = m * GSTRIDE + q * 16;
+    // DMA slot s of a tile: address of this lane's pixel-table entry (s wave-uniform)
+    auto slot_entry = [&](int s) -> unsigned {
+        const int L0 = s * WG_THREADS + wave * 64;
+        int e = ((L0 >> 2) & 255) + (lane >> 2);
+        if (L0 >= ngp) {
+            const int l = L0 - ngp;
+            const int nt = (l >= n4) + (l >= 2 * n4) + (l >= 3 * n4);
+            e = 256 + ((l - nt * n4) >> 2) + (lane >> 2);
+        }
+        return tab + (unsigned)min(e, 255 + p.npixp) * 8;
+    };
+    // issue DMA slot s of tile `o` into LDS buffer `buf`; ent = that lane's table entry
+    auto issue = [&](int s, const uint2 ent, const TileOrg& o, int buf) {
+        const int L0 = s * WG_THREADS + wave * 64;                 // wave-uniform
+        if (L0 >= npieces) return;
+        lds_ptr_t dst = (lds_ptr_t)(smem + buf * p.bufbytes + L0 * 16);
+        const unsigned ch = ent.y & 0xffffu, cw = ent.y >> 16;
+        if (L0 < ngp) {
+            const int chn = m0 + (L0 >> 10) * 32 + q8;   // channels past M inside a stored 8-run are the producer's zero padding
+            const bool ok = (unsigned)(o.gh0 + (int)ch) < (unsigned)p.Hg && (unsigned)(o.gw0 + (int)cw) < (unsigned)p.Wg &&
+                            chn < p.M && p.g_off + chn + 8 <= p.g_cs;
+            const unsigned voff = ok ? o.gorg + ent.x + (unsigned)(p.g_off + chn) * 2 : 0xffffffffu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rg, dst, 16, voff, 0, 0, 0);
         } else {
-            const int pc = idc - ngp;
-            const int pix = pc / XCPR, cl = pc - pix * XCPR;
-            const int rr = (int)__umulhi((unsigned)pix, p.magic_pw), c = pix - rr * p.PW;
-            const int cls = (int)__umulhi((unsigned)rr, p.magic_ph), r = rr - cls * p.PH;
-            int h = o.hin0 + r * p.dh, w = o.win0 + cls * p.stride + c * p.dw;
-            bool ok = reflect || (h >= 0 && h < p.Hx && w >= 0 && w < p.Wx);
-            h = reflect ? reflect_index(h, p.Hx) : min(max(h, 0), p.Hx - 1);
-            w = reflect ? reflect_index(w, p.Wx) : min(max(w, 0), p.Wx - 1);
-            const int ch = n0 + cl * 8;
-            ok = ok && ch < p.N && p.x_off + ch + 8 <= p.x_cs;
-            const int cc = min(p.x_off + ch, p.x_cs - 8);
-            const uint4 rv = *(const uint4*)(p.x + (((long long)o.b * p.Hx + h) * p.Wx + w) * p.x_cs + cc);
-            v = ok ? rv : make_uint4(0u, 0u, 0u, 0u);
-            dst = gbytes + pix * XSTRIDE + cl * 16;
+            const int l = L0 - ngp;
+            const int nt = (l >= n4) + (l >= 2 * n4) + (l >= 3 * n4);
+            const int chn = n0 + nt * 32 + q8;
+            const int h = o.xh0 + (int)ch, w = o.xw0 + (int)cw;
+            bool ok = (unsigned)h < (unsigned)p.Hx && (unsigned)w < (unsigned)p.Wx;
+            unsigned voff = o.xorg + ent.x;
+            if (o.xslow) {     // ReflectionPad2d border tile: mirror the coordinates
+                const int hr = reflect_index(h, p.Hx), wr = reflect_index(w, p.Wx);
+                voff = (unsigned)((hr * p.Wx + wr) * p.x_cs * 2);
+                ok = ent.y != 0x7fff7fffu && (unsigned)hr < (unsigned)p.Hx && (unsigned)wr < (unsigned)p.Wx;
+            }
+            ok = ok && chn < p.N && p.x_off + chn + 8 <= p.x_cs;
+            voff = ok ? voff + (unsigned)(p.x_off + chn) * 2 : 0xffffffffu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rx, dst, 16, voff, 0, 0, 0);
         }
     };
-    // stage a whole pixel tile synchronously into buffer `buf`
-    auto stage_all = [&](int step, int buf) {
-        const Origin o = origin_of(step);
-        for (int id0 = 0; id0 < npieces; id0 += WG_THREADS * 4) {
-            uint4 v[4];
-            int d[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) fetch_piece(o, id0 + tid + WG_THREADS * u, v[u], d[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (id0 + tid + WG_THREADS * u < npieces) *(uint4*)(smem + buf * bufbytes + d[u]) = v[u];
+    auto issue_all = [&](const TileOrg& o, int buf) {
+        for (int s = 0; s < nslots; ++s) {
+            uint2 ent = lds_read64(slot_entry(s));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent));
+            issue(s, ent, o, buf);
         }
     };
 
     const int step0 = split * p.steps_per_split;
     const int step1 = min(step0 + p.steps_per_split, p.nsteps);
     int cur = 0;
-    if (step0 < step1 && p.dbuf) stage_all(step0, 0);
+    __syncthreads();                               // pixel table complete
+    if (step0 < step1) issue_all(origin_of(step0), 0);
     for (int step = step0; step < step1; ++step) {
-        if (!p.dbuf) {
-            __syncthreads();                       // previous tile's LDS reads are done
-            stage_all(step, 0);
-        }
-        __syncthreads();                           // tile `step` is complete in buffer `cur`
-        const bool more = p.dbuf && step + 1 < step1 && !(p.dbg & 1);
-        const Origin onext = origin_of(more ? step + 1 : step);
-        const unsigned gb = sbase + cur * bufbytes, xb = gb + gbytes;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                           // tile `step` has landed in buffer `cur`; buffer cur^1 is free
+        const bool more = step + 1 < step1 && !(p.dbg & 1);
+        const TileOrg onext = origin_of(more ? step + 1 : step);
+        const bool prefetch = p.dbuf && more;
+        const unsigned gb = sbase + cur * p.bufbytes, xb = gb + gbytes;
 #pragma unroll 1
         for (int ks = 0; ks < 16; ++ks) {
-            // 1/16th of the next tile: global loads now, LDS stores after this k-step's MFMAs
-            uint4 pv[2];
-            int pd[2];
-            if (more) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    if (j < p.ppk) fetch_piece(onext, (ks * p.ppk + j) * WG_THREADS + tid, pv[j], pd[j]);
-            }
+            uint2 ent = make_uint2(0u, 0u);
+            if (prefetch) ent = lds_read64(slot_entry(ks));
             const int k0 = ks * 16 + krow, k1 = k0 + 4;
             uint2 a0[MT], a1[MT];
             const bool rd = !(p.dbg & 2) || ks == 0;
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
-                const unsigned ga = gb + k0 * GSTRIDE + a * 64 + chan_off;
-                if (rd) { a0[a] = lds_tr(ga); a1[a] = lds_tr(ga + 4 * GSTRIDE); } else { a0[a] = make_uint2(ks, k0); a1[a] = a0[a]; }
+                const unsigned ga = gb + a * (256 * 64) + k0 * 64 + chan_off;
+                if (rd) { a0[a] = lds_tr(ga); a1[a] = lds_tr(ga + 4 * 64); } else { a0[a] = make_uint2(ks, k0); a1[a] = a0[a]; }
             }
             const int pp0 = (((k0 >> lsh) * p.PH + ((k0 >> p.logTW) & THm) * p.stride) * p.PW + (k0 & TWm) * p.stride);
             const int pp1 = (((k1 >> lsh) * p.PH + ((k1 >> p.logTW) & THm) * p.stride) * p.PW + (k1 & TWm) * p.stride);
-            const unsigned xa = xb + pp0 * XSTRIDE + chan_off;
-            const unsigned xs = (unsigned)((pp1 - pp0) * XSTRIDE);
+            const unsigned xa = xb + pp0 * 64 + chan_off;
+            const unsigned xs = (unsigned)((pp1 - pp0) * 64);
             uint2 b0[WG_PAIRS], b1[WG_PAIRS];
 #pragma unroll
             for (int u = 0; u < WG_PAIRS; ++u) {
                 if (rd) { b0[u] = lds_tr(xa + toff[u]); b1[u] = lds_tr(xa + toff[u] + xs); } else { b0[u] = make_uint2(xa, u); b1[u] = b0[u]; }
             }
             // the waits name their registers so that every consumer is ordered behind them
-            if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a1[0]));
-            if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[1]), "+v"(a1[1]));
+            if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]));
+            if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[1]), "+v"(a1[1]));
             if constexpr (MT == 3)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[1]), "+v"(a1[1]), "+v"(a0[2]), "+v"(a1[2]));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[1]), "+v"(a1[1]), "+v"(a0[2]), "+v"(a1[2]));
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2]), "+v"(b0[3]), "+v"(b1[3]));
+            if (prefetch) issue(ks, ent, onext, cur ^ 1);
 #pragma unroll
             for (int u = 0; u < WG_PAIRS; ++u) {
                 if (wave + WG_WAVES * u < npairs) {
@@ -215,14 +256,13 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
                     }
                 }
             }
-            if (more) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    if (j < p.ppk && (ks * p.ppk + j) * WG_THREADS + tid < npieces)
-                        *(uint4*)(smem + (cur ^ 1) * bufbytes + pd[j]) = pv[j];
-            }
         }
-        if (p.dbuf) cur ^= 1;
+        if (p.dbuf) {
+            cur ^= 1;
+        } else if (more) {
+            __syncthreads();                       // every wave is done reading the single buffer
+            issue_all(onext, 0);
+        }
     }
     // ---- write this split's partial tiles: D[row = m][col = n], row = (reg&3)+8*(reg>>2)+4*(lane>>5), col = lane&31
     float* out = p.partial + (size_t)split * taps * p.Mp * p.Np;
@@ -242,7 +282,9 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             }
         }
     }
+#endif
 }
+
 
 // dW[m][n][tap] (+)= sum over splits of partial[s][tap][m][n]; also used for 1x1 / Linear weights.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int ksplit, int taps, int M, int N, int Mp,
@@ -288,29 +330,34 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     if (ntb > ntiles_n) ntb = ntiles_n >= 4 ? 4 : (ntiles_n >= 2 ? 2 : 1);
     const int mgroups = (ntiles_m + 2) / 3;
     const int mt = (ntiles_m + mgroups - 1) / mgroups;          // 1..3 m-tiles per workgroup, balanced
-    const int gstride = mt == 1 ? 64 : 192;
     const int Hc = (d->Hg + d->dil_h - 1) / d->dil_h, Wc = (d->Wg + d->dil_w - 1) / d->dil_w;
+    if ((uint64_t)d->Hg * d->Wg * d->g_cs * 2 >= 0xffffff00ull || (uint64_t)d->Hx * d->Wx * d->x_cs * 2 >= 0xffffff00ull) {
+        sos_set_error("sos_conv2d_wgrad: one image of an operand exceeds 4 GB");
+        return SOS_ENOSPC;
+    }
     // pixel tile (NC x TH x TW = 256): fewest k-steps among the shapes whose operands fit LDS (double
-    // buffered if possible); shrink the channel tile if none fits
-    size_t lds = 0;
+    // buffered, <= 16 DMA slots, if possible); shrink the channel tile if none fits
+    const size_t lds_max = 160 * 1024;
     for (;;) {
-        const int xstride = ntb == 1 ? 64 : (ntb == 2 ? 192 : 320);
         double best = 1e300;
         int bnc = 0, bth = 0, btw = 0, bdb = 0;
         for (int lnc = 0; lnc <= 6; ++lnc) {
             const int NC = 1 << lnc;
-            if (NC > 1 && (d->stride > 1 || NC > d->dil_w)) break;
+            if (NC > 1 && (d->stride > 1 || NC > d->dil_w || d->dil_w % NC)) break;
             for (int lth = 0; lth + lnc <= 8; ++lth) {
                 const int ltw = 8 - lnc - lth;
                 if (ltw < 2) continue;
                 const int TH = 1 << lth, TW = 1 << ltw;
                 const int PH = (TH - 1) * d->stride + d->kh, PW = (TW - 1) * d->stride + d->kw;
-                const size_t one = (size_t)256 * gstride + (size_t)NC * PH * PW * xstride;
-                if (one > 160 * 1024) continue;
-                const int db = 2 * one <= 160 * 1024;
+                if ((TH - 1 + d->kh) * d->dil_h >= 0x7fff || (d->stride * NC + (PW - 1) * d->dil_w) >= 0x7fff) continue;
+                const int npixp = (NC * PH * PW + 15) / 16 * 16;
+                const size_t one = ((size_t)256 * 64 * mt + (size_t)npixp * 64 * ntb + 1023) / 1024 * 1024;
+                const size_t tabb = (size_t)(256 + npixp) * 8;
+                if (one + tabb > lds_max) continue;
+                const int db = 2 * one + tabb <= lds_max && one <= 16 * 8192;
                 const double steps = (double)((Hc + TH - 1) / TH) * ((Wc + TW - 1) / TW) * ((d->dil_w + NC - 1) / NC);
                 const double cost = steps * (256.0 * taps + (db ? 1.0 : 6.0) * NC * PH * PW);
-                if (cost < best) { best = cost; bnc = NC; bth = lth; btw = ltw; bdb = db; lds = db ? 2 * one : one; }
+                if (cost < best) { best = cost; bnc = NC; bth = lth; btw = ltw; bdb = db; p.bufbytes = (int)one; p.npixp = npixp; }
             }
         }
         if (bnc) { p.NC = bnc; p.logTH = bth; p.logTW = btw; p.dbuf = bdb; break; }
@@ -323,39 +370,27 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
         p.PH = (TH - 1) * d->stride + d->kh; p.PW = (TW - 1) * d->stride + d->kw;
         p.npix = p.NC * p.PH * p.PW;
     }
-    {
-        const int np = 256 * mt * 4 + p.npix * ntb * 4;
-        p.ppk = (np + WG_THREADS * 16 - 1) / (WG_THREADS * 16);
-        if (p.ppk > 2) { p.dbuf = 0; lds = (size_t)256 * gstride + (size_t)p.npix * (ntb == 1 ? 64 : (ntb == 2 ? 192 : 320)); }
-    }
+    const size_t lds = (size_t)p.bufbytes * (p.dbuf ? 2 : 1) + (size_t)(256 + p.npixp) * 8;
     { const char* e = getenv("SOS_WGRAD_DBG"); p.dbg = e ? atoi(e) : 0; }
-    p.magic_pw = (unsigned)((0x100000000ULL + p.PW - 1) / p.PW);
-    p.magic_ph = (unsigned)((0x100000000ULL + p.PH - 1) / p.PH);
     p.nsteps = d->B * d->dil_h * p.ngw * p.tiles_h * p.tiles_w;
     p.ksplit = d->ksplit;
     p.steps_per_split = (p.nsteps + d->ksplit - 1) / d->ksplit;
     dim3 grid((unsigned)d->ksplit, (unsigned)mgroups, (unsigned)((ntiles_n + ntb - 1) / ntb));
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
-#define SOS_WG_CASE(MTV, NTBV)                                                                                       \
-    if (mt == MTV && ntb == NTBV) {                                                                                  \
-        hipLaunchKernelGGL((wgrad_kernel<MTV, NTBV>), grid, dim3(WG_THREADS), lds, s, p);                            \
-    }
+#define SOS_WG_ATTR(MTV, NTBV) \
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<MTV, NTBV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define SOS_WG_CASE(MTV, NTBV) \
+    if (mt == MTV && ntb == NTBV) hipLaunchKernelGGL((wgrad_kernel<MTV, NTBV>), grid, dim3(WG_THREADS), lds, s, p);
     if (!attr_done) {       // every instantiation may use the full 160 KB of LDS
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        SOS_WG_ATTR(1, 1) SOS_WG_ATTR(1, 2) SOS_WG_ATTR(1, 4) SOS_WG_ATTR(2, 1) SOS_WG_ATTR(2, 2) SOS_WG_ATTR(2, 4)
+        SOS_WG_ATTR(3, 1) SOS_WG_ATTR(3, 2) SOS_WG_ATTR(3, 4)
         attr_done = true;
     }
     SOS_WG_CASE(1, 1) SOS_WG_CASE(1, 2) SOS_WG_CASE(1, 4) SOS_WG_CASE(2, 1) SOS_WG_CASE(2, 2) SOS_WG_CASE(2, 4)
     SOS_WG_CASE(3, 1) SOS_WG_CASE(3, 2) SOS_WG_CASE(3, 4)
 #undef SOS_WG_CASE
+#undef SOS_WG_ATTR
     int rc = sos_check_launch("sos_conv2d_wgrad");
     if (rc) return rc;
     const long long total = (long long)d->M * d->N * taps;
