@@ -75,7 +75,6 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     const int ximg = p.npixp * 64;                                // bytes of one X sub-image
     const int n4 = p.npixp * 4;                                   // pieces of one X sub-image
     const int npieces = ngp + NTB * n4;
-    const int nslots = (npieces + WG_THREADS - 1) / WG_THREADS;
     const unsigned sbase = (unsigned)(uintptr_t)smem;
     const unsigned tab = sbase + (unsigned)p.bufbytes * (p.dbuf ? 2 : 1);   // [256 + npixp] x {rel, crd}
 
@@ -110,8 +109,6 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
         }
         *(uint2*)(smem + (tab - sbase) + e * 8) = make_uint2(r, c);
     }
-    // this lane's channel run inside a pixel's 64-byte sub-image row (same in every slot)
-    const int q8 = (lane & 3) * 8;
 
     f32x16 acc[MT][WG_PAIRS];
 #pragma unroll
@@ -136,7 +133,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
         __amdgpu_buffer_rsrc_t rg, rx;
         int gh0, gw0, xh0, xw0;
         unsigned gorg, xorg;
-        bool xslow;
+        bool xslow, gfast, xfast;   // reflect border tile; every pixel of the G tile / X patch is inside its image
     };
     const unsigned gimg_bytes = (unsigned)p.Hg * p.Wg * p.g_cs * 2, ximg_bytes = (unsigned)p.Hx * p.Wx * p.x_cs * 2;
     const int xspan_h = (p.PH - 1) * p.dh, xspan_w = (p.NC - 1) * p.stride + (p.PW - 1) * p.dw;
@@ -151,58 +148,74 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
         o.xh0 = o.gh0 * p.stride - p.pad_t; o.xw0 = o.gw0 * p.stride - p.pad_l;
         o.gorg = (unsigned)((o.gh0 * p.Wg + o.gw0) * p.g_cs * 2);
         o.xorg = (unsigned)((o.xh0 * p.Wx + o.xw0) * p.x_cs * 2);      // may be "negative": wraps, valid lanes land in range
-        o.xslow = reflect && (o.xh0 < 0 || o.xw0 < 0 || o.xh0 + xspan_h >= p.Hx || o.xw0 + xspan_w >= p.Wx);
+        o.xfast = o.xh0 >= 0 && o.xw0 >= 0 && o.xh0 + xspan_h < p.Hx && o.xw0 + xspan_w < p.Wx;
+        o.xslow = reflect && !o.xfast;
+        o.gfast = o.gh0 + (TH - 1) * p.dh < p.Hg && o.gw0 + (p.NC - 1) + (TW - 1) * p.dw < p.Wg;
         o.rg = __builtin_amdgcn_make_buffer_rsrc((void*)(p.g + (size_t)t * p.Hg * p.Wg * p.g_cs), 0, gimg_bytes, 0x00020000);
         o.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)t * p.Hx * p.Wx * p.x_cs), 0, ximg_bytes, 0x00020000);
         return o;
     };
-    // DMA slot s of a tile: address of this lane's pixel-table entry (s wave-uniform)
-    auto slot_entry = [&](int s) -> unsigned {
-        const int L0 = s * WG_THREADS + wave * 64;
-        int e = ((L0 >> 2) & 255) + (lane >> 2);
+    // A DMA instruction moves 64 consecutive pieces (1 KB of LDS); instruction i covers pieces [64 i, 64 i + 64).
+    // Address of this lane's pixel-table entry for instruction i (i wave-uniform):
+    const int ninstr = (npieces + 63) >> 6;
+    const int lane4 = lane >> 2;
+    auto entry_addr = [&](int i) -> unsigned {
+        const int L0 = i * 64;
+        int e = ((L0 >> 2) & 255) + lane4;
         if (L0 >= ngp) {
             const int l = L0 - ngp;
             const int nt = (l >= n4) + (l >= 2 * n4) + (l >= 3 * n4);
-            e = 256 + ((l - nt * n4) >> 2) + (lane >> 2);
+            e = 256 + ((l - nt * n4) >> 2) + lane4;
         }
-        return tab + (unsigned)min(e, 255 + p.npixp) * 8;
+        return tab + (unsigned)e * 8;
     };
-    // issue DMA slot s of tile `o` into LDS buffer `buf`; ent = that lane's table entry
-    auto issue = [&](int s, const uint2 ent, const TileOrg& o, int buf) {
-        const int L0 = s * WG_THREADS + wave * 64;                 // wave-uniform
-        if (L0 >= npieces) return;
+    // this lane's channel run inside a pixel's 64-byte sub-image row (same in every instruction)
+    const int q8 = (lane & 3) * 8;
+    const int glim = min(p.M - m0, p.g_cs - p.g_off - m0 - 7), xlim = min(p.N - n0, p.x_cs - p.x_off - n0 - 7);
+    const unsigned gq = (unsigned)(p.g_off + m0 + q8) * 2, xq = (unsigned)(p.x_off + n0 + q8) * 2;
+    // issue DMA instruction i of tile `o` into LDS buffer `buf`; ent = that lane's table entry
+    auto issue = [&](int i, const uint2 ent, const TileOrg& o, int buf) {
+        const int L0 = i * 64;                                     // wave-uniform
+        if (i >= ninstr) return;
         lds_ptr_t dst = (lds_ptr_t)(smem + buf * p.bufbytes + L0 * 16);
-        const unsigned ch = ent.y & 0xffffu, cw = ent.y >> 16;
         if (L0 < ngp) {
-            const int chn = m0 + (L0 >> 10) * 32 + q8;   // channels past M inside a stored 8-run are the producer's zero padding
-            const bool ok = (unsigned)(o.gh0 + (int)ch) < (unsigned)p.Hg && (unsigned)(o.gw0 + (int)cw) < (unsigned)p.Wg &&
-                            chn < p.M && p.g_off + chn + 8 <= p.g_cs;
-            const unsigned voff = ok ? o.gorg + ent.x + (unsigned)(p.g_off + chn) * 2 : 0xffffffffu;
+            const int a = L0 >> 10;      // channels past M inside a stored 8-run are the producer's zero padding
+            bool ok = a * 32 + q8 < glim;
+            if (!o.gfast)
+                ok = ok && (unsigned)(o.gh0 + (int)(ent.y & 0xffffu)) < (unsigned)p.Hg && (unsigned)(o.gw0 + (int)(ent.y >> 16)) < (unsigned)p.Wg;
+            const unsigned voff = ok ? ent.x + gq + (o.gorg + (unsigned)a * 64u) : 0xffffffffu;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rg, dst, 16, voff, 0, 0, 0);
         } else {
             const int l = L0 - ngp;
             const int nt = (l >= n4) + (l >= 2 * n4) + (l >= 3 * n4);
-            const int chn = n0 + nt * 32 + q8;
-            const int h = o.xh0 + (int)ch, w = o.xw0 + (int)cw;
-            bool ok = (unsigned)h < (unsigned)p.Hx && (unsigned)w < (unsigned)p.Wx;
-            unsigned voff = o.xorg + ent.x;
-            if (o.xslow) {     // ReflectionPad2d border tile: mirror the coordinates
-                const int hr = reflect_index(h, p.Hx), wr = reflect_index(w, p.Wx);
-                voff = (unsigned)((hr * p.Wx + wr) * p.x_cs * 2);
-                ok = ent.y != 0x7fff7fffu && (unsigned)hr < (unsigned)p.Hx && (unsigned)wr < (unsigned)p.Wx;
+            bool ok = nt * 32 + q8 < xlim && ent.y != 0x7fff7fffu;
+            unsigned voff = ent.x + xq + (o.xorg + (unsigned)nt * 64u);
+            if (!o.xfast) {
+                const int h = o.xh0 + (int)(ent.y & 0xffffu), w = o.xw0 + (int)(ent.y >> 16);
+                if (o.xslow) {     // ReflectionPad2d border tile: mirror the coordinates
+                    const int hr = reflect_index(h, p.Hx), wr = reflect_index(w, p.Wx);
+                    voff = (unsigned)((hr * p.Wx + wr) * p.x_cs * 2) + xq + (unsigned)nt * 64u;
+                    ok = ok && (unsigned)hr < (unsigned)p.Hx && (unsigned)wr < (unsigned)p.Wx;
+                } else {
+                    ok = ok && (unsigned)h < (unsigned)p.Hx && (unsigned)w < (unsigned)p.Wx;
+                }
             }
-            ok = ok && chn < p.N && p.x_off + chn + 8 <= p.x_cs;
-            voff = ok ? voff + (unsigned)(p.x_off + chn) * 2 : 0xffffffffu;
+            voff = ok ? voff : 0xffffffffu;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rx, dst, 16, voff, 0, 0, 0);
         }
     };
     auto issue_all = [&](const TileOrg& o, int buf) {
-        for (int s = 0; s < nslots; ++s) {
-            uint2 ent = lds_read64(slot_entry(s));
+        for (int i = wave; i < ninstr; i += WG_WAVES) {
+            uint2 ent = lds_read64(entry_addr(i));
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent));
-            issue(s, ent, o, buf);
+            issue(i, ent, o, buf);
         }
     };
+    // While a tile is multiplied, the next one is fetched by the "light" waves: those that own one (tap, n-tile)
+    // pair fewer than the others (25 taps on 8 waves: wave 0 has 4 pairs, waves 1..7 have 3).
+    int heavy = npairs & (WG_WAVES - 1);
+    if ((WG_WAVES - heavy) * 16 < ninstr) heavy = 0;
+    const int nlight = WG_WAVES - heavy, lw = wave - heavy;       // lw < 0: this wave issues no DMA in the k-loop
 
     const int step0 = split * p.steps_per_split;
     const int step1 = min(step0 + p.steps_per_split, p.nsteps);
@@ -210,7 +223,8 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     __syncthreads();                               // pixel table complete
     if (step0 < step1) issue_all(origin_of(step0), 0);
     for (int step = step0; step < step1; ++step) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(p.dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (p.dbg & 4) __builtin_amdgcn_s_barrier(); else
         __syncthreads();                           // tile `step` has landed in buffer `cur`; buffer cur^1 is free
         const bool more = step + 1 < step1 && !(p.dbg & 1);
         const TileOrg onext = origin_of(more ? step + 1 : step);
@@ -219,34 +233,52 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
 #pragma unroll 1
         for (int ks = 0; ks < 16; ++ks) {
             uint2 ent = make_uint2(0u, 0u);
-            if (prefetch) ent = lds_read64(slot_entry(ks));
+            const int di = ks * nlight + lw;                      // this wave's DMA instruction in this k-step
+            const bool dma = prefetch && lw >= 0 && di < ninstr;
+            if (dma) ent = lds_read64(entry_addr(di));
             const int k0 = ks * 16 + krow, k1 = k0 + 4;
-            uint2 a0[MT], a1[MT];
-            const bool rd = !(p.dbg & 2) || ks == 0;
-#pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                const unsigned ga = gb + a * (256 * 64) + k0 * 64 + chan_off;
-                if (rd) { a0[a] = lds_tr(ga); a1[a] = lds_tr(ga + 4 * 64); } else { a0[a] = make_uint2(ks, k0); a1[a] = a0[a]; }
-            }
             const int pp0 = (((k0 >> lsh) * p.PH + ((k0 >> p.logTW) & THm) * p.stride) * p.PW + (k0 & TWm) * p.stride);
             const int pp1 = (((k1 >> lsh) * p.PH + ((k1 >> p.logTW) & THm) * p.stride) * p.PW + (k1 & TWm) * p.stride);
+            const unsigned ga = gb + k0 * 64 + chan_off;
             const unsigned xa = xb + pp0 * 64 + chan_off;
             const unsigned xs = (unsigned)((pp1 - pp0) * 64);
-            uint2 b0[WG_PAIRS], b1[WG_PAIRS];
+            // LDS reads in the order the MFMAs consume them (LDS returns in order): every MFMA group waits only
+            // for its own fragments, so the first MFMAs start while the later fragments are still in flight.
+            // The waits name their registers so that every consumer is ordered behind them.
+            uint2 a0[MT], a1[MT], b0[WG_PAIRS], b1[WG_PAIRS];
+            a0[0] = lds_tr(ga); a1[0] = lds_tr(ga + 4 * 64);
+            b0[0] = lds_tr(xa + toff[0]); b1[0] = lds_tr(xa + toff[0] + xs);
 #pragma unroll
-            for (int u = 0; u < WG_PAIRS; ++u) {
-                if (rd) { b0[u] = lds_tr(xa + toff[u]); b1[u] = lds_tr(xa + toff[u] + xs); } else { b0[u] = make_uint2(xa, u); b1[u] = b0[u]; }
+            for (int a = 1; a < MT; ++a) { a0[a] = lds_tr(ga + a * (256 * 64)); a1[a] = lds_tr(ga + a * (256 * 64) + 4 * 64); }
+#pragma unroll
+            for (int u = 1; u < WG_PAIRS; ++u) { b0[u] = lds_tr(xa + toff[u]); b1[u] = lds_tr(xa + toff[u] + xs); }
+            constexpr int REST = 2 * (WG_PAIRS - 1);              // reads behind pair 0 / m-tile a
+            if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(b0[0]) , "+v"(b1[0]) : "n"(REST));
+            if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(b0[0]) , "+v"(b1[0]) : "n"(REST + 2));
+            if constexpr (MT == 3) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(b0[0]) , "+v"(b1[0]) : "n"(REST + 4));
+            if (dma) issue(di, ent, onext, cur ^ 1);
+            const bool on0 = wave < npairs;
+            {
+                const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(b0[0].x, b0[0].y, b1[0].x, b1[0].y));
+                const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(a0[0].x, a0[0].y, a1[0].x, a1[0].y));
+                if (on0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[0][0], 0, 0, 0);
+                if constexpr (MT >= 2) {
+                    if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a0[1]), "+v"(a1[1]) : "n"(REST));
+                    if constexpr (MT == 3) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a0[1]), "+v"(a1[1]) : "n"(REST + 2));
+                    const bf16x8 af1 = __builtin_bit_cast(bf16x8, make_uint4(a0[1].x, a0[1].y, a1[1].x, a1[1].y));
+                    if (on0) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1, bfr, acc[1][0], 0, 0, 0);
+                }
+                if constexpr (MT >= 3) {
+                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a0[2]), "+v"(a1[2]) : "n"(REST));
+                    const bf16x8 af2 = __builtin_bit_cast(bf16x8, make_uint4(a0[2].x, a0[2].y, a1[2].x, a1[2].y));
+                    if (on0) acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2, bfr, acc[2][0], 0, 0, 0);
+                }
             }
-            // the waits name their registers so that every consumer is ordered behind them
-            if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]));
-            if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[1]), "+v"(a1[1]));
-            if constexpr (MT == 3)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[1]), "+v"(a1[1]), "+v"(a0[2]), "+v"(a1[2]));
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2]), "+v"(b0[3]), "+v"(b1[3]));
-            if (prefetch) issue(ks, ent, onext, cur ^ 1);
 #pragma unroll
-            for (int u = 0; u < WG_PAIRS; ++u) {
+            for (int u = 1; u < WG_PAIRS; ++u) {
+                if (u == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b0[1]), "+v"(b1[1]));
+                if (u == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(b0[2]), "+v"(b1[2]));
+                if (u == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0[3]), "+v"(b1[3]));
                 if (wave + WG_WAVES * u < npairs) {
                     const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(b0[u].x, b0[u].y, b1[u].x, b1[u].y));
 #pragma unroll
@@ -354,7 +386,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
                 const size_t one = ((size_t)256 * 64 * mt + (size_t)npixp * 64 * ntb + 1023) / 1024 * 1024;
                 const size_t tabb = (size_t)(256 + npixp) * 8;
                 if (one + tabb > lds_max) continue;
-                const int db = 2 * one + tabb <= lds_max && one <= 16 * 8192;
+                const int db = 2 * one + tabb <= lds_max;
                 const double steps = (double)((Hc + TH - 1) / TH) * ((Wc + TW - 1) / TW) * ((d->dil_w + NC - 1) / NC);
                 const double cost = steps * (256.0 * taps + (db ? 1.0 : 6.0) * NC * PH * PW);
                 if (cost < best) { best = cost; bnc = NC; bth = lth; btw = ltw; bdb = db; p.bufbytes = (int)one; p.npixp = npixp; }
