@@ -22,10 +22,20 @@
 #include <string.h>
 #include <algorithm>
 #include <map>
+#include <type_traits>
 #include <vector>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Ablation switches (SOS_CONV_DBG bit mask: 1 patch staging, 2 tap loop, 4 epilogue, 8 weight-slab
+// loads, 16 tap barrier, 64 re-read one slab) exist only in `make ABLATE=1` builds: as run-time
+// branches they cost the production tap loop a dozen scalar branches and ~40 register moves per tap.
+#ifdef SOS_ABLATE
+#define CDBG(bit) (p.dbg & (bit))
+#else
+#define CDBG(bit) 0
+#endif
 
 struct ConvParams {
     const bf16_t* in;
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         // ---- stage the input patch of this channel chunk: CPR lanes per pixel, 16 B per lane.
         // Batches of PU pixels per thread: all PU global loads are issued before the first LDS
         // store, so a batch costs one memory latency instead of PU of them.
-        if (!(p.dbg & 1)) {
+        if (!CDBG(1)) {
             const long long cbase = (long long)p.cin_off + (long long)(cc / p.cps) * p.seg_stride + (long long)(cc % p.cps) * KC;
             // (uniform) specialisations keep the optional column-gather load and the reflect
             // arithmetic out of the common loop: a data-dependent load inside it would force a
@@ -205,54 +215,54 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 
         // Fragment pipeline: operands of k-step kk+1 are read from LDS while the MFMAs of kk run;
         // the pixel operand of the NEXT tap's first k-step is read before the barrier (the patch
-        // does not change inside a chunk), only the weight operand has to wait for it.
-        bf16x8 af[2][2], wfr[2][NT], anext[2];
-        anext[0] = lds_frag(patch + abase[0]);
-        anext[1] = lds_frag(patch + abase[1]);
+        // does not change inside a chunk), only the weight operand has to wait for it.  The two
+        // fragment buffers alternate along the flat (tap, k-step) sequence; F is the buffer a tap
+        // starts in -- a compile-time constant, so the rotation costs no register moves (for odd KS
+        // the tap loop is unrolled by two).
+        bf16x8 af[2][2], wfr[2][NT];
+        af[0][0] = lds_frag(patch + abase[0]);
+        af[0][1] = lds_frag(patch + abase[1]);
         int ta = 0, tb = 0;   // tap row / col
         const bf16_t* wtap = p.wgt + ((long long)n0 * p.ktot + (long long)cc * KC);
-        for (int tap = 0; tap < ((p.dbg & 2) ? 0 : ntaps); ++tap) {
+        auto tap_body = [&](auto ftag, const int tap) {
+            constexpr int F = decltype(ftag)::value;
             const int cur = tap & 1;
             // prefetch the next tap's weight slab into registers (lands while the MFMAs run).  The
-            // loads are unconditional (last tap re-reads itself) so that breg stays in VGPRs: a
+            // loads are unconditional (last tap re-reads itself) so that the registers stay VGPRs: a
             // conditionally-defined array is demoted to scratch and the loads become synchronous.
             // (named scalars, not an array: with the scheduling barriers below an array is left in
             // scratch memory, which makes the "prefetch" synchronous)
             uint4 br0, br1, br2, br3, br4, br5, br6, br7;
-            if (tap + 1 < ntaps) wtap += tap_stride;
-#define SOS_BLOAD(i) if constexpr (NBREG > i) { if (!(p.dbg & 8)) br##i = *(const uint4*)(wtap + bsrc[i]); else br##i = make_uint4(0,0,0,0); }
+            if (tap + 1 < ntaps && !CDBG(64)) wtap += tap_stride;
+#define SOS_BLOAD(i) if constexpr (NBREG > i) { if (!CDBG(8)) br##i = *(const uint4*)(wtap + bsrc[i]); else br##i = make_uint4(0,0,0,0); }
             SOS_BLOAD(0) SOS_BLOAD(1) SOS_BLOAD(2) SOS_BLOAD(3) SOS_BLOAD(4) SOS_BLOAD(5) SOS_BLOAD(6) SOS_BLOAD(7)
 #undef SOS_BLOAD
             // hipcc otherwise sinks these loads to the end of the tap (right before their use) and
             // hoists every ds_read to just before its MFMA; pin the software pipeline explicitly.
             __builtin_amdgcn_sched_barrier(0);
 
-            const char* ap0 = patch + abase[0] + (ta * p.PW + tb) * PSTRIDE;
-            const char* ap1 = patch + abase[1] + (ta * p.PW + tb) * PSTRIDE;
+            const int toff = (ta * p.PW + tb) * PSTRIDE;
+            const char* ap0 = patch + abase[0] + toff;
+            const char* ap1 = patch + abase[1] + toff;
             int tan = ta, tbn = tb + 1;
             if (tbn == p.kw) { tbn = 0; ++tan; }
             if (tap + 1 == ntaps) { tan = ta; tbn = tb; }
             const int toffn = (tan * p.PW + tbn) * PSTRIDE;
             const char* bp = smem + boff0 + cur * BBYTES + bfrag_off;
-            af[0][0] = anext[0];
-            af[0][1] = anext[1];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wfr[0][nt] = lds_frag(bp + nt * 32 * BSTRIDE);
+            for (int nt = 0; nt < NT; ++nt) wfr[F][nt] = lds_frag(bp + nt * 32 * BSTRIDE);
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
-                const int cb = kk & 1, nb = cb ^ 1;
-                if (p.dbg & 32) {
-                    af[nb][0] = af[cb][0]; af[nb][1] = af[cb][1];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) wfr[nb][nt] = wfr[cb][nt];
-                } else if (kk + 1 < KS) {
+                constexpr int dummy = 0; (void)dummy;
+                const int cb = (F + kk) & 1, nb = cb ^ 1;
+                if (kk + 1 < KS) {
                     af[nb][0] = lds_frag(ap0 + (kk + 1) * 32);
                     af[nb][1] = lds_frag(ap1 + (kk + 1) * 32);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) wfr[nb][nt] = lds_frag(bp + nt * 32 * BSTRIDE + (kk + 1) * 32);
                 } else {
-                    anext[0] = lds_frag(patch + abase[0] + toffn);
-                    anext[1] = lds_frag(patch + abase[1] + toffn);
+                    af[nb][0] = lds_frag(patch + abase[0] + toffn);
+                    af[nb][1] = lds_frag(patch + abase[1] + toffn);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -264,20 +274,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
             }
 #define SOS_BSTORE(i)                                                                      \
     if constexpr (NBREG > i) {                                                               \
-        if (!(p.dbg & 8) && ((i + 1) * 256 <= BPIECES || tid + i * 256 < BPIECES))          \
+        if (!CDBG(8) && ((i + 1) * 256 <= BPIECES || tid + i * 256 < BPIECES))              \
             *(uint4*)(smem + boff0 + (cur ^ 1) * BBYTES + bdst[i]) = br##i;                  \
     }
             SOS_BSTORE(0) SOS_BSTORE(1) SOS_BSTORE(2) SOS_BSTORE(3) SOS_BSTORE(4) SOS_BSTORE(5) SOS_BSTORE(6) SOS_BSTORE(7)
 #undef SOS_BSTORE
-            if (!(p.dbg & 16)) __syncthreads();
+            if (!CDBG(16)) __syncthreads();
             ta = tan; tb = tbn;
+        };
+        const int ntaps_run = CDBG(2) ? 0 : ntaps;
+        if constexpr (KS % 2 == 0) {
+            for (int tap = 0; tap < ntaps_run; ++tap) tap_body(std::integral_constant<int, 0>{}, tap);
+        } else {
+            int tap = 0;
+            for (; tap + 1 < ntaps_run; tap += 2) {
+                tap_body(std::integral_constant<int, 0>{}, tap);
+                tap_body(std::integral_constant<int, 1>{}, tap + 1);
+            }
+            if (tap < ntaps_run) tap_body(std::integral_constant<int, 0>{}, tap);
         }
     }
 
     // ---- fused epilogue.  Accumulator layout of v_mfma_f32_32x32x*: column = lane&31 (pixel),
     // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (output channel within the 32-row tile).
     const float slope = (p.act == SOS_ACT_PRELU && p.slope) ? p.slope[0] : 0.f;
-    if (p.dbg & 4) return;
+    if (CDBG(4)) return;
     const bool staged = p.out_dtype != SOS_DT_F32 && p.sc == 1;
     const bool x3 = p.out_dtype == SOS_DT_BF16X3;
     constexpr int OROW = NT * 64 + 16;           // bytes per staged output pixel row

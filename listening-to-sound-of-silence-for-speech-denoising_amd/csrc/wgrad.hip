@@ -183,7 +183,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             bool ok = a * 32 + q8 < glim;
             if (!o.gfast)
                 ok = ok && (unsigned)(o.gh0 + (int)(ent.y & 0xffffu)) < (unsigned)p.Hg && (unsigned)(o.gw0 + (int)(ent.y >> 16)) < (unsigned)p.Wg;
-            const unsigned voff = ok ? ent.x + gq + (o.gorg + (unsigned)a * 64u) : 0xffffffffu;
+            const unsigned voff = ok && !(p.dbg & 8) ? ent.x + gq + (o.gorg + (unsigned)a * 64u) : ((p.dbg & 16) ? 0u : 0xffffffffu);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rg, dst, 16, voff, 0, 0, 0);
         } else {
             const int l = L0 - ngp;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
                     ok = ok && (unsigned)h < (unsigned)p.Hx && (unsigned)w < (unsigned)p.Wx;
                 }
             }
-            voff = ok ? voff : 0xffffffffu;
+            voff = ok && !(p.dbg & 8) ? voff : ((p.dbg & 16) ? 0u : 0xffffffffu);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rx, dst, 16, voff, 0, 0, 0);
         }
     };
