@@ -64,49 +64,49 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* p) {
     return __builtin_bit_cast(bf16x8, *(const uint4*)p);
 }
 
-// Stage the input patch of one channel chunk: CPR lanes per pixel, 16 B per lane.  Batches of PU
-// pixels per thread: all PU global loads are issued before the first LDS store, so a batch costs
-// one memory latency instead of PU of them.
-template <int CPR, int PSTRIDE, bool GATHER>
-__device__ __forceinline__ void stage_patch(const ConvParams& p, char* patch, int tid, long long in_b,
-                                            long long cbase, int hin0, int win0, int rw0) {
-    constexpr int PU = 8;
-    constexpr int PPP = 256 / CPR;               // pixels per pass of the workgroup
-    const int pl = tid / CPR, cl = tid - pl * CPR;
-    const bool lane_on = pl < PPP;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// Byte offset (inside its image) of every pixel of the workgroup's input patch, or ~0 for a pixel that
+// is zero padding.  Built once per tile; every channel chunk's staging pass reuses it.
+__device__ __forceinline__ void build_pixel_table(const ConvParams& p, unsigned* tab, int tid, int hin0, int win0, int rw0) {
     const bool reflect = p.pad_mode == SOS_PAD_REFLECT;
-    const bf16_t* src0 = p.in + cbase + cl * 8;
-    // pixel index advances by PPP per step: walk (column c, combined row rr = cls*PH + r) with carries
-    const int dq = PPP / p.PW, dr = PPP - dq * p.PW;
-    int c0 = pl % p.PW, rr0 = pl / p.PW;
-    for (int pix0 = pl; pix0 < p.npix; pix0 += PPP * PU) {
-        uint4 v[PU];
-        bool okv[PU];
-#pragma unroll
-        for (int u = 0; u < PU; ++u) {
-            const bool inside = pix0 + PPP * u < p.npix;
-            const int c = inside ? c0 : 0, rr = inside ? rr0 : 0;
-            int r = rr, cls = 0;
-            if (p.NC > 1) { cls = rr / p.PH; r = rr - cls * p.PH; }
-            int h = hin0 + r * p.dh;
-            int w = win0 + cls * p.stride + c * p.dw;
-            bool ok = (rw0 + cls) < p.dw || cls == 0;
-            const int hr = reflect_index(h, p.H), wr = reflect_index(w, p.Wl);
-            ok = ok && (reflect || (h >= 0 && h < p.H && w >= 0 && w < p.Wl));
-            h = reflect ? hr : min(max(h, 0), p.H - 1);      // always a legal address: load, then select
-            w = reflect ? wr : min(max(w, 0), p.Wl - 1);
-            if (GATHER) w = p.wgather[w];
-            okv[u] = ok;
-            v[u] = *(const uint4*)(src0 + (in_b + (long long)h * p.W + w) * p.in_cs);
-            c0 += dr; rr0 += dq;
-            if (c0 >= p.PW) { c0 -= p.PW; ++rr0; }
+    for (int pix = tid; pix < p.npix; pix += 256) {
+        const int rr = pix / p.PW, c = pix - rr * p.PW;
+        int r = rr, cls = 0;
+        if (p.NC > 1) { cls = rr / p.PH; r = rr - cls * p.PH; }
+        int h = hin0 + r * p.dh;
+        int w = win0 + cls * p.stride + c * p.dw;
+        bool ok = (rw0 + cls) < p.dw || cls == 0;
+        if (reflect) { h = reflect_index(h, p.H); w = reflect_index(w, p.Wl); }
+        ok = ok && h >= 0 && h < p.H && w >= 0 && w < p.Wl;
+        unsigned off = 0xffffffffu;
+        if (ok) {
+            if (p.wgather) w = p.wgather[w];
+            off = (unsigned)((h * p.W + w) * p.in_cs) * 2u;
         }
-#pragma unroll
-        for (int u = 0; u < PU; ++u) {
-            const int pix = pix0 + PPP * u;
-            if (lane_on && pix < p.npix)
-                *(uint4*)(patch + pix * PSTRIDE + cl * 16) = okv[u] ? v[u] : make_uint4(0u, 0u, 0u, 0u);
-        }
+        tab[pix] = off;
+    }
+}
+
+// Stage the input patch of one channel chunk with LDS-DMA (buffer_load_dwordx4 ... lds): the patch image
+// is [npix][CPR + 1] 16-byte pieces (the last piece of a row is the bank-conflict pad), instruction i of
+// a wave fills pieces [64 i, 64 i + 64).  A lane's source is table[pixel] + chunk offset; zero padding,
+// the pad piece and lanes past the image get an out-of-range offset (the hardware writes zeros).  No data
+// registers, no ds_write, and all of a wave's pieces are in flight at once.
+template <int CPR>
+__device__ __forceinline__ void stage_patch_dma(const ConvParams& p, char* patch, unsigned tab_addr, int lane, int wave,
+                                                __amdgpu_buffer_rsrc_t rsrc, unsigned cbytes) {
+    constexpr int RP = CPR + 1;
+    const int total = p.npix * RP;
+    const int ninstr = (total + 63) >> 6;
+    for (int i = wave; i < ninstr; i += 4) {
+        const int L = i * 64 + lane;
+        const int pix = L / RP, q = L - pix * RP;
+        unsigned ent;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ent) : "v"(tab_addr + (unsigned)min(pix, p.npix - 1) * 4u));
+        const bool ok = q < CPR && ent != 0xffffffffu;
+        const unsigned voff = ok ? ent + cbytes + (unsigned)q * 16u : 0xffffffffu;
+        if (L < total) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(patch + i * 1024), 16, voff, 0, 0, 0);
     }
 }
 
@@ -120,9 +120,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     constexpr int BPIECES = BROWS * CPR;
     constexpr int NBREG = (BPIECES + 255) / 256;
     constexpr int BBYTES = BROWS * BSTRIDE;
+#if __HIP_DEVICE_COMPILE__     // buffer-resource builtins exist in the device pass only; the host pass needs just the stub
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
     const int boff0 = p.npix * PSTRIDE;          // weight slab buffers follow the patch
+    unsigned* pixtab = (unsigned*)(smem + boff0 + 2 * BBYTES);   // then the per-pixel source offsets
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -188,19 +190,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 
     const int ntaps = p.kh * p.kw;
     const long long in_b = (long long)b * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + in_b * p.in_cs), 0, (unsigned)(p.H * p.W * p.in_cs) * 2u, 0x00020000);
+    build_pixel_table(p, pixtab, tid, hin0, win0, rw0);
 
     for (int cc = 0; cc < p.nchunks; ++cc) {
         __syncthreads();   // everyone is done reading the previous chunk's patch / weight buffers
-        // ---- stage the input patch of this channel chunk: CPR lanes per pixel, 16 B per lane.
-        // Batches of PU pixels per thread: all PU global loads are issued before the first LDS
-        // store, so a batch costs one memory latency instead of PU of them.
+        // ---- stage the input patch of this channel chunk (the first barrier above also publishes the pixel table)
         if (!CDBG(1)) {
             const long long cbase = (long long)p.cin_off + (long long)(cc / p.cps) * p.seg_stride + (long long)(cc % p.cps) * KC;
-            // (uniform) specialisations keep the optional column-gather load and the reflect
-            // arithmetic out of the common loop: a data-dependent load inside it would force a
-            // vmcnt(0) per pixel and serialise the whole batch.
-            if (p.wgather) stage_patch<CPR, PSTRIDE, true>(p, patch, tid, in_b, cbase, hin0, win0, rw0);
-            else stage_patch<CPR, PSTRIDE, false>(p, patch, tid, in_b, cbase, hin0, win0, rw0);
+            stage_patch_dma<CPR>(p, patch, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc,
+                                 (unsigned)(cbase * 2));
         }
         // ---- weight slab of tap 0 straight into buffer 0
         {
@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
                 if ((u + 1) * 256 <= BPIECES || tid + u * 256 < BPIECES) *(uint4*)(smem + boff0 + bdst[u]) = v;
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's patch pieces have landed
         __syncthreads();
 
         // Fragment pipeline: operands of k-step kk+1 are read from LDS while the MFMAs of kk run;
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
             }
         }
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------ host side
@@ -479,7 +481,7 @@ static int launch_ks(int ks, const ConvParams& p, dim3 grid, size_t lds, hipStre
 
 static size_t lds_bytes(int npix, int nt, int ks) {
     const size_t row = (size_t)ks * 32 + 16;
-    return (size_t)npix * row + 2 * (size_t)nt * 32 * row;
+    return (size_t)npix * row + 2 * (size_t)nt * 32 * row + (size_t)npix * 4;
 }
 
 // One tiling choice: NC residue classes x (1<<lth) x (1<<ltw) pixels, 16*ks channels per chunk.
@@ -561,6 +563,10 @@ static int validate(const sos_conv_desc* d) {
         sos_set_error("sos_conv2d_fwd: bad descriptor (cin=%d in_cs=%d cin_off=%d cout=%d/%d k=%dx%d s=%d d=%dx%d)",
                       d->cin, d->in_cs, d->cin_off, d->cout, d->cout_pad, d->kh, d->kw, d->stride, d->dil_h, d->dil_w);
         return SOS_EINVAL;
+    }
+    if ((uint64_t)d->H * d->W * d->in_cs * 2 >= 0xfff00000ull) {
+        sos_set_error("sos_conv2d_fwd: one input image exceeds 4 GB");
+        return SOS_ENOSPC;
     }
     if (d->pad_mode == SOS_PAD_REFLECT && (d->pad_top >= d->H || d->pad_left >= d->Wl)) {
         sos_set_error("sos_conv2d_fwd: reflect pad %d/%d needs a larger input (%dx%d)", d->pad_top, d->pad_left, d->H, d->Wl);
