@@ -18,6 +18,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+// two floats -> packed bf16 pair (round to nearest even) with gfx950's v_cvt_pk_bf16_f32
+typedef __bf16 sos_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float sos_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2bf(float a, float b) {
+    const sos_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, sos_bf16x2));
+}
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 
 __device__ __forceinline__ int reflect_index(int i, int n) {
