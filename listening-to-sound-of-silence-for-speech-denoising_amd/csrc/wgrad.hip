@@ -25,6 +25,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define WG_THREADS (WG_WAVES * 64)
 #define WG_PAIRS 4            // (tap, n-tile) pairs per wave; x MT m-tiles = accumulator tiles per wave
 
+// Ablation switches (SOS_WGRAD_DBG bit mask: 1 no prefetch DMA, 8 DMA lanes all out of range, 16 ... all offset 0)
+// exist only in `make ABLATE=1` builds.
+#ifdef SOS_ABLATE
+#define WDBG(bit) (p.dbg & (bit))
+#else
+#define WDBG(bit) 0
+#endif
+
 struct WgParams {
     const bf16_t* g;          // [B][Hg][Wg][g_cs]   (tile side, m channels)
     const bf16_t* x;          // [B][Hx][Wx][x_cs]   (patch side, n channels)
@@ -46,6 +54,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ __forceinline__ uint2 lds_tr(unsigned addr) {
     uint2 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ uint2 lds_tr_off(unsigned addr) {      // same with an immediate byte offset
+    uint2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
 __device__ __forceinline__ uint2 lds_read64(unsigned addr) {     // opaque to hipcc's LDS-DMA alias tracking
@@ -183,7 +197,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             bool ok = a * 32 + q8 < glim;
             if (!o.gfast)
                 ok = ok && (unsigned)(o.gh0 + (int)(ent.y & 0xffffu)) < (unsigned)p.Hg && (unsigned)(o.gw0 + (int)(ent.y >> 16)) < (unsigned)p.Wg;
-            const unsigned voff = ok && !(p.dbg & 8) ? ent.x + gq + (o.gorg + (unsigned)a * 64u) : ((p.dbg & 16) ? 0u : 0xffffffffu);
+            const unsigned voff = ok && !WDBG(8) ? ent.x + gq + (o.gorg + (unsigned)a * 64u) : (WDBG(16) ? 0u : 0xffffffffu);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rg, dst, 16, voff, 0, 0, 0);
         } else {
             const int l = L0 - ngp;
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
                     ok = ok && (unsigned)h < (unsigned)p.Hx && (unsigned)w < (unsigned)p.Wx;
                 }
             }
-            voff = ok && !(p.dbg & 8) ? voff : ((p.dbg & 16) ? 0u : 0xffffffffu);
+            voff = ok && !WDBG(8) ? voff : (WDBG(16) ? 0u : 0xffffffffu);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rx, dst, 16, voff, 0, 0, 0);
         }
     };
@@ -217,16 +231,20 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     if ((WG_WAVES - heavy) * 16 < ninstr) heavy = 0;
     const int nlight = WG_WAVES - heavy, lw = wave - heavy;       // lw < 0: this wave issues no DMA in the k-loop
 
+    // patch pixel of tile pixel k (k-order = (class, row, column) of the 256-pixel tile)
+    auto pp_of = [&](int k) { return ((k >> lsh) * p.PH + ((k >> p.logTW) & THm) * p.stride) * p.PW + (k & TWm) * p.stride; };
+    const unsigned glane = (unsigned)(krow * 64 + chan_off);
+    const unsigned xlane0 = (unsigned)(pp_of(krow) * 64 + chan_off), xlane1 = (unsigned)(pp_of(krow + 4) * 64 + chan_off);
+
     const int step0 = split * p.steps_per_split;
     const int step1 = min(step0 + p.steps_per_split, p.nsteps);
     int cur = 0;
     __syncthreads();                               // pixel table complete
     if (step0 < step1) issue_all(origin_of(step0), 0);
     for (int step = step0; step < step1; ++step) {
-        if (!(p.dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (p.dbg & 4) __builtin_amdgcn_s_barrier(); else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // tile `step` has landed in buffer `cur`; buffer cur^1 is free
-        const bool more = step + 1 < step1 && !(p.dbg & 1);
+        const bool more = step + 1 < step1 && !WDBG(1);
         const TileOrg onext = origin_of(more ? step + 1 : step);
         const bool prefetch = p.dbuf && more;
         const unsigned gb = sbase + cur * p.bufbytes, xb = gb + gbytes;
@@ -236,22 +254,20 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             const int di = ks * nlight + lw;                      // this wave's DMA instruction in this k-step
             const bool dma = prefetch && lw >= 0 && di < ninstr;
             if (dma) ent = lds_read64(entry_addr(di));
-            const int k0 = ks * 16 + krow, k1 = k0 + 4;
-            const int pp0 = (((k0 >> lsh) * p.PH + ((k0 >> p.logTW) & THm) * p.stride) * p.PW + (k0 & TWm) * p.stride);
-            const int pp1 = (((k1 >> lsh) * p.PH + ((k1 >> p.logTW) & THm) * p.stride) * p.PW + (k1 & TWm) * p.stride);
-            const unsigned ga = gb + k0 * 64 + chan_off;
-            const unsigned xa = xb + pp0 * 64 + chan_off;
-            const unsigned xs = (unsigned)((pp1 - pp0) * 64);
+            // k = 16 ks + krow: the bits of 16 ks and of krow (< 16) are disjoint, so the patch pixel of k is
+            // pp(16 ks) + pp(krow) -- a scalar term per k-step plus two per-lane constants.
+            const unsigned ga = (gb + (unsigned)ks * 1024u) + glane;
+            const unsigned xk = xb + (unsigned)pp_of(ks * 16) * 64u;            // wave-uniform
             // LDS reads in the order the MFMAs consume them (LDS returns in order): every MFMA group waits only
             // for its own fragments, so the first MFMAs start while the later fragments are still in flight.
             // The waits name their registers so that every consumer is ordered behind them.
             uint2 a0[MT], a1[MT], b0[WG_PAIRS], b1[WG_PAIRS];
-            a0[0] = lds_tr(ga); a1[0] = lds_tr(ga + 4 * 64);
-            b0[0] = lds_tr(xa + toff[0]); b1[0] = lds_tr(xa + toff[0] + xs);
+            a0[0] = lds_tr(ga); a1[0] = lds_tr_off<256>(ga);
+            b0[0] = lds_tr(xlane0 + (xk + toff[0])); b1[0] = lds_tr(xlane1 + (xk + toff[0]));
+            if constexpr (MT >= 2) { a0[1] = lds_tr_off<16384>(ga); a1[1] = lds_tr_off<16384 + 256>(ga); }
+            if constexpr (MT >= 3) { a0[2] = lds_tr_off<32768>(ga); a1[2] = lds_tr_off<32768 + 256>(ga); }
 #pragma unroll
-            for (int a = 1; a < MT; ++a) { a0[a] = lds_tr(ga + a * (256 * 64)); a1[a] = lds_tr(ga + a * (256 * 64) + 4 * 64); }
-#pragma unroll
-            for (int u = 1; u < WG_PAIRS; ++u) { b0[u] = lds_tr(xa + toff[u]); b1[u] = lds_tr(xa + toff[u] + xs); }
+            for (int u = 1; u < WG_PAIRS; ++u) { b0[u] = lds_tr(xlane0 + (xk + toff[u])); b1[u] = lds_tr(xlane1 + (xk + toff[u])); }
             constexpr int REST = 2 * (WG_PAIRS - 1);              // reads behind pair 0 / m-tile a
             if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(b0[0]) , "+v"(b1[0]) : "n"(REST));
             if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(b0[0]) , "+v"(b1[0]) : "n"(REST + 2));
