@@ -363,6 +363,16 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
         sos_set_error("sos_conv2d_wgrad: bad descriptor");
         return SOS_EINVAL;
     }
+    // 1x1 kernels (Linear layers, LSTM projections): the pixel arrays of G and X are congruent, so the batch
+    // is one long row -- full 256-pixel tiles instead of one ragged tile per (short) image.
+    sos_wgrad_desc flat = *d;
+    if (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_top == 0 && d->pad_left == 0 && d->Hg == d->Hx && d->Wg == d->Wx) {
+        const uint64_t npx = (uint64_t)d->B * d->Hg * d->Wg;
+        if (npx * (uint64_t)d->g_cs * 2 < 0xfff00000ull && npx * (uint64_t)d->x_cs * 2 < 0xfff00000ull) {
+            flat.B = 1; flat.Hg = flat.Hx = 1; flat.Wg = flat.Wx = (int)npx;
+        }
+    }
+    d = &flat;
     WgParams p;
     p.g = (const bf16_t*)d->g; p.x = (const bf16_t*)d->x; p.partial = d->partial;
     p.B = d->B; p.Hg = d->Hg; p.Wg = d->Wg; p.g_cs = d->g_cs; p.g_off = d->g_off;
@@ -421,9 +431,10 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     const size_t lds = (size_t)p.bufbytes * (p.dbuf ? 2 : 1) + (size_t)(256 + p.npixp) * 8;
     { const char* e = getenv("SOS_WGRAD_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.nsteps = d->B * d->dil_h * p.ngw * p.tiles_h * p.tiles_w;
-    p.ksplit = d->ksplit;
-    p.steps_per_split = (p.nsteps + d->ksplit - 1) / d->ksplit;
-    dim3 grid((unsigned)d->ksplit, (unsigned)mgroups, (unsigned)((ntiles_n + ntb - 1) / ntb));
+    const int ksplit = d->ksplit < p.nsteps ? d->ksplit : p.nsteps;      // never an empty split
+    p.ksplit = ksplit;
+    p.steps_per_split = (p.nsteps + ksplit - 1) / ksplit;
+    dim3 grid((unsigned)ksplit, (unsigned)mgroups, (unsigned)((ntiles_n + ntb - 1) / ntb));
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
 #define SOS_WG_ATTR(MTV, NTBV) \
@@ -444,7 +455,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     const long long total = (long long)d->M * d->N * taps;
     long long gb = (total + 255) / 256;
     if (gb > 4096) gb = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, d->partial, d->ksplit, taps, d->M, d->N,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, d->partial, ksplit, taps, d->M, d->N,
                        p.Mp, p.Np, d->dw, d->accumulate, d->scale);
     return sos_check_launch("sos_conv2d_wgrad(reduce)");
 }
