@@ -68,29 +68,157 @@ __device__ __forceinline__ uint2 lds_read64(unsigned addr) {     // opaque to hi
     return v;
 }
 
+#if __HIP_DEVICE_COMPILE__     // buffer-resource builtins exist in the device pass only; the host pass needs just the stubs
+// origin of a pixel tile (wave-uniform, computed once per tile)
+struct WgTile {
+    __amdgpu_buffer_rsrc_t rg, rx;
+    int gh0, gw0, xh0, xw0;
+    unsigned gorg, xorg;
+    bool xslow, gfast, xfast;   // reflect border tile; every pixel of the G tile / X patch is inside its image
+};
+
+// Operand staging shared by the MFMA kernels below: LDS-DMA (buffer_load_dwordx4 ... lds, no registers, no
+// ds_write).  The LDS images are sub-images of CW = 8 << LP channels with a pixel pitch of 16 << LP bytes:
+//     G: [GSUB sub-images][256 tile pixels][CW channels]     X: [XSUB sub-images][npixp patch pixels][CW channels]
+// A DMA instruction moves 64 consecutive 16-byte pieces (1 KB of LDS) per wave.  The source offset of a pixel
+// relative to the tile origin is the same for every tile, so it is decoded ONCE per kernel into an LDS table
+// {byte offset, row | column << 16}; per tile a lane's piece costs one table read, an add, two range checks
+// (out-of-range lanes get an offset beyond the buffer: the hardware writes zeros) and the DMA issue.
+template <int LP>
+struct WgStage {
+    static constexpr int CW = 8 << LP;            // channels per sub-image
+    const WgParams& p;
+    char* smem;
+    unsigned tab;                                 // LDS address of the pixel table [256 + npixp] x {rel, crd}
+    int lane, wave, lanepix, q8;
+    int ngp, nx, npieces, ninstr;                 // pieces of the G image / of one X sub-image / total; DMA instructions
+    int glim, xlim;
+    unsigned gq, xq;
+    int TH, TW, xspan_h, xspan_w;
+    unsigned gimg_bytes, ximg_bytes;
+    bool reflect;
+
+    __device__ __forceinline__ WgStage(const WgParams& p_, char* smem_, int tid, int gsub, int xsub, int m0, int n0)
+        : p(p_), smem(smem_) {
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        lanepix = lane >> LP;
+        q8 = (lane & ((1 << LP) - 1)) * 8;        // this lane's channel run inside a pixel's sub-image row
+        ngp = gsub * (256 << LP);
+        nx = p.npixp << LP;
+        npieces = ngp + xsub * nx;
+        ninstr = (npieces + 63) >> 6;
+        tab = (unsigned)(uintptr_t)smem + (unsigned)p.bufbytes * (p.dbuf ? 2 : 1);
+        glim = min(p.M - m0, p.g_cs - p.g_off - m0 - 7);
+        xlim = min(p.N - n0, p.x_cs - p.x_off - n0 - 7);
+        gq = (unsigned)(p.g_off + m0 + q8) * 2;
+        xq = (unsigned)(p.x_off + n0 + q8) * 2;
+        TH = 1 << p.logTH; TW = 1 << p.logTW;
+        xspan_h = (p.PH - 1) * p.dh; xspan_w = (p.NC - 1) * p.stride + (p.PW - 1) * p.dw;
+        gimg_bytes = (unsigned)p.Hg * p.Wg * p.g_cs * 2; ximg_bytes = (unsigned)p.Hx * p.Wx * p.x_cs * 2;
+        reflect = p.pad_mode == SOS_PAD_REFLECT;
+        // ---- tile-invariant pixel table
+        const int lsh = p.logTW + p.logTH;
+        for (int e = tid; e < 256 + p.npixp; e += WG_THREADS) {
+            unsigned r = 0u, c = 0x7fff7fffu;                     // invalid: always out of range
+            if (e < 256) {
+                const int j = e & (TW - 1), i = (e >> p.logTW) & (TH - 1), cls = e >> lsh;
+                const int hrel = i * p.dh, wrel = cls + j * p.dw;
+                r = (unsigned)((hrel * p.Wg + wrel) * p.g_cs * 2);
+                c = (unsigned)hrel | ((unsigned)wrel << 16);
+            } else if (e - 256 < p.npix) {
+                const int pix = e - 256;
+                const int rr = pix / p.PW, cc = pix - rr * p.PW;
+                const int cls = rr / p.PH, row = rr - cls * p.PH;
+                const int hrel = row * p.dh, wrel = cls * p.stride + cc * p.dw;
+                r = (unsigned)((hrel * p.Wx + wrel) * p.x_cs * 2);
+                c = (unsigned)hrel | ((unsigned)wrel << 16);
+            }
+            *(uint2*)(smem + (tab - (unsigned)(uintptr_t)smem) + e * 8) = make_uint2(r, c);
+        }
+    }
+    __device__ __forceinline__ WgTile origin_of(int step) const {
+        int t = step;
+        const int tj = t % p.tiles_w; t /= p.tiles_w;
+        const int ti = t % p.tiles_h; t /= p.tiles_h;
+        const int gw = t % p.ngw; t /= p.ngw;
+        const int rh = t % p.dh; t /= p.dh;
+        WgTile o;
+        o.gh0 = rh + ti * TH * p.dh; o.gw0 = gw * p.NC + tj * TW * p.dw;
+        o.xh0 = o.gh0 * p.stride - p.pad_t; o.xw0 = o.gw0 * p.stride - p.pad_l;
+        o.gorg = (unsigned)((o.gh0 * p.Wg + o.gw0) * p.g_cs * 2);
+        o.xorg = (unsigned)((o.xh0 * p.Wx + o.xw0) * p.x_cs * 2);      // may be "negative": wraps, valid lanes land in range
+        o.xfast = o.xh0 >= 0 && o.xw0 >= 0 && o.xh0 + xspan_h < p.Hx && o.xw0 + xspan_w < p.Wx;
+        o.xslow = reflect && !o.xfast;
+        o.gfast = o.gh0 + (TH - 1) * p.dh < p.Hg && o.gw0 + (p.NC - 1) + (TW - 1) * p.dw < p.Wg;
+        o.rg = __builtin_amdgcn_make_buffer_rsrc((void*)(p.g + (size_t)t * p.Hg * p.Wg * p.g_cs), 0, gimg_bytes, 0x00020000);
+        o.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)t * p.Hx * p.Wx * p.x_cs), 0, ximg_bytes, 0x00020000);
+        return o;
+    }
+    // sub-image index of X piece l (wave-uniform)
+    __device__ __forceinline__ int xsub_of(int l) const { return (l >= nx) + (l >= 2 * nx) + (l >= 3 * nx); }
+    // LDS address of this lane's pixel-table entry for DMA instruction i (pieces [64 i, 64 i + 64), i wave-uniform)
+    __device__ __forceinline__ unsigned entry_addr(int i) const {
+        const int L0 = i * 64;
+        int e = ((L0 >> LP) & 255) + lanepix;
+        if (L0 >= ngp) {
+            const int l = L0 - ngp;
+            e = 256 + ((l - xsub_of(l) * nx) >> LP) + lanepix;
+        }
+        return tab + (unsigned)e * 8;
+    }
+    // issue DMA instruction i of tile `o` into LDS buffer `buf`; ent = that lane's table entry
+    __device__ __forceinline__ void issue(int i, const uint2 ent, const WgTile& o, int buf) const {
+        const int L0 = i * 64;                                     // wave-uniform
+        if (i >= ninstr) return;
+        lds_ptr_t dst = (lds_ptr_t)(smem + buf * p.bufbytes + L0 * 16);
+        if (L0 < ngp) {
+            const int a = L0 >> (8 + LP);    // channels past M inside a stored 8-run are the producer's zero padding
+            bool ok = a * CW + q8 < glim;
+            if (!o.gfast)
+                ok = ok && (unsigned)(o.gh0 + (int)(ent.y & 0xffffu)) < (unsigned)p.Hg && (unsigned)(o.gw0 + (int)(ent.y >> 16)) < (unsigned)p.Wg;
+            const unsigned voff = ok && !WDBG(8) ? ent.x + gq + (o.gorg + (unsigned)a * (2u * CW)) : (WDBG(16) ? 0u : 0xffffffffu);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rg, dst, 16, voff, 0, 0, 0);
+        } else {
+            const int nt = xsub_of(L0 - ngp);
+            bool ok = nt * CW + q8 < xlim && ent.y != 0x7fff7fffu;
+            unsigned voff = ent.x + xq + (o.xorg + (unsigned)nt * (2u * CW));
+            if (!o.xfast) {
+                const int h = o.xh0 + (int)(ent.y & 0xffffu), w = o.xw0 + (int)(ent.y >> 16);
+                if (o.xslow) {     // ReflectionPad2d border tile: mirror the coordinates
+                    const int hr = reflect_index(h, p.Hx), wr = reflect_index(w, p.Wx);
+                    voff = (unsigned)((hr * p.Wx + wr) * p.x_cs * 2) + xq + (unsigned)nt * (2u * CW);
+                    ok = ok && (unsigned)hr < (unsigned)p.Hx && (unsigned)wr < (unsigned)p.Wx;
+                } else {
+                    ok = ok && (unsigned)h < (unsigned)p.Hx && (unsigned)w < (unsigned)p.Wx;
+                }
+            }
+            voff = ok && !WDBG(8) ? voff : (WDBG(16) ? 0u : 0xffffffffu);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rx, dst, 16, voff, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void issue_all(const WgTile& o, int buf) const {
+        for (int i = wave; i < ninstr; i += WG_WAVES) {
+            uint2 ent = lds_read64(entry_addr(i));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent));
+            issue(i, ent, o, buf);
+        }
+    }
+};
+#endif
+
 // Workgroup = MT m-tiles (32 rows of dW each) x NTB n-tiles x all taps, 8 waves.  Wave w owns the
 // (tap, n-tile) pairs {w, w+8, w+16, w+24} for ALL MT m-tiles, so every transposed X fragment feeds
-// MT MFMAs and every G fragment WG_PAIRS of them.
-//
-// Operand staging is LDS-DMA (buffer_load_dwordx4 ... lds, no registers, no ds_write).  LDS images:
-//     G: [MT sub-images][256 pixels][32 channels]      X: [NTB sub-images][npixp patch pixels][32 channels]
-// Every sub-image has a 64-byte pixel pitch (conflict free for the transpose reads); a DMA "slot" is one
-// instruction per wave = 8 KB of consecutive LDS per workgroup.  The source offset of a pixel relative
-// to the tile origin is the same for every tile, so it is decoded ONCE per kernel into an LDS table
-// (byte offset, row | column << 16); per tile a lane's slot costs one table read, an add, two range
-// checks (out-of-range lanes get an offset beyond the buffer: the hardware writes zeros) and the DMA
-// issue.  With double buffering slot ks of the next tile is issued in k-step ks of the current one.
+// MT MFMAs and every G fragment WG_PAIRS of them.  Operands: WgStage<2> (32-channel sub-images, 64-byte
+// pixel pitch: conflict free for the transpose reads); with double buffering the DMA instructions of the
+// next tile are issued one per k-step by the "light" waves while the MFMAs of the current tile run.
 template <int MT, int NTB>
 __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
-#if __HIP_DEVICE_COMPILE__     // buffer-resource builtins exist in the device pass only; the host pass needs just the stub
+#if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int gbytes = 256 * 64 * MT;
-    constexpr int ngp = 256 * 4 * MT;                             // 16-byte pieces of the G image
     const int ximg = p.npixp * 64;                                // bytes of one X sub-image
-    const int n4 = p.npixp * 4;                                   // pieces of one X sub-image
-    const int npieces = ngp + NTB * n4;
     const unsigned sbase = (unsigned)(uintptr_t)smem;
-    const unsigned tab = sbase + (unsigned)p.bufbytes * (p.dbuf ? 2 : 1);   // [256 + npixp] x {rel, crd}
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,28 +229,10 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     const int g4 = lane >> 4, s16 = lane & 15;
     const int chan_off = (16 * (g4 & 1) + 4 * (s16 & 3)) * 2;    // byte offset of this lane's 4-channel run
     const int krow = 8 * (g4 >> 1) + (s16 >> 2);                 // pixel (k) inside a 16-pixel k-step; +4 for 2nd read
-    const int TH = 1 << p.logTH, TW = 1 << p.logTW;
-    const int TWm = TW - 1, THm = TH - 1, lsh = p.logTW + p.logTH;
-    const bool reflect = p.pad_mode == SOS_PAD_REFLECT;
+    const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTH) - 1, lsh = p.logTW + p.logTH;
 
-    // ---- tile-invariant pixel table
-    for (int e = tid; e < 256 + p.npixp; e += WG_THREADS) {
-        unsigned r = 0u, c = 0x7fff7fffu;                         // invalid: always out of range
-        if (e < 256) {
-            const int j = e & TWm, i = (e >> p.logTW) & THm, cls = e >> lsh;
-            const int hrel = i * p.dh, wrel = cls + j * p.dw;
-            r = (unsigned)((hrel * p.Wg + wrel) * p.g_cs * 2);
-            c = (unsigned)hrel | ((unsigned)wrel << 16);
-        } else if (e - 256 < p.npix) {
-            const int pix = e - 256;
-            const int rr = pix / p.PW, cc = pix - rr * p.PW;
-            const int cls = rr / p.PH, row = rr - cls * p.PH;
-            const int hrel = row * p.dh, wrel = cls * p.stride + cc * p.dw;
-            r = (unsigned)((hrel * p.Wx + wrel) * p.x_cs * 2);
-            c = (unsigned)hrel | ((unsigned)wrel << 16);
-        }
-        *(uint2*)(smem + (tab - sbase) + e * 8) = make_uint2(r, c);
-    }
+    const WgStage<2> st(p, smem, tid, MT, NTB, m0, n0);
+    const int ninstr = st.ninstr;
 
     f32x16 acc[MT][WG_PAIRS];
 #pragma unroll
@@ -141,90 +251,6 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
         const int ta = tap / p.kw, tb = tap - ta * p.kw;
         toff[u] = (unsigned)((ta * p.PW + tb) * 64 + nt * ximg);
     }
-
-    // origin of pixel tile `step` (wave-uniform, once per tile)
-    struct TileOrg {
-        __amdgpu_buffer_rsrc_t rg, rx;
-        int gh0, gw0, xh0, xw0;
-        unsigned gorg, xorg;
-        bool xslow, gfast, xfast;   // reflect border tile; every pixel of the G tile / X patch is inside its image
-    };
-    const unsigned gimg_bytes = (unsigned)p.Hg * p.Wg * p.g_cs * 2, ximg_bytes = (unsigned)p.Hx * p.Wx * p.x_cs * 2;
-    const int xspan_h = (p.PH - 1) * p.dh, xspan_w = (p.NC - 1) * p.stride + (p.PW - 1) * p.dw;
-    auto origin_of = [&](int step) {
-        int t = step;
-        const int tj = t % p.tiles_w; t /= p.tiles_w;
-        const int ti = t % p.tiles_h; t /= p.tiles_h;
-        const int gw = t % p.ngw; t /= p.ngw;
-        const int rh = t % p.dh; t /= p.dh;
-        TileOrg o;
-        o.gh0 = rh + ti * TH * p.dh; o.gw0 = gw * p.NC + tj * TW * p.dw;
-        o.xh0 = o.gh0 * p.stride - p.pad_t; o.xw0 = o.gw0 * p.stride - p.pad_l;
-        o.gorg = (unsigned)((o.gh0 * p.Wg + o.gw0) * p.g_cs * 2);
-        o.xorg = (unsigned)((o.xh0 * p.Wx + o.xw0) * p.x_cs * 2);      // may be "negative": wraps, valid lanes land in range
-        o.xfast = o.xh0 >= 0 && o.xw0 >= 0 && o.xh0 + xspan_h < p.Hx && o.xw0 + xspan_w < p.Wx;
-        o.xslow = reflect && !o.xfast;
-        o.gfast = o.gh0 + (TH - 1) * p.dh < p.Hg && o.gw0 + (p.NC - 1) + (TW - 1) * p.dw < p.Wg;
-        o.rg = __builtin_amdgcn_make_buffer_rsrc((void*)(p.g + (size_t)t * p.Hg * p.Wg * p.g_cs), 0, gimg_bytes, 0x00020000);
-        o.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)t * p.Hx * p.Wx * p.x_cs), 0, ximg_bytes, 0x00020000);
-        return o;
-    };
-    // A DMA instruction moves 64 consecutive pieces (1 KB of LDS); instruction i covers pieces [64 i, 64 i + 64).
-    // Address of this lane's pixel-table entry for instruction i (i wave-uniform):
-    const int ninstr = (npieces + 63) >> 6;
-    const int lane4 = lane >> 2;
-    auto entry_addr = [&](int i) -> unsigned {
-        const int L0 = i * 64;
-        int e = ((L0 >> 2) & 255) + lane4;
-        if (L0 >= ngp) {
-            const int l = L0 - ngp;
-            const int nt = (l >= n4) + (l >= 2 * n4) + (l >= 3 * n4);
-            e = 256 + ((l - nt * n4) >> 2) + lane4;
-        }
-        return tab + (unsigned)e * 8;
-    };
-    // this lane's channel run inside a pixel's 64-byte sub-image row (same in every instruction)
-    const int q8 = (lane & 3) * 8;
-    const int glim = min(p.M - m0, p.g_cs - p.g_off - m0 - 7), xlim = min(p.N - n0, p.x_cs - p.x_off - n0 - 7);
-    const unsigned gq = (unsigned)(p.g_off + m0 + q8) * 2, xq = (unsigned)(p.x_off + n0 + q8) * 2;
-    // issue DMA instruction i of tile `o` into LDS buffer `buf`; ent = that lane's table entry
-    auto issue = [&](int i, const uint2 ent, const TileOrg& o, int buf) {
-        const int L0 = i * 64;                                     // wave-uniform
-        if (i >= ninstr) return;
-        lds_ptr_t dst = (lds_ptr_t)(smem + buf * p.bufbytes + L0 * 16);
-        if (L0 < ngp) {
-            const int a = L0 >> 10;      // channels past M inside a stored 8-run are the producer's zero padding
-            bool ok = a * 32 + q8 < glim;
-            if (!o.gfast)
-                ok = ok && (unsigned)(o.gh0 + (int)(ent.y & 0xffffu)) < (unsigned)p.Hg && (unsigned)(o.gw0 + (int)(ent.y >> 16)) < (unsigned)p.Wg;
-            const unsigned voff = ok && !WDBG(8) ? ent.x + gq + (o.gorg + (unsigned)a * 64u) : (WDBG(16) ? 0u : 0xffffffffu);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rg, dst, 16, voff, 0, 0, 0);
-        } else {
-            const int l = L0 - ngp;
-            const int nt = (l >= n4) + (l >= 2 * n4) + (l >= 3 * n4);
-            bool ok = nt * 32 + q8 < xlim && ent.y != 0x7fff7fffu;
-            unsigned voff = ent.x + xq + (o.xorg + (unsigned)nt * 64u);
-            if (!o.xfast) {
-                const int h = o.xh0 + (int)(ent.y & 0xffffu), w = o.xw0 + (int)(ent.y >> 16);
-                if (o.xslow) {     // ReflectionPad2d border tile: mirror the coordinates
-                    const int hr = reflect_index(h, p.Hx), wr = reflect_index(w, p.Wx);
-                    voff = (unsigned)((hr * p.Wx + wr) * p.x_cs * 2) + xq + (unsigned)nt * 64u;
-                    ok = ok && (unsigned)hr < (unsigned)p.Hx && (unsigned)wr < (unsigned)p.Wx;
-                } else {
-                    ok = ok && (unsigned)h < (unsigned)p.Hx && (unsigned)w < (unsigned)p.Wx;
-                }
-            }
-            voff = ok && !WDBG(8) ? voff : (WDBG(16) ? 0u : 0xffffffffu);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rx, dst, 16, voff, 0, 0, 0);
-        }
-    };
-    auto issue_all = [&](const TileOrg& o, int buf) {
-        for (int i = wave; i < ninstr; i += WG_WAVES) {
-            uint2 ent = lds_read64(entry_addr(i));
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent));
-            issue(i, ent, o, buf);
-        }
-    };
     // While a tile is multiplied, the next one is fetched by the "light" waves: those that own one (tap, n-tile)
     // pair fewer than the others (25 taps on 8 waves: wave 0 has 4 pairs, waves 1..7 have 3).
     int heavy = npairs & (WG_WAVES - 1);
@@ -240,12 +266,12 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     const int step1 = min(step0 + p.steps_per_split, p.nsteps);
     int cur = 0;
     __syncthreads();                               // pixel table complete
-    if (step0 < step1) issue_all(origin_of(step0), 0);
+    if (step0 < step1) st.issue_all(st.origin_of(step0), 0);
     for (int step = step0; step < step1; ++step) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // tile `step` has landed in buffer `cur`; buffer cur^1 is free
         const bool more = step + 1 < step1 && !WDBG(1);
-        const TileOrg onext = origin_of(more ? step + 1 : step);
+        const WgTile onext = st.origin_of(more ? step + 1 : step);
         const bool prefetch = p.dbuf && more;
         const unsigned gb = sbase + cur * p.bufbytes, xb = gb + gbytes;
 #pragma unroll 1
@@ -253,7 +279,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             uint2 ent = make_uint2(0u, 0u);
             const int di = ks * nlight + lw;                      // this wave's DMA instruction in this k-step
             const bool dma = prefetch && lw >= 0 && di < ninstr;
-            if (dma) ent = lds_read64(entry_addr(di));
+            if (dma) ent = lds_read64(st.entry_addr(di));
             // k = 16 ks + krow: the bits of 16 ks and of krow (< 16) are disjoint, so the patch pixel of k is
             // pp(16 ks) + pp(krow) -- a scalar term per k-step plus two per-lane constants.
             const unsigned ga = (gb + (unsigned)ks * 1024u) + glane;
@@ -272,7 +298,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(b0[0]) , "+v"(b1[0]) : "n"(REST));
             if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(b0[0]) , "+v"(b1[0]) : "n"(REST + 2));
             if constexpr (MT == 3) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(b0[0]) , "+v"(b1[0]) : "n"(REST + 4));
-            if (dma) issue(di, ent, onext, cur ^ 1);
+            if (dma) st.issue(di, ent, onext, cur ^ 1);
             const bool on0 = wave < npairs;
             {
                 const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(b0[0].x, b0[0].y, b1[0].x, b1[0].y));
@@ -309,7 +335,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             cur ^= 1;
         } else if (more) {
             __syncthreads();                       // every wave is done reading the single buffer
-            issue_all(onext, 0);
+            st.issue_all(onext, 0);
         }
     }
     // ---- write this split's partial tiles: D[row = m][col = n], row = (reg&3)+8*(reg>>2)+4*(lane>>5), col = lane&31
@@ -333,6 +359,169 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
 #endif
 }
 
+
+// ---- small channel counts (the 48-channel context layers): v_mfma_f32_16x16x32_bf16.
+// With 32x32 tiles a 48 x 48 gradient pays for 64 x 64; here one workgroup owns ALL of dW: M16 x N16 tiles of
+// 16 x 16 per tap.  Wave w owns the taps {w, w+8, ...} (FT = taps / 8 of them) for every (m, n) tile, and the one
+// remainder tap (25 = 3*8 + 1, 9 = 8 + 1) is split into M16 single-m-tile units for the waves 0..M16-1.
+// Operands: WgStage<1> (16-channel sub-images, 32-byte pixel pitch).  A k-step is 32 tile pixels; MFMA k-slot
+// (lane group g, element e) is tile pixel 4 g + e (e < 4) or 16 + 4 g + (e - 4): the first transpose read of a
+// wave then covers 16 consecutive pixels x 32 B = 128 consecutive dwords (conflict free), the second the next 16.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int M16, int N16, int FT>
+__global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int gbytes = 256 * 32 * M16;
+    const int ximg = p.npixp * 32;                                // bytes of one X sub-image
+    const unsigned sbase = (unsigned)(uintptr_t)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x;
+    const int taps = p.kh * p.kw;
+    const int rem = taps - FT * WG_WAVES;                         // remainder taps (launcher: rem * M16 <= 8)
+    const bool has_e = wave < rem * M16;
+    const int tap_e = min(FT * WG_WAVES + wave / M16, taps - 1), mt_e = wave % M16;
+    const int g4 = lane >> 4, s16 = lane & 15;
+    const int krow = 4 * g4 + (s16 >> 2);                         // tile pixel of the first read inside the k-step; +16 second
+    const int colb = (s16 & 3) * 8;
+    const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTH) - 1, lsh = p.logTW + p.logTH;
+
+    const WgStage<1> st(p, smem, tid, M16, N16, 0, 0);
+    const int ninstr = st.ninstr;
+
+    f32x4 acc[FT][M16][N16], acce[N16];
+#pragma unroll
+    for (int f = 0; f < FT; ++f)
+#pragma unroll
+        for (int a = 0; a < M16; ++a)
+#pragma unroll
+            for (int n = 0; n < N16; ++n) acc[f][a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < N16; ++n) acce[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    unsigned toff[FT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+        const int tap = wave + WG_WAVES * f;
+        const int ta = tap / p.kw, tb = tap - ta * p.kw;
+        toff[f] = (unsigned)((ta * p.PW + tb) * 32);
+    }
+    const unsigned toffe = (unsigned)(((tap_e / p.kw) * p.PW + (tap_e % p.kw)) * 32);
+    auto pp_of = [&](int k) { return ((k >> lsh) * p.PH + ((k >> p.logTW) & THm) * p.stride) * p.PW + (k & TWm) * p.stride; };
+    const unsigned glane = (unsigned)(krow * 32 + colb);
+    const unsigned xlane0 = (unsigned)(pp_of(krow) * 32 + colb), xlane1 = (unsigned)(pp_of(krow + 16) * 32 + colb);
+
+    const int step0 = split * p.steps_per_split;
+    const int step1 = min(step0 + p.steps_per_split, p.nsteps);
+    int cur = 0;
+    __syncthreads();                               // pixel table complete
+    if (step0 < step1) st.issue_all(st.origin_of(step0), 0);
+    for (int step = step0; step < step1; ++step) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                           // tile `step` has landed in buffer `cur`; buffer cur^1 is free
+        const bool more = step + 1 < step1 && !WDBG(1);
+        const WgTile onext = st.origin_of(more ? step + 1 : step);
+        const bool prefetch = p.dbuf && more;
+        const unsigned gb = sbase + cur * p.bufbytes, xb = gb + gbytes;
+#pragma unroll 1
+        for (int ks = 0; ks < 8; ++ks) {
+            if (prefetch) {                        // the next tile: 8 waves x 8 k-steps DMA slots (more rounds if the patch is big)
+                for (int di = ks * WG_WAVES + wave; di < ninstr; di += 8 * WG_WAVES) {
+                    uint2 ent = lds_read64(st.entry_addr(di));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent));
+                    st.issue(di, ent, onext, cur ^ 1);
+                }
+            }
+            const unsigned ga = (gb + (unsigned)ks * 1024u) + glane;
+            const unsigned xk = xb + (unsigned)pp_of(ks * 32) * 32u;            // wave-uniform
+            // reads in consumption order (LDS returns in order): remainder unit, G, then tap by tap
+            uint2 ae0 = make_uint2(0u, 0u), ae1 = ae0, be0[N16], be1[N16];
+#pragma unroll
+            for (int n = 0; n < N16; ++n) { be0[n] = ae0; be1[n] = ae0; }
+            if (has_e) {
+                ae0 = lds_tr(ga + (unsigned)mt_e * 8192u); ae1 = lds_tr_off<512>(ga + (unsigned)mt_e * 8192u);
+#pragma unroll
+                for (int n = 0; n < N16; ++n) {
+                    be0[n] = lds_tr(xlane0 + (xk + toffe + (unsigned)(n * ximg)));
+                    be1[n] = lds_tr(xlane1 + (xk + toffe + (unsigned)(n * ximg)));
+                }
+            }
+            uint2 a0[M16], a1[M16], b0[FT][N16], b1[FT][N16];
+            a0[0] = lds_tr(ga); a1[0] = lds_tr_off<512>(ga);
+            if constexpr (M16 >= 2) { a0[1] = lds_tr_off<8192>(ga); a1[1] = lds_tr_off<8192 + 512>(ga); }
+            if constexpr (M16 >= 3) { a0[2] = lds_tr_off<16384>(ga); a1[2] = lds_tr_off<16384 + 512>(ga); }
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int n = 0; n < N16; ++n) {
+                    b0[f][n] = lds_tr(xlane0 + (xk + toff[f] + (unsigned)(n * ximg)));
+                    b1[f][n] = lds_tr(xlane1 + (xk + toff[f] + (unsigned)(n * ximg)));
+                }
+#pragma unroll
+            for (int f = 0; f < FT; ++f) {
+                // everything up to tap f has landed when 2 N16 (FT - 1 - f) reads are still outstanding
+                if constexpr (N16 == 3) {
+                    if (f == 0) {
+                        if constexpr (M16 == 3)
+                            asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[1]), "+v"(a1[1]), "+v"(a0[2]), "+v"(a1[2]),
+                                         "+v"(b0[0][0]), "+v"(b1[0][0]), "+v"(b0[0][1]), "+v"(b1[0][1]), "+v"(b0[0][2]), "+v"(b1[0][2]) : "n"(6 * (FT - 1)));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(b0[f][0]), "+v"(b1[f][0]), "+v"(b0[f][1]), "+v"(b1[f][1]), "+v"(b0[f][2]), "+v"(b1[f][2])
+                                     : "n"(6 * (FT - 1 - f)));
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < N16; ++n) {
+                    const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(b0[f][n].x, b0[f][n].y, b1[f][n].x, b1[f][n].y));
+#pragma unroll
+                    for (int a = 0; a < M16; ++a) {
+                        const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(a0[a].x, a0[a].y, a1[a].x, a1[a].y));
+                        acc[f][a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[f][a][n], 0, 0, 0);
+                    }
+                }
+            }
+            if (has_e) {
+                if constexpr (N16 == 3)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ae0), "+v"(ae1), "+v"(be0[0]), "+v"(be1[0]), "+v"(be0[1]), "+v"(be1[1]), "+v"(be0[2]), "+v"(be1[2]));
+                const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(ae0.x, ae0.y, ae1.x, ae1.y));
+#pragma unroll
+                for (int n = 0; n < N16; ++n) {
+                    const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(be0[n].x, be0[n].y, be1[n].x, be1[n].y));
+                    acce[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acce[n], 0, 0, 0);
+                }
+            }
+        }
+        if (p.dbuf) {
+            cur ^= 1;
+        } else if (more) {
+            __syncthreads();                       // every wave is done reading the single buffer
+            st.issue_all(onext, 0);
+        }
+    }
+    // ---- partial tiles: D[m][n] of v_mfma_f32_16x16x32: n = lane & 15, m = 4 (lane >> 4) + reg
+    float* out = p.partial + (size_t)split * taps * p.Mp * p.Np;
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+        const int tap = wave + WG_WAVES * f;
+#pragma unroll
+        for (int a = 0; a < M16; ++a)
+#pragma unroll
+            for (int n = 0; n < N16; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[((size_t)tap * p.Mp + a * 16 + 4 * g4 + r) * p.Np + n * 16 + s16] = acc[f][a][n][r];
+    }
+    if (has_e) {
+#pragma unroll
+        for (int n = 0; n < N16; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[((size_t)tap_e * p.Mp + mt_e * 16 + 4 * g4 + r) * p.Np + n * 16 + s16] = acce[n][r];
+    }
+#endif
+}
 
 // dW[m][n][tap] (+)= sum over splits of partial[s][tap][m][n]; also used for 1x1 / Linear weights.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int ksplit, int taps, int M, int N, int Mp,
@@ -393,6 +582,9 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
         sos_set_error("sos_conv2d_wgrad: one image of an operand exceeds 4 GB");
         return SOS_ENOSPC;
     }
+    // small channel counts: the 16x16x32 kernel owns all of dW in one workgroup (no padding to 32)
+    const int m16 = (d->M + 15) / 16, n16 = (d->N + 15) / 16;
+    const bool use16 = m16 == 3 && n16 == 3 && (taps == 25 || taps == 9) && !getenv("SOS_WGRAD_NO16");
     // pixel tile (NC x TH x TW = 256): fewest k-steps among the shapes whose operands fit LDS (double
     // buffered, <= 16 DMA slots, if possible); shrink the channel tile if none fits
     const size_t lds_max = 160 * 1024;
@@ -408,8 +600,9 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
                 const int TH = 1 << lth, TW = 1 << ltw;
                 const int PH = (TH - 1) * d->stride + d->kh, PW = (TW - 1) * d->stride + d->kw;
                 if ((TH - 1 + d->kh) * d->dil_h >= 0x7fff || (d->stride * NC + (PW - 1) * d->dil_w) >= 0x7fff) continue;
-                const int npixp = (NC * PH * PW + 15) / 16 * 16;
-                const size_t one = ((size_t)256 * 64 * mt + (size_t)npixp * 64 * ntb + 1023) / 1024 * 1024;
+                const int npixp = use16 ? (NC * PH * PW + 31) / 32 * 32 : (NC * PH * PW + 15) / 16 * 16;
+                const size_t one = use16 ? ((size_t)256 * 32 * m16 + (size_t)npixp * 32 * n16 + 1023) / 1024 * 1024
+                                         : ((size_t)256 * 64 * mt + (size_t)npixp * 64 * ntb + 1023) / 1024 * 1024;
                 const size_t tabb = (size_t)(256 + npixp) * 8;
                 if (one + tabb > lds_max) continue;
                 const int db = 2 * one + tabb <= lds_max;
@@ -419,7 +612,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
             }
         }
         if (bnc) { p.NC = bnc; p.logTH = bth; p.logTW = btw; p.dbuf = bdb; break; }
-        if (ntb == 1) { sos_set_error("sos_conv2d_wgrad: patch does not fit LDS"); return SOS_ENOSPC; }
+        if (ntb == 1 || use16) { sos_set_error("sos_conv2d_wgrad: patch does not fit LDS"); return SOS_ENOSPC; }
         ntb >>= 1;
     }
     {
@@ -437,6 +630,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     dim3 grid((unsigned)ksplit, (unsigned)mgroups, (unsigned)((ntiles_n + ntb - 1) / ntb));
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
+    if (use16) grid = dim3((unsigned)ksplit, 1, 1);
 #define SOS_WG_ATTR(MTV, NTBV) \
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<MTV, NTBV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #define SOS_WG_CASE(MTV, NTBV) \
@@ -444,10 +638,17 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     if (!attr_done) {       // every instantiation may use the full 160 KB of LDS
         SOS_WG_ATTR(1, 1) SOS_WG_ATTR(1, 2) SOS_WG_ATTR(1, 4) SOS_WG_ATTR(2, 1) SOS_WG_ATTR(2, 2) SOS_WG_ATTR(2, 4)
         SOS_WG_ATTR(3, 1) SOS_WG_ATTR(3, 2) SOS_WG_ATTR(3, 4)
+        (void)hipFuncSetAttribute((const void*)wgrad16_kernel<3, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad16_kernel<3, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    SOS_WG_CASE(1, 1) SOS_WG_CASE(1, 2) SOS_WG_CASE(1, 4) SOS_WG_CASE(2, 1) SOS_WG_CASE(2, 2) SOS_WG_CASE(2, 4)
-    SOS_WG_CASE(3, 1) SOS_WG_CASE(3, 2) SOS_WG_CASE(3, 4)
+    if (use16) {
+        if (taps == 25) hipLaunchKernelGGL((wgrad16_kernel<3, 3, 3>), grid, dim3(WG_THREADS), lds, s, p);
+        else hipLaunchKernelGGL((wgrad16_kernel<3, 3, 1>), grid, dim3(WG_THREADS), lds, s, p);
+    } else {
+        SOS_WG_CASE(1, 1) SOS_WG_CASE(1, 2) SOS_WG_CASE(1, 4) SOS_WG_CASE(2, 1) SOS_WG_CASE(2, 2) SOS_WG_CASE(2, 4)
+        SOS_WG_CASE(3, 1) SOS_WG_CASE(3, 2) SOS_WG_CASE(3, 4)
+    }
 #undef SOS_WG_CASE
 #undef SOS_WG_ATTR
     int rc = sos_check_launch("sos_conv2d_wgrad");

@@ -73,6 +73,10 @@ CASES = [
     ("5x5 s2 reflect", 128, 64, (5, 5), 2, (1, 1), (2, 2), "reflect", 18, 41),
     ("1x1 linear", 100, 200, (1, 1), 1, (1, 1), (0, 0), "zeros", 1, 77),
     ("3x3 narrow", 2, 64, (3, 3), 1, (1, 1), (1, 1), "reflect", 12, 19),
+    # 16x16x32 kernel (M, N in (32, 48], 25 or 9 taps): dense, dilated with residue classes, reflect border
+    ("16: 5x5 48x48", 48, 48, (5, 5), 1, (1, 1), (2, 2), "zeros", 37, 50),
+    ("16: 5x5 dil(4,4) 48x40", 48, 40, (5, 5), 1, (4, 4), (8, 8), "zeros", 30, 41),
+    ("16: 3x3 reflect 40x48", 40, 48, (3, 3), 1, (1, 1), (1, 1), "reflect", 21, 35),
 ]
 
 
