@@ -136,11 +136,17 @@ int sos_conv2d_tune_load(const char* path);
 /* ---- a7/a11 recurrent part of nn.LSTM(bidirectional=True), gate order i,f,g,o
  * (M1/networks.py:95,143-148; M2/networks.py:64,88).  The input projection
  * x@W_ih^T + b_ih + b_hh is a sos_conv2d_fwd (1x1) producing xproj.
- * xproj f32 [B][T][2][4H] (dir 0 fwd, 1 reverse); whh_t f32 [2][H][4H] (transposed
- * W_hh); out_f32 (optional) [B][T][2H]; out_bf16 (optional) bf16 [B][T][out_cs]
- * (+ thirds when dtype == SOS_DT_BF16X3). */
-int sos_lstm_bidir_fwd(const float* xproj, const float* whh_t, int64_t B, int64_t T, int H,
-                       float* out_f32, void* out_bf16, int out_cs, int out_dtype, int64_t out_third,
+ * W_hh (f32 [2][4H][H], the layout torch stores: weight_hh_l0, weight_hh_l0_reverse) is packed once per
+ * weight version into MFMA fragment order: sos_lstm_pack_bytes(H, 0 / 1) = bytes of ONE forward /
+ * backward array; the lo arrays (both or neither) hold the bf16 remainders for the three-pass
+ * hi*hi + hi*lo + lo*hi product of the bf16x3 precision mode.  H % 4 == 0, H <= 256.
+ * xproj f32 [B][T][2][4H] (dir 0 fwd, 1 reverse); out_bf16 bf16 [B][T][out_cs] (+ thirds when
+ * dtype == SOS_DT_BF16X3). */
+int64_t sos_lstm_pack_bytes(int H, int backward);
+int sos_lstm_pack_whh(const float* whh, int H, void* fwd_hi, void* fwd_lo, void* bwd_hi, void* bwd_lo,
+                      sos_stream_t stream);
+int sos_lstm_bidir_fwd(const float* xproj, const void* wpk_hi, const void* wpk_lo /* optional */, int64_t B, int64_t T,
+                       int H, void* out_bf16, int out_cs, int out_dtype, int64_t out_third,
                        float* save_gates /* optional f32 [B][T][2][4H] post-activation i,f,g,o */,
                        float* save_c /* optional f32 [B][T][2][H] */, sos_stream_t stream);
 
@@ -217,12 +223,12 @@ int sos_pack_grad_f32(const float* g, const float* y, int act, int64_t outer, in
 int sos_feat_to_nhwc(const sos_view* feat, int B, int H, int W, int Wo, const int32_t* lo, const int32_t* hi,
                      const sos_view* out, sos_stream_t stream);
 /* ---- BPTT of the recurrent part of nn.LSTM (autograd of M1/networks.py:148, M2/networks.py:88).
- * dh_out: bf16 grad of the LSTM output [B][T][dh_cs]; gates/csave from the forward; whh f32
- * [2][4H][H]; dgates f32 [B][T][2][4H] (gate pre-activation grads; dW_ih, dW_hh, bias and input
- * grads are GEMMs over it). */
+ * dh_out: bf16 grad of the LSTM output [B][T][dh_cs] (dh_cs % 4 == 0); gates/csave from the forward;
+ * wtk_hi / wtk_lo: the backward arrays of sos_lstm_pack_whh; dgates f32 [B][T][2][4H] (gate
+ * pre-activation grads; dW_ih, dW_hh, bias and input grads are GEMMs over it). */
 int sos_lstm_bidir_bwd(const void* dh_out, int dh_cs, int dh_dtype, int64_t dh_third, const float* gates,
-                       const float* csave, const float* whh, int64_t B, int64_t T, int H, float* dgates,
-                       sos_stream_t stream);
+                       const float* csave, const void* wtk_hi, const void* wtk_lo /* optional */, int64_t B, int64_t T,
+                       int H, float* dgates, sos_stream_t stream);
 /* ---- losses (M2/agent.py:174,188-189; M1/agent.py:187,202) and optimizer (M1/agent.py:177). */
 int sos_mse_loss(const float* a, const float* b, int64_t n, float upstream, float* loss, float* grad, float* partial,
                  sos_stream_t stream);

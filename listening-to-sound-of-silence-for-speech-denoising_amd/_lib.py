@@ -64,14 +64,16 @@ SIGNATURES = {
     "sos_conv2d_tune": [C.POINTER(ConvDesc), _I, _I, C.POINTER(C.c_float), _P],
     "sos_conv2d_tune_save": [C.c_char_p],
     "sos_conv2d_tune_load": [C.c_char_p],
-    "sos_lstm_bidir_fwd": [_P, _P, _L, _L, _I, _P, _P, _I, _I, _L, _P, _P, _P],
+    "sos_lstm_pack_bytes": [_I, _I],
+    "sos_lstm_pack_whh": [_P, _I, _P, _P, _P, _P, _P],
+    "sos_lstm_bidir_fwd": [_P, _P, _P, _L, _L, _I, _P, _I, _I, _L, _P, _P, _P],
     "sos_bn_bwd": [C.POINTER(View), C.POINTER(View), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(View), _P],
     "sos_act_bwd_from_y": [C.POINTER(View), C.POINTER(View), _I, C.POINTER(View), _P],
     "sos_pack_grad_f32": [_P, _P, _I, _L, _L, _I, _L, _L, _L, C.POINTER(View), _P],
     "sos_feat_to_nhwc": [C.POINTER(View), _I, _I, _I, _I, _P, _P, C.POINTER(View), _P],
     "sos_reflect_fold": [C.POINTER(View), _I, _I, _I, C.POINTER(View), _I, _P],
     "sos_copy_crop": [C.POINTER(View), _I, _I, C.POINTER(View), _I, _I, _P],
-    "sos_lstm_bidir_bwd": [_P, _I, _I, _L, _P, _P, _P, _L, _L, _I, _P, _P],
+    "sos_lstm_bidir_bwd": [_P, _I, _I, _L, _P, _P, _P, _P, _L, _L, _I, _P, _P],
     "sos_mse_loss": [_P, _P, _L, _F, _P, _P, _P, _P],
     "sos_bce_logits_loss": [_P, _P, _L, _F, _P, _P, _P, _P],
     "sos_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P],
@@ -99,7 +101,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
-            fn.restype = C.c_int64 if name == "sos_wgrad_workspace_bytes" else C.c_int
+            fn.restype = C.c_int64 if name in ("sos_wgrad_workspace_bytes", "sos_lstm_pack_bytes") else C.c_int
         h.sos_last_error.restype = C.c_char_p
         h.sos_last_error.argtypes = []
         _lib = h

@@ -77,9 +77,8 @@ def lstm_plan(lstm, cin_store, x3):
     w_ih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse], dim=0).detach()
     bias = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse]).detach()
     w = E.pack_weight(w_ih[:, :, None, None], cin_store, x3)
-    whh_t = torch.stack([lstm.weight_hh_l0.detach().t(), lstm.weight_hh_l0_reverse.detach().t()]).float().contiguous()
     return dict(w=w, scale=E.pad_vec(torch.ones(8 * H, device=w.device), w.shape[1], 1.0),
-                shift=E.pad_vec(bias, w.shape[1]), whh_t=whh_t, H=H, cin_store=cin_store)
+                shift=E.pad_vec(bias, w.shape[1]), wpk=E.lstm_pack(lstm, x3), H=H, cin_store=cin_store)
 
 
 def run_lstm(lp, feat_dims, B, T, x3, device):
@@ -89,7 +88,7 @@ def run_lstm(lp, feat_dims, B, T, x3, device):
     E.conv(None, 0, lp["cin_store"], lp["w"], 1, 1, 8 * H, lp["scale"], lp["shift"], L.ACT_NONE,
            out=xproj, out_dtype=L.DT_F32, sb=T * 8 * H, sh=0, sw=8 * H, sc=1, Ho=1, Wo=T, in_dims=feat_dims)
     h = E.Act(B, 1, T, E.pad_to(2 * H, 16), x3, device, zero=True)
-    E.lstm(xproj, lp["whh_t"], B, T, H, h)
+    E.lstm(xproj, lp["wpk"], B, T, H, h)
     return h
 
 

@@ -112,6 +112,7 @@ __device__ __forceinline__ void stage_patch_dma(const ConvParams& p, char* patch
 
 template <int NT, int KS>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
+#if __HIP_DEVICE_COMPILE__     // buffer-resource builtins exist in the device pass only; the host pass needs just the stub
     constexpr int KC = 16 * KS;                 // channels per chunk
     constexpr int PSTRIDE = KC * 2 + 16;        // bytes per patch pixel row (padded)
     constexpr int BSTRIDE = KC * 2 + 16;        // bytes per weight row (padded)
@@ -120,7 +121,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     constexpr int BPIECES = BROWS * CPR;
     constexpr int NBREG = (BPIECES + 255) / 256;
     constexpr int BBYTES = BROWS * BSTRIDE;
-#if __HIP_DEVICE_COMPILE__     // buffer-resource builtins exist in the device pass only; the host pass needs just the stub
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
     const int boff0 = p.npix * PSTRIDE;          // weight slab buffers follow the patch

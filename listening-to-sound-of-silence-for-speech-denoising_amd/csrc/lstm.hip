@@ -1,114 +1,166 @@
-// lstm.hip -- recurrent half of nn.LSTM(num_layers=1, bidirectional=True), fp32 (gfx950).
+// lstm.hip -- recurrent half of nn.LSTM(num_layers=1, bidirectional=True) on MFMA (gfx950).
 //
 // Reference: M1/networks.py:95,143-148 (input 2048, hidden 100) and M2/networks.py:64,88
 // (input 3072, hidden 200); gate order i,f,g,o.  The input projection (x @ W_ih^T + b_ih + b_hh,
-// > 99 % of the LSTM FLOPs) is done by sos_conv2d_fwd as a 1x1 conv on MFMA; this kernel does
-// the strictly sequential part: one persistent workgroup per (direction, slice of NB clips) walks
-// the T steps; thread j owns hidden unit j for all NB clips (cell state in registers), h_{t-1} is
-// exchanged through a double-buffered LDS tile laid out [k][NB] so one 32-byte broadcast read
-// feeds 8 clips, and W_hh^T ([k][4H], coalesced over j) streams from L2 every step.
+// > 99 % of the LSTM FLOPs) is done by sos_conv2d_fwd as a 1x1 conv; these kernels do the strictly
+// sequential part, forward and BPTT.
+//
+// One persistent workgroup (8 waves) per (direction, 16 clips) walks the T steps.  The recurrent
+// product of a step is v_mfma_f32_16x16x32_bf16 with the 16 clips as the N dimension:
+//   forward   gates[4H x 16]  = W_hh [4H x H]  . h_{t-1} [H x 16]      (+ xproj)
+//   backward  dh_rec[H x 16]  = W_hh^T [H x 4H] . dgates_t [4H x 16]
+// W_hh is pre-packed once per weight version (sos_lstm_pack_whh) into the MFMA A-fragment order, so
+// a fragment is one coalesced 1 KB load; it streams from L2 every step (320 KB per step for H = 200).
+// The forward packs the rows of a 16-row tile as (unit u, gate q) -> row 4u + q: the accumulator
+// layout (lane = clip + 16 * (row / 4), register = row % 4) then hands every lane the four gates
+// of ONE (hidden unit, clip), so the cell update runs in registers with the cell state resident in
+// a register; only h_t (bf16) goes through LDS, [clip][k], double buffered: one barrier per step.
+// The backward gets dh_rec of (4 consecutive units, clip) per lane and does the gate-gradient
+// arithmetic on it directly; dgates_t goes to global (f32, for the dW GEMMs) and to LDS (bf16,
+// the next product's B operand).  With lo arrays given (bf16x3 mode) every product is the three
+// passes hi*hi + hi*lo + lo*hi.
 #include "sos_common.h"
 
-#define LSTM_NB 8
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LM_NB 16              // clips per workgroup (MFMA N)
+#define LM_WAVES 8
+#define LM_THREADS (LM_WAVES * 64)
+#define LM_FT 8               // forward: 4-unit tiles per wave (H <= 256)
+#define LM_BT 2               // backward: 16-unit tiles per wave
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f / (1.0f + expf(2.0f * x)); }   // |err| ~1e-7
+__device__ __forceinline__ bf16x8 frag(const uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-// Thread layout: thread = (gate q, group of 4 consecutive hidden units) -> one 16-byte W_hh^T load
-// per k feeds 4 units x NB clips; the four gate pre-activations of a unit meet in LDS, then the
-// first H threads do the cell update (cell state lives in LDS, [j][NB]).
-__global__ __launch_bounds__(256) void lstm_kernel(const float* __restrict__ xproj, const float* __restrict__ whh_t,
-                                                   int B, int T, int H, float* __restrict__ out_f32,
-                                                   bf16_t* __restrict__ out_bf16, int out_cs, int x3,
-                                                   long long third, float* __restrict__ save_gates,
-                                                   float* __restrict__ save_c) {
+static inline int lm_kf(int H) { return (H + 31) / 32; }        // forward k-fragments (K = H)
+static inline int lm_kb(int H) { return (4 * H + 31) / 32; }    // backward k-fragments (K = 4H)
+static inline int lm_nj(int H) { return (H + 15) / 16; }        // backward 16-unit row tiles
+
+// ---- packing: fwd [2][H/4 tiles][KF][64 lanes][8], bwd [2][NJ][KB][64][8] (bf16 hi, optional lo)
+__global__ void lstm_pack_kernel(const float* __restrict__ whh, int H, bf16_t* __restrict__ fh, bf16_t* __restrict__ fl,
+                                 bf16_t* __restrict__ bh, bf16_t* __restrict__ bl) {
+    const int G = 4 * H, NT = H >> 2, KF = (H + 31) / 32, NJ = (H + 15) / 16, KB = (G + 31) / 32;
+    const long long nf = 2LL * NT * KF * 512, nb = 2LL * NJ * KB * 512;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += (long long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        bf16_t *ph, *pl;
+        if (i < nf) {
+            const int e = (int)(i & 7), l = (int)((i >> 3) & 63);
+            long long f = i >> 9;
+            const int kk = (int)(f % KF); f /= KF;
+            const int tile = (int)(f % NT), dir = (int)(f / NT);
+            const int r = l & 15, row = (r & 3) * H + 4 * tile + (r >> 2), k = kk * 32 + 8 * (l >> 4) + e;
+            if (k < H) v = whh[((size_t)dir * G + row) * H + k];
+            ph = fh + i; pl = fl ? fl + i : nullptr;
+        } else {
+            const long long i2 = i - nf;
+            const int e = (int)(i2 & 7), l = (int)((i2 >> 3) & 63);
+            long long f = i2 >> 9;
+            const int kk = (int)(f % KB); f /= KB;
+            const int jt = (int)(f % NJ), dir = (int)(f / NJ);
+            const int j = jt * 16 + (l & 15), r = kk * 32 + 8 * (l >> 4) + e;
+            if (j < H && r < G) v = whh[((size_t)dir * G + r) * H + j];
+            ph = bh + i2; pl = bl ? bl + i2 : nullptr;
+        }
+        const bf16_t hi = f2bf(v);
+        *ph = hi;
+        if (pl) *pl = f2bf(v - bf2f(hi));
+    }
+}
+
+extern "C" int64_t sos_lstm_pack_bytes(int H, int backward) {
+    if (H < 4 || H > 256 || (H & 3)) return -1;
+    return backward ? 2LL * lm_nj(H) * lm_kb(H) * 1024 : 2LL * (H / 4) * lm_kf(H) * 1024;
+}
+
+extern "C" int sos_lstm_pack_whh(const float* whh, int H, void* fwd_hi, void* fwd_lo, void* bwd_hi, void* bwd_lo,
+                                 sos_stream_t stream) {
+    if (!whh || !fwd_hi || !bwd_hi || H < 4 || H > 256 || (H & 3) || ((fwd_lo == nullptr) != (bwd_lo == nullptr))) {
+        sos_set_error("sos_lstm_pack_whh: bad args (H=%d)", H);
+        return SOS_EINVAL;
+    }
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, whh, H, (bf16_t*)fwd_hi,
+                       (bf16_t*)fwd_lo, (bf16_t*)bwd_hi, (bf16_t*)bwd_lo);
+    return sos_check_launch("sos_lstm_pack_whh");
+}
+
+// ----------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __restrict__ xproj, const uint4* __restrict__ wh,
+                                                               const uint4* __restrict__ wl, int B, int T, int H,
+                                                               bf16_t* __restrict__ out, int out_cs, int out_x3,
+                                                               long long third, float* __restrict__ save_gates,
+                                                               float* __restrict__ save_c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* hbuf = (float*)smem;                           // [2][H][NB]
-    float* gbuf = hbuf + 2 * H * LSTM_NB;                 // [4H][NB] gate pre-activations
-    float* cbuf = gbuf + 4 * H * LSTM_NB;                 // [H][NB] cell state
-    const int tid = threadIdx.x;
-    const int dir = blockIdx.y;
-    const int b0 = blockIdx.x * LSTM_NB;
-    const int G = 4 * H;
-    const float* W = whh_t + (size_t)dir * H * G;         // [k][4H]
-    const int nact = G >> 2;                               // active threads (4 gate columns each)
-    const int col0 = tid * 4;                              // first gate column of this thread
-    for (int idx = tid; idx < 2 * H * LSTM_NB + 4 * H * LSTM_NB + H * LSTM_NB; idx += blockDim.x) hbuf[idx] = 0.f;
+    const int KF = (H + 31) / 32, NT = H >> 2, G = 4 * H;
+    const int HP = KF * 64 + 16;                         // bytes of one clip's h row (bf16, k padded to 32, +16: banks)
+    const int P = wl ? 2 : 1;                            // hi (+ lo) planes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, b0 = blockIdx.x * LM_NB;
+    const int n = lane & 15, g4 = lane >> 4;
+    const int b = b0 + n;
+    const bool live = b < B;
+    for (int i = tid; i < 2 * P * LM_NB * HP / 4; i += LM_THREADS) ((unsigned*)smem)[i] = 0u;
+    float creg[LM_FT];
+#pragma unroll
+    for (int ti = 0; ti < LM_FT; ++ti) creg[ti] = 0.f;
+    const uint4* whd = wh + (size_t)dir * NT * KF * 64 + lane;
+    const uint4* wld = wl ? wl + (size_t)dir * NT * KF * 64 + lane : nullptr;
     __syncthreads();
 
     for (int step = 0; step < T; ++step) {
         const int t = dir == 0 ? step : T - 1 - step;
-        const float* hcur = hbuf + (size_t)(step & 1) * H * LSTM_NB;
-        float* hnext = hbuf + (size_t)((step + 1) & 1) * H * LSTM_NB;
-        if (tid < nact) {
-            float g[4][LSTM_NB];
+        const char* hb = smem + (size_t)(step & 1) * P * LM_NB * HP;
+        char* hn = smem + (size_t)((step + 1) & 1) * P * LM_NB * HP;
+        // B fragments: h_{t-1}[k][clip], lane = clip + 16 * (k / 8)
+        uint4 hf[8], hl[8];
 #pragma unroll
-            for (int n = 0; n < LSTM_NB; ++n) {
-                const int b = b0 + n;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (b < B) x = *(const float4*)(xproj + (((size_t)b * T + t) * 2 + dir) * G + col0);
-                g[0][n] = x.x; g[1][n] = x.y; g[2][n] = x.z; g[3][n] = x.w;
-            }
-            const float* wp = W + col0;
-#pragma unroll 8
-            for (int k = 0; k < H; ++k) {
-                const float4 w = *(const float4*)(wp + (size_t)k * G);
-                const float4 ha = *(const float4*)(hcur + k * LSTM_NB);
-                const float4 hb = *(const float4*)(hcur + k * LSTM_NB + 4);
-                const float hv[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
-#pragma unroll
-                for (int n = 0; n < LSTM_NB; ++n) {
-                    g[0][n] = fmaf(w.x, hv[n], g[0][n]);
-                    g[1][n] = fmaf(w.y, hv[n], g[1][n]);
-                    g[2][n] = fmaf(w.z, hv[n], g[2][n]);
-                    g[3][n] = fmaf(w.w, hv[n], g[3][n]);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                *(float4*)(gbuf + (col0 + e) * LSTM_NB) = make_float4(g[e][0], g[e][1], g[e][2], g[e][3]);
-                *(float4*)(gbuf + (col0 + e) * LSTM_NB + 4) = make_float4(g[e][4], g[e][5], g[e][6], g[e][7]);
+        for (int kk = 0; kk < 8; ++kk) {
+            if (kk < KF) {
+                hf[kk] = *(const uint4*)(hb + n * HP + kk * 64 + g4 * 16);
+                if (wl) hl[kk] = *(const uint4*)(hb + LM_NB * HP + n * HP + kk * 64 + g4 * 16);
             }
         }
-        __syncthreads();
-        // cell update: thread (j, half) handles 4 clips of hidden unit j
-        for (int idx = tid; idx < 2 * H; idx += blockDim.x) {
-            const int j = idx >> 1, n0 = (idx & 1) * 4;
-            const float4 gi = *(const float4*)(gbuf + (0 * H + j) * LSTM_NB + n0);
-            const float4 gf = *(const float4*)(gbuf + (1 * H + j) * LSTM_NB + n0);
-            const float4 gg = *(const float4*)(gbuf + (2 * H + j) * LSTM_NB + n0);
-            const float4 go = *(const float4*)(gbuf + (3 * H + j) * LSTM_NB + n0);
-            float4 c4 = *(const float4*)(cbuf + j * LSTM_NB + n0);
-            const float iv[4] = {gi.x, gi.y, gi.z, gi.w}, fv[4] = {gf.x, gf.y, gf.z, gf.w};
-            const float gv[4] = {gg.x, gg.y, gg.z, gg.w}, ov[4] = {go.x, go.y, go.z, go.w};
-            float cv[4] = {c4.x, c4.y, c4.z, c4.w}, hv[4];
+        const size_t row = (size_t)b * T + t;
+        const float* xp = xproj + (row * 2 + dir) * G;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float ig = sigmoidf_(iv[e]), fg = sigmoidf_(fv[e]), gt = tanhf(gv[e]), og = sigmoidf_(ov[e]);
-                cv[e] = fg * cv[e] + ig * gt;
-                hv[e] = og * tanhf(cv[e]);
-                const int bb = b0 + n0 + e;
-                if (save_gates && bb < B) {
-                    float* sg = save_gates + (((size_t)bb * T + t) * 2 + dir) * G;
-                    sg[j] = ig; sg[H + j] = fg; sg[2 * H + j] = gt; sg[3 * H + j] = og;
-                    save_c[(((size_t)bb * T + t) * 2 + dir) * H + j] = cv[e];
+        for (int ti = 0; ti < LM_FT; ++ti) {
+            const int tile = wave + LM_WAVES * ti;       // wave-uniform
+            if (tile >= NT) break;
+            const int j = tile * 4 + g4;                 // this lane's hidden unit; registers = gates i,f,g,o
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (live) { acc[0] = xp[j]; acc[1] = xp[H + j]; acc[2] = xp[2 * H + j]; acc[3] = xp[3 * H + j]; }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                if (kk < KF) {
+                    const uint4 w = whd[((size_t)tile * KF + kk) * 64];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w), frag(hf[kk]), acc, 0, 0, 0);
+                    if (wl) {
+                        const uint4 w2 = wld[((size_t)tile * KF + kk) * 64];
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w), frag(hl[kk]), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w2), frag(hf[kk]), acc, 0, 0, 0);
+                    }
                 }
             }
-            *(float4*)(cbuf + j * LSTM_NB + n0) = make_float4(cv[0], cv[1], cv[2], cv[3]);
-            *(float4*)(hnext + j * LSTM_NB + n0) = make_float4(hv[0], hv[1], hv[2], hv[3]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int b = b0 + n0 + e;
-                if (b >= B) continue;
-                const size_t row = (size_t)b * T + t;
-                if (out_f32) out_f32[row * (2 * H) + dir * H + j] = hv[e];
-                if (out_bf16) {
-                    bf16_t* o = out_bf16 + row * out_cs + dir * H + j;
-                    const bf16_t hi = f2bf(hv[e]);
-                    o[0] = hi;
-                    if (x3) {
-                        o[third] = hi;
-                        o[2 * third] = f2bf(hv[e] - bf2f(hi));
-                    }
+            const float ig = sigmoidf_(acc[0]), fg = sigmoidf_(acc[1]), gt = tanhf_(acc[2]), og = sigmoidf_(acc[3]);
+            const float c = fg * creg[ti] + ig * gt;
+            const float h = og * tanhf_(c);
+            creg[ti] = c;
+            const bf16_t hi = f2bf(h);
+            *(bf16_t*)(hn + n * HP + j * 2) = hi;
+            bf16_t lo = 0;
+            if (wl || out_x3) lo = f2bf(h - bf2f(hi));
+            if (wl) *(bf16_t*)(hn + LM_NB * HP + n * HP + j * 2) = lo;
+            if (live) {
+                bf16_t* o = out + row * out_cs + dir * H + j;
+                o[0] = hi;
+                if (out_x3) { o[third] = hi; o[2 * third] = lo; }
+                if (save_gates) {
+                    float* sg = save_gates + (row * 2 + dir) * G;
+                    sg[j] = ig; sg[H + j] = fg; sg[2 * H + j] = gt; sg[3 * H + j] = og;
+                    save_c[(row * 2 + dir) * H + j] = c;
                 }
             }
         }
@@ -116,140 +168,144 @@ __global__ __launch_bounds__(256) void lstm_kernel(const float* __restrict__ xpr
     }
 }
 
-extern "C" int sos_lstm_bidir_fwd(const float* xproj, const float* whh_t, int64_t B, int64_t T, int H,
-                                  float* out_f32, void* out_bf16, int out_cs, int out_dtype, int64_t out_third,
-                                  float* save_gates, float* save_c, sos_stream_t stream) {
-    if (!xproj || !whh_t || (!out_f32 && !out_bf16) || B < 1 || T < 1 || H < 4 || H > 256 || (H & 3) ||
-        (out_bf16 && out_cs < 2 * H) || (out_dtype != SOS_DT_BF16 && out_dtype != SOS_DT_BF16X3) ||
-        ((save_gates == nullptr) != (save_c == nullptr))) {
+extern "C" int sos_lstm_bidir_fwd(const float* xproj, const void* wpk_hi, const void* wpk_lo, int64_t B, int64_t T, int H,
+                                  void* out_bf16, int out_cs, int out_dtype, int64_t out_third, float* save_gates,
+                                  float* save_c, sos_stream_t stream) {
+    if (!xproj || !wpk_hi || !out_bf16 || B < 1 || T < 1 || H < 4 || H > 256 || (H & 3) || out_cs < 2 * H ||
+        (out_dtype != SOS_DT_BF16 && out_dtype != SOS_DT_BF16X3) || ((save_gates == nullptr) != (save_c == nullptr))) {
         sos_set_error("sos_lstm_bidir_fwd: bad args (B=%lld T=%lld H=%d)", (long long)B, (long long)T, H);
         return SOS_EINVAL;
     }
-    dim3 grid((unsigned)((B + LSTM_NB - 1) / LSTM_NB), 2);
-    const size_t lds = (size_t)(2 + 4 + 1) * H * LSTM_NB * sizeof(float);
-    hipLaunchKernelGGL(lstm_kernel, grid, dim3(256), lds, (hipStream_t)stream, xproj, whh_t, (int)B, (int)T, H,
-                       out_f32, (bf16_t*)out_bf16, out_cs, out_dtype == SOS_DT_BF16X3 ? 1 : 0,
+    dim3 grid((unsigned)((B + LM_NB - 1) / LM_NB), 2);
+    const size_t lds = (size_t)2 * (wpk_lo ? 2 : 1) * LM_NB * (lm_kf(H) * 64 + 16);
+    hipLaunchKernelGGL(lstm_fwd_kernel, grid, dim3(LM_THREADS), lds, (hipStream_t)stream, xproj, (const uint4*)wpk_hi,
+                       (const uint4*)wpk_lo, (int)B, (int)T, H, (bf16_t*)out_bf16, out_cs, out_dtype == SOS_DT_BF16X3 ? 1 : 0,
                        (long long)out_third, save_gates, save_c);
     return sos_check_launch("sos_lstm_bidir_fwd");
 }
 
 // ------------------------------------------------------------------------ backward through time
-// One workgroup per (direction, NB clips) walks the steps in reverse.  Per step:
-//   A) per (hidden unit, clip): dh = dh_out + dh_rec, dc = dc_rec + dh*o*(1-tanh(c)^2); gate
-//      pre-activation grads di,df,dg,do -> LDS [4H][NB] and global dgates (fp32 [B][T][2][4H]);
-//      dc_rec = dc*f.
-//   B) dh_rec[k] = sum_r W_hh[r][k] * dgate[r]: thread = (4 consecutive k, slice of rows); the
-//      slices meet in LDS.  W_hh ([4H][H], the layout torch stores) streams from L2.
+// Per step: A) per lane (4 consecutive hidden units, clip): dh = dh_out + dh_rec, dc = dc_rec +
+// dh*o*(1-tanh(c)^2), gate pre-activation grads di,df,dg,do -> global dgates (f32 [B][T][2][4H]) and
+// LDS [clip][4H] (bf16); dc_rec = dc*f.  B) dh_rec = W_hh^T . dgates on MFMA (accumulator layout = A's).
 // dW_ih, dW_hh, the bias gradient and dx are GEMMs over dgates done by the wgrad / conv kernels.
-__global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_t* __restrict__ dh_out, int dh_cs, int dh_x3,
-                                                       long long dh_third, const float* __restrict__ gates,
-                                                       const float* __restrict__ csave, const float* __restrict__ whh,
-                                                       int B, int T, int H, float* __restrict__ dgates) {
+__global__ __launch_bounds__(LM_THREADS) void lstm_bwd_kernel(const bf16_t* __restrict__ dh_out, int dh_cs, int dh_x3,
+                                                               long long dh_third, const float* __restrict__ gates,
+                                                               const float* __restrict__ csave, const uint4* __restrict__ wh,
+                                                               const uint4* __restrict__ wl, int B, int T, int H,
+                                                               float* __restrict__ dgates) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int G = 4 * H;
-    float* dgl = (float*)smem;                 // [4H][NB]
-    float* dhr = dgl + G * LSTM_NB;            // [H][NB]  recurrent dh
-    float* dcr = dhr + H * LSTM_NB;            // [H][NB]  recurrent dc
-    float* part = dcr + H * LSTM_NB;           // [RS][H][NB] partial dh_rec
-    const int tid = threadIdx.x;
-    const int dir = blockIdx.y;
-    const int b0 = blockIdx.x * LSTM_NB;
-    const float* W = whh + (size_t)dir * G * H;   // [4H][H]
-    const int KG = H >> 2;                         // groups of 4 consecutive k
-    const int RS = 256 / KG;                       // row slices
-    const int rows_per = (G + RS - 1) / RS;
-    for (int idx = tid; idx < 2 * H * LSTM_NB; idx += 256) dhr[idx] = 0.f;   // dhr and dcr are adjacent
+    const int G = 4 * H, NJ = (H + 15) / 16, KB = (G + 31) / 32;
+    const int GP = KB * 64 + 16;                         // bytes of one clip's dgates row (bf16, padded)
+    const int P = wl ? 2 : 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, b0 = blockIdx.x * LM_NB;
+    const int n = lane & 15, g4 = lane >> 4;
+    const int b = b0 + n;
+    const bool live = b < B;
+    for (int i = tid; i < 2 * P * LM_NB * GP / 4; i += LM_THREADS) ((unsigned*)smem)[i] = 0u;
+    f32x4 dhr[LM_BT], dcr[LM_BT];
+#pragma unroll
+    for (int ti = 0; ti < LM_BT; ++ti) { dhr[ti] = f32x4{0.f, 0.f, 0.f, 0.f}; dcr[ti] = dhr[ti]; }
+    const uint4* whd = wh + (size_t)dir * NJ * KB * 64 + lane;
+    const uint4* wld = wl ? wl + (size_t)dir * NJ * KB * 64 + lane : nullptr;
     __syncthreads();
+
     for (int step = 0; step < T; ++step) {
         const int t = dir == 0 ? T - 1 - step : step;     // reverse of the forward order
         const int tprev = dir == 0 ? t - 1 : t + 1;       // time index the forward pass came from
-        for (int idx = tid; idx < H * LSTM_NB; idx += 256) {
-            const int j = idx / LSTM_NB, n = idx - j * LSTM_NB;
-            const int b = b0 + n;
-            float di = 0.f, df = 0.f, dg = 0.f, dov = 0.f, dcn = 0.f;
-            if (b < B) {
-                const size_t row = (size_t)b * T + t;
-                const bf16_t* dp = dh_out + row * dh_cs + dir * H + j;
-                float dh = bf2f(dp[0]);
-                if (dh_x3) dh += bf2f(dp[2 * dh_third]);
-                dh += dhr[idx];
-                const float* gp = gates + (row * 2 + dir) * G;
-                const float ig = gp[j], fg = gp[H + j], gt = gp[2 * H + j], og = gp[3 * H + j];
-                const float c = csave[(row * 2 + dir) * H + j];
-                const float cprev = (tprev >= 0 && tprev < T) ? csave[(((size_t)b * T + tprev) * 2 + dir) * H + j] : 0.f;
-                const float tc = tanhf(c);
-                const float dc = dcr[idx] + dh * og * (1.f - tc * tc);
-                di = dc * gt * ig * (1.f - ig);
-                df = dc * cprev * fg * (1.f - fg);
-                dg = dc * ig * (1.f - gt * gt);
-                dov = dh * tc * og * (1.f - og);
-                dcn = dc * fg;
-                float* dgp = dgates + (row * 2 + dir) * G;
-                dgp[j] = di; dgp[H + j] = df; dgp[2 * H + j] = dg; dgp[3 * H + j] = dov;
+        char* dg = smem + (size_t)(step & 1) * P * LM_NB * GP;
+        const size_t row = (size_t)b * T + t;
+#pragma unroll
+        for (int ti = 0; ti < LM_BT; ++ti) {
+            const int jt = wave + LM_WAVES * ti;
+            const int j0 = jt * 16 + 4 * g4;              // 4 consecutive hidden units (H % 4 == 0: all or none valid)
+            if (jt >= NJ || j0 >= H || !live) continue;
+            const bf16_t* dp = dh_out + row * dh_cs + dir * H + j0;
+            const uint2 dhv = *(const uint2*)dp;
+            float dh[4] = {bf2f((bf16_t)(dhv.x & 0xffffu)), bf2f((bf16_t)(dhv.x >> 16)), bf2f((bf16_t)(dhv.y & 0xffffu)),
+                           bf2f((bf16_t)(dhv.y >> 16))};
+            if (dh_x3) {
+                const uint2 dl = *(const uint2*)(dp + 2 * dh_third);
+                dh[0] += bf2f((bf16_t)(dl.x & 0xffffu)); dh[1] += bf2f((bf16_t)(dl.x >> 16));
+                dh[2] += bf2f((bf16_t)(dl.y & 0xffffu)); dh[3] += bf2f((bf16_t)(dl.y >> 16));
             }
-            dcr[idx] = dcn;
-            dgl[(0 * H + j) * LSTM_NB + n] = di;
-            dgl[(1 * H + j) * LSTM_NB + n] = df;
-            dgl[(2 * H + j) * LSTM_NB + n] = dg;
-            dgl[(3 * H + j) * LSTM_NB + n] = dov;
-        }
-        __syncthreads();
-        {
-            const int kg = tid % KG, rs = tid / KG;
-            if (rs < RS) {
-                float acc[4][LSTM_NB];
+            const float* gp = gates + (row * 2 + dir) * G + j0;
+            const float4 ig4 = *(const float4*)gp, fg4 = *(const float4*)(gp + H), gt4 = *(const float4*)(gp + 2 * H),
+                         og4 = *(const float4*)(gp + 3 * H);
+            const float4 c4 = *(const float4*)(csave + (row * 2 + dir) * H + j0);
+            float4 cp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tprev >= 0 && tprev < T) cp4 = *(const float4*)(csave + (((size_t)b * T + tprev) * 2 + dir) * H + j0);
+            const float igv[4] = {ig4.x, ig4.y, ig4.z, ig4.w}, fgv[4] = {fg4.x, fg4.y, fg4.z, fg4.w};
+            const float gtv[4] = {gt4.x, gt4.y, gt4.z, gt4.w}, ogv[4] = {og4.x, og4.y, og4.z, og4.w};
+            const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, cpv[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+            float di[4], df[4], dgg[4], dov[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e) {
+                const float dhe = dh[e] + dhr[ti][e];
+                const float tc = tanhf_(cv[e]);
+                const float dc = dcr[ti][e] + dhe * ogv[e] * (1.f - tc * tc);
+                di[e] = dc * gtv[e] * igv[e] * (1.f - igv[e]);
+                df[e] = dc * cpv[e] * fgv[e] * (1.f - fgv[e]);
+                dgg[e] = dc * igv[e] * (1.f - gtv[e] * gtv[e]);
+                dov[e] = dhe * tc * ogv[e] * (1.f - ogv[e]);
+                dcr[ti][e] = dc * fgv[e];
+            }
+            float* dgp = dgates + (row * 2 + dir) * G + j0;
+            *(float4*)dgp = make_float4(di[0], di[1], di[2], di[3]);
+            *(float4*)(dgp + H) = make_float4(df[0], df[1], df[2], df[3]);
+            *(float4*)(dgp + 2 * H) = make_float4(dgg[0], dgg[1], dgg[2], dgg[3]);
+            *(float4*)(dgp + 3 * H) = make_float4(dov[0], dov[1], dov[2], dov[3]);
+            const float* q4[4] = {di, df, dgg, dov};
 #pragma unroll
-                    for (int n = 0; n < LSTM_NB; ++n) acc[e][n] = 0.f;
-                const int r0 = rs * rows_per, r1 = min(r0 + rows_per, G);
-#pragma unroll 4
-                for (int r = r0; r < r1; ++r) {
-                    const float4 w = *(const float4*)(W + (size_t)r * H + kg * 4);
-                    const float4 da = *(const float4*)(dgl + r * LSTM_NB);
-                    const float4 db = *(const float4*)(dgl + r * LSTM_NB + 4);
-                    const float dv[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
-#pragma unroll
-                    for (int n = 0; n < LSTM_NB; ++n) {
-                        acc[0][n] = fmaf(w.x, dv[n], acc[0][n]);
-                        acc[1][n] = fmaf(w.y, dv[n], acc[1][n]);
-                        acc[2][n] = fmaf(w.z, dv[n], acc[2][n]);
-                        acc[3][n] = fmaf(w.w, dv[n], acc[3][n]);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float* pp = part + ((size_t)rs * H + kg * 4 + e) * LSTM_NB;
-                    *(float4*)pp = make_float4(acc[e][0], acc[e][1], acc[e][2], acc[e][3]);
-                    *(float4*)(pp + 4) = make_float4(acc[e][4], acc[e][5], acc[e][6], acc[e][7]);
+            for (int q = 0; q < 4; ++q) {
+                const unsigned h01 = pack2bf(q4[q][0], q4[q][1]), h23 = pack2bf(q4[q][2], q4[q][3]);
+                *(uint2*)(dg + n * GP + (q * H + j0) * 2) = make_uint2(h01, h23);
+                if (wl) {
+                    const unsigned l01 = pack2bf(q4[q][0] - bf2f((bf16_t)(h01 & 0xffffu)), q4[q][1] - bf2f((bf16_t)(h01 >> 16)));
+                    const unsigned l23 = pack2bf(q4[q][2] - bf2f((bf16_t)(h23 & 0xffffu)), q4[q][3] - bf2f((bf16_t)(h23 >> 16)));
+                    *(uint2*)(dg + LM_NB * GP + n * GP + (q * H + j0) * 2) = make_uint2(l01, l23);
                 }
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < H * LSTM_NB; idx += 256) {
-            float s = 0.f;
-            for (int rs = 0; rs < RS; ++rs) s += part[(size_t)rs * H * LSTM_NB + idx];
-            dhr[idx] = s;
+#pragma unroll
+        for (int ti = 0; ti < LM_BT; ++ti) {
+            const int jt = wave + LM_WAVES * ti;
+            if (jt >= NJ) break;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int kk = 0; kk < KB; ++kk) {
+                const uint4 w = whd[((size_t)jt * KB + kk) * 64];
+                const uint4 d0 = *(const uint4*)(dg + n * GP + kk * 64 + g4 * 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w), frag(d0), acc, 0, 0, 0);
+                if (wl) {
+                    const uint4 w2 = wld[((size_t)jt * KB + kk) * 64];
+                    const uint4 d1 = *(const uint4*)(dg + LM_NB * GP + n * GP + kk * 64 + g4 * 16);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w), frag(d1), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w2), frag(d0), acc, 0, 0, 0);
+                }
+            }
+            dhr[ti] = acc;
         }
-        __syncthreads();
     }
 }
 
 extern "C" int sos_lstm_bidir_bwd(const void* dh_out, int dh_cs, int dh_dtype, int64_t dh_third, const float* gates,
-                                  const float* csave, const float* whh, int64_t B, int64_t T, int H, float* dgates,
-                                  sos_stream_t stream) {
-    if (!dh_out || !gates || !csave || !whh || !dgates || B < 1 || T < 1 || H < 4 || H > 256 || (H & 3) || dh_cs < 2 * H ||
-        (dh_dtype != SOS_DT_BF16 && dh_dtype != SOS_DT_BF16X3)) {
+                                  const float* csave, const void* wtk_hi, const void* wtk_lo, int64_t B, int64_t T, int H,
+                                  float* dgates, sos_stream_t stream) {
+    if (!dh_out || !gates || !csave || !wtk_hi || !dgates || B < 1 || T < 1 || H < 4 || H > 256 || (H & 3) || dh_cs < 2 * H ||
+        (dh_cs & 3) || (dh_dtype != SOS_DT_BF16 && dh_dtype != SOS_DT_BF16X3)) {
         sos_set_error("sos_lstm_bidir_bwd: bad args");
         return SOS_EINVAL;
     }
-    const int KG = H >> 2, RS = 256 / KG;
-    const size_t lds = (size_t)(4 + 1 + 1 + RS) * H * LSTM_NB * sizeof(float);
+    const size_t lds = (size_t)2 * (wtk_lo ? 2 : 1) * LM_NB * (lm_kb(H) * 64 + 16);
     if (lds > 160 * 1024) { sos_set_error("sos_lstm_bidir_bwd: LDS"); return SOS_ENOSPC; }
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    dim3 grid((unsigned)((B + LSTM_NB - 1) / LSTM_NB), 2);
-    hipLaunchKernelGGL(lstm_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dh_out, dh_cs,
-                       dh_dtype == SOS_DT_BF16X3 ? 1 : 0, (long long)dh_third, gates, csave, whh, (int)B, (int)T, H, dgates);
+    dim3 grid((unsigned)((B + LM_NB - 1) / LM_NB), 2);
+    hipLaunchKernelGGL(lstm_bwd_kernel, grid, dim3(LM_THREADS), lds, (hipStream_t)stream, (const bf16_t*)dh_out, dh_cs,
+                       dh_dtype == SOS_DT_BF16X3 ? 1 : 0, (long long)dh_third, gates, csave, (const uint4*)wtk_hi,
+                       (const uint4*)wtk_lo, (int)B, (int)T, H, dgates);
     return sos_check_launch("sos_lstm_bidir_bwd");
 }

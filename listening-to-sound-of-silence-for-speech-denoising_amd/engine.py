@@ -199,9 +199,25 @@ def conv_to_act(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, dst, c_
          cout_store=cout if cout_store is None else cout_store, third=dst.cs, **kw_)
 
 
-def lstm(xproj, whh_t, B, T, H, out_act, save_gates=None, save_c=None):
-    """Recurrent part (sos_lstm_bidir_fwd); out_act: Act [B,1,T,cs>=2H] pre-zeroed."""
-    L.check(L.lib().sos_lstm_bidir_fwd(L.ptr(xproj), L.ptr(whh_t), B, T, H, None, L.ptr(out_act.t),
+def lstm_pack(lstm_mod, x3):
+    """W_hh of both directions -> the MFMA fragment arrays of the recurrent kernels (sos_lstm_pack_whh);
+    the lo arrays exist only in bf16x3 mode."""
+    H = lstm_mod.hidden_size
+    whh = torch.stack([lstm_mod.weight_hh_l0.detach(), lstm_mod.weight_hh_l0_reverse.detach()]).float().contiguous()
+    L.require_cuda(whh)
+    nf, nb = L.lib().sos_lstm_pack_bytes(H, 0), L.lib().sos_lstm_pack_bytes(H, 1)
+    if nf < 0:
+        raise RuntimeError(f"LSTM hidden size {H} not supported (multiple of 4, <= 256)")
+    mk = lambda n: torch.empty(n // 2, dtype=torch.bfloat16, device=whh.device)   # noqa: E731
+    pk = dict(fh=mk(nf), bh=mk(nb), fl=mk(nf) if x3 else None, bl=mk(nb) if x3 else None)
+    L.check(L.lib().sos_lstm_pack_whh(L.ptr(whh), H, L.ptr(pk["fh"]), L.ptr(pk["fl"]), L.ptr(pk["bh"]), L.ptr(pk["bl"]),
+                                      L.stream_ptr()), "sos_lstm_pack_whh")
+    return pk
+
+
+def lstm(xproj, wpk, B, T, H, out_act, save_gates=None, save_c=None):
+    """Recurrent part (sos_lstm_bidir_fwd); wpk from lstm_pack; out_act: Act [B,1,T,cs>=2H] pre-zeroed."""
+    L.check(L.lib().sos_lstm_bidir_fwd(L.ptr(xproj), L.ptr(wpk["fh"]), L.ptr(wpk["fl"]), B, T, H, L.ptr(out_act.t),
                                        out_act.nseg * out_act.cs, out_act.dtype_code, out_act.cs,
                                        L.ptr(save_gates), L.ptr(save_c), L.stream_ptr()), "sos_lstm_bidir_fwd")
 

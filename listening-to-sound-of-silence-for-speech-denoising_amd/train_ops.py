@@ -163,10 +163,8 @@ def lstm_train_plan(lstm, cin_store, x3):
     bias = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse]).detach()
     w = E.pack_weight(w_ih[:, :, None, None], cin_store, x3)
     wd = E.pack_weight(w_ih.t().contiguous()[:, :, None, None], E.pad_to(8 * H, 16), x3)      # (I, 8H)
-    whh_t = torch.stack([lstm.weight_hh_l0.detach().t(), lstm.weight_hh_l0_reverse.detach().t()]).float().contiguous()
-    whh = torch.stack([lstm.weight_hh_l0.detach(), lstm.weight_hh_l0_reverse.detach()]).float().contiguous()
     dev = w.device
-    return dict(w=w, wd=wd, whh_t=whh_t, whh=whh, H=H, I=lstm.input_size, cin_store=cin_store,
+    return dict(w=w, wd=wd, wpk=E.lstm_pack(lstm, x3), H=H, I=lstm.input_size, cin_store=cin_store,
                 scale=E.pad_vec(torch.ones(8 * H, device=dev), w.shape[1], 1.0), shift=E.pad_vec(bias, w.shape[1]))
 
 
@@ -178,7 +176,7 @@ def lstm_forward_train(lp, feat_dims, B, T, x3, dev):
     h = E.Act(B, 1, T, E.pad_to(2 * H, 16), x3, dev, zero=True)
     gates = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=dev)
     csave = torch.empty((B, T, 2, H), dtype=torch.float32, device=dev)
-    E.lstm(xproj, lp["whh_t"], B, T, H, h, gates, csave)
+    E.lstm(xproj, lp["wpk"], B, T, H, h, gates, csave)
     return h, dict(gates=gates, csave=csave, h=h, feat_dims=feat_dims)
 
 
@@ -187,7 +185,7 @@ def lstm_backward(lp, tape, dh, grads, prefix, B, T, x3, dev):
     H, I = lp["H"], lp["I"]
     dgates = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=dev)
     L.check(L.lib().sos_lstm_bidir_bwd(L.ptr(dh.t), dh.nseg * dh.cs, dh.dtype_code, dh.cs, L.ptr(tape["gates"]),
-                                       L.ptr(tape["csave"]), L.ptr(lp["whh"]), B, T, H, L.ptr(dgates), L.stream_ptr()),
+                                       L.ptr(tape["csave"]), L.ptr(lp["wpk"]["bh"]), L.ptr(lp["wpk"]["bl"]), B, T, H, L.ptr(dgates), L.stream_ptr()),
             "sos_lstm_bidir_bwd")
     dga = E.Act(B, 1, T, E.pad_to(8 * H, 16), x3, dev, zero=(8 * H) % 16 != 0)
     pack_grad(dgates, None, L.ACT_NONE, B, T, 8 * H, T * 8 * H, 8 * H, 1, dga)
