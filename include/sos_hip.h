@@ -147,8 +147,10 @@ int sos_lstm_pack_whh(const float* whh, int H, void* fwd_hi, void* fwd_lo, void*
                       sos_stream_t stream);
 int sos_lstm_bidir_fwd(const float* xproj, const void* wpk_hi, const void* wpk_lo /* optional */, int64_t B, int64_t T,
                        int H, void* out_bf16, int out_cs, int out_dtype, int64_t out_third,
-                       float* save_gates /* optional f32 [B][T][2][4H] post-activation i,f,g,o */,
-                       float* save_c /* optional f32 [B][T][2][H] */, sos_stream_t stream);
+                       float* save_gates /* optional f32, ceil16(B)*T*2*4H: post-activation i,f,g,o */,
+                       float* save_c /* optional f32, ceil16(B)*T*2*H: cell state */, sos_stream_t stream);
+/* save_gates / save_c are consumed only by sos_lstm_bidir_bwd; their layout is the forward kernel's MFMA lane order
+ * [16-clip group][t][dir][4-unit tile][lane = clip + 16*unit][i,f,g,o] (one coalesced store per tile and step). */
 
 /* ---------------------------------------------------------------- training-mode kernels
  * A `sos_view` describes a channel slice of a bf16 NHWC activation: element (pix, c) lives at

@@ -29,9 +29,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LM_THREADS (LM_WAVES * 64)
 #define LM_FT 8               // forward: 4-unit tiles per wave (H <= 256)
 #define LM_BT 2               // backward: 16-unit tiles per wave
+// ablation switches (SOS_LSTM_DBG: 1 no output stores, 2 no xproj loads, 4 one W tile re-read) only in `make ABLATE=1` builds
+#ifdef SOS_ABLATE
+#include <stdlib.h>
+#define LDBG(bit) (dbg & (bit))
+#else
+#define LDBG(bit) 0
+#endif
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f / (1.0f + expf(2.0f * x)); }   // |err| ~1e-7
+// hardware exp2 / reciprocal (1 ulp each): |err| ~2e-7, a dozen VALU cycles instead of ~100 for expf + IEEE division
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 __device__ __forceinline__ bf16x8 frag(const uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 static inline int lm_kf(int H) { return (H + 31) / 32; }        // forward k-fragments (K = H)
@@ -87,15 +95,20 @@ extern "C" int sos_lstm_pack_whh(const float* whh, int H, void* fwd_hi, void* fw
 }
 
 // ----------------------------------------------------------------------------------- forward
+// X3 = false (bf16): the W fragments of the NEXT tile (wrapping to the first tile of the next step: W does not
+// depend on h) are in flight while the current tile is computed.  X3 = true (three-pass precision mode): hi and
+// lo fragments of the current tile only (register budget).  In both, a tile's xproj values for the NEXT step
+// are re-loaded right after this step consumed them.
+template <bool X3>
 __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __restrict__ xproj, const uint4* __restrict__ wh,
                                                                const uint4* __restrict__ wl, int B, int T, int H,
                                                                bf16_t* __restrict__ out, int out_cs, int out_x3,
                                                                long long third, float* __restrict__ save_gates,
-                                                               float* __restrict__ save_c) {
+                                                               float* __restrict__ save_c, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KF = (H + 31) / 32, NT = H >> 2, G = 4 * H;
     const int HP = KF * 64 + 16;                         // bytes of one clip's h row (bf16, k padded to 32, +16: banks)
-    const int P = wl ? 2 : 1;                            // hi (+ lo) planes
+    constexpr int P = X3 ? 2 : 1;                        // hi (+ lo) planes
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dir = blockIdx.y, b0 = blockIdx.x * LM_NB;
@@ -107,7 +120,26 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
 #pragma unroll
     for (int ti = 0; ti < LM_FT; ++ti) creg[ti] = 0.f;
     const uint4* whd = wh + (size_t)dir * NT * KF * 64 + lane;
-    const uint4* wld = wl ? wl + (size_t)dir * NT * KF * 64 + lane : nullptr;
+    const uint4* wld = X3 ? wl + (size_t)dir * NT * KF * 64 + lane : nullptr;
+    const int cnt = NT > wave ? (NT - wave + LM_WAVES - 1) / LM_WAVES : 0;      // this wave's tiles (wave-uniform)
+    uint4 w0[8], w1[8];                                  // bf16: ping-pong of hi fragments; x3: hi and lo of the current tile
+    f32x4 xc[LM_FT];
+    auto load_frags = [&](uint4 (&w)[8], const uint4* base, const int tile) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            if (kk < KF) w[kk] = base[((size_t)(LDBG(4) ? 0 : tile) * KF + kk) * 64];
+    };
+    auto load_x = [&](const int ti, const int step) {
+        const int t = dir == 0 ? step : T - 1 - step;
+        const float* xp = xproj + (((size_t)b * T + t) * 2 + dir) * G + (wave + LM_WAVES * ti) * 4 + g4;
+        if (live && step < T && !LDBG(2)) xc[ti] = f32x4{xp[0], xp[H], xp[2 * H], xp[3 * H]};
+    };
+#pragma unroll
+    for (int ti = 0; ti < LM_FT; ++ti) {
+        xc[ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ti < cnt) load_x(ti, 0);
+    }
+    if (!X3 && cnt > 0) load_frags(w0, whd, wave);
     __syncthreads();
 
     for (int step = 0; step < T; ++step) {
@@ -120,27 +152,52 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
         for (int kk = 0; kk < 8; ++kk) {
             if (kk < KF) {
                 hf[kk] = *(const uint4*)(hb + n * HP + kk * 64 + g4 * 16);
-                if (wl) hl[kk] = *(const uint4*)(hb + LM_NB * HP + n * HP + kk * 64 + g4 * 16);
+                if (X3) hl[kk] = *(const uint4*)(hb + LM_NB * HP + n * HP + kk * 64 + g4 * 16);
+            }
+        }
+        // h_{t-1} (this step's B operand) is also the previous step's OUTPUT: flush its rows to global here, as
+        // whole 16-byte pieces of a clip's [dir*H, dir*H + H) run (H % 8 == 0; otherwise element stores below)
+        if (step > 0 && (H & 7) == 0 && !LDBG(1)) {
+            const int tp = dir == 0 ? step - 1 : T - step;
+            const int ppr = H >> 3;                      // pieces per clip row
+            for (int i = tid; i < LM_NB * ppr; i += LM_THREADS) {
+                const int c = i / ppr, q = i - c * ppr;
+                if (b0 + c < B) {
+                    bf16_t* o = out + ((size_t)(b0 + c) * T + tp) * out_cs + dir * H + q * 8;
+                    const uint4 hv = *(const uint4*)(hb + c * HP + q * 16);
+                    *(uint4*)o = hv;
+                    if (out_x3) { *(uint4*)(o + third) = hv; *(uint4*)(o + 2 * third) = *(const uint4*)(hb + LM_NB * HP + c * HP + q * 16); }
+                }
             }
         }
         const size_t row = (size_t)b * T + t;
-        const float* xp = xproj + (row * 2 + dir) * G;
+        // saved activations: MFMA-native layout [clip group][t][dir][tile][lane][i,f,g,o] -- one coalesced 1 KB store per tile
+        const size_t nat = (((size_t)blockIdx.x * T + t) * 2 + dir) * NT;
 #pragma unroll
         for (int ti = 0; ti < LM_FT; ++ti) {
             const int tile = wave + LM_WAVES * ti;       // wave-uniform
-            if (tile >= NT) break;
+            if (ti >= cnt) break;
+            constexpr int dummy = 0; (void)dummy;
+            if (X3) {
+                load_frags(w0, whd, tile);
+                load_frags(w1, wld, tile);
+            } else {
+                const int nxt = ti + 1 < cnt ? tile + LM_WAVES : wave;
+                if (ti & 1) load_frags(w0, whd, nxt); else load_frags(w1, whd, nxt);
+                __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of this tile's MFMAs
+            }
             const int j = tile * 4 + g4;                 // this lane's hidden unit; registers = gates i,f,g,o
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (live) { acc[0] = xp[j]; acc[1] = xp[H + j]; acc[2] = xp[2 * H + j]; acc[3] = xp[3 * H + j]; }
+            f32x4 acc = xc[ti];
+            load_x(ti, step + 1);
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 if (kk < KF) {
-                    const uint4 w = whd[((size_t)tile * KF + kk) * 64];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w), frag(hf[kk]), acc, 0, 0, 0);
-                    if (wl) {
-                        const uint4 w2 = wld[((size_t)tile * KF + kk) * 64];
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w), frag(hl[kk]), acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w2), frag(hf[kk]), acc, 0, 0, 0);
+                    if (X3) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w0[kk]), frag(hf[kk]), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w0[kk]), frag(hl[kk]), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w1[kk]), frag(hf[kk]), acc, 0, 0, 0);
+                    } else {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag((ti & 1) ? w1[kk] : w0[kk]), frag(hf[kk]), acc, 0, 0, 0);
                     }
                 }
             }
@@ -151,20 +208,39 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
             const bf16_t hi = f2bf(h);
             *(bf16_t*)(hn + n * HP + j * 2) = hi;
             bf16_t lo = 0;
-            if (wl || out_x3) lo = f2bf(h - bf2f(hi));
-            if (wl) *(bf16_t*)(hn + LM_NB * HP + n * HP + j * 2) = lo;
-            if (live) {
-                bf16_t* o = out + row * out_cs + dir * H + j;
-                o[0] = hi;
-                if (out_x3) { o[third] = hi; o[2 * third] = lo; }
+            if (X3 || out_x3) lo = f2bf(h - bf2f(hi));
+            if (X3) *(bf16_t*)(hn + LM_NB * HP + n * HP + j * 2) = lo;
+            if (!LDBG(1)) {
+                if (live && (H & 7)) {
+                    bf16_t* o = out + row * out_cs + dir * H + j;
+                    o[0] = hi;
+                    if (out_x3) { o[third] = hi; o[2 * third] = lo; }
+                }
                 if (save_gates) {
-                    float* sg = save_gates + (row * 2 + dir) * G;
-                    sg[j] = ig; sg[H + j] = fg; sg[2 * H + j] = gt; sg[3 * H + j] = og;
-                    save_c[(row * 2 + dir) * H + j] = c;
+                    *(float4*)(save_gates + ((nat + tile) * 64 + lane) * 4) = make_float4(ig, fg, gt, og);
+                    save_c[(nat + tile) * 64 + lane] = c;
                 }
             }
         }
+        if (!X3 && (cnt & 1)) {                          // the wrap-around prefetch landed in w1: the next step starts in w0
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) w0[kk] = w1[kk];
+        }
         __syncthreads();
+    }
+    if ((H & 7) == 0 && !LDBG(1)) {                      // the last step's output
+        const char* hb = smem + (size_t)(T & 1) * P * LM_NB * HP;
+        const int tp = dir == 0 ? T - 1 : 0;
+        const int ppr = H >> 3;
+        for (int i = tid; i < LM_NB * ppr; i += LM_THREADS) {
+            const int c = i / ppr, q = i - c * ppr;
+            if (b0 + c < B) {
+                bf16_t* o = out + ((size_t)(b0 + c) * T + tp) * out_cs + dir * H + q * 8;
+                const uint4 hv = *(const uint4*)(hb + c * HP + q * 16);
+                *(uint4*)o = hv;
+                if (out_x3) { *(uint4*)(o + third) = hv; *(uint4*)(o + 2 * third) = *(const uint4*)(hb + LM_NB * HP + c * HP + q * 16); }
+            }
+        }
     }
 }
 
@@ -172,15 +248,25 @@ extern "C" int sos_lstm_bidir_fwd(const float* xproj, const void* wpk_hi, const 
                                   void* out_bf16, int out_cs, int out_dtype, int64_t out_third, float* save_gates,
                                   float* save_c, sos_stream_t stream) {
     if (!xproj || !wpk_hi || !out_bf16 || B < 1 || T < 1 || H < 4 || H > 256 || (H & 3) || out_cs < 2 * H ||
-        (out_dtype != SOS_DT_BF16 && out_dtype != SOS_DT_BF16X3) || ((save_gates == nullptr) != (save_c == nullptr))) {
+        (out_dtype != SOS_DT_BF16 && out_dtype != SOS_DT_BF16X3) || ((save_gates == nullptr) != (save_c == nullptr)) ||
+        ((out_dtype == SOS_DT_BF16X3) != (wpk_lo != nullptr)) || (out_cs & 7) || (out_third & 7)) {
         sos_set_error("sos_lstm_bidir_fwd: bad args (B=%lld T=%lld H=%d)", (long long)B, (long long)T, H);
         return SOS_EINVAL;
     }
     dim3 grid((unsigned)((B + LM_NB - 1) / LM_NB), 2);
+    int dbg = 0;
+#ifdef SOS_ABLATE
+    { const char* e = getenv("SOS_LSTM_DBG"); dbg = e ? atoi(e) : 0; }
+#endif
     const size_t lds = (size_t)2 * (wpk_lo ? 2 : 1) * LM_NB * (lm_kf(H) * 64 + 16);
-    hipLaunchKernelGGL(lstm_fwd_kernel, grid, dim3(LM_THREADS), lds, (hipStream_t)stream, xproj, (const uint4*)wpk_hi,
-                       (const uint4*)wpk_lo, (int)B, (int)T, H, (bf16_t*)out_bf16, out_cs, out_dtype == SOS_DT_BF16X3 ? 1 : 0,
-                       (long long)out_third, save_gates, save_c);
+    if (wpk_lo)
+        hipLaunchKernelGGL(lstm_fwd_kernel<true>, grid, dim3(LM_THREADS), lds, (hipStream_t)stream, xproj, (const uint4*)wpk_hi,
+                           (const uint4*)wpk_lo, (int)B, (int)T, H, (bf16_t*)out_bf16, out_cs,
+                           out_dtype == SOS_DT_BF16X3 ? 1 : 0, (long long)out_third, save_gates, save_c, dbg);
+    else
+        hipLaunchKernelGGL(lstm_fwd_kernel<false>, grid, dim3(LM_THREADS), lds, (hipStream_t)stream, xproj, (const uint4*)wpk_hi,
+                           (const uint4*)wpk_lo, (int)B, (int)T, H, (bf16_t*)out_bf16, out_cs,
+                           out_dtype == SOS_DT_BF16X3 ? 1 : 0, (long long)out_third, save_gates, save_c, dbg);
     return sos_check_launch("sos_lstm_bidir_fwd");
 }
 
@@ -231,15 +317,18 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_bwd_kernel(const bf16_t* __re
                 dh[0] += bf2f((bf16_t)(dl.x & 0xffffu)); dh[1] += bf2f((bf16_t)(dl.x >> 16));
                 dh[2] += bf2f((bf16_t)(dl.y & 0xffffu)); dh[3] += bf2f((bf16_t)(dl.y >> 16));
             }
-            const float* gp = gates + (row * 2 + dir) * G + j0;
-            const float4 ig4 = *(const float4*)gp, fg4 = *(const float4*)(gp + H), gt4 = *(const float4*)(gp + 2 * H),
-                         og4 = *(const float4*)(gp + 3 * H);
-            const float4 c4 = *(const float4*)(csave + (row * 2 + dir) * H + j0);
-            float4 cp4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tprev >= 0 && tprev < T) cp4 = *(const float4*)(csave + (((size_t)b * T + tprev) * 2 + dir) * H + j0);
-            const float igv[4] = {ig4.x, ig4.y, ig4.z, ig4.w}, fgv[4] = {fg4.x, fg4.y, fg4.z, fg4.w};
-            const float gtv[4] = {gt4.x, gt4.y, gt4.z, gt4.w}, ogv[4] = {og4.x, og4.y, og4.z, og4.w};
-            const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, cpv[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+            // forward-native layout: units j0..j0+3 are the lanes n, n+16, n+32, n+48 of forward tile j0/4
+            const size_t nat = ((((size_t)blockIdx.x * T + t) * 2 + dir) * (H >> 2) + (j0 >> 2)) * 64 + n;
+            const size_t natp = ((((size_t)blockIdx.x * T + tprev) * 2 + dir) * (H >> 2) + (j0 >> 2)) * 64 + n;
+            const bool hasp = tprev >= 0 && tprev < T;
+            float igv[4], fgv[4], gtv[4], ogv[4], cv[4], cpv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 g4v = *(const float4*)(gates + (nat + 16 * u) * 4);
+                igv[u] = g4v.x; fgv[u] = g4v.y; gtv[u] = g4v.z; ogv[u] = g4v.w;
+                cv[u] = csave[nat + 16 * u];
+                cpv[u] = hasp ? csave[natp + 16 * u] : 0.f;
+            }
             float di[4], df[4], dgg[4], dov[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -275,16 +364,41 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_bwd_kernel(const bf16_t* __re
             const int jt = wave + LM_WAVES * ti;
             if (jt >= NJ) break;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int kk = 0; kk < KB; ++kk) {
-                const uint4 w = whd[((size_t)jt * KB + kk) * 64];
-                const uint4 d0 = *(const uint4*)(dg + n * GP + kk * 64 + g4 * 16);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w), frag(d0), acc, 0, 0, 0);
-                if (wl) {
-                    const uint4 w2 = wld[((size_t)jt * KB + kk) * 64];
-                    const uint4 d1 = *(const uint4*)(dg + LM_NB * GP + n * GP + kk * 64 + g4 * 16);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w), frag(d1), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w2), frag(d0), acc, 0, 0, 0);
+            // chunks of 4 k-fragments, the next chunk's W loads in flight while this chunk is multiplied
+            const uint4* wp = whd + (size_t)jt * KB * 64;
+            const uint4* wp2 = wl ? wld + (size_t)jt * KB * 64 : nullptr;
+            uint4 wa[4], wc2[4], la[4], lc2[4];
+            auto load4 = [&](uint4 (&w)[4], uint4 (&l)[4], const int k0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = min(k0 + u, KB - 1);
+                    w[u] = wp[(size_t)kk * 64];
+                    if (wl) l[u] = wp2[(size_t)kk * 64];
                 }
+            };
+            auto mul4 = [&](const uint4 (&w)[4], const uint4 (&l)[4], const int k0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = k0 + u;
+                    if (kk < KB) {
+                        const uint4 d0 = *(const uint4*)(dg + n * GP + kk * 64 + g4 * 16);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w[u]), frag(d0), acc, 0, 0, 0);
+                        if (wl) {
+                            const uint4 d1 = *(const uint4*)(dg + LM_NB * GP + n * GP + kk * 64 + g4 * 16);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w[u]), frag(d1), acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(l[u]), frag(d0), acc, 0, 0, 0);
+                        }
+                    }
+                }
+            };
+            load4(wa, la, 0);
+            for (int k0 = 0; k0 < KB; k0 += 8) {
+                load4(wc2, lc2, k0 + 4);
+                __builtin_amdgcn_sched_barrier(0);
+                mul4(wa, la, k0);
+                load4(wa, la, k0 + 8);
+                __builtin_amdgcn_sched_barrier(0);
+                mul4(wc2, lc2, k0 + 4);
             }
             dhr[ti] = acc;
         }

@@ -174,8 +174,9 @@ def lstm_forward_train(lp, feat_dims, B, T, x3, dev):
     E.conv(None, 0, lp["cin_store"], lp["w"], 1, 1, 8 * H, lp["scale"], lp["shift"], L.ACT_NONE, out=xproj,
            out_dtype=L.DT_F32, sb=T * 8 * H, sh=0, sw=8 * H, sc=1, Ho=1, Wo=T, in_dims=feat_dims)
     h = E.Act(B, 1, T, E.pad_to(2 * H, 16), x3, dev, zero=True)
-    gates = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=dev)
-    csave = torch.empty((B, T, 2, H), dtype=torch.float32, device=dev)
+    Bp = (B + 15) // 16 * 16                       # kernel-native layout, 16-clip groups (sos_hip.h)
+    gates = torch.empty((Bp, T, 2, 4 * H), dtype=torch.float32, device=dev)
+    csave = torch.empty((Bp, T, 2, H), dtype=torch.float32, device=dev)
     E.lstm(xproj, lp["wpk"], B, T, H, h, gates, csave)
     return h, dict(gates=gates, csave=csave, h=h, feat_dims=feat_dims)
 
