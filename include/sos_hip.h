@@ -197,7 +197,8 @@ typedef struct sos_wgrad_desc {
     const void* x;
     int32_t Hx, Wx, x_cs, x_off;
     int32_t M, N, kh, kw, stride, dil_h, dil_w, pad_top, pad_left, pad_mode;
-    int32_t ksplit;         /* pixel-range split (parallelism); partial sums reduced deterministically */
+    int32_t ksplit;         /* pixel-range split (parallelism), <= 0: automatic (one workgroup per CU); partial
+                             * sums are reduced deterministically.  Size `partial` with sos_wgrad_workspace_bytes */
     float* partial;
     float* dw;
     int32_t accumulate;     /* 0: dw = result, 1: dw += result */

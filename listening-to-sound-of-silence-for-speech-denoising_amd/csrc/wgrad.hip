@@ -538,17 +538,27 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int kspli
     }
 }
 
+// ksplit <= 0 in the descriptor = automatic: one workgroup per CU (MI355X: 256) over (pixel split, m-group, n-group),
+// bounded by 256 MB of partial sums.
+static const int WG_NCU = 256;
+static int wg_max_split(const sos_wgrad_desc* d) {
+    const int64_t Mp = (d->M + 31) / 32 * 32, Np = (d->N + 31) / 32 * 32;
+    const int64_t per = (int64_t)d->kh * d->kw * Mp * Np * 4;
+    const int64_t cap = ((int64_t)256 << 20) / per;
+    return (int)(cap < 1 ? 1 : (cap > WG_NCU ? WG_NCU : cap));
+}
+
 extern "C" int64_t sos_wgrad_workspace_bytes(const sos_wgrad_desc* d) {
     if (!d) return -1;
     const int64_t Mp = (d->M + 31) / 32 * 32, Np = (d->N + 31) / 32 * 32;
-    return (int64_t)d->ksplit * d->kh * d->kw * Mp * Np * 4;
+    return (int64_t)(d->ksplit > 0 ? d->ksplit : wg_max_split(d)) * d->kh * d->kw * Mp * Np * 4;
 }
 
 extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     if (!d || !d->g || !d->x || !d->partial || !d->dw) { sos_set_error("sos_conv2d_wgrad: null pointer"); return SOS_EINVAL; }
     if (d->M < 1 || d->N < 1 || d->g_cs % 8 || d->x_cs % 8 || d->g_off % 8 || d->x_off % 8 || d->kh < 1 || d->kw < 1 ||
         d->stride < 1 || d->dil_h < 1 || d->dil_w < 1 || (d->stride > 1 && (d->dil_h > 1 || d->dil_w > 1)) ||
-        d->ksplit < 1 || d->B < 1) {
+        d->B < 1) {
         sos_set_error("sos_conv2d_wgrad: bad descriptor");
         return SOS_EINVAL;
     }
@@ -624,7 +634,15 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     const size_t lds = (size_t)p.bufbytes * (p.dbuf ? 2 : 1) + (size_t)(256 + p.npixp) * 8;
     { const char* e = getenv("SOS_WGRAD_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.nsteps = d->B * d->dil_h * p.ngw * p.tiles_h * p.tiles_w;
-    const int ksplit = d->ksplit < p.nsteps ? d->ksplit : p.nsteps;      // never an empty split
+    int ksplit = d->ksplit;
+    if (ksplit <= 0) {
+        const int groups = use16 ? 1 : mgroups * ((ntiles_n + ntb - 1) / ntb);
+        ksplit = WG_NCU / groups;
+        if (ksplit < 1) ksplit = 1;
+        const int cap = wg_max_split(d);
+        if (ksplit > cap) ksplit = cap;
+    }
+    if (ksplit > p.nsteps) ksplit = p.nsteps;                            // never an empty split
     p.ksplit = ksplit;
     p.steps_per_split = (p.nsteps + ksplit - 1) / ksplit;
     dim3 grid((unsigned)ksplit, (unsigned)mgroups, (unsigned)((ntiles_n + ntb - 1) / ntb));

@@ -324,9 +324,7 @@ def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0,
         d.M, d.N, d.kh, d.kw, d.stride, d.dil_h, d.dil_w = M, N, kh, kw, stride, dil[0], dil[1]
         d.pad_top, d.pad_left, d.pad_mode = pad[0], pad[1], pad_mode
         npix = g.B * g.H * g.W
-        # pixel-range splits: >= 2 tiles of 256 pixels each, <= 256 splits, <= 64 MB of partial sums
-        mp, np_ = (M + 31) // 32 * 32, (N + 31) // 32 * 32
-        d.ksplit = max(1, min(256, npix // 512, (64 << 20) // (kh * kw * mp * np_ * 4)))
+        d.ksplit = 0                               # automatic pixel-range split (one workgroup per CU)
         need = L.lib().sos_wgrad_workspace_bytes(ctypes.byref(d))
         key = str(dev)
         if key not in _wg_ws or _wg_ws[key].numel() * 4 < need:

@@ -1,0 +1,39 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): regenerates the measured artefacts that profiles/ keeps (copy them from gpurun_out/).
+#   bench JSON lines (train = BASELINE configs[1], infer), rocprofv3 --kernel-trace --stats summaries of both,
+#   and the HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs) of the dominant conv kernel.
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/refresh; mkdir -p $O
+export SOS_CONV_TUNE_CACHE=/tmp/tune.txt
+python bench.py --steps 10 --warmup 3 > $O/bench_train.json 2> $O/bench_train.err
+python bench.py --mode infer --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_infer.json 2> $O/bench_infer.err
+python tools/conv_bench.py > $O/conv_bench.txt 2>&1
+python tools/wgrad_bench.py > $O/wgrad_bench.txt 2>&1
+python tools/lstm_bench.py > $O/lstm_bench.txt 2>&1
+export SOS_CONV_TUNE_FROZEN=1
+rocprofv3 --kernel-trace --stats -d $O/prof_train -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_train.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_infer -o t -- python bench.py --mode infer --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_infer.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+  n=$(echo $c | tr ' ' '_')
+  rocprofv3 --pmc $c --kernel-include-regex conv_mfma -d $O/pmc_$n -o p --output-format csv -- python tools/conv_bench.py --only "ctx96 d1x1" --iters 3 --warm 0.05 > $O/pmc_$n.log 2>&1
+done
+python - <<'PY'
+import csv, glob, json, collections
+acc = collections.defaultdict(list)
+for f in glob.glob("gpurun_out/refresh/pmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+avg = {k: sum(v) / len(v) for k, v in acc.items()}
+B, H, W, C = 64, 256, 178, 96
+out = {"kernel": "conv_mfma_kernel 96->96 5x5 B=64 (tools/conv_bench.py --only 'ctx96 d1x1')",
+       "FETCH_SIZE_KB": avg.get("FETCH_SIZE"), "WRITE_SIZE_KB": avg.get("WRITE_SIZE"),
+       "hbm_bytes_per_launch": (2 * avg.get("FETCH_SIZE", 0) + avg.get("WRITE_SIZE", 0)) * 1024,
+       "algorithmic_bytes_per_launch": 2 * B * H * W * C * 2,
+       "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md HBM section)",
+       "l2_hit": avg.get("TCC_HIT_sum"), "l2_miss": avg.get("TCC_MISS_sum")}
+json.dump(out, open("gpurun_out/refresh/pmc_conv96.json", "w"), indent=1)
+print(json.dumps(out))
+PY
+python profiles/summarize_rocpd.py $O/prof_train/t_results.db > $O/train_kernels.md 2>&1
+python profiles/summarize_rocpd.py $O/prof_infer/t_results.db > $O/infer_kernels.md 2>&1
+cat $O/bench_train.json | cut -c1-600; cat $O/bench_infer.json | cut -c1-300
