@@ -8,6 +8,7 @@
 // Each thread moves 16-byte channel runs (8 bf16), so every pass streams the tensor once at
 // full line width.
 #include "sos_common.h"
+#include <stdlib.h>
 
 struct View {
     bf16_t* ptr;
@@ -51,6 +52,37 @@ __device__ __forceinline__ void load8(const View& v, long long pix, int c8, floa
     }
 }
 
+// U pixels (pix, pix + step, ...) of one 8-channel group: all loads are issued before the first conversion, so a
+// thread keeps U (2U in hi|hi|lo mode) 16-byte requests in flight.  Pixels past the end are clamped (callers skip them).
+template <int BN_U>
+__device__ __forceinline__ void load8u(const View& v, long long pix, long long step, int c8, float (&f)[BN_U][8]) {
+    uint4 h[BN_U], l[BN_U];
+#pragma unroll
+    for (int u = 0; u < BN_U; ++u) {
+        const long long pp = pix + u * step < v.npix ? pix + u * step : v.npix - 1;
+        const bf16_t* p = v.ptr + pp * v.row + v.c_off + c8;
+        h[u] = *(const uint4*)p;
+        if (v.x3) l[u] = *(const uint4*)(p + 2 * v.third);
+    }
+#pragma unroll
+    for (int u = 0; u < BN_U; ++u) {
+        const unsigned hw[4] = {h[u].x, h[u].y, h[u].z, h[u].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[u][2 * i] = __uint_as_float(hw[i] << 16);
+            f[u][2 * i + 1] = __uint_as_float(hw[i] & 0xffff0000u);
+        }
+        if (v.x3) {
+            const unsigned lw[4] = {l[u].x, l[u].y, l[u].z, l[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f[u][2 * i] += __uint_as_float(lw[i] << 16);
+                f[u][2 * i + 1] += __uint_as_float(lw[i] & 0xffff0000u);
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void store8(const View& v, long long pix, int c8, const float (&f)[8]) {
     bf16_t* p = v.ptr + pix * v.row + v.c_off + c8;
     unsigned hw[4], lw[4];
@@ -79,6 +111,7 @@ extern "C" int sos_bn_stats_blocks(int64_t npix) {
 
 // thread = (pixel lane, 8-channel group); per-thread sums, then an LDS tree over the pixel lanes.
 __global__ __launch_bounds__(256) void bn_stats_kernel(View x, float* __restrict__ partial) {
+    constexpr int BN_U = 4;
     __shared__ float red[256 * 16];
     const int CG = (x.C + 7) / 8;           // <= 256 (C <= 2048)
     const int PL = 256 / CG;
@@ -88,11 +121,16 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(View x, float* __restrict
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
     if (pl < PL) {
-        for (long long pix = (long long)blockIdx.x * PL + pl; pix < x.npix; pix += (long long)gridDim.x * PL) {
-            float f[8];
-            load8(x, pix, cg * 8, f);
+        const long long step = (long long)gridDim.x * PL;
+        for (long long pix = (long long)blockIdx.x * PL + pl; pix < x.npix; pix += BN_U * step) {
+            float f[BN_U][8];
+            load8u<BN_U>(x, pix, step, cg * 8, f);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { s[i] += f[i]; q[i] = fmaf(f[i], f[i], q[i]); }
+            for (int u = 0; u < BN_U; ++u) {
+                if (pix + u * step >= x.npix) break;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { s[i] += f[u][i]; q[i] = fmaf(f[u][i], f[u][i], q[i]); }
+            }
         }
     }
 #pragma unroll
@@ -178,6 +216,7 @@ __device__ __forceinline__ float apply_act(float z, int act, float slope) {
 __global__ __launch_bounds__(256) void bn_apply_kernel(View x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int act,
                                                        const float* __restrict__ slope_p, View y) {
+    constexpr int BN_U = 4;
     const int CG = (x.C + 7) / 8;
     const int PL = 256 / CG;
     const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
@@ -189,12 +228,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(View x, const float* __re
         const int c = min(cg * 8 + e, x.C - 1);
         sc[e] = scale[c]; sh[e] = shift[c];
     }
-    for (long long pix = (long long)blockIdx.x * PL + pl; pix < x.npix; pix += (long long)gridDim.x * PL) {
-        float f[8];
-        load8(x, pix, cg * 8, f);
+    const long long step = (long long)gridDim.x * PL;
+    for (long long pix = (long long)blockIdx.x * PL + pl; pix < x.npix; pix += BN_U * step) {
+        float f[BN_U][8];
+        load8u<BN_U>(x, pix, step, cg * 8, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (cg * 8 + e < x.C) ? apply_act(fmaf(f[e], sc[e], sh[e]), act, slope) : 0.f;
-        store8(y, pix, cg * 8, f);
+        for (int u = 0; u < BN_U; ++u) {
+            if (pix + u * step >= x.npix) break;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[u][e] = (cg * 8 + e < x.C) ? apply_act(fmaf(f[u][e], sc[e], sh[e]), act, slope) : 0.f;
+            store8(y, pix + u * step, cg * 8, f[u]);
+        }
     }
 }
 
@@ -230,7 +274,9 @@ __global__ __launch_bounds__(256) void bn_apply_feat_kernel(View x, const float*
 
 static inline unsigned grid_for(long long total) {
     long long g = (total + 255) / 256;
-    if (g > 8192) g = 8192;
+    static const char* cap_env = getenv("SOS_BN_GRID");
+    const long long cap = cap_env ? atoll(cap_env) : 1536;
+    if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (unsigned)g;
 }
@@ -279,6 +325,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(View dy, View x, con
                                                             const float* __restrict__ invstd, int act,
                                                             const float* __restrict__ slope_p,
                                                             float* __restrict__ partial) {
+    constexpr int BN_U = 2;
     __shared__ float red[256 * 24];
     const int CG = (x.C + 7) / 8;
     const int PL = 256 / CG;
@@ -294,17 +341,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(View dy, View x, con
         mu[i] = mean ? mean[c] : 0.f; is[i] = invstd ? invstd[c] : 1.f;
     }
     if (pl < PL) {
-        for (long long pix = (long long)blockIdx.x * PL + pl; pix < x.npix; pix += (long long)gridDim.x * PL) {
-            float fx[8], fg[8];
-            load8(x, pix, cg * 8, fx);
-            load8(dy, pix, cg * 8, fg);
+        const long long step = (long long)gridDim.x * PL;
+        for (long long pix = (long long)blockIdx.x * PL + pl; pix < x.npix; pix += BN_U * step) {
+            float fx[BN_U][8], fg[BN_U][8];
+            load8u<BN_U>(x, pix, step, cg * 8, fx);
+            load8u<BN_U>(dy, pix, step, cg * 8, fg);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float z = fmaf(fx[i], sc[i], sh[i]);
-                const float dz = fg[i] * act_grad(z, act, slope);
-                s1[i] += dz;
-                s2[i] = fmaf(dz, (fx[i] - mu[i]) * is[i], s2[i]);
-                if (z < 0.f) s3[i] = fmaf(fg[i], z, s3[i]);
+            for (int u = 0; u < BN_U; ++u) {
+                if (pix + u * step >= x.npix) break;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float z = fmaf(fx[u][i], sc[i], sh[i]);
+                    const float dz = fg[u][i] * act_grad(z, act, slope);
+                    s1[i] += dz;
+                    s2[i] = fmaf(dz, (fx[u][i] - mu[i]) * is[i], s2[i]);
+                    if (z < 0.f) s3[i] = fmaf(fg[u][i], z, s3[i]);
+                }
             }
         }
     }
@@ -373,6 +425,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View x, cons
                                                            const float* __restrict__ slope_p,
                                                            const float* __restrict__ ca, const float* __restrict__ cb,
                                                            const float* __restrict__ cc, View dx) {
+    constexpr int BN_U = 2;
     const int CG = (x.C + 7) / 8;
     const int PL = 256 / CG;
     const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
@@ -386,18 +439,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View x, cons
         mu[e] = mean ? mean[c] : 0.f; is[e] = mean ? invstd[c] : 0.f;
         a[e] = ca[c]; b[e] = cb[c]; c0[e] = cc[c];
     }
-    for (long long pix = (long long)blockIdx.x * PL + pl; pix < x.npix; pix += (long long)gridDim.x * PL) {
-        float fx[8], fg[8], o[8];
-        load8(x, pix, cg * 8, fx);
-        load8(dy, pix, cg * 8, fg);
+    const long long step = (long long)gridDim.x * PL;
+    for (long long pix = (long long)blockIdx.x * PL + pl; pix < x.npix; pix += BN_U * step) {
+        float fx[BN_U][8], fg[BN_U][8];
+        load8u<BN_U>(x, pix, step, cg * 8, fx);
+        load8u<BN_U>(dy, pix, step, cg * 8, fg);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float z = fmaf(fx[e], sc[e], sh[e]);
-            const float dz = fg[e] * act_grad(z, act, slope);
-            const float xh = (fx[e] - mu[e]) * is[e];
-            o[e] = (cg * 8 + e < x.C) ? fmaf(a[e], dz, fmaf(b[e], xh, c0[e])) : 0.f;
+        for (int u = 0; u < BN_U; ++u) {
+            if (pix + u * step >= x.npix) break;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float z = fmaf(fx[u][e], sc[e], sh[e]);
+                const float dz = fg[u][e] * act_grad(z, act, slope);
+                const float xh = (fx[u][e] - mu[e]) * is[e];
+                o[e] = (cg * 8 + e < x.C) ? fmaf(a[e], dz, fmaf(b[e], xh, c0[e])) : 0.f;
+            }
+            store8(dx, pix + u * step, cg * 8, o);
         }
-        store8(dx, pix, cg * 8, o);
     }
 }
 
