@@ -368,6 +368,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
 // (lane group g, element e) is tile pixel 4 g + e (e < 4) or 16 + 4 g + (e - 4): the first transpose read of a
 // wave then covers 16 consecutive pixels x 32 B = 128 consecutive dwords (conflict free), the second the next 16.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int M16, int N16, int FT>
 __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
@@ -436,61 +437,56 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
             }
             const unsigned ga = (gb + (unsigned)ks * 1024u) + glane;
             const unsigned xk = xb + (unsigned)pp_of(ks * 32) * 32u;            // wave-uniform
-            // reads in consumption order (LDS returns in order): remainder unit, G, then tap by tap
-            uint2 ae0 = make_uint2(0u, 0u), ae1 = ae0, be0[N16], be1[N16];
-#pragma unroll
-            for (int n = 0; n < N16; ++n) { be0[n] = ae0; be1[n] = ae0; }
+            // reads in consumption order (LDS returns in order): remainder unit, G, then tap by tap.  The two
+            // 64-bit halves of an operand are assembled into ONE 128-bit value before the counted wait names it,
+            // so the register coalescer lets each transpose read write its half in place (no v_mov).
+            auto rd2 = [&](const unsigned a0addr, const unsigned a1addr) {
+                const uint2 lo = lds_tr(a0addr), hi = lds_tr(a1addr);
+                return u32x4{lo.x, lo.y, hi.x, hi.y};
+            };
+            u32x4 ae, be[N16];                                   // only defined (and used) when has_e
             if (has_e) {
-                ae0 = lds_tr(ga + (unsigned)mt_e * 8192u); ae1 = lds_tr_off<512>(ga + (unsigned)mt_e * 8192u);
+                ae = rd2(ga + (unsigned)mt_e * 8192u, ga + (unsigned)mt_e * 8192u + 512u);
 #pragma unroll
-                for (int n = 0; n < N16; ++n) {
-                    be0[n] = lds_tr(xlane0 + (xk + toffe + (unsigned)(n * ximg)));
-                    be1[n] = lds_tr(xlane1 + (xk + toffe + (unsigned)(n * ximg)));
-                }
+                for (int n = 0; n < N16; ++n)
+                    be[n] = rd2(xlane0 + (xk + toffe + (unsigned)(n * ximg)), xlane1 + (xk + toffe + (unsigned)(n * ximg)));
             }
-            uint2 a0[M16], a1[M16], b0[FT][N16], b1[FT][N16];
-            a0[0] = lds_tr(ga); a1[0] = lds_tr_off<512>(ga);
-            if constexpr (M16 >= 2) { a0[1] = lds_tr_off<8192>(ga); a1[1] = lds_tr_off<8192 + 512>(ga); }
-            if constexpr (M16 >= 3) { a0[2] = lds_tr_off<16384>(ga); a1[2] = lds_tr_off<16384 + 512>(ga); }
+            u32x4 av[M16], bv[FT][N16];
+            {
+                const uint2 lo = lds_tr(ga), hi = lds_tr_off<512>(ga);
+                av[0] = u32x4{lo.x, lo.y, hi.x, hi.y};
+            }
+            if constexpr (M16 >= 2) { const uint2 lo = lds_tr_off<8192>(ga), hi = lds_tr_off<8192 + 512>(ga); av[1] = u32x4{lo.x, lo.y, hi.x, hi.y}; }
+            if constexpr (M16 >= 3) { const uint2 lo = lds_tr_off<16384>(ga), hi = lds_tr_off<16384 + 512>(ga); av[2] = u32x4{lo.x, lo.y, hi.x, hi.y}; }
 #pragma unroll
             for (int f = 0; f < FT; ++f)
 #pragma unroll
-                for (int n = 0; n < N16; ++n) {
-                    b0[f][n] = lds_tr(xlane0 + (xk + toff[f] + (unsigned)(n * ximg)));
-                    b1[f][n] = lds_tr(xlane1 + (xk + toff[f] + (unsigned)(n * ximg)));
-                }
+                for (int n = 0; n < N16; ++n)
+                    bv[f][n] = rd2(xlane0 + (xk + toff[f] + (unsigned)(n * ximg)), xlane1 + (xk + toff[f] + (unsigned)(n * ximg)));
 #pragma unroll
             for (int f = 0; f < FT; ++f) {
                 // everything up to tap f has landed when 2 N16 (FT - 1 - f) reads are still outstanding
-                if constexpr (N16 == 3) {
-                    if (f == 0) {
-                        if constexpr (M16 == 3)
-                            asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[1]), "+v"(a1[1]), "+v"(a0[2]), "+v"(a1[2]),
-                                         "+v"(b0[0][0]), "+v"(b1[0][0]), "+v"(b0[0][1]), "+v"(b1[0][1]), "+v"(b0[0][2]), "+v"(b1[0][2]) : "n"(6 * (FT - 1)));
-                    } else {
-                        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(b0[f][0]), "+v"(b1[f][0]), "+v"(b0[f][1]), "+v"(b1[f][1]), "+v"(b0[f][2]), "+v"(b1[f][2])
-                                     : "n"(6 * (FT - 1 - f)));
-                    }
+                if constexpr (N16 == 3 && M16 == 3) {
+                    if (f == 0)
+                        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(bv[0][0]), "+v"(bv[0][1]), "+v"(bv[0][2])
+                                     : "n"(6 * (FT - 1)));
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(bv[f][0]), "+v"(bv[f][1]), "+v"(bv[f][2]) : "n"(6 * (FT - 1 - f)));
                 }
 #pragma unroll
                 for (int n = 0; n < N16; ++n) {
-                    const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(b0[f][n].x, b0[f][n].y, b1[f][n].x, b1[f][n].y));
 #pragma unroll
-                    for (int a = 0; a < M16; ++a) {
-                        const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(a0[a].x, a0[a].y, a1[a].x, a1[a].y));
-                        acc[f][a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[f][a][n], 0, 0, 0);
-                    }
+                    for (int a = 0; a < M16; ++a)
+                        acc[f][a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[a]),
+                                                                               __builtin_bit_cast(bf16x8, bv[f][n]), acc[f][a][n], 0, 0, 0);
                 }
             }
             if (has_e) {
-                if constexpr (N16 == 3)
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ae0), "+v"(ae1), "+v"(be0[0]), "+v"(be1[0]), "+v"(be0[1]), "+v"(be1[1]), "+v"(be0[2]), "+v"(be1[2]));
-                const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(ae0.x, ae0.y, ae1.x, ae1.y));
+                if constexpr (N16 == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ae), "+v"(be[0]), "+v"(be[1]), "+v"(be[2]));
 #pragma unroll
-                for (int n = 0; n < N16; ++n) {
-                    const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(be0[n].x, be0[n].y, be1[n].x, be1[n].y));
-                    acce[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acce[n], 0, 0, 0);
-                }
+                for (int n = 0; n < N16; ++n)
+                    acce[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ae), __builtin_bit_cast(bf16x8, be[n]),
+                                                                      acce[n], 0, 0, 0);
             }
         }
         if (p.dbuf) {
