@@ -20,6 +20,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define WG_WAVES 8            // waves per workgroup (512 threads, two per SIMD)
 #define WG_THREADS (WG_WAVES * 64)
@@ -287,47 +288,44 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             // LDS reads in the order the MFMAs consume them (LDS returns in order): every MFMA group waits only
             // for its own fragments, so the first MFMAs start while the later fragments are still in flight.
             // The waits name their registers so that every consumer is ordered behind them.
-            uint2 a0[MT], a1[MT], b0[WG_PAIRS], b1[WG_PAIRS];
-            a0[0] = lds_tr(ga); a1[0] = lds_tr_off<256>(ga);
-            b0[0] = lds_tr(xlane0 + (xk + toff[0])); b1[0] = lds_tr(xlane1 + (xk + toff[0]));
-            if constexpr (MT >= 2) { a0[1] = lds_tr_off<16384>(ga); a1[1] = lds_tr_off<16384 + 256>(ga); }
-            if constexpr (MT >= 3) { a0[2] = lds_tr_off<32768>(ga); a1[2] = lds_tr_off<32768 + 256>(ga); }
+            // (the two 64-bit halves of an operand are assembled into one 128-bit value first: no register moves)
+            u32x4 av[MT], bv[WG_PAIRS];
+            auto rd2 = [&](const unsigned a0addr, const unsigned a1addr) {
+                const uint2 lo = lds_tr(a0addr), hi = lds_tr(a1addr);
+                return u32x4{lo.x, lo.y, hi.x, hi.y};
+            };
+            { const uint2 lo = lds_tr(ga), hi = lds_tr_off<256>(ga); av[0] = u32x4{lo.x, lo.y, hi.x, hi.y}; }
+            bv[0] = rd2(xlane0 + (xk + toff[0]), xlane1 + (xk + toff[0]));
+            if constexpr (MT >= 2) { const uint2 lo = lds_tr_off<16384>(ga), hi = lds_tr_off<16384 + 256>(ga); av[1] = u32x4{lo.x, lo.y, hi.x, hi.y}; }
+            if constexpr (MT >= 3) { const uint2 lo = lds_tr_off<32768>(ga), hi = lds_tr_off<32768 + 256>(ga); av[2] = u32x4{lo.x, lo.y, hi.x, hi.y}; }
 #pragma unroll
-            for (int u = 1; u < WG_PAIRS; ++u) { b0[u] = lds_tr(xlane0 + (xk + toff[u])); b1[u] = lds_tr(xlane1 + (xk + toff[u])); }
+            for (int u = 1; u < WG_PAIRS; ++u) bv[u] = rd2(xlane0 + (xk + toff[u]), xlane1 + (xk + toff[u]));
             constexpr int REST = 2 * (WG_PAIRS - 1);              // reads behind pair 0 / m-tile a
-            if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(b0[0]) , "+v"(b1[0]) : "n"(REST));
-            if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(b0[0]) , "+v"(b1[0]) : "n"(REST + 2));
-            if constexpr (MT == 3) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(ent), "+v"(a0[0]), "+v"(a1[0]), "+v"(b0[0]) , "+v"(b1[0]) : "n"(REST + 4));
+            asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(ent), "+v"(av[0]), "+v"(bv[0]) : "n"(REST + 2 * (MT - 1)));
             if (dma) st.issue(di, ent, onext, cur ^ 1);
             const bool on0 = wave < npairs;
             {
-                const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(b0[0].x, b0[0].y, b1[0].x, b1[0].y));
-                const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(a0[0].x, a0[0].y, a1[0].x, a1[0].y));
-                if (on0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[0][0], 0, 0, 0);
+                const bf16x8 bfr = __builtin_bit_cast(bf16x8, bv[0]);
+                if (on0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[0]), bfr, acc[0][0], 0, 0, 0);
                 if constexpr (MT >= 2) {
-                    if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a0[1]), "+v"(a1[1]) : "n"(REST));
-                    if constexpr (MT == 3) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a0[1]), "+v"(a1[1]) : "n"(REST + 2));
-                    const bf16x8 af1 = __builtin_bit_cast(bf16x8, make_uint4(a0[1].x, a0[1].y, a1[1].x, a1[1].y));
-                    if (on0) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1, bfr, acc[1][0], 0, 0, 0);
+                    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(av[1]) : "n"(REST + 2 * (MT - 2)));
+                    if (on0) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[1]), bfr, acc[1][0], 0, 0, 0);
                 }
                 if constexpr (MT >= 3) {
-                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a0[2]), "+v"(a1[2]) : "n"(REST));
-                    const bf16x8 af2 = __builtin_bit_cast(bf16x8, make_uint4(a0[2].x, a0[2].y, a1[2].x, a1[2].y));
-                    if (on0) acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2, bfr, acc[2][0], 0, 0, 0);
+                    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(av[2]) : "n"(REST));
+                    if (on0) acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[2]), bfr, acc[2][0], 0, 0, 0);
                 }
             }
 #pragma unroll
             for (int u = 1; u < WG_PAIRS; ++u) {
-                if (u == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b0[1]), "+v"(b1[1]));
-                if (u == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(b0[2]), "+v"(b1[2]));
-                if (u == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0[3]), "+v"(b1[3]));
+                if (u == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bv[1]));
+                if (u == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bv[2]));
+                if (u == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[3]));
                 if (wave + WG_WAVES * u < npairs) {
-                    const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(b0[u].x, b0[u].y, b1[u].x, b1[u].y));
+                    const bf16x8 bfr = __builtin_bit_cast(bf16x8, bv[u]);
 #pragma unroll
-                    for (int a = 0; a < MT; ++a) {
-                        const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(a0[a].x, a0[a].y, a1[a].x, a1[a].y));
-                        acc[a][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[a][u], 0, 0, 0);
-                    }
+                    for (int a = 0; a < MT; ++a)
+                        acc[a][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[a]), bfr, acc[a][u], 0, 0, 0);
                 }
             }
         }
@@ -368,7 +366,6 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
 // (lane group g, element e) is tile pixel 4 g + e (e < 4) or 16 + 4 g + (e - 4): the first transpose read of a
 // wave then covers 16 consecutive pixels x 32 B = 128 consecutive dwords (conflict free), the second the next 16.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int M16, int N16, int FT>
 __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
