@@ -6,7 +6,8 @@ torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
 
 A "step" is one pass of the hot path over one batch of synthetic 2 s clips resident in HBM:
   --mode train (default, BASELINE.json configs[1]): detector forward/backward/Adam (BCE) AND denoiser
-               forward/backward/Adam (MSE + MSE through the mask apply) on the same B clips, bf16;
+               forward/backward/Adam (MSE + MSE through the mask apply) on the same B clips, bf16, the two
+               (independent) models on one HIP stream each;
                for N > 1 the gradients are averaged with bucketed RCCL all-reduces overlapped with backward
   --mode infer: STFT -> detector -> bits->mask -> STFT(noise) -> JointModel -> mask apply -> ISTFT
 Each rank processes its own batch (independent utterances): weak scaling.
@@ -67,6 +68,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="train mode: run the two models back to back on one stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,8 +112,11 @@ def main():
         ag_jm = agent.DenoiserAgent(jm.train(), lr=1e-3)
 
         def step():
-            ag_det.train_func(batch_det)
-            ag_jm.train_func(batch_jm)
+            if args.serial:
+                ag_det.train_func(batch_det)
+                ag_jm.train_func(batch_jm)
+            else:           # the two models are independent: one HIP stream each
+                agent.train_concurrent([(ag_jm, batch_jm), (ag_det, batch_det)])
     else:
         def step():
             return pipeline.denoise(det, jm, mixed)
@@ -167,6 +172,7 @@ def main():
                                    "detector + two-stage denoiser, random-init weights (manual_seed 0)"
                                    + (", detector BCE + denoiser 2xMSE, Adam lr 1e-3, per-rank BatchNorm" if train else ""),
                        "clips_per_gpu": B, "n_samples": N_SAMPLES, "mode": args.mode,
+                       "streams": 2 if (train and not args.serial) else 1,
                        "realtime_factor": value * N_SAMPLES / 14000.0,
                        "end_to_end_tflops": value * gflop / 1e3 / world},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -255,6 +255,23 @@ class BaseAgent(object):
             return self.forward(data)
 
 
+def train_concurrent(jobs):
+    """One training step of several independent agents (the reference trains its two models in two separate
+    processes), each on its own HIP stream: [(agent, batch), ...] -> [(outputs, losses), ...].  The MFMA-bound
+    kernels of one model overlap the HBM-bound BatchNorm passes and the latency-bound LSTM steps of the other."""
+    cur = torch.cuda.current_stream()
+    outs = []
+    for ag, data in jobs:
+        if getattr(ag, "stream", None) is None:
+            ag.stream = torch.cuda.Stream(device=ag.device)
+        ag.stream.wait_stream(cur)
+        with torch.cuda.stream(ag.stream):
+            outs.append(ag.train_func(data))
+    for ag, _ in jobs:
+        cur.wait_stream(ag.stream)
+    return outs
+
+
 class DetectorAgent(BaseAgent):
     """MyAgent of M1/agent.py:153-206."""
 

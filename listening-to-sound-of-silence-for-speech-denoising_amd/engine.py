@@ -326,7 +326,7 @@ def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0,
         npix = g.B * g.H * g.W
         d.ksplit = 0                               # automatic pixel-range split (one workgroup per CU)
         need = L.lib().sos_wgrad_workspace_bytes(ctypes.byref(d))
-        key = str(dev)
+        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)     # one workspace per stream: agents may run concurrently
         if key not in _wg_ws or _wg_ws[key].numel() * 4 < need:
             _wg_ws[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
         d.partial = _wg_ws[key].data_ptr()

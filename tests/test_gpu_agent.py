@@ -94,3 +94,34 @@ def test_agents_train_step_and_checkpoint(tmp_path):
     assert torch.equal(o2, out) and torch.equal(n2, n_pred)
     with pytest.raises(ValueError):
         ag3.load_ckpt(99)
+
+
+def test_train_concurrent_matches_serial():
+    """The two models trained on two HIP streams (agent.train_concurrent) end up bit-identical to back-to-back
+    training: the kernels are deterministic and the agents share no mutable device state."""
+    import sos_amd
+    from sos_amd import agent
+    from sos_amd.common import MyConfig
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+    sos_amd.set_precision("bf16")
+    B, T = 2, 89
+    x = spec_input(100 + B, B, T).cuda()
+    clean = (spec_input(300, B, T) * 0.5).cuda()
+    bj = {"mixed": x, "noise": silent_gate(x.cpu()).cuda(), "clean": clean, "full_noise": x - clean}
+    bd = {"label": (torch.from_numpy(hashed(301, (B, 60))) > 0).float().cuda(), "audio": x}
+
+    def make():
+        det = dnet.get_network(); det.load_state_dict(onet.closed_form_state(onet.detector_spec(), seed=1))
+        jm = jnet.get_network(MyConfig()); jm.load_state_dict(onet.closed_form_state(onet.joint_spec(), seed=2))
+        return agent.DetectorAgent(det, lr=1e-3), agent.DenoiserAgent(jm, lr=1e-3)
+
+    d1, j1 = make()
+    d2, j2 = make()
+    for _ in range(2):
+        d1.train_func(bd); j1.train_func(bj)
+        agent.train_concurrent([(j2, bj), (d2, bd)])
+    torch.cuda.synchronize()
+    for a, b in ((d1, d2), (j1, j2)):
+        for (k, p), (_, q) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
+            assert torch.equal(p, q), k
