@@ -37,3 +37,25 @@ def denoise(detector, denoiser, mixed, sr=SR, fps=FPS, bits=None, return_all=Fal
         return dict(out=out, logits=logits, bits=bits, mask=mask, n_pred=n_pred, crm=crm, S_mixed=S_mixed,
                     S_noise=S_noise, S_out=S_out)
     return out
+
+
+@torch.no_grad()
+def denoise_ragged(detector, denoiser, clips, sr=SR, fps=FPS, max_batch=64):
+    """Variable-length inference (BASELINE configs[3]): `clips` = list of 1-D f32 GPU tensors of ANY lengths.
+    The reference denoises one file at a time at its own length (M2/predict.py:377-447: no padding, so reflect
+    padding, frame count and video-frame count follow the clip); clips of equal length are bucketed into one
+    batch (<= max_batch; same result as one by one up to the summation order of the tuned conv tilings) and the
+    outputs come back in input order, each hop*(T-1) samples long."""
+    order = {}
+    for i, c in enumerate(clips):
+        if c.dim() != 1:
+            raise ValueError("denoise_ragged expects 1-D waveforms")
+        order.setdefault(int(c.numel()), []).append(i)
+    outs = [None] * len(clips)
+    for n, idx in sorted(order.items()):
+        for j in range(0, len(idx), max_batch):
+            part = idx[j:j + max_batch]
+            y = denoise(detector, denoiser, torch.stack([clips[i] for i in part]).contiguous(), sr, fps)
+            for k, i in enumerate(part):
+                outs[i] = y[k]
+    return outs

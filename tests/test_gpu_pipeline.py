@@ -78,3 +78,49 @@ def test_pipeline_matches_oracle_and_si_sdr(precision):
                 assert d_sdr < 0.05
             else:
                 assert d_sdr < 0.5
+
+
+def test_ragged_batch_matches_per_clip_and_oracle():
+    """BASELINE configs[3] (variable-length inference): clips of 1 s, 2.01 s (odd T) and 3.7 s in one ragged call:
+    equal lengths are batched, outputs equal the per-clip calls (up to the summation order of the per-shape
+    conv tilings) and the oracle within tolerance."""
+    from sos_amd import pipeline
+    from sos_amd.common import MyConfig
+    from sos_amd.dataset import synth_batch
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+    sd1 = onet.closed_form_state(onet.detector_spec(), seed=1)
+    sd2 = onet.closed_form_state(onet.joint_spec(), seed=2)
+    det = dnet.get_network(); det.load_state_dict(sd1)
+    jm = jnet.get_network(MyConfig()); jm.load_state_dict(sd2)
+    det, jm = det.cuda().eval(), jm.cuda().eval()
+    base = synth_batch(70, 4)["mixed"]
+    long = np.concatenate([base[0], base[1]])
+    lens = [14000, 28123 - 28000 + 28000 - 0, 14000, 51800]
+    waves = [base[0][:14000], np.concatenate([base[1], base[2][:123]]), base[3][:14000], long[:51800]]
+    assert [len(w) for w in waves] == [14000, 28123, 14000, 51800] and lens
+    clips = [torch.from_numpy(np.ascontiguousarray(w)).cuda() for w in waves]
+    sos_amd.set_precision("bf16x3")
+    try:
+        outs = pipeline.denoise_ragged(det, jm, clips)
+        singles = [pipeline.denoise(det, jm, c[None])[0] for c in clips]
+    finally:
+        sos_amd.set_precision("bf16")
+    for w, o, s1 in zip(waves, outs, singles):
+        T = 1 + len(w) // 158
+        assert o.shape == (158 * (T - 1),)
+        assert float((o - s1).abs().max() / s1.abs().max()) < 2e-4
+    # oracle parity on the odd-length and the long clip (frame decisions are excluded by feeding the oracle's bits)
+    for i in (1, 3):
+        w = waves[i]
+        nf = pipeline.n_video_frames(len(w))
+        lo, bits, mask, y = _oracle_chain(sd1, sd2, w, nf)
+        sos_amd.set_precision("bf16x3")
+        try:
+            yg = pipeline.denoise(det, jm, clips[i][None], bits=torch.from_numpy(bits[None]).cuda())[0].cpu().numpy()
+        finally:
+            sos_amd.set_precision("bf16")
+        n = min(len(y), len(yg))
+        err = np.abs(yg[:n] - y[:n]).max() / max(np.abs(y[:n]).max(), 1e-9)
+        print("ragged clip", i, "len", len(w), "rel err", err)
+        assert err < 1e-3
