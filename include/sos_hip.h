@@ -111,7 +111,7 @@ typedef struct sos_conv_desc {
     int32_t out_c_off;
     int32_t cout_store;     /* channels [cout, cout_store) are written as zero          */
     int64_t out_third;      /* SOS_DT_BF16X3: element distance between hi|hi|lo thirds  */
-    /* epilogue: y = act(acc*scale[co] + shift[co])                                     */
+    /* epilogue: y = act(acc*scale[co] + shift[co]); scale == shift == NULL: y = act(acc)  */
     const float* scale;     /* [cout_pad]                                               */
     const float* shift;     /* [cout_pad]                                               */
     int32_t act;            /* SOS_ACT_*                                                */

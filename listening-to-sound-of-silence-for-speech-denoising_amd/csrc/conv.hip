@@ -323,7 +323,30 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     // Common case (bf16 NHWC output, ReLU / PReLU / linear): the activation is the branch-free
     // max(y,0) + sn*min(y,0) and the conversion is the packed hardware one -- ~4 VALU per value and no
     // scalar branches; the general path below handles sigmoid, f32 / strided and hi|hi|lo outputs.
-    if (staged && !x3 && p.act != SOS_ACT_SIGMOID) {
+    if (staged && !x3 && p.act == SOS_ACT_NONE && !p.scale) {
+        // raw output (training-mode forward convs, data gradients): accumulators straight to bf16
+        const bool partial = n0 + NT * 32 > p.cout;           // channels past cout are stored as zeros
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = nt * 32 + g * 8 + lhi * 4;
+                const int co = n0 + col;
+                if (co >= p.cout_store) continue;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][g * 4 + e];
+                    if (partial) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (co + e < p.cout) ? v[e] : 0.f;
+                    }
+                    *(uint2*)(ost_hi + mrow[mt] + col * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                }
+            }
+        }
+    } else if (staged && !x3 && p.act != SOS_ACT_SIGMOID && p.scale) {
         const float sn = p.act == SOS_ACT_RELU ? 0.f : (p.act == SOS_ACT_PRELU ? slope : 1.f);
         const bool partial = n0 + NT * 32 > p.cout;           // channels past cout are stored as zeros
 #pragma unroll
@@ -361,8 +384,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
             const int col = nt * 32 + g * 8 + lhi * 4;
             const int co = n0 + col;                          // 4 consecutive channels co..co+3
             if (co >= p.cout_store) continue;
-            const float4 sc4 = *(const float4*)(p.scale + co);
-            const float4 sh4 = *(const float4*)(p.shift + co);
+            float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.scale) { sc4 = *(const float4*)(p.scale + co); sh4 = *(const float4*)(p.shift + co); }
             const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
             const float shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
 #pragma unroll
@@ -586,7 +609,7 @@ static std::map<ShapeKey, ConvCfg>& tuned_cache() {
 }
 
 static int validate(const sos_conv_desc* d) {
-    if (!d || !d->in || !d->wgt || !d->out || !d->scale || !d->shift) {
+    if (!d || !d->in || !d->wgt || !d->out || ((d->scale == nullptr) != (d->shift == nullptr))) {
         sos_set_error("sos_conv2d_fwd: null pointer");
         return SOS_EINVAL;
     }

@@ -161,7 +161,7 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
     d.out_c_off = c_off
     d.cout_store = cout if cout_store is None else cout_store
     d.out_third = third
-    d.scale, d.shift = scale.data_ptr(), shift.data_ptr()
+    d.scale, d.shift = (scale.data_ptr(), shift.data_ptr()) if scale is not None else (None, None)
     d.act = act
     d.act_param = slope.data_ptr() if slope is not None else None
     d.accumulate = 1 if accumulate else 0
