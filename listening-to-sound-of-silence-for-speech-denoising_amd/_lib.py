@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsos_hip.so")
+LIB_PATH = os.environ.get("SOS_HIP_LIB", os.path.join(_HERE, "libsos_hip.so"))     # override: A/B timing of two builds
 
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1

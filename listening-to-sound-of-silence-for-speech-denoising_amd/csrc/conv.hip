@@ -441,12 +441,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     }
     }
     if (!staged) return;
+    // element offset of every tile pixel inside its output image (-1: outside), one entry per thread
+    int* otab = (int*)(smem + 256 * OROW * (x3 ? 2 : 1));
+    {
+        const int m = tid;
+        const int j = m & (TW - 1);
+        const int i = (m >> p.logTW) & (TH - 1);
+        const int cls = m >> (p.logTW + p.logTH);
+        const int ho = ho_base + i * p.dh;
+        const int wo = wo_base + cls + j * p.dw;
+        otab[m] = (ho < p.Ho && wo < p.Wo && (cls == 0 || rw0 + cls < p.dw)) ? ho * (int)p.sh + wo * (int)p.sw : -1;
+    }
     __syncthreads();
     // ---- cooperative store: consecutive lanes write consecutive 16-byte pieces of a pixel's
     // channel run (and consecutive pixels of a tile row are adjacent in memory when dil_w == 1).
     constexpr int PPX = NT * 4;                  // 16-byte pieces per pixel
     bf16_t* op = (bf16_t*)p.out + (long long)b * p.sb + p.c_off + n0;
     const int ish = (int)p.sh, isw = (int)p.sw, ith = (int)p.third;
+    if (!x3 && !p.accum && ((p.cout_store - n0) & 7) == 0) {          // common case: whole 8-channel pieces, plain store
+        const int npiece = min(PPX, (p.cout_store - n0) >> 3);
+#pragma unroll 4
+        for (int idx = tid; idx < 256 * PPX; idx += 256) {
+            const int m = idx / PPX, q = idx - m * PPX;
+            const int off = otab[m];
+            if (q < npiece && off >= 0) *(uint4*)(op + off + q * 8) = *(const uint4*)(ost_hi + m * OROW + q * 16);
+        }
+        return;
+    }
 #pragma unroll 4
     for (int idx = tid; idx < 256 * PPX; idx += 256) {
         const int m = idx / PPX, q = idx - m * PPX;
@@ -661,7 +682,7 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     dim3 grid((unsigned)nblk, (unsigned)nby);
     size_t lds = lds_bytes(p.npix, nt, c.ks);
     if (d->out_dtype != SOS_DT_F32 && d->out_sc == 1) {
-        const size_t stage = (size_t)256 * (nt * 64 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1);
+        const size_t stage = (size_t)256 * (nt * 64 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + 1024;   // + pixel offsets
         if (stage > lds) lds = stage;
     }
     switch (nt) {
