@@ -140,8 +140,9 @@ int sos_conv2d_tune_load(const char* path);
  * weight version into MFMA fragment order: sos_lstm_pack_bytes(H, 0 / 1) = bytes of ONE forward /
  * backward array; the lo arrays (both or neither) hold the bf16 remainders for the three-pass
  * hi*hi + hi*lo + lo*hi product of the bf16x3 precision mode.  H % 4 == 0, H <= 256.
- * xproj f32 [B][T][2][4H] (dir 0 fwd, 1 reverse); out_bf16 bf16 [B][T][out_cs] (+ thirds when
- * dtype == SOS_DT_BF16X3). */
+ * xproj f32 [B][T][2][4H] (dir 0 fwd, 1 reverse) in GATE-INTERLEAVED order: channel dir*4H + 4*j + q for
+ * hidden unit j and gate q in i,f,g,o (permute the rows of W_ih and of the bias; torch's order is q*H + j);
+ * out_bf16 bf16 [B][T][out_cs] (+ thirds when dtype == SOS_DT_BF16X3). */
 int64_t sos_lstm_pack_bytes(int H, int backward);
 int sos_lstm_pack_whh(const float* whh, int H, void* fwd_hi, void* fwd_lo, void* bwd_hi, void* bwd_lo,
                       sos_stream_t stream);
@@ -228,7 +229,7 @@ int sos_feat_to_nhwc(const sos_view* feat, int B, int H, int W, int Wo, const in
 /* ---- BPTT of the recurrent part of nn.LSTM (autograd of M1/networks.py:148, M2/networks.py:88).
  * dh_out: bf16 grad of the LSTM output [B][T][dh_cs] (dh_cs % 4 == 0); gates/csave from the forward;
  * wtk_hi / wtk_lo: the backward arrays of sos_lstm_pack_whh; dgates f32 [B][T][2][4H] (gate
- * pre-activation grads; dW_ih, dW_hh, bias and input grads are GEMMs over it). */
+ * pre-activation grads, gate-interleaved like xproj; dW_ih, dW_hh, bias and input grads are GEMMs over it). */
 int sos_lstm_bidir_bwd(const void* dh_out, int dh_cs, int dh_dtype, int64_t dh_third, const float* gates,
                        const float* csave, const void* wtk_hi, const void* wtk_lo /* optional */, int64_t B, int64_t T,
                        int H, float* dgates, sos_stream_t stream);

@@ -74,8 +74,9 @@ def run_encoder(plan, a, feat, feat_row, feat_third, feat_c_off, x3, w_gather=No
 
 def lstm_plan(lstm, cin_store, x3):
     H = lstm.hidden_size
-    w_ih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse], dim=0).detach()
-    bias = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse]).detach()
+    perm, _ = E.lstm_gate_perm(H, lstm.weight_ih_l0.device)       # gate-interleaved projection rows (sos_hip.h)
+    w_ih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse], dim=0).detach()[perm]
+    bias = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse]).detach()[perm]
     w = E.pack_weight(w_ih[:, :, None, None], cin_store, x3)
     return dict(w=w, scale=E.pad_vec(torch.ones(8 * H, device=w.device), w.shape[1], 1.0),
                 shift=E.pad_vec(bias, w.shape[1]), wpk=E.lstm_pack(lstm, x3), H=H, cin_store=cin_store)

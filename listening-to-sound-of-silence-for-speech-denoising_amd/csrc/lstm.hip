@@ -95,6 +95,9 @@ extern "C" int sos_lstm_pack_whh(const float* whh, int H, void* fwd_hi, void* fw
 }
 
 // ----------------------------------------------------------------------------------- forward
+// xproj and dgates use the GATE-INTERLEAVED channel order [dir][unit j][i,f,g,o] (index dir*4H + 4j + q instead of
+// torch's dir*4H + q*H + j): the four gate values a lane needs / produces are one 16-byte access.  The caller
+// permutes the rows of W_ih and of the bias accordingly (and un-permutes the weight gradients).
 // X3 = false (bf16): the W fragments of the NEXT tile (wrapping to the first tile of the next step: W does not
 // depend on h) are in flight while the current tile is computed.  X3 = true (three-pass precision mode): hi and
 // lo fragments of the current tile only (register budget).  In both, a tile's xproj values for the NEXT step
@@ -131,8 +134,11 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
     };
     auto load_x = [&](const int ti, const int step) {
         const int t = dir == 0 ? step : T - 1 - step;
-        const float* xp = xproj + (((size_t)b * T + t) * 2 + dir) * G + (wave + LM_WAVES * ti) * 4 + g4;
-        if (live && step < T && !LDBG(2)) xc[ti] = f32x4{xp[0], xp[H], xp[2 * H], xp[3 * H]};
+        const float* xp = xproj + (((size_t)b * T + t) * 2 + dir) * G + ((wave + LM_WAVES * ti) * 4 + g4) * 4;
+        if (live && step < T && !LDBG(2)) {
+            const float4 x4 = *(const float4*)xp;          // gate-interleaved projection: one 16-byte load
+            xc[ti] = f32x4{x4.x, x4.y, x4.z, x4.w};
+        }
     };
 #pragma unroll
     for (int ti = 0; ti < LM_FT; ++ti) {
@@ -341,11 +347,9 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_bwd_kernel(const bf16_t* __re
                 dov[e] = dhe * tc * ogv[e] * (1.f - ogv[e]);
                 dcr[ti][e] = dc * fgv[e];
             }
-            float* dgp = dgates + (row * 2 + dir) * G + j0;
-            *(float4*)dgp = make_float4(di[0], di[1], di[2], di[3]);
-            *(float4*)(dgp + H) = make_float4(df[0], df[1], df[2], df[3]);
-            *(float4*)(dgp + 2 * H) = make_float4(dgg[0], dgg[1], dgg[2], dgg[3]);
-            *(float4*)(dgp + 3 * H) = make_float4(dov[0], dov[1], dov[2], dov[3]);
+            float* dgp = dgates + (row * 2 + dir) * G + j0 * 4;     // gate-interleaved: [unit][i,f,g,o], 64 contiguous bytes
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *(float4*)(dgp + 4 * u) = make_float4(di[u], df[u], dgg[u], dov[u]);
             const float* q4[4] = {di, df, dgg, dov};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

@@ -199,6 +199,17 @@ def conv_to_act(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, dst, c_
          cout_store=cout if cout_store is None else cout_store, third=dst.cs, **kw_)
 
 
+def lstm_gate_perm(H, device):
+    """Row permutation torch order (dir, gate q, unit j) -> the kernels' gate-interleaved order (dir, j, q):
+    new[n] = old[perm[n]]; inv undoes it (old[o] = new[inv[o]])."""
+    n = torch.arange(8 * H, device=device)
+    d, r = n // (4 * H), n % (4 * H)
+    perm = d * 4 * H + (r % 4) * H + r // 4
+    inv = torch.empty_like(perm)
+    inv[perm] = n
+    return perm, inv
+
+
 def lstm_pack(lstm_mod, x3):
     """W_hh of both directions -> the MFMA fragment arrays of the recurrent kernels (sos_lstm_pack_whh);
     the lo arrays exist only in bf16x3 mode."""

@@ -157,12 +157,13 @@ def feat_grad_to_nhwc(dfeat, row, third, c_off, C, B, H, W, Wo, x3, lo=None, hi=
 # ------------------------------------------------------------------------------------------ LSTM
 def lstm_train_plan(lstm, cin_store, x3):
     H = lstm.hidden_size
-    w_ih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse], dim=0).detach()          # (8H, I)
-    bias = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse]).detach()
+    perm, inv = E.lstm_gate_perm(H, lstm.weight_ih_l0.device)     # gate-interleaved projection rows (sos_hip.h)
+    w_ih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse], dim=0).detach()[perm]    # (8H, I)
+    bias = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse]).detach()[perm]
     w = E.pack_weight(w_ih[:, :, None, None], cin_store, x3)
     wd = E.pack_weight(w_ih.t().contiguous()[:, :, None, None], E.pad_to(8 * H, 16), x3)      # (I, 8H)
     dev = w.device
-    return dict(w=w, wd=wd, wpk=E.lstm_pack(lstm, x3), H=H, I=lstm.input_size, cin_store=cin_store,
+    return dict(w=w, wd=wd, wpk=E.lstm_pack(lstm, x3), H=H, I=lstm.input_size, cin_store=cin_store, inv=inv,
                 scale=E.pad_vec(torch.ones(8 * H, device=dev), w.shape[1], 1.0), shift=E.pad_vec(bias, w.shape[1]))
 
 
@@ -189,7 +190,8 @@ def lstm_backward(lp, tape, dh, grads, prefix, B, T, x3, dev):
     dga = E.Act(B, 1, T, E.pad_to(8 * H, 16), x3, dev, zero=(8 * H) % 16 != 0)
     pack_grad(dgates, None, L.ACT_NONE, B, T, 8 * H, T * 8 * H, 8 * H, 1, dga)
     # biases: both b_ih and b_hh receive sum over (b,t) of the gate grads
-    db = colsum(dga, 0, 8 * H)
+    inv = lp["inv"]                                # gate-interleaved rows -> torch's (gate, unit) order
+    db = colsum(dga, 0, 8 * H)[inv]
     grads[f"{prefix}.bias_ih_l0"] = db[:4 * H]
     grads[f"{prefix}.bias_hh_l0"] = db[:4 * H]
     grads[f"{prefix}.bias_ih_l0_reverse"] = db[4 * H:]
@@ -200,6 +202,7 @@ def lstm_backward(lp, tape, dh, grads, prefix, B, T, x3, dev):
     feat_act.t, feat_act.B, feat_act.H, feat_act.W, feat_act.cs, feat_act.x3, feat_act.nseg = ft, fB, 1, fW, fcs, x3, fnseg
     dwih = torch.empty((8 * H, I), dtype=torch.float32, device=dev)
     E.wgrad(dga, 0, 8 * H, feat_act, 0, I, 1, 1, dwih)
+    dwih = dwih[inv]
     grads[f"{prefix}.weight_ih_l0"] = dwih[:4 * H]
     grads[f"{prefix}.weight_ih_l0_reverse"] = dwih[4 * H:]
     # W_hh: dgate[t] (x) h[t-1] (forward) / h[t+1] (reverse): a 1-tap "conv" shifted by +-1 frame
@@ -209,7 +212,7 @@ def lstm_backward(lp, tape, dh, grads, prefix, B, T, x3, dev):
     for d, sfx, pad_l in ((0, "", 1), (1, "_reverse", -1)):
         dwhh = torch.empty((4 * H, 2 * H), dtype=torch.float32, device=dev)
         E.wgrad(dga, d * 4 * H, 4 * H, hact, 0, 2 * H, 1, 1, dwhh, pad=(0, pad_l))
-        grads[f"{prefix}.weight_hh_l0{sfx}"] = dwhh[:, d * H:(d + 1) * H]
+        grads[f"{prefix}.weight_hh_l0{sfx}"] = dwhh[inv[:4 * H], d * H:(d + 1) * H]
     # input gradient
     nseg = 3 if x3 else 1
     dfeat = torch.empty((B, T, nseg * I), dtype=torch.bfloat16, device=dev)
