@@ -151,7 +151,7 @@ int sos_lstm_bidir_fwd(const float* xproj, const void* wpk_hi, const void* wpk_l
                        float* save_gates /* optional f32, ceil16(B)*T*2*4H: post-activation i,f,g,o */,
                        float* save_c /* optional f32, ceil16(B)*T*2*H: cell state */, sos_stream_t stream);
 /* save_gates / save_c are consumed only by sos_lstm_bidir_bwd; their layout is the forward kernel's MFMA lane order
- * [16-clip group][t][dir][4-unit tile][lane = clip + 16*unit][i,f,g,o] (one coalesced store per tile and step). */
+ * [16-clip group][t][dir][4-unit tile][clip][unit][i,f,g,o] (one coalesced store per tile and step). */
 
 /* ---------------------------------------------------------------- training-mode kernels
  * A `sos_view` describes a channel slice of a bf16 NHWC activation: element (pix, c) lives at

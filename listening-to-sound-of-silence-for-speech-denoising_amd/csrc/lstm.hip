@@ -177,7 +177,7 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
             }
         }
         const size_t row = (size_t)b * T + t;
-        // saved activations: MFMA-native layout [clip group][t][dir][tile][lane][i,f,g,o] -- one coalesced 1 KB store per tile
+        // saved activations: kernel-native layout [clip group][t][dir][tile][clip][unit][i,f,g,o] -- one coalesced 1 KB store per tile
         const size_t nat = (((size_t)blockIdx.x * T + t) * 2 + dir) * NT;
 #pragma unroll
         for (int ti = 0; ti < LM_FT; ++ti) {
@@ -223,8 +223,8 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
                     if (out_x3) { o[third] = hi; o[2 * third] = lo; }
                 }
                 if (save_gates) {
-                    *(float4*)(save_gates + ((nat + tile) * 64 + lane) * 4) = make_float4(ig, fg, gt, og);
-                    save_c[(nat + tile) * 64 + lane] = c;
+                    *(float4*)(save_gates + ((nat + tile) * 64 + n * 4 + g4) * 4) = make_float4(ig, fg, gt, og);
+                    save_c[(nat + tile) * 64 + n * 4 + g4] = c;
                 }
             }
         }
@@ -323,18 +323,19 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_bwd_kernel(const bf16_t* __re
                 dh[0] += bf2f((bf16_t)(dl.x & 0xffffu)); dh[1] += bf2f((bf16_t)(dl.x >> 16));
                 dh[2] += bf2f((bf16_t)(dl.y & 0xffffu)); dh[3] += bf2f((bf16_t)(dl.y >> 16));
             }
-            // forward-native layout: units j0..j0+3 are the lanes n, n+16, n+32, n+48 of forward tile j0/4
-            const size_t nat = ((((size_t)blockIdx.x * T + t) * 2 + dir) * (H >> 2) + (j0 >> 2)) * 64 + n;
-            const size_t natp = ((((size_t)blockIdx.x * T + tprev) * 2 + dir) * (H >> 2) + (j0 >> 2)) * 64 + n;
-            const bool hasp = tprev >= 0 && tprev < T;
-            float igv[4], fgv[4], gtv[4], ogv[4], cv[4], cpv[4];
+            // forward-native layout [tile = 4 units][clip][unit][i,f,g,o]: this lane's 4 units x 4 gates are 64 contiguous bytes
+            const size_t nat = ((((size_t)blockIdx.x * T + t) * 2 + dir) * (H >> 2) + (j0 >> 2)) * 64 + n * 4;
+            const size_t natp = ((((size_t)blockIdx.x * T + tprev) * 2 + dir) * (H >> 2) + (j0 >> 2)) * 64 + n * 4;
+            float igv[4], fgv[4], gtv[4], ogv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float4 g4v = *(const float4*)(gates + (nat + 16 * u) * 4);
+                const float4 g4v = *(const float4*)(gates + (nat + u) * 4);
                 igv[u] = g4v.x; fgv[u] = g4v.y; gtv[u] = g4v.z; ogv[u] = g4v.w;
-                cv[u] = csave[nat + 16 * u];
-                cpv[u] = hasp ? csave[natp + 16 * u] : 0.f;
             }
+            const float4 c4 = *(const float4*)(csave + nat);
+            float4 cp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tprev >= 0 && tprev < T) cp4 = *(const float4*)(csave + natp);
+            const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, cpv[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
             float di[4], df[4], dgg[4], dov[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
