@@ -93,10 +93,10 @@ __device__ __forceinline__ void build_pixel_table(const ConvParams& p, unsigned*
 // a wave fills pieces [64 i, 64 i + 64).  A lane's source is table[pixel] + chunk offset; zero padding,
 // the pad piece and lanes past the image get an out-of-range offset (the hardware writes zeros).  No data
 // registers, no ds_write, and all of a wave's pieces are in flight at once.
-template <int CPR>
+template <int CPR, bool PAD = true>
 __device__ __forceinline__ void stage_patch_dma(const ConvParams& p, char* patch, unsigned tab_addr, int lane, int wave,
                                                 __amdgpu_buffer_rsrc_t rsrc, unsigned cbytes) {
-    constexpr int RP = CPR + 1;
+    constexpr int RP = CPR + (PAD ? 1 : 0);
     const int total = p.npix * RP;
     const int ninstr = (total + 63) >> 6;
     for (int i = wave; i < ninstr; i += 4) {
@@ -109,6 +109,97 @@ __device__ __forceinline__ void stage_patch_dma(const ConvParams& p, char* patch
         if (L < total) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(patch + i * 1024), 16, voff, 0, 0, 0);
     }
 }
+
+#if __HIP_DEVICE_COMPILE__
+// ---- cooperative store of the staged bf16 output tile ([256 pixels][OROW bytes] in LDS at smem, the lo
+// plane of the hi|hi|lo mode behind it): consecutive lanes write consecutive 16-byte pieces of a pixel's channel
+// run (and consecutive pixels of a tile row are adjacent in memory when dil_w == 1).  PPX = 16-byte pieces per pixel.
+template <int PPX, int OROW>
+__device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* smem, const int tid, const int b, const int n0,
+                                                  const int ho_base, const int wo_base, const int rw0, const bool x3) {
+    const int TH = 1 << p.logTH, TW = 1 << p.logTW;
+    char* ost_hi = smem;
+    char* ost_lo = smem + 256 * OROW;
+    // element offset of every tile pixel inside its output image (-1: outside), one entry per thread
+    int* otab = (int*)(smem + 256 * OROW * (x3 ? 2 : 1));
+    {
+        const int m = tid;
+        const int j = m & (TW - 1);
+        const int i = (m >> p.logTW) & (TH - 1);
+        const int cls = m >> (p.logTW + p.logTH);
+        const int ho = ho_base + i * p.dh;
+        const int wo = wo_base + cls + j * p.dw;
+        otab[m] = (ho < p.Ho && wo < p.Wo && (cls == 0 || rw0 + cls < p.dw)) ? ho * (int)p.sh + wo * (int)p.sw : -1;
+    }
+    __syncthreads();
+    // ---- cooperative store: consecutive lanes write consecutive 16-byte pieces of a pixel's
+    // channel run (and consecutive pixels of a tile row are adjacent in memory when dil_w == 1).
+    bf16_t* op = (bf16_t*)p.out + (long long)b * p.sb + p.c_off + n0;
+    const int ish = (int)p.sh, isw = (int)p.sw, ith = (int)p.third;
+    if (!x3 && !p.accum && ((p.cout_store - n0) & 7) == 0) {          // common case: whole 8-channel pieces, plain store
+        const int npiece = min(PPX, (p.cout_store - n0) >> 3);
+#pragma unroll 4
+        for (int idx = tid; idx < 256 * PPX; idx += 256) {
+            const int m = idx / PPX, q = idx - m * PPX;
+            const int off = otab[m];
+            if (q < npiece && off >= 0) *(uint4*)(op + off + q * 8) = *(const uint4*)(ost_hi + m * OROW + q * 16);
+        }
+        return;
+    }
+#pragma unroll 4
+    for (int idx = tid; idx < 256 * PPX; idx += 256) {
+        const int m = idx / PPX, q = idx - m * PPX;
+        const int co = n0 + q * 8;
+        if (co >= p.cout_store) continue;
+        const int j = m & (TW - 1);
+        const int i = (m >> p.logTW) & (TH - 1);
+        const int cls = m >> (p.logTW + p.logTH);
+        const int ho = ho_base + i * p.dh;
+        const int wo = wo_base + cls + j * p.dw;
+        if (!(ho < p.Ho && wo < p.Wo && (cls == 0 || rw0 + cls < p.dw))) continue;
+        const int o = ho * ish + wo * isw + q * 8;
+        uint4 hv = *(const uint4*)(ost_hi + m * OROW + q * 16);
+        if (co + 8 <= p.cout_store) {
+            uint4 lv = make_uint4(0u, 0u, 0u, 0u);
+            if (x3) lv = *(const uint4*)(ost_lo + m * OROW + q * 16);
+            if (p.accum) {
+                // gradient fan-in: new = old + this, re-split into hi (+ lo)
+                const uint4 oh = *(const uint4*)(op + o);
+                uint4 ol = make_uint4(0u, 0u, 0u, 0u);
+                if (x3) ol = *(const uint4*)(op + o + 2 * ith);
+                const unsigned nh[4] = {hv.x, hv.y, hv.z, hv.w}, nl[4] = {lv.x, lv.y, lv.z, lv.w};
+                const unsigned ph[4] = {oh.x, oh.y, oh.z, oh.w}, pl[4] = {ol.x, ol.y, ol.z, ol.w};
+                unsigned rh[4], rl[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = __uint_as_float(nh[e] << 16) + __uint_as_float(nl[e] << 16) +
+                                     __uint_as_float(ph[e] << 16) + __uint_as_float(pl[e] << 16);
+                    const float a1 = __uint_as_float(nh[e] & 0xffff0000u) + __uint_as_float(nl[e] & 0xffff0000u) +
+                                     __uint_as_float(ph[e] & 0xffff0000u) + __uint_as_float(pl[e] & 0xffff0000u);
+                    const bf16_t h0 = f2bf(a0), h1 = f2bf(a1);
+                    rh[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    rl[e] = (unsigned)f2bf(a0 - bf2f(h0)) | ((unsigned)f2bf(a1 - bf2f(h1)) << 16);
+                }
+                hv = make_uint4(rh[0], rh[1], rh[2], rh[3]);
+                lv = make_uint4(rl[0], rl[1], rl[2], rl[3]);
+            }
+            *(uint4*)(op + o) = hv;
+            if (x3) {
+                *(uint4*)(op + o + ith) = hv;
+                *(uint4*)(op + o + 2 * ith) = lv;
+            }
+        } else {
+            const bf16_t* hs = (const bf16_t*)(ost_hi + m * OROW + q * 16);
+            const bf16_t* ls = (const bf16_t*)(ost_lo + m * OROW + q * 16);
+            for (int e = 0; co + e < p.cout_store; ++e) {
+                op[o + e] = hs[e];
+                if (x3) { op[o + e + ith] = hs[e]; op[o + e + 2 * ith] = ls[e]; }
+            }
+        }
+    }
+}
+
+#endif
 
 template <int NT, int KS>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
@@ -441,84 +532,190 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     }
     }
     if (!staged) return;
-    // element offset of every tile pixel inside its output image (-1: outside), one entry per thread
-    int* otab = (int*)(smem + 256 * OROW * (x3 ? 2 : 1));
+    store_staged_tile<NT * 4, OROW>(p, smem, tid, b, n0, ho_base, wo_base, rw0, x3);
+#endif
+}
+
+// ---- 16-row variant for small output-channel counts (cout <= 16 or 33..48; the 48-channel context layers):
+// v_mfma_f32_16x16x32_bf16, NT16 tiles of 16 output channels instead of tiles of 32 (48 channels pay for 48, not 64).
+// K = 32 per MFMA while a tap contributes cin = 16 KS channels, so the contraction runs over the FLAT (tap, channel)
+// sequence in windows of two taps (2 * cin is a multiple of 32 for every cin % 16 == 0): lane group g of K-block kb
+// reads 8-channel group q = 4 kb + g of the window, i.e. tap q / (cin/8) and channels 8 (q % (cin/8)) -- both the
+// weight fragment (from the window's [2 taps][rows][cin] slab) and the pixel fragment (patch shifted by THAT tap).
+// These per-lane offsets are window invariant.  One barrier per TWO taps; an odd last tap gets a zero slab.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT16, int KS>
+__global__ __launch_bounds__(256) void conv16_kernel(ConvParams p) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int KC = 16 * KS, G8 = 2 * KS;     // channels / 8-channel groups per tap
+    // unpadded row pitches: lanes 16..31 of a fragment read address the SAME 16 rows as lanes 0..15, 16 bytes further
+    // (next 8-channel group); with pitches of 32 / 96 bytes every 16-lane ds_read_b128 group covers all 64 banks once
+    constexpr int PSTRIDE = KC * 2, BSTRIDE = KC * 2, CPR = 2 * KS;
+    constexpr int BW = KS;                        // K-blocks of 32 channels per two-tap window
+    constexpr int ROWS = NT16 * 16;
+    constexpr int TAPBYTES = ROWS * BSTRIDE, WBYTES = 2 * TAPBYTES;
+    constexpr int TPIECES = ROWS * CPR, WPIECES = 2 * TPIECES;
+    constexpr int NBREG = (WPIECES + 255) / 256;
+    constexpr int OROW = NT16 * 32 + 16;          // bytes per staged output pixel row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch = smem;
+    const int boff0 = p.npix * PSTRIDE;
+    unsigned* pixtab = (unsigned*)(smem + boff0 + 2 * WBYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    int bid = blockIdx.x;
     {
-        const int m = tid;
-        const int j = m & (TW - 1);
-        const int i = (m >> p.logTW) & (TH - 1);
-        const int cls = m >> (p.logTW + p.logTH);
-        const int ho = ho_base + i * p.dh;
-        const int wo = wo_base + cls + j * p.dw;
-        otab[m] = (ho < p.Ho && wo < p.Wo && (cls == 0 || rw0 + cls < p.dw)) ? ho * (int)p.sh + wo * (int)p.sw : -1;
+        const int nx = 8, q = p.nblk / nx, r = p.nblk % nx;
+        const int xcd = bid % nx, loc = bid / nx;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    __syncthreads();
-    // ---- cooperative store: consecutive lanes write consecutive 16-byte pieces of a pixel's
-    // channel run (and consecutive pixels of a tile row are adjacent in memory when dil_w == 1).
-    constexpr int PPX = NT * 4;                  // 16-byte pieces per pixel
-    bf16_t* op = (bf16_t*)p.out + (long long)b * p.sb + p.c_off + n0;
-    const int ish = (int)p.sh, isw = (int)p.sw, ith = (int)p.third;
-    if (!x3 && !p.accum && ((p.cout_store - n0) & 7) == 0) {          // common case: whole 8-channel pieces, plain store
-        const int npiece = min(PPX, (p.cout_store - n0) >> 3);
-#pragma unroll 4
-        for (int idx = tid; idx < 256 * PPX; idx += 256) {
-            const int m = idx / PPX, q = idx - m * PPX;
-            const int off = otab[m];
-            if (q < npiece && off >= 0) *(uint4*)(op + off + q * 8) = *(const uint4*)(ost_hi + m * OROW + q * 16);
-        }
-        return;
-    }
-#pragma unroll 4
-    for (int idx = tid; idx < 256 * PPX; idx += 256) {
-        const int m = idx / PPX, q = idx - m * PPX;
-        const int co = n0 + q * 8;
-        if (co >= p.cout_store) continue;
-        const int j = m & (TW - 1);
-        const int i = (m >> p.logTW) & (TH - 1);
-        const int cls = m >> (p.logTW + p.logTH);
-        const int ho = ho_base + i * p.dh;
-        const int wo = wo_base + cls + j * p.dw;
-        if (!(ho < p.Ho && wo < p.Wo && (cls == 0 || rw0 + cls < p.dw))) continue;
-        const int o = ho * ish + wo * isw + q * 8;
-        uint4 hv = *(const uint4*)(ost_hi + m * OROW + q * 16);
-        if (co + 8 <= p.cout_store) {
-            uint4 lv = make_uint4(0u, 0u, 0u, 0u);
-            if (x3) lv = *(const uint4*)(ost_lo + m * OROW + q * 16);
-            if (p.accum) {
-                // gradient fan-in: new = old + this, re-split into hi (+ lo)
-                const uint4 oh = *(const uint4*)(op + o);
-                uint4 ol = make_uint4(0u, 0u, 0u, 0u);
-                if (x3) ol = *(const uint4*)(op + o + 2 * ith);
-                const unsigned nh[4] = {hv.x, hv.y, hv.z, hv.w}, nl[4] = {lv.x, lv.y, lv.z, lv.w};
-                const unsigned ph[4] = {oh.x, oh.y, oh.z, oh.w}, pl[4] = {ol.x, ol.y, ol.z, ol.w};
-                unsigned rh[4], rl[4];
+    int t = bid;
+    const int tj = t % p.tiles_w; t /= p.tiles_w;
+    const int gw = t % p.ngw; t /= p.ngw;
+    const int ti = t % p.tiles_h; t /= p.tiles_h;
+    const int rh = t % p.dh; t /= p.dh;
+    const int b = t;
+    const int TH = 1 << p.logTH, TW = 1 << p.logTW;
+    const int rw0 = gw * p.NC;
+    const int ho_base = rh + ti * TH * p.dh, wo_base = rw0 + tj * TW * p.dw;
+    const int hin0 = ho_base * p.stride - p.pad_t, win0 = wo_base * p.stride - p.pad_l;
+
+    // per-lane pixel operand base (tap (0,0)) of the wave's four 16-pixel column tiles
+    int pbase[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a0 = __uint_as_float(nh[e] << 16) + __uint_as_float(nl[e] << 16) +
-                                     __uint_as_float(ph[e] << 16) + __uint_as_float(pl[e] << 16);
-                    const float a1 = __uint_as_float(nh[e] & 0xffff0000u) + __uint_as_float(nl[e] & 0xffff0000u) +
-                                     __uint_as_float(ph[e] & 0xffff0000u) + __uint_as_float(pl[e] & 0xffff0000u);
-                    const bf16_t h0 = f2bf(a0), h1 = f2bf(a1);
-                    rh[e] = (unsigned)h0 | ((unsigned)h1 << 16);
-                    rl[e] = (unsigned)f2bf(a0 - bf2f(h0)) | ((unsigned)f2bf(a1 - bf2f(h1)) << 16);
-                }
-                hv = make_uint4(rh[0], rh[1], rh[2], rh[3]);
-                lv = make_uint4(rl[0], rl[1], rl[2], rl[3]);
+    for (int pt = 0; pt < 4; ++pt) {
+        const int m = wave * 64 + pt * 16 + l15;
+        const int j = m & (TW - 1), i = (m >> p.logTW) & (TH - 1), cls = m >> (p.logTW + p.logTH);
+        pbase[pt] = ((cls * p.PH + i * p.stride) * p.PW + j * p.stride) * PSTRIDE;
+    }
+    // per-lane, window-invariant fragment offsets of the BW K-blocks
+    int aoff[BW], coff[BW];
+    bool tap1[BW];
+#pragma unroll
+    for (int kb = 0; kb < BW; ++kb) {
+        const int q = 4 * kb + g, tl = q / G8, c8 = q - tl * G8;
+        aoff[kb] = tl * TAPBYTES + l15 * BSTRIDE + c8 * 16;
+        coff[kb] = c8 * 16;
+        tap1[kb] = tl != 0;
+    }
+    // slab staging: the piece a thread moves is window invariant
+    int bsrc[NBREG], bdst[NBREG];
+    bool btap1[NBREG];
+#pragma unroll
+    for (int u = 0; u < NBREG; ++u) {
+        const int idx = min(tid + u * 256, WPIECES - 1);
+        const int tl = idx / TPIECES, rem = idx - tl * TPIECES;
+        const int row = rem / CPR, c = rem - row * CPR;
+        bsrc[u] = row * p.ktot + c * 8;
+        bdst[u] = tl * TAPBYTES + row * BSTRIDE + c * 16;
+        btap1[u] = tl != 0;
+    }
+    const long long tap_stride = (long long)p.cout_pad * p.ktot;
+
+    f32x4 acc[4][NT16];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+        for (int nt = 0; nt < NT16; ++nt) acc[pt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntaps = p.kh * p.kw, nwin = (ntaps + 1) >> 1;
+    const long long in_b = (long long)b * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + in_b * p.in_cs), 0, (unsigned)(p.H * p.W * p.in_cs) * 2u, 0x00020000);
+    build_pixel_table(p, pixtab, tid, hin0, win0, rw0);
+    __syncthreads();
+    stage_patch_dma<CPR, false>(p, patch, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc,
+                                (unsigned)(p.cin_off * 2));
+    // weights [tap][cout_pad][ktot] (one channel segment): a thread's piece of window w is wp[u] + w * 2 taps
+    const bf16_t* wp[NBREG];
+#pragma unroll
+    for (int u = 0; u < NBREG; ++u) wp[u] = p.wgt + (btap1[u] ? tap_stride : 0) + bsrc[u];
+    const bool odd = ntaps & 1;
+    auto load_window = [&](const int w, uint4 (&r)[NBREG]) {
+        const bool last_half = odd && w == nwin - 1;            // the window's second tap does not exist: zero slab
+        const long long woff = (long long)w * 2 * tap_stride;
+#pragma unroll
+        for (int u = 0; u < NBREG; ++u) {
+            const bool dead = last_half && btap1[u];
+            const uint4 v = *(const uint4*)(wp[u] + (dead ? woff - tap_stride : woff));
+            r[u] = dead ? make_uint4(0u, 0u, 0u, 0u) : v;
+        }
+    };
+    auto store_window = [&](const int buf, const uint4 (&r)[NBREG]) {
+#pragma unroll
+        for (int u = 0; u < NBREG; ++u)
+            if ((u + 1) * 256 <= WPIECES || tid + u * 256 < WPIECES) *(uint4*)(smem + boff0 + buf * WBYTES + bdst[u]) = r[u];
+    };
+    {
+        uint4 r0[NBREG];
+        load_window(0, r0);
+        store_window(0, r0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's patch pieces have landed
+    __syncthreads();
+
+    for (int w = 0; w < nwin; ++w) {
+        const int cur = w & 1;
+        uint4 rn[NBREG];
+        load_window(w + 1 < nwin ? w + 1 : w, rn);       // next window's slab (lands while the MFMAs run)
+        __builtin_amdgcn_sched_barrier(0);
+        const int t0 = 2 * w, t1 = min(2 * w + 1, ntaps - 1);
+        const int toff0 = ((t0 / p.kw) * p.PW + (t0 % p.kw)) * PSTRIDE;
+        const int toff1 = ((t1 / p.kw) * p.PW + (t1 % p.kw)) * PSTRIDE;
+        const char* slab = smem + boff0 + cur * WBYTES;
+        bf16x8 fa[2][NT16], fb[2][4];
+        auto read_block = [&](const int kb, const int buf) {
+#pragma unroll
+            for (int nt = 0; nt < NT16; ++nt) fa[buf][nt] = lds_frag(slab + aoff[kb] + nt * 16 * BSTRIDE);
+            const int po = (tap1[kb] ? toff1 : toff0) + coff[kb];
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) fb[buf][pt] = lds_frag(patch + pbase[pt] + po);
+        };
+        read_block(0, 0);
+#pragma unroll
+        for (int kb = 0; kb < BW; ++kb) {
+            const int cb = kb & 1;
+            if (kb + 1 < BW) read_block(kb + 1, cb ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NT16; ++nt)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+                    acc[pt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cb][nt], fb[cb][pt], acc[pt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        store_window(cur ^ 1, rn);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[m = cout][n = pixel]: lane = pixel + 16 * (cout / 4), register = cout % 4
+    const float slope = (p.act == SOS_ACT_PRELU && p.slope) ? p.slope[0] : 0.f;
+    const bool partial = ROWS > p.cout, sig = p.act == SOS_ACT_SIGMOID;
+    const float sn = p.act == SOS_ACT_RELU ? 0.f : (p.act == SOS_ACT_PRELU ? slope : 1.f);   // max(y,0) + sn*min(y,0)
+#pragma unroll
+    for (int nt = 0; nt < NT16; ++nt) {
+        const int co = nt * 16 + 4 * g;                   // 4 consecutive channels co..co+3
+        if (co >= p.cout_store) continue;
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) { sc4 = *(const float4*)(p.scale + co); sh4 = *(const float4*)(p.shift + co); }
+        const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float y = fmaf(acc[pt][nt][e], scv[e], shv[e]);
+                if (sig) y = 1.0f / (1.0f + expf(-y));
+                else y = fmaf(sn, fminf(y, 0.f), fmaxf(y, 0.f));
+                v[e] = (!partial || co + e < p.cout) ? y : 0.f;
             }
-            *(uint4*)(op + o) = hv;
-            if (x3) {
-                *(uint4*)(op + o + ith) = hv;
-                *(uint4*)(op + o + 2 * ith) = lv;
-            }
-        } else {
-            const bf16_t* hs = (const bf16_t*)(ost_hi + m * OROW + q * 16);
-            const bf16_t* ls = (const bf16_t*)(ost_lo + m * OROW + q * 16);
-            for (int e = 0; co + e < p.cout_store; ++e) {
-                op[o + e] = hs[e];
-                if (x3) { op[o + e + ith] = hs[e]; op[o + e + 2 * ith] = ls[e]; }
-            }
+            const int m = wave * 64 + pt * 16 + l15;
+            *(uint2*)(smem + m * OROW + co * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
         }
     }
+    store_staged_tile<NT16 * 2, OROW>(p, smem, tid, b, 0, ho_base, wo_base, rw0, false);
 #endif
 }
 
@@ -563,7 +760,21 @@ static size_t lds_bytes(int npix, int nt, int ks) {
     return (size_t)npix * row + 2 * (size_t)nt * 32 * row + (size_t)npix * 4;
 }
 
-// One tiling choice: NC residue classes x (1<<lth) x (1<<ltw) pixels, 16*ks channels per chunk.
+// the 16-row kernel (conv16_kernel) handles: one bf16 channel segment of 16 or 48 channels, bf16 NHWC output,
+// cout <= 16 or 33..48 (i.e. shapes where tiles of 32 output channels waste MFMA rows)
+static int nt16_for(const sos_conv_desc* d) {
+    if (d->in_nseg != 1 || d->out_dtype != SOS_DT_BF16 || d->out_sc != 1 || (d->cin != 16 && d->cin != 48)) return 0;
+    if (d->cout <= 16) return 1;
+    if (d->cout > 32 && d->cout <= 48) return 3;
+    return 0;
+}
+static size_t lds_bytes16(int npix, int nt16, int ks) {
+    const size_t row = (size_t)ks * 32;            // unpadded pitches
+    return (size_t)npix * row + 2 * (size_t)2 * nt16 * 16 * row + (size_t)npix * 4;
+}
+
+// One tiling choice: NC residue classes x (1<<lth) x (1<<ltw) pixels, 16*ks channels per chunk (ks == 0: the
+// 16-row kernel, whole cin in one chunk).
 struct ConvCfg {
     int NC, lth, ltw, ks;
     double cost;
@@ -596,6 +807,14 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
             const int npix = NC * PH * PW;
             const long long th = (Hc + TH - 1) / TH, tw = (Wc + TW - 1) / TW, ngw = (d->dil_w + NC - 1) / NC;
             const double blocks = (double)th * tw * ngw * d->dil_h;
+            if (const int nt16 = nt16_for(d)) {               // 16-row kernel on the same pixel tiling
+                const size_t lds = lds_bytes16(npix, nt16, k16);
+                if (lds <= LDS_LIMIT) {
+                    double per_block = 0.75 * (256.0 * taps * k16 + 3.0 * npix * k16 + 40.0 * (6 + taps / 2));
+                    if (lds > LDS_LIMIT / 2) per_block *= 1.3;
+                    out.push_back({NC, lth, ltw, 0, blocks * per_block});
+                }
+            }
             for (int ks : kscand) {
                 if (k16 % ks) continue;
                 const size_t lds = lds_bytes(npix, nt, ks);
@@ -612,14 +831,15 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
 }
 
 struct ShapeKey {
-    int v[18];
+    int v[19];
     bool operator<(const ShapeKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
 };
 
 static ShapeKey shape_key(const sos_conv_desc* d) {
     ShapeKey k;
-    const int vals[18] = {d->B, d->H, d->W, d->Wl, d->cin, d->in_nseg, d->cout_pad, d->kh, d->kw, d->stride, d->dil_h,
-                          d->dil_w, d->Ho, d->Wo, d->out_dtype, d->out_sc == 1 ? 1 : 0, d->pad_mode, d->w_gather ? 1 : 0};
+    const int vals[19] = {d->B, d->H, d->W, d->Wl, d->cin, d->in_nseg, d->cout_pad, d->kh, d->kw, d->stride, d->dil_h,
+                          d->dil_w, d->Ho, d->Wo, d->out_dtype, d->out_sc == 1 ? 1 : 0, d->pad_mode, d->w_gather ? 1 : 0,
+                          d->cout};
     memcpy(k.v, vals, sizeof(vals));
     return k;
 }
@@ -670,7 +890,7 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     const int TH = 1 << c.lth, TW = 1 << c.ltw;
     p.PH = (TH - 1) * d->stride + d->kh; p.PW = (TW - 1) * d->stride + d->kw;
     p.npix = p.NC * p.PH * p.PW;
-    p.cps = d->cin / (16 * c.ks);
+    p.cps = c.ks ? d->cin / (16 * c.ks) : 1;
     p.nchunks = p.cps * d->in_nseg;
     p.ktot = d->cin * d->in_nseg;
     p.seg_stride = d->in_seg_stride;
@@ -679,6 +899,29 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     if (nblk > 0x7fffffffLL) { sos_set_error("sos_conv2d_fwd: grid too large"); return SOS_EINVAL; }
     p.nblk = (int)nblk;
     { const char* e = getenv("SOS_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
+    if (c.ks == 0) {                                     // 16-row kernel
+        const int nt16 = nt16_for(d), ks16 = d->cin / 16;
+        if (!nt16) { sos_set_error("sos_conv2d_fwd: internal: 16-row tiling for an ineligible shape"); return SOS_EINVAL; }
+        p.cps = 1; p.nchunks = 1;
+        size_t lds16 = lds_bytes16(p.npix, nt16, ks16);
+        const size_t stage16 = (size_t)256 * (nt16 * 32 + 16) + 1024;
+        if (stage16 > lds16) lds16 = stage16;
+        conv_kernel_t k = nullptr;
+        if (nt16 == 1 && ks16 == 1) k = conv16_kernel<1, 1>;
+        if (nt16 == 1 && ks16 == 3) k = conv16_kernel<1, 3>;
+        if (nt16 == 3 && ks16 == 1) k = conv16_kernel<3, 1>;
+        if (nt16 == 3 && ks16 == 3) k = conv16_kernel<3, 3>;
+        static bool attr16 = false;
+        if (!attr16) {
+            (void)hipFuncSetAttribute((const void*)conv16_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+            (void)hipFuncSetAttribute((const void*)conv16_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+            (void)hipFuncSetAttribute((const void*)conv16_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+            (void)hipFuncSetAttribute((const void*)conv16_kernel<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+            attr16 = true;
+        }
+        hipLaunchKernelGGL(k, dim3((unsigned)nblk, 1), dim3(256), lds16, s, p);
+        return sos_check_launch("sos_conv2d_fwd(16)");
+    }
     dim3 grid((unsigned)nblk, (unsigned)nby);
     size_t lds = lds_bytes(p.npix, nt, c.ks);
     if (d->out_dtype != SOS_DT_F32 && d->out_sc == 1) {
@@ -756,13 +999,13 @@ extern "C" int sos_conv2d_tune(const sos_conv_desc* d, int max_candidates, int i
     return SOS_OK;
 }
 
-// Persist / restore the tuned tilings (text file: 18 shape ints + 4 config ints per line) so that
+// Persist / restore the tuned tilings (text file: 19 shape ints + 4 config ints per line; ks == 0: 16-row kernel) so that
 // profiling and benchmark runs do not have to repeat the tuning launches.
 extern "C" int sos_conv2d_tune_save(const char* path) {
     FILE* f = fopen(path, "w");
     if (!f) { sos_set_error("sos_conv2d_tune_save: cannot open %s", path); return SOS_EINVAL; }
     for (const auto& kv : tuned_cache()) {
-        for (int i = 0; i < 18; ++i) fprintf(f, "%d ", kv.first.v[i]);
+        for (int i = 0; i < 19; ++i) fprintf(f, "%d ", kv.first.v[i]);
         fprintf(f, "%d %d %d %d\n", kv.second.NC, kv.second.lth, kv.second.ltw, kv.second.ks);
     }
     fclose(f);
@@ -777,10 +1020,10 @@ extern "C" int sos_conv2d_tune_load(const char* path) {
         ShapeKey k;
         ConvCfg c;
         bool ok = true;
-        for (int i = 0; i < 18 && ok; ++i) ok = fscanf(f, "%d", &k.v[i]) == 1;
+        for (int i = 0; i < 19 && ok; ++i) ok = fscanf(f, "%d", &k.v[i]) == 1;
         if (!ok || fscanf(f, "%d %d %d %d", &c.NC, &c.lth, &c.ltw, &c.ks) != 4) break;
         c.cost = 0;
-        if (c.NC < 1 || c.lth < 0 || c.ltw < 0 || c.lth + c.ltw > 8 || c.ks < 1 || c.ks > 8) continue;
+        if (c.NC < 1 || c.lth < 0 || c.ltw < 0 || c.lth + c.ltw > 8 || c.ks < 0 || c.ks > 8) continue;
         tuned_cache()[k] = c;
         ++n;
     }

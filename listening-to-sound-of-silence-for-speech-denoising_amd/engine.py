@@ -167,7 +167,7 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
     d.accumulate = 1 if accumulate else 0
     _load_tune_cache()
     if AUTOTUNE:
-        key = (B, H, W, d.Wl, cin, d.in_nseg, d.cout_pad, kh, kw, stride, dil, Ho, Wo, out_dtype, sc == 1, pad_mode,
+        key = (B, H, W, d.Wl, cin, d.in_nseg, d.cout_pad, cout, kh, kw, stride, dil, Ho, Wo, out_dtype, sc == 1, pad_mode,
                w_gather is not None)
         if key not in _tuned and not torch.cuda.is_current_stream_capturing():
             if accumulate:
