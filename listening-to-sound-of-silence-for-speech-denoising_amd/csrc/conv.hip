@@ -545,8 +545,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 // These per-lane offsets are window invariant.  One barrier per TWO taps; an odd last tap gets a zero slab.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NT16, int KS>
-__global__ __launch_bounds__(256) void conv16_kernel(ConvParams p) {
+template <int NT16, int KS, bool SB>
+__global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {     // 2 (3: single slab buffer) workgroups per CU
 #if __HIP_DEVICE_COMPILE__
     constexpr int KC = 16 * KS, G8 = 2 * KS;     // channels / 8-channel groups per tap
     // unpadded row pitches: lanes 16..31 of a fragment read address the SAME 16 rows as lanes 0..15, 16 bytes further
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
     const int boff0 = p.npix * PSTRIDE;
-    unsigned* pixtab = (unsigned*)(smem + boff0 + 2 * WBYTES);
+    unsigned* pixtab = (unsigned*)(smem + boff0 + (SB ? 1 : 2) * WBYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
 
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(ConvParams p) {
     __syncthreads();
 
     for (int w = 0; w < nwin; ++w) {
-        const int cur = w & 1;
+        const int cur = SB ? 0 : (w & 1);
         uint4 rn[NBREG];
         load_window(w + 1 < nwin ? w + 1 : w, rn);       // next window's slab (lands while the MFMAs run)
         __builtin_amdgcn_sched_barrier(0);
@@ -686,7 +686,8 @@ __global__ __launch_bounds__(256) void conv16_kernel(ConvParams p) {
                     acc[pt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cb][nt], fb[cb][pt], acc[pt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        store_window(cur ^ 1, rn);
+        if (SB) __syncthreads();                          // every wave is done with the (single) slab buffer
+        store_window(SB ? 0 : cur ^ 1, rn);
         __syncthreads();
     }
 
@@ -694,6 +695,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(ConvParams p) {
     const float slope = (p.act == SOS_ACT_PRELU && p.slope) ? p.slope[0] : 0.f;
     const bool partial = ROWS > p.cout, sig = p.act == SOS_ACT_SIGMOID;
     const float sn = p.act == SOS_ACT_RELU ? 0.f : (p.act == SOS_ACT_PRELU ? slope : 1.f);   // max(y,0) + sn*min(y,0)
+    const bool raw = !p.scale && p.act == SOS_ACT_NONE;          // training forward convs, data gradients
 #pragma unroll
     for (int nt = 0; nt < NT16; ++nt) {
         const int co = nt * 16 + 4 * g;                   // 4 consecutive channels co..co+3
@@ -704,12 +706,20 @@ __global__ __launch_bounds__(256) void conv16_kernel(ConvParams p) {
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
             float v[4];
+            if (raw) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float y = fmaf(acc[pt][nt][e], scv[e], shv[e]);
-                if (sig) y = 1.0f / (1.0f + expf(-y));
-                else y = fmaf(sn, fminf(y, 0.f), fmaxf(y, 0.f));
-                v[e] = (!partial || co + e < p.cout) ? y : 0.f;
+                for (int e = 0; e < 4; ++e) v[e] = acc[pt][nt][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = fmaf(acc[pt][nt][e], scv[e], shv[e]);
+                    if (sig) v[e] = 1.0f / (1.0f + expf(-y));
+                    else v[e] = fmaf(sn, fminf(y, 0.f), fmaxf(y, 0.f));
+                }
+            }
+            if (partial) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (co + e < p.cout) ? v[e] : 0.f;
             }
             const int m = wave * 64 + pt * 16 + l15;
             *(uint2*)(smem + m * OROW + co * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
@@ -768,9 +778,9 @@ static int nt16_for(const sos_conv_desc* d) {
     if (d->cout > 32 && d->cout <= 48) return 3;
     return 0;
 }
-static size_t lds_bytes16(int npix, int nt16, int ks) {
+static size_t lds_bytes16(int npix, int nt16, int ks, bool single) {
     const size_t row = (size_t)ks * 32;            // unpadded pitches
-    return (size_t)npix * row + 2 * (size_t)2 * nt16 * 16 * row + (size_t)npix * 4;
+    return (size_t)npix * row + (single ? 1 : 2) * (size_t)2 * nt16 * 16 * row + (size_t)npix * 4;
 }
 
 // One tiling choice: NC residue classes x (1<<lth) x (1<<ltw) pixels, 16*ks channels per chunk (ks == 0: the
@@ -807,12 +817,14 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
             const int npix = NC * PH * PW;
             const long long th = (Hc + TH - 1) / TH, tw = (Wc + TW - 1) / TW, ngw = (d->dil_w + NC - 1) / NC;
             const double blocks = (double)th * tw * ngw * d->dil_h;
-            if (const int nt16 = nt16_for(d)) {               // 16-row kernel on the same pixel tiling
-                const size_t lds = lds_bytes16(npix, nt16, k16);
-                if (lds <= LDS_LIMIT) {
+            if (const int nt16 = nt16_for(d)) {               // 16-row kernel on the same pixel tiling (ks 0: double, -1: single slab)
+                for (int single = 0; single < 2; ++single) {
+                    const size_t lds = lds_bytes16(npix, nt16, k16, single);
+                    if (lds > LDS_LIMIT) continue;
                     double per_block = 0.75 * (256.0 * taps * k16 + 3.0 * npix * k16 + 40.0 * (6 + taps / 2));
                     if (lds > LDS_LIMIT / 2) per_block *= 1.3;
-                    out.push_back({NC, lth, ltw, 0, blocks * per_block});
+                    else if (lds <= LDS_LIMIT / 3) per_block *= 0.95;
+                    out.push_back({NC, lth, ltw, single ? -1 : 0, blocks * per_block});
                 }
             }
             for (int ks : kscand) {
@@ -890,7 +902,7 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     const int TH = 1 << c.lth, TW = 1 << c.ltw;
     p.PH = (TH - 1) * d->stride + d->kh; p.PW = (TW - 1) * d->stride + d->kw;
     p.npix = p.NC * p.PH * p.PW;
-    p.cps = c.ks ? d->cin / (16 * c.ks) : 1;
+    p.cps = c.ks > 0 ? d->cin / (16 * c.ks) : 1;
     p.nchunks = p.cps * d->in_nseg;
     p.ktot = d->cin * d->in_nseg;
     p.seg_stride = d->in_seg_stride;
@@ -899,24 +911,26 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     if (nblk > 0x7fffffffLL) { sos_set_error("sos_conv2d_fwd: grid too large"); return SOS_EINVAL; }
     p.nblk = (int)nblk;
     { const char* e = getenv("SOS_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
-    if (c.ks == 0) {                                     // 16-row kernel
+    if (c.ks <= 0) {                                     // 16-row kernel (ks 0: double-buffered slab, -1: single)
+        const bool single = c.ks < 0;
         const int nt16 = nt16_for(d), ks16 = d->cin / 16;
         if (!nt16) { sos_set_error("sos_conv2d_fwd: internal: 16-row tiling for an ineligible shape"); return SOS_EINVAL; }
         p.cps = 1; p.nchunks = 1;
-        size_t lds16 = lds_bytes16(p.npix, nt16, ks16);
+        size_t lds16 = lds_bytes16(p.npix, nt16, ks16, single);
         const size_t stage16 = (size_t)256 * (nt16 * 32 + 16) + 1024;
         if (stage16 > lds16) lds16 = stage16;
         conv_kernel_t k = nullptr;
-        if (nt16 == 1 && ks16 == 1) k = conv16_kernel<1, 1>;
-        if (nt16 == 1 && ks16 == 3) k = conv16_kernel<1, 3>;
-        if (nt16 == 3 && ks16 == 1) k = conv16_kernel<3, 1>;
-        if (nt16 == 3 && ks16 == 3) k = conv16_kernel<3, 3>;
+#define SOS_C16(NTV, KSV)                                                                        \
+        if (nt16 == NTV && ks16 == KSV) k = single ? conv16_kernel<NTV, KSV, true> : conv16_kernel<NTV, KSV, false>;
+        SOS_C16(1, 1) SOS_C16(1, 3) SOS_C16(3, 1) SOS_C16(3, 3)
+#undef SOS_C16
         static bool attr16 = false;
         if (!attr16) {
-            (void)hipFuncSetAttribute((const void*)conv16_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
-            (void)hipFuncSetAttribute((const void*)conv16_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
-            (void)hipFuncSetAttribute((const void*)conv16_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
-            (void)hipFuncSetAttribute((const void*)conv16_kernel<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+#define SOS_C16A(NTV, KSV)                                                                                                        \
+            (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);  \
+            (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+            SOS_C16A(1, 1) SOS_C16A(1, 3) SOS_C16A(3, 1) SOS_C16A(3, 3)
+#undef SOS_C16A
             attr16 = true;
         }
         hipLaunchKernelGGL(k, dim3((unsigned)nblk, 1), dim3(256), lds16, s, p);
@@ -1023,7 +1037,7 @@ extern "C" int sos_conv2d_tune_load(const char* path) {
         for (int i = 0; i < 19 && ok; ++i) ok = fscanf(f, "%d", &k.v[i]) == 1;
         if (!ok || fscanf(f, "%d %d %d %d", &c.NC, &c.lth, &c.ltw, &c.ks) != 4) break;
         c.cost = 0;
-        if (c.NC < 1 || c.lth < 0 || c.ltw < 0 || c.lth + c.ltw > 8 || c.ks < 0 || c.ks > 8) continue;
+        if (c.NC < 1 || c.lth < 0 || c.ltw < 0 || c.lth + c.ltw > 8 || c.ks < -1 || c.ks > 8) continue;
         tuned_cache()[k] = c;
         ++n;
     }
