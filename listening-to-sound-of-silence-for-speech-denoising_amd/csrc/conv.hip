@@ -201,8 +201,9 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
 
 #endif
 
-template <int NT, int KS>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
+// SB: single weight-slab buffer (an extra barrier per tap, but a third workgroup fits a CU's LDS)
+template <int NT, int KS, bool SB>
+__global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p) {
 #if __HIP_DEVICE_COMPILE__     // buffer-resource builtins exist in the device pass only; the host pass needs just the stub
     constexpr int KC = 16 * KS;                 // channels per chunk
     constexpr int PSTRIDE = KC * 2 + 16;        // bytes per patch pixel row (padded)
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
     const int boff0 = p.npix * PSTRIDE;          // weight slab buffers follow the patch
-    unsigned* pixtab = (unsigned*)(smem + boff0 + 2 * BBYTES);   // then the per-pixel source offsets
+    unsigned* pixtab = (unsigned*)(smem + boff0 + (SB ? 1 : 2) * BBYTES);   // then the per-pixel source offsets
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         const bf16_t* wtap = p.wgt + ((long long)n0 * p.ktot + (long long)cc * KC);
         auto tap_body = [&](auto ftag, const int tap) {
             constexpr int F = decltype(ftag)::value;
-            const int cur = tap & 1;
+            const int cur = SB ? 0 : (tap & 1);
             // prefetch the next tap's weight slab into registers (lands while the MFMAs run).  The
             // loads are unconditional (last tap re-reads itself) so that the registers stay VGPRs: a
             // conditionally-defined array is demoted to scratch and the loads become synchronous.
@@ -364,10 +365,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (SB) __syncthreads();                      // every wave is done with the (single) slab buffer
 #define SOS_BSTORE(i)                                                                      \
     if constexpr (NBREG > i) {                                                               \
         if (!CDBG(8) && ((i + 1) * 256 <= BPIECES || tid + i * 256 < BPIECES))              \
-            *(uint4*)(smem + boff0 + (cur ^ 1) * BBYTES + bdst[i]) = br##i;                  \
+            *(uint4*)(smem + boff0 + (SB ? 0 : (cur ^ 1)) * BBYTES + bdst[i]) = br##i;       \
     }
             SOS_BSTORE(0) SOS_BSTORE(1) SOS_BSTORE(2) SOS_BSTORE(3) SOS_BSTORE(4) SOS_BSTORE(5) SOS_BSTORE(6) SOS_BSTORE(7)
 #undef SOS_BSTORE
@@ -734,10 +736,10 @@ static const size_t LDS_LIMIT = 160 * 1024;
 
 typedef void (*conv_kernel_t)(ConvParams);
 
-template <int NT, int KS>
+template <int NT, int KS, bool SB>
 static int launch_one(const ConvParams& p, dim3 grid, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
-    conv_kernel_t k = conv_mfma_kernel<NT, KS>;
+    conv_kernel_t k = conv_mfma_kernel<NT, KS, SB>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         if (e != hipSuccess) {
@@ -750,24 +752,35 @@ static int launch_one(const ConvParams& p, dim3 grid, size_t lds, hipStream_t st
     return sos_check_launch("sos_conv2d_fwd");
 }
 
+// ks: k-steps per channel chunk; + 100: single weight-slab buffer (NT <= 3, ks <= 4 only)
 template <int NT>
 static int launch_ks(int ks, const ConvParams& p, dim3 grid, size_t lds, hipStream_t stream) {
+    if constexpr (NT <= 3) {
+        switch (ks) {
+            case 101: return launch_one<NT, 1, true>(p, grid, lds, stream);
+            case 102: return launch_one<NT, 2, true>(p, grid, lds, stream);
+            case 103: return launch_one<NT, 3, true>(p, grid, lds, stream);
+            case 104: return launch_one<NT, 4, true>(p, grid, lds, stream);
+        }
+    }
     switch (ks) {
-        case 1: return launch_one<NT, 1>(p, grid, lds, stream);
-        case 2: return launch_one<NT, 2>(p, grid, lds, stream);
-        case 3: return launch_one<NT, 3>(p, grid, lds, stream);
-        case 4: return launch_one<NT, 4>(p, grid, lds, stream);
-        case 5: return launch_one<NT, 5>(p, grid, lds, stream);
-        case 6: return launch_one<NT, 6>(p, grid, lds, stream);
-        case 8: return launch_one<NT, 8>(p, grid, lds, stream);
+        case 1: return launch_one<NT, 1, false>(p, grid, lds, stream);
+        case 2: return launch_one<NT, 2, false>(p, grid, lds, stream);
+        case 3: return launch_one<NT, 3, false>(p, grid, lds, stream);
+        case 4: return launch_one<NT, 4, false>(p, grid, lds, stream);
+        case 5: return launch_one<NT, 5, false>(p, grid, lds, stream);
+        case 6: return launch_one<NT, 6, false>(p, grid, lds, stream);
+        case 8: return launch_one<NT, 8, false>(p, grid, lds, stream);
     }
     sos_set_error("sos_conv2d_fwd: unsupported k-steps %d", ks);
     return SOS_EINVAL;
 }
 
-static size_t lds_bytes(int npix, int nt, int ks) {
+static size_t lds_bytes(int npix, int nt, int ks) {           // ks >= 100: single slab buffer
+    const bool single = ks >= 100;
+    if (single) ks -= 100;
     const size_t row = (size_t)ks * 32 + 16;
-    return (size_t)npix * row + 2 * (size_t)nt * 32 * row + (size_t)npix * 4;
+    return (size_t)npix * row + (single ? 1 : 2) * (size_t)nt * 32 * row + (size_t)npix * 4;
 }
 
 // the 16-row kernel (conv16_kernel) handles: one bf16 channel segment of 16 or 48 channels, bf16 NHWC output,
@@ -835,6 +848,10 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
                 double per_block = 256.0 * taps * nchunks * ks + 3.0 * npix * nchunks * ks + 40.0 * nchunks * (6 + taps);
                 if (lds > LDS_LIMIT / 2) per_block *= 1.3;     // a lone workgroup per CU hides nothing
                 out.push_back({NC, lth, ltw, ks, blocks * per_block});
+                // single slab buffer: worth it only when it lets a third workgroup into the CU
+                const size_t lds1 = lds_bytes(npix, nt, ks + 100);
+                if (nt <= 3 && ks <= 4 && lds1 <= LDS_LIMIT / 3 && lds > LDS_LIMIT / 3)
+                    out.push_back({NC, lth, ltw, ks + 100, blocks * per_block * 0.93});
             }
         }
     }
@@ -902,7 +919,7 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     const int TH = 1 << c.lth, TW = 1 << c.ltw;
     p.PH = (TH - 1) * d->stride + d->kh; p.PW = (TW - 1) * d->stride + d->kw;
     p.npix = p.NC * p.PH * p.PW;
-    p.cps = c.ks > 0 ? d->cin / (16 * c.ks) : 1;
+    p.cps = c.ks > 0 ? d->cin / (16 * (c.ks % 100)) : 1;
     p.nchunks = p.cps * d->in_nseg;
     p.ktot = d->cin * d->in_nseg;
     p.seg_stride = d->in_seg_stride;
@@ -1037,7 +1054,7 @@ extern "C" int sos_conv2d_tune_load(const char* path) {
         for (int i = 0; i < 19 && ok; ++i) ok = fscanf(f, "%d", &k.v[i]) == 1;
         if (!ok || fscanf(f, "%d %d %d %d", &c.NC, &c.lth, &c.ltw, &c.ks) != 4) break;
         c.cost = 0;
-        if (c.NC < 1 || c.lth < 0 || c.ltw < 0 || c.lth + c.ltw > 8 || c.ks < -1 || c.ks > 8) continue;
+        if (c.NC < 1 || c.lth < 0 || c.ltw < 0 || c.lth + c.ltw > 8 || c.ks < -1 || (c.ks > 8 && (c.ks < 101 || c.ks > 104))) continue;
         tuned_cache()[k] = c;
         ++n;
     }
