@@ -985,6 +985,9 @@ extern "C" int sos_conv2d_fwd(const sos_conv_desc* d, sos_stream_t stream) {
         return SOS_ENOSPC;
     }
     const size_t pick = force ? (size_t)atol(force) % cfgs.size() : 0;
+    if (getenv("SOS_CONV_LIST"))      // debugging aid: the chosen candidate of the cost-ordered list
+        fprintf(stderr, "sos_conv2d_fwd: cfg %zu/%zu NC=%d TH=%d TW=%d ks=%d\n", pick, cfgs.size(), cfgs[pick].NC, 1 << cfgs[pick].lth,
+                1 << cfgs[pick].ltw, cfgs[pick].ks);
     return launch_cfg(d, cfgs[pick], (hipStream_t)stream);
 }
 
