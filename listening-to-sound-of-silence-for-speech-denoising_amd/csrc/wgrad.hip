@@ -517,17 +517,22 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
 }
 
 // dW[m][n][tap] (+)= sum over splits of partial[s][tap][m][n]; also used for 1x1 / Linear weights.
+// A thread owns one (tap, m, n) with n fastest -- the partial buffers' own order, so the ksplit reads of a wave are
+// coalesced 256-byte rows; only the single write per element is strided (by taps).
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int ksplit, int taps, int M, int N, int Mp,
                                     int Np, float* __restrict__ dw, int accumulate, float scale) {
-    const long long total = (long long)M * N * taps;
+    const long long total = (long long)taps * M * N;
+    const size_t sstride = (size_t)taps * Mp * Np;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int tap = (int)(i % taps);
-        const long long r = i / taps;
-        const int n = (int)(r % N), m = (int)(r / N);
+        const int n = (int)(i % N);
+        const long long r = i / N;
+        const int m = (int)(r % M), tap = (int)(r / M);
+        const float* pp = partial + ((size_t)tap * Mp + m) * Np + n;
         float acc = 0.f;
-        for (int s = 0; s < ksplit; ++s) acc += partial[(((size_t)s * taps + tap) * Mp + m) * Np + n];
+        for (int s = 0; s < ksplit; ++s) acc += pp[s * sstride];
         acc *= scale;
-        dw[i] = accumulate ? dw[i] + acc : acc;
+        const size_t o = ((size_t)m * N + n) * taps + tap;
+        dw[o] = accumulate ? dw[o] + acc : acc;
     }
 }
 
