@@ -343,6 +343,23 @@ extern "C" int sos_threshold_bits(const float* logits, int64_t n, float threshol
 __global__ void pack_kernel(const float* __restrict__ in, int C, int64_t HW, int64_t total, bf16_t* __restrict__ out,
                             int cs, int x3) {
     const int third = x3 ? cs / 3 : cs;
+    if (!x3 && (cs & 7) == 0) {          // common case: a pixel's channel run as whole 16-byte stores
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t b = i / HW, r = i - b * HW;
+            const float* ip = in + b * C * HW + r;
+            for (int c0 = 0; c0 < cs; c0 += 8) {
+                unsigned w4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = c0 + 2 * e;
+                    const float v0 = c < C ? ip[(int64_t)c * HW] : 0.f, v1 = c + 1 < C ? ip[(int64_t)(c + 1) * HW] : 0.f;
+                    w4[e] = pack2bf(v0, v1);
+                }
+                *(uint4*)(out + i * cs + c0) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / HW, r = i - b * HW;
         bf16_t* o = out + i * cs;
