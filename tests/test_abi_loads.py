@@ -50,3 +50,18 @@ def test_no_cpu_fallback():
         det(torch.zeros(1, 2, 256, 64))
     with pytest.raises(RuntimeError):
         transform.stft_batch(torch.zeros(1, 28000))
+
+
+def test_lstm_gate_permutation_is_consistent():
+    """engine.lstm_gate_perm: torch's (dir, gate, unit) row order -> the kernels' gate-interleaved (dir, unit, gate)
+    order (include/sos_hip.h: channel dir*4H + 4*j + q), and its inverse."""
+    import torch
+    from sos_amd import engine as E
+    H = 12
+    perm, inv = E.lstm_gate_perm(H, torch.device("cpu"))
+    assert sorted(perm.tolist()) == list(range(8 * H))
+    assert torch.equal(perm[inv], torch.arange(8 * H)) and torch.equal(inv[perm], torch.arange(8 * H))
+    for d in range(2):
+        for j in range(H):
+            for q in range(4):
+                assert int(perm[d * 4 * H + 4 * j + q]) == d * 4 * H + q * H + j
