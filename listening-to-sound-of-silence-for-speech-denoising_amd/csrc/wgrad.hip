@@ -263,6 +263,8 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     const unsigned glane = (unsigned)(krow * 64 + chan_off);
     const unsigned xlane0 = (unsigned)(pp_of(krow) * 64 + chan_off), xlane1 = (unsigned)(pp_of(krow + 4) * 64 + chan_off);
 
+    const unsigned ppk = (unsigned)pp_of((lane & 15) * 16) * 64u;      // lane ks: X-image byte offset of k-step ks
+
     const int step0 = split * p.steps_per_split;
     const int step1 = min(step0 + p.steps_per_split, p.nsteps);
     int cur = 0;
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             // k = 16 ks + krow: the bits of 16 ks and of krow (< 16) are disjoint, so the patch pixel of k is
             // pp(16 ks) + pp(krow) -- a scalar term per k-step plus two per-lane constants.
             const unsigned ga = (gb + (unsigned)ks * 1024u) + glane;
-            const unsigned xk = xb + (unsigned)pp_of(ks * 16) * 64u;            // wave-uniform
+            const unsigned xk = xb + (unsigned)__builtin_amdgcn_readlane((int)ppk, ks);   // wave-uniform (tile invariant: lane ks of ppk)
             // LDS reads in the order the MFMAs consume them (LDS returns in order): every MFMA group waits only
             // for its own fragments, so the first MFMAs start while the later fragments are still in flight.
             // The waits name their registers so that every consumer is ordered behind them.
