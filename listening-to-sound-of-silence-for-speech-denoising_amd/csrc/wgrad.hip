@@ -85,7 +85,7 @@ struct WgTile {
 // relative to the tile origin is the same for every tile, so it is decoded ONCE per kernel into an LDS table
 // {byte offset, row | column << 16}; per tile a lane's piece costs one table read, an add, two range checks
 // (out-of-range lanes get an offset beyond the buffer: the hardware writes zeros) and the DMA issue.
-template <int LP>
+template <int LP, int XSUB>
 struct WgStage {
     static constexpr int CW = 8 << LP;            // channels per sub-image
     const WgParams& p;
@@ -157,7 +157,12 @@ struct WgStage {
         return o;
     }
     // sub-image index of X piece l (wave-uniform)
-    __device__ __forceinline__ int xsub_of(int l) const { return (l >= nx) + (l >= 2 * nx) + (l >= 3 * nx); }
+    __device__ __forceinline__ int xsub_of(int l) const {
+        if constexpr (XSUB == 1) return 0;
+        else if constexpr (XSUB == 2) return l >= nx;
+        else if constexpr (XSUB == 3) return (l >= nx) + (l >= 2 * nx);
+        else return (l >= nx) + (l >= 2 * nx) + (l >= 3 * nx);
+    }
     // LDS address of this lane's pixel-table entry for DMA instruction i (pieces [64 i, 64 i + 64), i wave-uniform)
     __device__ __forceinline__ unsigned entry_addr(int i) const {
         const int L0 = i * 64;
@@ -175,24 +180,21 @@ struct WgStage {
         lds_ptr_t dst = (lds_ptr_t)(smem + buf * p.bufbytes + L0 * 16);
         if (L0 < ngp) {
             const int a = L0 >> (8 + LP);    // channels past M inside a stored 8-run are the producer's zero padding
-            bool ok = a * CW + q8 < glim;
-            if (!o.gfast)
-                ok = ok && (unsigned)(o.gh0 + (int)(ent.y & 0xffffu)) < (unsigned)p.Hg && (unsigned)(o.gw0 + (int)(ent.y >> 16)) < (unsigned)p.Wg;
+            const bool ok = a * CW + q8 < glim && (unsigned)(o.gh0 + (int)(ent.y & 0xffffu)) < (unsigned)p.Hg &&
+                            (unsigned)(o.gw0 + (int)(ent.y >> 16)) < (unsigned)p.Wg;
             const unsigned voff = ok && !WDBG(8) ? ent.x + gq + (o.gorg + (unsigned)a * (2u * CW)) : (WDBG(16) ? 0u : 0xffffffffu);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rg, dst, 16, voff, 0, 0, 0);
         } else {
             const int nt = xsub_of(L0 - ngp);
+            const int h = o.xh0 + (int)(ent.y & 0xffffu), w = o.xw0 + (int)(ent.y >> 16);
             bool ok = nt * CW + q8 < xlim && ent.y != 0x7fff7fffu;
             unsigned voff = ent.x + xq + (o.xorg + (unsigned)nt * (2u * CW));
-            if (!o.xfast) {
-                const int h = o.xh0 + (int)(ent.y & 0xffffu), w = o.xw0 + (int)(ent.y >> 16);
-                if (o.xslow) {     // ReflectionPad2d border tile: mirror the coordinates
-                    const int hr = reflect_index(h, p.Hx), wr = reflect_index(w, p.Wx);
-                    voff = (unsigned)((hr * p.Wx + wr) * p.x_cs * 2) + xq + (unsigned)nt * (2u * CW);
-                    ok = ok && (unsigned)hr < (unsigned)p.Hx && (unsigned)wr < (unsigned)p.Wx;
-                } else {
-                    ok = ok && (unsigned)h < (unsigned)p.Hx && (unsigned)w < (unsigned)p.Wx;
-                }
+            if (o.xslow) {     // ReflectionPad2d border tile: mirror the coordinates
+                const int hr = reflect_index(h, p.Hx), wr = reflect_index(w, p.Wx);
+                voff = (unsigned)((hr * p.Wx + wr) * p.x_cs * 2) + xq + (unsigned)nt * (2u * CW);
+                ok = ok && (unsigned)hr < (unsigned)p.Hx && (unsigned)wr < (unsigned)p.Wx;
+            } else {           // zero padding (and interior tiles): plain range check
+                ok = ok && (unsigned)h < (unsigned)p.Hx && (unsigned)w < (unsigned)p.Wx;
             }
             voff = ok && !WDBG(8) ? voff : (WDBG(16) ? 0u : 0xffffffffu);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rx, dst, 16, voff, 0, 0, 0);
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     const int krow = 8 * (g4 >> 1) + (s16 >> 2);                 // pixel (k) inside a 16-pixel k-step; +4 for 2nd read
     const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTH) - 1, lsh = p.logTW + p.logTH;
 
-    const WgStage<2> st(p, smem, tid, MT, NTB, m0, n0);
+    const WgStage<2, NTB> st(p, smem, tid, MT, NTB, m0, n0);
     const int ninstr = st.ninstr;
 
     f32x16 acc[MT][WG_PAIRS];
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
     const int colb = (s16 & 3) * 8;
     const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTH) - 1, lsh = p.logTW + p.logTH;
 
-    const WgStage<1> st(p, smem, tid, M16, N16, 0, 0);
+    const WgStage<1, N16> st(p, smem, tid, M16, N16, 0, 0);
     const int ninstr = st.ninstr;
 
     f32x4 acc[FT][M16][N16], acce[N16];
@@ -412,6 +414,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
     auto pp_of = [&](int k) { return ((k >> lsh) * p.PH + ((k >> p.logTW) & THm) * p.stride) * p.PW + (k & TWm) * p.stride; };
     const unsigned glane = (unsigned)(krow * 32 + colb);
     const unsigned xlane0 = (unsigned)(pp_of(krow) * 32 + colb), xlane1 = (unsigned)(pp_of(krow + 16) * 32 + colb);
+    const unsigned ppk = (unsigned)pp_of((lane & 7) * 32) * 32u;        // lane ks: X-image byte offset of k-step ks
 
     const int step0 = split * p.steps_per_split;
     const int step1 = min(step0 + p.steps_per_split, p.nsteps);
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
                 }
             }
             const unsigned ga = (gb + (unsigned)ks * 1024u) + glane;
-            const unsigned xk = xb + (unsigned)pp_of(ks * 32) * 32u;            // wave-uniform
+            const unsigned xk = xb + (unsigned)__builtin_amdgcn_readlane((int)ppk, ks);   // wave-uniform (lane ks of ppk)
             // reads in consumption order (LDS returns in order): remainder unit, G, then tap by tap.  The two
             // 64-bit halves of an operand are assembled into ONE 128-bit value before the counted wait names it,
             // so the register coalescer lets each transpose read write its half in place (no v_mov).
