@@ -281,6 +281,9 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
             for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
 
     const int ntaps = p.kh * p.kw;
+    // lane t: patch byte offset of tap t (<= 64 taps; validated on the host) -- one v_readlane per tap instead of
+    // scalar row/column bookkeeping
+    const int tapoff = ((min(lane, ntaps - 1) / p.kw) * p.PW + (min(lane, ntaps - 1) % p.kw)) * PSTRIDE;
     const long long in_b = (long long)b * p.H * p.W;
     const __amdgpu_buffer_rsrc_t in_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + in_b * p.in_cs), 0, (unsigned)(p.H * p.W * p.in_cs) * 2u, 0x00020000);
@@ -315,7 +318,6 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
         bf16x8 af[2][2], wfr[2][NT];
         af[0][0] = lds_frag(patch + abase[0]);
         af[0][1] = lds_frag(patch + abase[1]);
-        int ta = 0, tb = 0;   // tap row / col
         const bf16_t* wtap = p.wgt + ((long long)n0 * p.ktot + (long long)cc * KC);
         auto tap_body = [&](auto ftag, const int tap) {
             constexpr int F = decltype(ftag)::value;
@@ -334,13 +336,11 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
             // hoists every ds_read to just before its MFMA; pin the software pipeline explicitly.
             __builtin_amdgcn_sched_barrier(0);
 
-            const int toff = (ta * p.PW + tb) * PSTRIDE;
+            // patch byte offset of this tap and of the next one (lane t of tapoff; the last tap repeats itself)
+            const int toff = __builtin_amdgcn_readlane(tapoff, tap);
+            const int toffn = __builtin_amdgcn_readlane(tapoff, min(tap + 1, ntaps - 1));
             const char* ap0 = patch + abase[0] + toff;
             const char* ap1 = patch + abase[1] + toff;
-            int tan = ta, tbn = tb + 1;
-            if (tbn == p.kw) { tbn = 0; ++tan; }
-            if (tap + 1 == ntaps) { tan = ta; tbn = tb; }
-            const int toffn = (tan * p.PW + tbn) * PSTRIDE;
             const char* bp = smem + boff0 + cur * BBYTES + bfrag_off;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wfr[F][nt] = lds_frag(bp + nt * 32 * BSTRIDE);
@@ -374,7 +374,6 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
             SOS_BSTORE(0) SOS_BSTORE(1) SOS_BSTORE(2) SOS_BSTORE(3) SOS_BSTORE(4) SOS_BSTORE(5) SOS_BSTORE(6) SOS_BSTORE(7)
 #undef SOS_BSTORE
             if (!CDBG(16)) __syncthreads();
-            ta = tan; tb = tbn;
         };
         const int ntaps_run = CDBG(2) ? 0 : ntaps;
         if constexpr (KS % 2 == 0) {
@@ -884,7 +883,7 @@ static int validate(const sos_conv_desc* d) {
         return SOS_EINVAL;
     }
     if (d->cin < 16 || d->cin % 16 || d->in_cs % 8 || d->cin_off % 8 || d->cout_pad % 32 || d->cout > d->cout_pad ||
-        d->cout < 1 || d->kh < 1 || d->kw < 1 || d->stride < 1 || d->dil_h < 1 || d->dil_w < 1 ||
+        d->cout < 1 || d->kh < 1 || d->kw < 1 || d->kh * d->kw > 64 || d->stride < 1 || d->dil_h < 1 || d->dil_w < 1 ||
         (d->stride > 1 && (d->dil_h > 1 || d->dil_w > 1)) || d->B < 1 || d->Ho < 1 || d->Wo < 1 ||
         d->in_nseg < 1 || d->in_seg_stride % 8 || d->cin_off + (d->in_nseg - 1) * d->in_seg_stride + d->cin > d->in_cs ||
         d->cout_store < d->cout || d->out_dtype < 0 || d->out_dtype > 2 || (d->w_gather == nullptr && d->Wl != d->W)) {
