@@ -58,8 +58,10 @@ def test_detector_train_step_matches_reference_autograd(golden, precision):
         # few dozen ReLU decisions (|z| ~ 0) of the 364k outputs of a block, and BatchNorm's
         # backward sums (d_beta = sum dz) cancel heavily, so single elements move by ~1e-2 even
         # though every kernel matches torch to ~1e-5 in isolation (test_encoder_block_backward_exact,
-        # tools/probe/det_bwd_debug.py).  Norms stay within a few 1e-3.
-        tol = 5e-3 if precision == "bf16x3" else 0.25
+        # tools/probe/det_bwd_debug.py).  Norms stay within a few 1e-3 with the tuned tilings; other (equally valid)
+        # conv tilings change the summation order and moved single tensors to 1.3e-2 (test_gpu_forced_tilings.py),
+        # so the bound leaves room for whatever tiling the autotuner picks on a given box.
+        tol = 2e-2 if precision == "bf16x3" else 0.25
         e_lo = rel_err(logits, g["train_det_logits"])
         print(precision, "train logits rel err", e_lo, "loss", float(loss), "ref", float(g["train_bce"]))
         assert e_lo < (1e-3 if precision == "bf16x3" else 0.1)
@@ -103,7 +105,7 @@ def test_denoiser_train_step_matches_reference_autograd(golden, precision):
         assert abs(float(l1) / float(g["train_l1"]) - 1) < (1e-3 if x3 else 5e-2)
         assert abs(float(l2) / float(g["train_l2"]) - 1) < (1e-3 if x3 else 5e-2)
         worst = _check_grads(list(jm.named_parameters()), g["train_jm_gradnorm"], g["train_jm_gradhead"],
-                             1e-2 if x3 else 0.4, precision)
+                             3e-2 if x3 else 0.4, precision)      # see the note on conditioning above
         print(precision, "worst grad err", worst)
     finally:
         sos_amd.set_precision("bf16")
