@@ -118,9 +118,17 @@ typedef struct sos_conv_desc {
     const float* act_param; /* device scalar (PReLU slope) or NULL                      */
     int32_t accumulate;     /* 1: add to the existing bf16 output (dense NHWC outputs only): gradient
                                fan-in of skip connections in the backward pass            */
+    /* optional fused BatchNorm statistics of the (bf16-rounded) output, dense bf16 NHWC outputs only:
+     * stats[tile][0][c] = sum, stats[tile][1][c] = sum of squares over the tile's valid pixels, c < stats_c;
+     * tile < sos_conv2d_tile_count(desc); feed to sos_bn_finalize(partial = stats, nblk = tile count). */
+    float* stats;
+    int32_t stats_c;
 } sos_conv_desc;
 
 int sos_conv2d_fwd(const sos_conv_desc* desc /* host pointer */, sos_stream_t stream);
+/* number of pixel tiles (workgroup columns) the NEXT sos_conv2d_fwd of this shape will use: the tuned tiling if
+ * sos_conv2d_tune has run for the shape, the default otherwise */
+int64_t sos_conv2d_tile_count(const sos_conv_desc* desc);
 
 /* One-time autotune for the SHAPE of `desc` (not its pointers): runs the `max_candidates` most
  * promising tilings `iters` times each, timed with HIP events on `stream` (this call

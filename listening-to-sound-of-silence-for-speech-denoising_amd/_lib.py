@@ -28,6 +28,7 @@ class ConvDesc(C.Structure):
         ("out_c_off", C.c_int32), ("cout_store", C.c_int32), ("out_third", C.c_int64),
         ("scale", C.c_void_p), ("shift", C.c_void_p),
         ("act", C.c_int32), ("act_param", C.c_void_p), ("accumulate", C.c_int32),
+        ("stats", C.c_void_p), ("stats_c", C.c_int32),
     ]
 
 
@@ -64,6 +65,7 @@ SIGNATURES = {
     "sos_conv2d_tune": [C.POINTER(ConvDesc), _I, _I, C.POINTER(C.c_float), _P],
     "sos_conv2d_tune_save": [C.c_char_p],
     "sos_conv2d_tune_load": [C.c_char_p],
+    "sos_conv2d_tile_count": [C.POINTER(ConvDesc)],
     "sos_lstm_pack_bytes": [_I, _I],
     "sos_lstm_pack_whh": [_P, _I, _P, _P, _P, _P, _P],
     "sos_lstm_bidir_fwd": [_P, _P, _P, _L, _L, _I, _P, _I, _I, _L, _P, _P, _P],
@@ -101,7 +103,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
-            fn.restype = C.c_int64 if name in ("sos_wgrad_workspace_bytes", "sos_lstm_pack_bytes") else C.c_int
+            fn.restype = C.c_int64 if name in ("sos_wgrad_workspace_bytes", "sos_lstm_pack_bytes", "sos_conv2d_tile_count") else C.c_int
         h.sos_last_error.restype = C.c_char_p
         h.sos_last_error.argtypes = []
         _lib = h

@@ -50,6 +50,8 @@ struct ConvParams {
     int stride, dh, dw, pad_t, pad_l, pad_mode;
     int Ho, Wo;
     int out_dtype, c_off, act, accum;
+    float* stats;           // optional fused BatchNorm partial sums [tile][2][stats_c]
+    int stats_c;
     long long sb, sh, sw, sc, third;
     // tiling
     int NC, logTH, logTW, PH, PW;
@@ -132,6 +134,42 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
         otab[m] = (ho < p.Ho && wo < p.Wo && (cls == 0 || rw0 + cls < p.dw)) ? ho * (int)p.sh + wo * (int)p.sw : -1;
     }
     __syncthreads();
+    if (p.stats) {
+        // ---- fused BatchNorm statistics of this tile (of the bf16-rounded values, exactly what a separate pass over
+        // the stored tensor would see): thread = (8-channel group, pixel lane), then a fixed-order sum over the lanes
+        constexpr int PL = 256 / PPX;
+        const int cg = tid % PPX, pl = tid / PPX;
+        float s[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        if (pl < PL) {
+            for (int m = pl; m < 256; m += PL) {
+                if (otab[m] < 0) continue;
+                const uint4 hv = *(const uint4*)(ost_hi + m * OROW + cg * 16);
+                uint4 lv = make_uint4(0u, 0u, 0u, 0u);
+                if (x3) lv = *(const uint4*)(ost_lo + m * OROW + cg * 16);
+                const unsigned hw[4] = {hv.x, hv.y, hv.z, hv.w}, lw[4] = {lv.x, lv.y, lv.z, lv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v0 = __uint_as_float(hw[i] << 16) + __uint_as_float(lw[i] << 16);
+                    const float v1 = __uint_as_float(hw[i] & 0xffff0000u) + __uint_as_float(lw[i] & 0xffff0000u);
+                    s[2 * i] += v0; q[2 * i] = fmaf(v0, v0, q[2 * i]);
+                    s[2 * i + 1] += v1; q[2 * i + 1] = fmaf(v1, v1, q[2 * i + 1]);
+                }
+            }
+        }
+        float* red = (float*)(smem + 256 * OROW * (x3 ? 2 : 1) + 1024);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s[e]; red[tid * 16 + 8 + e] = q[e]; }
+        __syncthreads();
+        for (int o = tid; o < 2 * PPX * 8; o += 256) {
+            const int which = o / (PPX * 8), cc = o - which * (PPX * 8);
+            const int g8 = cc >> 3, e = cc & 7;
+            float acc = 0.f;
+            for (int l = 0; l < PL; ++l) acc += red[(l * PPX + g8) * 16 + which * 8 + e];
+            if (n0 + cc < p.stats_c) p.stats[((size_t)blockIdx.x * 2 + which) * p.stats_c + n0 + cc] = acc;
+        }
+    }
     // ---- cooperative store: consecutive lanes write consecutive 16-byte pieces of a pixel's
     // channel run (and consecutive pixels of a tile row are adjacent in memory when dil_w == 1).
     bf16_t* op = (bf16_t*)p.out + (long long)b * p.sb + p.c_off + n0;
@@ -891,6 +929,10 @@ static int validate(const sos_conv_desc* d) {
                       d->cin, d->in_cs, d->cin_off, d->cout, d->cout_pad, d->kh, d->kw, d->stride, d->dil_h, d->dil_w);
         return SOS_EINVAL;
     }
+    if (d->stats && (d->out_dtype == SOS_DT_F32 || d->out_sc != 1 || d->stats_c < 1 || d->stats_c > d->cout_pad || d->accumulate)) {
+        sos_set_error("sos_conv2d_fwd: fused statistics need a dense bf16 NHWC output without accumulation");
+        return SOS_EINVAL;
+    }
     if ((uint64_t)d->H * d->W * d->in_cs * 2 >= 0xfff00000ull) {
         sos_set_error("sos_conv2d_fwd: one input image exceeds 4 GB");
         return SOS_ENOSPC;
@@ -910,6 +952,7 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     p.kh = d->kh; p.kw = d->kw; p.cout = d->cout; p.cout_pad = d->cout_pad; p.cout_store = d->cout_store;
     p.stride = d->stride; p.dh = d->dil_h; p.dw = d->dil_w; p.pad_t = d->pad_top; p.pad_l = d->pad_left;
     p.pad_mode = d->pad_mode; p.Ho = d->Ho; p.Wo = d->Wo; p.out_dtype = d->out_dtype; p.c_off = d->out_c_off;
+    p.stats = d->stats; p.stats_c = d->stats_c;
     p.act = d->act; p.accum = d->accumulate; p.sb = d->out_sb; p.sh = d->out_sh; p.sw = d->out_sw; p.sc = d->out_sc; p.third = d->out_third;
     const int nt = nt_for(d);
     const int nby = (d->cout_pad / 32 + nt - 1) / nt;
@@ -933,7 +976,7 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
         if (!nt16) { sos_set_error("sos_conv2d_fwd: internal: 16-row tiling for an ineligible shape"); return SOS_EINVAL; }
         p.cps = 1; p.nchunks = 1;
         size_t lds16 = lds_bytes16(p.npix, nt16, ks16, single);
-        const size_t stage16 = (size_t)256 * (nt16 * 32 + 16) + 1024;
+        const size_t stage16 = (size_t)256 * (nt16 * 32 + 16) + 1024 + (d->stats ? 16384 : 0);
         if (stage16 > lds16) lds16 = stage16;
         conv_kernel_t k = nullptr;
 #define SOS_C16(NTV, KSV)                                                                        \
@@ -955,7 +998,8 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     dim3 grid((unsigned)nblk, (unsigned)nby);
     size_t lds = lds_bytes(p.npix, nt, c.ks);
     if (d->out_dtype != SOS_DT_F32 && d->out_sc == 1) {
-        const size_t stage = (size_t)256 * (nt * 64 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + 1024;   // + pixel offsets
+        const size_t stage = (size_t)256 * (nt * 64 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + 1024 +   // + pixel offsets
+                             (d->stats ? 16384 : 0);                                                       // + statistics scratch
         if (stage > lds) lds = stage;
     }
     switch (nt) {
@@ -966,6 +1010,24 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     }
     sos_set_error("sos_conv2d_fwd: internal: nt=%d", nt);
     return SOS_EINVAL;
+}
+
+static long long tiles_of(const sos_conv_desc* d, const ConvCfg& c) {
+    const int Hc = (d->Ho + d->dil_h - 1) / d->dil_h, Wc = (d->Wo + d->dil_w - 1) / d->dil_w;
+    const int TH = 1 << c.lth, TW = 1 << c.ltw;
+    return (long long)d->B * d->dil_h * ((Hc + TH - 1) / TH) * ((d->dil_w + c.NC - 1) / c.NC) * ((Wc + TW - 1) / TW);
+}
+
+extern "C" int64_t sos_conv2d_tile_count(const sos_conv_desc* d) {
+    if (validate(d)) return -1;
+    static const char* force = getenv("SOS_CONV_FORCE_CFG");
+    if (!force) {
+        auto it = tuned_cache().find(shape_key(d));
+        if (it != tuned_cache().end()) return tiles_of(d, it->second);
+    }
+    std::vector<ConvCfg> cfgs = enumerate_cfgs(d);
+    if (cfgs.empty()) { sos_set_error("sos_conv2d_tile_count: no tile fits LDS"); return -1; }
+    return tiles_of(d, cfgs[force ? (size_t)atol(force) % cfgs.size() : 0]);
 }
 
 extern "C" int sos_conv2d_fwd(const sos_conv_desc* d, sos_stream_t stream) {

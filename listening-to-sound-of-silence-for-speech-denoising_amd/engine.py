@@ -131,9 +131,10 @@ def fold_bn(bn, cout_pad):
 
 def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dtype, sb, sh, sw, sc,
          Ho, Wo, c_off=0, cout_store=None, third=0, stride=1, dil=(1, 1), pad=(0, 0), pad_mode=L.PAD_ZERO,
-         slope=None, w_gather=None, out_elem_offset=0, in_dims=None, accumulate=False):
+         slope=None, w_gather=None, out_elem_offset=0, in_dims=None, accumulate=False, stats_c=0):
     """Fill a sos_conv_desc and enqueue sos_conv2d_fwd.  `src` is an Act (or a (tensor,B,H,W,cs,nseg)
-    view described by in_dims)."""
+    view described by in_dims).  stats_c > 0: also return the fused BatchNorm partial sums of the first stats_c
+    output channels as (partial [tiles][2][stats_c], tiles) for sos_bn_finalize."""
     d = L.ConvDesc()
     if in_dims is None:
         t, B, H, W, cs, nseg = src.t, src.B, src.H, src.W, src.cs, src.nseg
@@ -186,17 +187,25 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
     if PROFILER is not None:
         sig = ("conv", kh, kw, dil[0], dil[1], stride, d.in_nseg * cin, cout, B, Ho, Wo)
         end = PROFILER.bracket(sig, 2.0 * B * Ho * Wo * cout * d.in_nseg * cin * kh * kw)
+    stats = None
+    if stats_c:
+        tiles = L.lib().sos_conv2d_tile_count(C.byref(d))
+        if tiles < 1:
+            raise RuntimeError("sos_conv2d_tile_count: " + (L.lib().sos_last_error() or b"").decode())
+        stats = (torch.empty((tiles, 2, stats_c), dtype=torch.float32, device=out.device), int(tiles))
+        d.stats, d.stats_c = stats[0].data_ptr(), stats_c
     L.check(L.lib().sos_conv2d_fwd(C.byref(d), L.stream_ptr()), "sos_conv2d_fwd")
     if end is not None:
         end.record()
+    return stats
 
 
 def conv_to_act(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, dst, c_off=0, cout_store=None, **kw_):
     """Conv whose output is (a channel slice of) a dense NHWC Act."""
     row = dst.nseg * dst.cs
-    conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, out=dst.t, out_dtype=dst.dtype_code,
-         sb=dst.H * dst.W * row, sh=dst.W * row, sw=row, sc=1, c_off=c_off,
-         cout_store=cout if cout_store is None else cout_store, third=dst.cs, **kw_)
+    return conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, out=dst.t, out_dtype=dst.dtype_code,
+                sb=dst.H * dst.W * row, sh=dst.W * row, sw=row, sc=1, c_off=c_off,
+                cout_store=cout if cout_store is None else cout_store, third=dst.cs, **kw_)
 
 
 def lstm_gate_perm(H, device):
@@ -267,15 +276,19 @@ def view(act, c_off=0, C=None, third_index=None):
     return v
 
 
-def bn_train(raw, c_off, Cn, bn, act, slope, dst, dst_c_off=0, feat=None):
+def bn_train(raw, c_off, Cn, bn, act, slope, dst, dst_c_off=0, feat=None, stats=None):
     """Training-mode BatchNorm (+activation) of the raw conv output `raw[:, c_off:c_off+C]`:
     stats -> finalize (updates bn.running_* in place like torch) -> apply into `dst`.
-    Returns the saved tensors for backward."""
+    `stats` = (partial, tiles) from the producing conv's fused statistics (engine.conv(stats_c=...)) skips the
+    separate statistics pass.  Returns the saved tensors for backward."""
     dev = raw.t.device
     xv = view(raw, c_off, Cn)
-    nblk = L.lib().sos_bn_stats_blocks(xv.npix)
-    partial = torch.empty((nblk, 2, Cn), dtype=torch.float32, device=dev)
-    L.check(L.lib().sos_bn_stats(C.byref(xv), L.ptr(partial), L.stream_ptr()), "sos_bn_stats")
+    if stats is not None:
+        partial, nblk = stats
+    else:
+        nblk = L.lib().sos_bn_stats_blocks(xv.npix)
+        partial = torch.empty((nblk, 2, Cn), dtype=torch.float32, device=dev)
+        L.check(L.lib().sos_bn_stats(C.byref(xv), L.ptr(partial), L.stream_ptr()), "sos_bn_stats")
     scale = torch.empty(Cn, dtype=torch.float32, device=dev)
     shift = torch.empty_like(scale)
     mean = torch.empty_like(scale)

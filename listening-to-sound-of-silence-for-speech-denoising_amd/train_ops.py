@@ -15,6 +15,10 @@ from . import engine as E
 
 
 
+# SOS_FUSED_STATS=0: separate sos_bn_stats pass instead of the statistics fused into the conv epilogue (A/B timing)
+FUSED_STATS = __import__("os").environ.get("SOS_FUSED_STATS", "1") != "0"
+
+
 def ones_zeros(n, device):
     """(scale, shift) of a conv with no affine epilogue: NULL for both (sos_conv_desc: y = act(acc))."""
     return None, None
@@ -95,11 +99,12 @@ def encoder_forward_train(plan, a, feat, x3):
         cs = E.pad_to(lp["cout"], 16)
         one, zero = ones_zeros(lp["w"].shape[1], dev)
         raw = E.Act(B, H, W, cs, x3, dev)
-        E.conv_to_act(cur, 0, lp["cin_store"], lp["w"], lp["kh"], lp["kw"], lp["cout"], one, zero, L.ACT_NONE, raw,
-                      cout_store=cs, dil=lp["dil"], pad=lp["pad"], Ho=H, Wo=W)
+        # the conv's epilogue also produces the BatchNorm partial sums of its (bf16) output tile
+        st = E.conv_to_act(cur, 0, lp["cin_store"], lp["w"], lp["kh"], lp["kw"], lp["cout"], one, zero, L.ACT_NONE, raw,
+                           cout_store=cs, dil=lp["dil"], pad=lp["pad"], Ho=H, Wo=W, stats_c=lp["cout"] if FUSED_STATS else 0)
         last = i == len(plan) - 1
         y = None if last else E.Act(B, H, W, cs, x3, dev, zero=cs > E.pad_to(lp["cout"], 8))
-        saved = E.bn_train(raw, 0, lp["cout"], lp["bn"], L.ACT_RELU, None, y, 0, feat if last else None)
+        saved = E.bn_train(raw, 0, lp["cout"], lp["bn"], L.ACT_RELU, None, y, 0, feat if last else None, stats=st)
         tape.append(dict(inp=cur, raw=raw, saved=saved))
         cur = y
     return tape
