@@ -889,6 +889,13 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
                 const size_t lds1 = lds_bytes(npix, nt, ks + 100);
                 if (nt <= 3 && ks <= 4 && lds1 <= LDS_LIMIT / 3 && lds > LDS_LIMIT / 3)
                     out.push_back({NC, lth, ltw, ks + 100, blocks * per_block * 0.93});
+                // 128 output channels per workgroup need ~400 registers and > 80 KB of LDS (one workgroup per CU): two
+                // n-blocks of 64 stage the patch twice but fit two or three workgroups (ks + 2000)
+                if (nt == 4) {
+                    const size_t lds2 = lds_bytes(npix, 2, ks);
+                    if (lds2 <= LDS_LIMIT / 2)
+                        out.push_back({NC, lth, ltw, ks + 2000, blocks * 2.0 * (128.0 * taps * nchunks * ks + 3.0 * npix * nchunks * ks + 40.0 * nchunks * (6 + taps)) * 0.9});
+                }
             }
         }
     }
@@ -954,14 +961,16 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     p.pad_mode = d->pad_mode; p.Ho = d->Ho; p.Wo = d->Wo; p.out_dtype = d->out_dtype; p.c_off = d->out_c_off;
     p.stats = d->stats; p.stats_c = d->stats_c;
     p.act = d->act; p.accum = d->accumulate; p.sb = d->out_sb; p.sh = d->out_sh; p.sw = d->out_sw; p.sc = d->out_sc; p.third = d->out_third;
-    const int nt = nt_for(d);
+    // c.ks encodes: k-steps per chunk (% 100), + 100 single slab buffer, + 1000 * n-tiles per workgroup (0: default)
+    const int nt = c.ks >= 1000 ? c.ks / 1000 : nt_for(d);
+    const int ks_enc = c.ks >= 1000 ? c.ks % 1000 : c.ks;
     const int nby = (d->cout_pad / 32 + nt - 1) / nt;
     const int Hc = (d->Ho + d->dil_h - 1) / d->dil_h, Wc = (d->Wo + d->dil_w - 1) / d->dil_w;
     p.NC = c.NC; p.logTH = c.lth; p.logTW = c.ltw;
     const int TH = 1 << c.lth, TW = 1 << c.ltw;
     p.PH = (TH - 1) * d->stride + d->kh; p.PW = (TW - 1) * d->stride + d->kw;
     p.npix = p.NC * p.PH * p.PW;
-    p.cps = c.ks > 0 ? d->cin / (16 * (c.ks % 100)) : 1;
+    p.cps = c.ks > 0 ? d->cin / (16 * (ks_enc % 100)) : 1;
     p.nchunks = p.cps * d->in_nseg;
     p.ktot = d->cin * d->in_nseg;
     p.seg_stride = d->in_seg_stride;
@@ -996,17 +1005,17 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
         return sos_check_launch("sos_conv2d_fwd(16)");
     }
     dim3 grid((unsigned)nblk, (unsigned)nby);
-    size_t lds = lds_bytes(p.npix, nt, c.ks);
+    size_t lds = lds_bytes(p.npix, nt, ks_enc);
     if (d->out_dtype != SOS_DT_F32 && d->out_sc == 1) {
         const size_t stage = (size_t)256 * (nt * 64 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + 1024 +   // + pixel offsets
                              (d->stats ? 16384 : 0);                                                       // + statistics scratch
         if (stage > lds) lds = stage;
     }
     switch (nt) {
-        case 1: return launch_ks<1>(c.ks, p, grid, lds, s);
-        case 2: return launch_ks<2>(c.ks, p, grid, lds, s);
-        case 3: return launch_ks<3>(c.ks, p, grid, lds, s);
-        case 4: return launch_ks<4>(c.ks, p, grid, lds, s);
+        case 1: return launch_ks<1>(ks_enc, p, grid, lds, s);
+        case 2: return launch_ks<2>(ks_enc, p, grid, lds, s);
+        case 3: return launch_ks<3>(ks_enc, p, grid, lds, s);
+        case 4: return launch_ks<4>(ks_enc, p, grid, lds, s);
     }
     sos_set_error("sos_conv2d_fwd: internal: nt=%d", nt);
     return SOS_EINVAL;
@@ -1118,7 +1127,12 @@ extern "C" int sos_conv2d_tune_load(const char* path) {
         for (int i = 0; i < 19 && ok; ++i) ok = fscanf(f, "%d", &k.v[i]) == 1;
         if (!ok || fscanf(f, "%d %d %d %d", &c.NC, &c.lth, &c.ltw, &c.ks) != 4) break;
         c.cost = 0;
-        if (c.NC < 1 || c.lth < 0 || c.ltw < 0 || c.lth + c.ltw > 8 || c.ks < -1 || (c.ks > 8 && (c.ks < 101 || c.ks > 104))) continue;
+        {
+            const int k = c.ks >= 1000 ? c.ks % 1000 : c.ks, ntv = c.ks / 1000;
+            if (c.NC < 1 || c.lth < 0 || c.ltw < 0 || c.lth + c.ltw > 8 || c.ks < -1 || (k > 8 && (k < 101 || k > 104)) || ntv > 4 ||
+                (c.ks >= 1000 && k < 1))
+                continue;
+        }
         tuned_cache()[k] = c;
         ++n;
     }
