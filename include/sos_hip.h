@@ -257,6 +257,25 @@ int sos_reflect_fold(const sos_view* padded, int H, int W, int pad, const sos_vi
  * (the crop that stands in for F.interpolate(out, skip.size()) at M2/networks.py:199-203, and its backward). */
 int sos_copy_crop(const sos_view* src, int Hs, int Ws, const sos_view* dst, int Hd, int Wd, sos_stream_t stream);
 
+/* ---- 8f-2  the wave front door: `librosa.load(path, sr=14000)` at M1/dataset.py:226, M2/predict.py:288,297,303
+ * (soundfile decode -> to_mono -> resampy 'kaiser_best' -> fix_length) and the samples handed to
+ * `librosa.output.write_wav` (M2/predict.py:515-528).  The RIFF container is parsed on the host; these take the
+ * decoded, still interleaved samples. */
+enum { SOS_PCM_S16 = 0, SOS_PCM_S32 = 1, SOS_PCM_F32 = 2, SOS_PCM_U8 = 3 };
+/* pcm: interleaved [n_frames][channels] device samples -> out f32 [n_frames] = mean over channels of
+ * sample / 2^(bits-1) (u8: (v-128)/128; f32: as is). */
+int sos_pcm_to_mono_f32(const void* pcm, int format, int channels, int64_t n_frames, float* out, sos_stream_t stream);
+/* Band-limited resampling by `ratio` = sr_new / sr_orig (resampy 0.2.2 `resample_f`): win = the filter's half
+ * window (nwin floats, num_table samples per zero crossing), already multiplied by min(1, ratio).  Writes
+ * out[0 .. n_out): the first floor(n_in * ratio) entries are resampled, the rest zero (librosa pads to
+ * ceil(n_in * ratio)).  (nwin + 1) * 4 bytes must fit the 160 KB LDS. */
+int sos_resample_f32(const float* x, int64_t n_in, double ratio, const float* win, int nwin, int num_table,
+                     float* out, int64_t n_out, sos_stream_t stream);
+/* Host-only helper (no GPU work): the piecewise-linear description of resampy's running f64 time register
+ * `time_register += 1/ratio` that sos_resample_f32 hands its kernel: time(t) = fma(t - k0[i], d[i], s0[i]) for
+ * the last i with k0[i] <= t.  Returns the number of segments (<= capacity) or a negative error. */
+int sos_resample_time_segments(double ratio, int64_t n_out, int64_t* k0, double* s0, double* d, int capacity);
+
 #ifdef __cplusplus
 }
 #endif

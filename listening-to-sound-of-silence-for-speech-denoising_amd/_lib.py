@@ -85,6 +85,9 @@ SIGNATURES = {
     "sos_bn_act_apply": [C.POINTER(View), _P, _P, _I, _P, C.POINTER(View), _I, _I, _I, _P, _P],
     "sos_wgrad_workspace_bytes": [C.POINTER(WgradDesc)],
     "sos_conv2d_wgrad": [C.POINTER(WgradDesc), _P],
+    "sos_pcm_to_mono_f32": [_P, _I, _I, _L, _P, _P],
+    "sos_resample_f32": [_P, _L, _D, _P, _I, _I, _P, _L, _P],
+    "sos_resample_time_segments": [_D, _L, _P, _P, _P, _I],
 }
 
 _lib = None
