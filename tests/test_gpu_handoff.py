@@ -1,0 +1,137 @@
+"""The file-level chain of the README's real-recording path through the on-disk hand-off formats
+(sos_amd/handoff.py): dataset JSON + WAVE files -> eval_results.json -> pred_data.json + recovered/*_mixed.wav ->
+denoised WAVE files, against the oracle run on the same decoded signals and weights (bf16x3 parity mode).
+Tolerances: bits exact away from the threshold, sample masks bit-exact, waveforms <= 1e-3 of peak."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.io.wavfile
+import torch
+
+import sos_amd
+from oracle import frontend as ofe
+from oracle import nets as onet
+from oracle import wave_io as owio
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_dataset(root):
+    rng = np.random.default_rng(5)
+    files = []
+    for name, sr0, ch, secs, dtype in (("rec_a", 44100, 2, 3.2, np.int16), ("rec_b", 14000, 1, 2.5, np.float32)):
+        n = int(sr0 * secs)
+        t = np.arange(n) / sr0
+        env = (np.sin(2 * np.pi * 0.7 * t) > -0.2).astype(np.float64)        # speech-like on/off envelope
+        sig = 0.3 * env * np.sin(2 * np.pi * 220 * t * (1 + 0.3 * np.sin(2 * np.pi * 3 * t))) + 0.05 * rng.standard_normal(n)
+        pcm = np.stack([sig, 0.8 * sig + 0.01 * rng.standard_normal(n)], axis=1)[:, :ch]
+        pcm = np.clip(pcm * 32768, -32768, 32767).astype(np.int16) if dtype == np.int16 else pcm.astype(np.float32)
+        os.makedirs(os.path.join(root, name), exist_ok=True)
+        path = os.path.join(root, name, name + "_0000001.wav")
+        scipy.io.wavfile.write(path, sr0, pcm if ch > 1 else pcm[:, 0])
+        nfr = int(round(secs * 30))
+        files.append(dict(path="/authors/machine/ds/%s/%s_0000001.wav" % (name, name), clip_start_time=0, clip_end_time=secs,
+                          face_x=0, face_y=0, framerate=30, audio_sample_rate=sr0, audio_samples=n, duration=secs,
+                          num_frames=nfr, bit_stream="1" * nfr, silence_total_ratio=0,
+                          avg_silenceInterval_silcenceTotal_ratio=0, frames_path=None, flows_path=None,
+                          audio_path="/authors/machine/ds/%s/%s_0000001.wav" % (name, name)))
+        files[-1]["_pcm"], files[-1]["_local"] = pcm if ch > 1 else pcm[:, 0], path
+    ds = dict(dataset_path="/authors/machine/ds", num_videos=len(files),
+              files=[{k: v for k, v in f.items() if not k.startswith("_")} for f in files])
+    with open(os.path.join(root, "dataset.json"), "w") as fp:
+        json.dump(ds, fp)
+    return files
+
+
+def test_file_chain_through_handoff_formats(tmp_path):
+    from sos_amd import handoff
+    from sos_amd.common import MyConfig
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+    root = str(tmp_path / "ds")
+    files = _make_dataset(root)
+    waves = [owio.load_from_pcm(f["_pcm"], f["audio_sample_rate"], 14000) for f in files]     # oracle decode + resample
+    sd1 = onet.closed_form_state(onet.detector_spec(), seed=1)
+    sd2 = onet.closed_form_state(onet.joint_spec(), seed=2)
+    # centre the logits so that both classes occur
+    S_or = [torch.from_numpy(ofe.fast_stft(w).transpose(2, 0, 1)[None].astype(np.float32)) for w in waves]
+    with torch.no_grad():
+        lo0 = [onet.detector_forward(sd1, S, f["num_frames"]) for S, f in zip(S_or, files)]
+        sd1["fc1.2.bias"] = sd1["fc1.2.bias"] - torch.cat([x.flatten() for x in lo0]).median()
+        lo = [(x - torch.cat([y.flatten() for y in lo0]).median())[0].numpy() for x in lo0]
+    det = dnet.get_network(); det.load_state_dict(sd1)
+    jm = jnet.get_network(MyConfig()); jm.load_state_dict(sd2)
+    det, jm = det.cuda().eval(), jm.cuda().eval()
+    out1 = str(tmp_path / "m1_out")
+    sos_amd.set_precision("bf16x3")
+    try:
+        stat = handoff.detect_files(det, os.path.join(root, "dataset.json"), out1, data_root=root)
+        pred_json = handoff.create_data_from_prediction(os.path.join(out1, "eval_results.json"), data_root=root)
+        data_list_info = handoff.get_data_from_first_model(pred_json, sr=14000)
+        out2 = str(tmp_path / "m2_out")
+        res = handoff.denoise_files(jm, data_list_info, out2)
+    finally:
+        sos_amd.set_precision("bf16")
+
+    # ---- eval_results.json: schema of M1/predict.py:133-147,194-232 and the detector's bits
+    with open(os.path.join(out1, "eval_results.json")) as fp:
+        ev = json.load(fp)
+    assert list(ev) == ["data_total_frames", "data_center_frames", "sigmoid_threshold", "snr", "prediction_statistics", "data"]
+    assert list(ev["data"][0]) == ["id", "path", "full_bit_stream", "num_frames", "framerate", "audio_sample_rate", "audio_samples",
+                                   "duration", "frame_start_idx", "label", "pred_label", "match", "confidence"]
+    by_id = {d["id"]: d for d in ev["data"]}
+    n_all = 0
+    for i, f in enumerate(files):
+        d = by_id[i]
+        assert len(d["pred_label"]) == len(d["label"]) == len(d["confidence"]) == f["num_frames"]
+        bits = (lo[i] >= 0).astype(np.uint8)
+        got = np.array([int(b) for b in d["pred_label"]], dtype=np.uint8)
+        unsure = np.abs(lo[i]) < 2e-4 * max(1.0, np.abs(lo[i]).max())
+        assert np.array_equal(got[~unsure], bits[~unsure])
+        conf = np.array([float(c) for c in d["confidence"]])
+        assert np.max(np.abs(conf - 1 / (1 + np.exp(-lo[i])))) < 2e-4
+        n_all += bits.sum()
+    assert 0 < n_all < sum(f["num_frames"] for f in files)
+    assert ev["prediction_statistics"]["all"]["num_samples"] == sum(f["num_frames"] for f in files)
+
+    # ---- pred_data.json + recovered/*_mixed.wav (M1/create_data_from_pred.py:60-92,212-221,250-271)
+    with open(pred_json) as fp:
+        pd = json.load(fp)
+    assert os.path.basename(pred_json) == "pred_data.json" and pd["dataset_path"] == "/authors/machine/ds" and pd["num_videos"] == 2
+    for i, (f, pf) in enumerate(zip(files, pd["files"])):
+        assert pf["mixed_audio"] == "recovered/%s_mixed.wav" % os.path.basename(f["_local"])[:-4]
+        assert pf["recovered_prediction"] == pf["predicted_bit_stream"] == "".join(by_id[i]["pred_label"])
+        sr, mixed = scipy.io.wavfile.read(os.path.join(out1, pf["mixed_audio"]))
+        assert sr == 14000 and mixed.dtype == np.float32 and mixed.shape == waves[i].shape
+        assert np.max(np.abs(mixed - waves[i])) <= 1e-5 * np.max(np.abs(waves[i]))
+
+    # ---- model 2 inputs and outputs, driven by the bit streams of the JSON
+    names = ("noisy_input", "noise_intervals", "predicted_full_noise", "denoised_output")
+    with open(os.path.join(out2, "eval_results.json")) as fp:
+        ev2 = json.load(fp)
+    assert list(ev2) == ["dataset_path", "num_videos", "data_total_frames", "data_center_frames", "sigmoid_threshold", "snr", "files"]
+    for i, (f, pf, item, info) in enumerate(zip(files, pd["files"], data_list_info[0], res)):
+        sr, mixed = scipy.io.wavfile.read(os.path.join(out1, pf["mixed_audio"]))
+        bits = [int(b) for b in pf["recovered_prediction"]]
+        mask = ofe.convert_bitstreammask_to_audiomask(mixed, 14000 / 30.0, bits)
+        assert np.array_equal(item["mask"].cpu().numpy(), mask)                          # integer work: bit-exact
+        S = torch.from_numpy(ofe.fast_stft(mixed).transpose(2, 0, 1)[None].astype(np.float32))
+        Sn = torch.from_numpy(ofe.fast_stft(mixed * mask).transpose(2, 0, 1)[None].astype(np.float32))
+        assert float((item["mixed"].cpu() - S).abs().max() / S.abs().max()) < 1e-5
+        with torch.no_grad():
+            n_pred, crm = onet.joint_forward(sd2, S, Sn)
+        rec = ofe.fast_icRM_sigmoid(S[0].permute(1, 2, 0).numpy(), crm[0].permute(1, 2, 0).numpy())
+        want = dict(noisy_input=ofe.fast_istft(S[0].permute(1, 2, 0).numpy()), noise_intervals=ofe.fast_istft(Sn[0].permute(1, 2, 0).numpy()),
+                    predicted_full_noise=ofe.fast_istft(n_pred[0].permute(1, 2, 0).numpy()), denoised_output=ofe.fast_istft(rec))
+        assert list(info)[:6] == ["id", "path", "mixed_audio_path", "bitstream", "sr", "snr"] and list(info)[6:] == list(names)
+        assert info["id"] == os.path.basename(f["_local"])[:-4]
+        with open(os.path.join(out2, info["id"], "stat.json")) as fp:
+            assert json.load(fp) == json.loads(json.dumps(info))
+        for name in names:
+            sr, y = scipy.io.wavfile.read(info[name])
+            assert sr == 14000 and y.dtype == np.float32 and y.shape == want[name].shape
+            err = np.max(np.abs(y - want[name])) / np.max(np.abs(want[name]))
+            print(info["id"], name, "rel err", err)
+            assert err < 1e-3
