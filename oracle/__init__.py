@@ -17,4 +17,10 @@ Pinning status
   stft/istft, filters.window_sumsquare) anchored on the reference call sites
   (transform.py:174,193,199) and is cross-checked against torch.stft /
   torch.istft in tests/test_oracle_frontend.py.
+* Wave decode / mono / resample (oracle/wave_io.py): soundfile + librosa 0.7.1 +
+  resampy>=0.2.2, all absent: **parity unpinned**; cross-checked against
+  analytic resampling of band-limited tones and scipy.signal.resample_poly in
+  tests/test_oracle_wave_io.py.
+* Hand-off formats: checked against the reference's own checked-in output files
+  (tests/golden/handoff/).
 """
