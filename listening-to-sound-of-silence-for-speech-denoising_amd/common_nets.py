@@ -99,9 +99,16 @@ def linear_plan(lin, cin_store, x3):
                 shift=E.pad_vec(lin.bias, w.shape[1]), cout=lin.out_features, cin_store=cin_store)
 
 
+_nearest_tables = {}
+
+
 def nearest_index(in_size, out_size, device):
     """Source column of F.interpolate(mode='nearest'): min(floor(dst * float32(in/out)), in-1)
-    (ATen nearest_idx); int32 table on the device."""
-    scale = np.float32(in_size) / np.float32(out_size)
-    idx = np.minimum(np.floor(np.arange(out_size, dtype=np.float32) * scale).astype(np.int64), in_size - 1)
-    return torch.from_numpy(idx.astype(np.int32)).to(device)
+    (ATen nearest_idx); int32 table on the device, uploaded once per (in, out, device) -- no host->device copy
+    on later calls (none is allowed inside a hipGraph capture)."""
+    key = (int(in_size), int(out_size), str(device))
+    if key not in _nearest_tables:
+        scale = np.float32(in_size) / np.float32(out_size)
+        idx = np.minimum(np.floor(np.arange(out_size, dtype=np.float32) * scale).astype(np.int64), in_size - 1)
+        _nearest_tables[key] = torch.from_numpy(idx.astype(np.int32)).to(device)
+    return _nearest_tables[key]

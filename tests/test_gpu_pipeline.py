@@ -130,3 +130,32 @@ def test_ragged_batch_matches_per_clip_and_oracle():
         err = np.abs(yg[:n] - y[:n]).max() / max(np.abs(y[:n]).max(), 1e-9)
         print("ragged clip", i, "len", len(w), "rel err", err)
         assert err < 1e-3
+
+
+def test_graph_replay_equals_eager_launches():
+    """BASELINE configs[3]: the hipGraph-captured chain replays the same kernels with the same tilings, so its
+    output is bit-identical to the eager launches -- for new inputs, for several shapes, and across evictions."""
+    from sos_amd import pipeline
+    from sos_amd.common import MyConfig
+    from sos_amd.dataset import synth_batch
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+    det = dnet.get_network(); det.load_state_dict(onet.closed_form_state(onet.detector_spec(), seed=1))
+    jm = jnet.get_network(MyConfig()); jm.load_state_dict(onet.closed_form_state(onet.joint_spec(), seed=2))
+    det, jm = det.cuda().eval(), jm.cuda().eval()
+    base = torch.from_numpy(synth_batch(90, 6)["mixed"]).cuda()
+    g = pipeline.GraphedDenoiser(det, jm, max_graphs=2)
+    shapes = [(1, 28000), (3, 14000), (2, 28123), (1, 28000)]          # the 4th evicted and re-captured
+    for k, (b, n) in enumerate(shapes):
+        for rep in range(2):
+            x = base[rep:rep + b, :n].contiguous() if n <= 28000 else torch.cat([base[rep:rep + b], base[rep + 1:rep + 1 + b, :n - 28000]], 1)
+            want = pipeline.denoise(det, jm, x)
+            got = g(x)
+            assert got.shape == want.shape == (b, 158 * (n // 158)) and torch.equal(got, want)
+        assert len(g._graphs) <= 2
+    clips = [base[0, :14000], base[1], base[2, :14000], base[3]]
+    ragged = g.denoise_ragged(clips)
+    eager = pipeline.denoise_ragged(det, jm, clips)
+    assert all(torch.equal(a, b) for a, b in zip(ragged, eager))
+    with pytest.raises(ValueError):
+        g(base[0])
