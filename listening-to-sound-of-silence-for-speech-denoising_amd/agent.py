@@ -135,6 +135,8 @@ class GradBucketer:
     def __init__(self, named_params, bucket_bytes=25 * 1024 * 1024, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # SOS_FORCE_BUCKETS=1: issue the collectives even in a world of one (exercises the RCCL path on a 1-GPU box)
+        self.collective = dist.is_initialized() and (self.world > 1 or os.environ.get("SOS_FORCE_BUCKETS") == "1")
         self.shapes = {n: p.shape for n, p in named_params}
         self.params = dict(named_params)
         self.bucket_bytes = bucket_bytes
@@ -144,7 +146,7 @@ class GradBucketer:
         self.buckets, self.cur, self.cur_fill, self.handles, self.views = [], None, 0, [], {}
 
     def _launch(self, flat, fill):
-        if self.world > 1:
+        if self.collective:
             self.handles.append(dist.all_reduce(flat[:fill], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def ready(self, name, g):
@@ -206,7 +208,8 @@ class BaseAgent(object):
         self.optimizer = FusedAdam(self.net.parameters(), lr)
         self.optimizer.grad_scale = 1.0 / self.world
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, lr_step_size)
-        self.bucketer = GradBucketer(list(self.net.named_parameters())) if self.world > 1 else None
+        force = dist.is_initialized() and os.environ.get("SOS_FORCE_BUCKETS") == "1"
+        self.bucketer = GradBucketer(list(self.net.named_parameters())) if (self.world > 1 or force) else None
         self.net.grad_sink_factory = (lambda: GradSink(self.bucketer)) if self.bucketer is not None else None
 
     # -- checkpoints: M1/agent.py:62-100

@@ -125,3 +125,59 @@ def test_train_concurrent_matches_serial():
     for a, b in ((d1, d2), (j1, j2)):
         for (k, p), (_, q) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
             assert torch.equal(p, q), k
+
+
+_RCCL_CHILD = r"""
+import os, sys
+sys.path.insert(0, os.environ["SOS_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SOS_ROOT"], "tests"))
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+import sos_amd
+from sos_amd import agent
+from sos_amd.common import MyConfig
+from sos_amd.denoiser import networks as jnet
+from sos_amd.detector import networks as dnet
+from oracle import nets as onet
+from util import hashed, silent_gate, spec_input
+B, T = 2, 89
+x = spec_input(100 + B, B, T).cuda()
+clean = (spec_input(300, B, T) * 0.5).cuda()
+bj = {"mixed": x, "noise": silent_gate(x.cpu()).cuda(), "clean": clean, "full_noise": x - clean}
+bd = {"label": (torch.from_numpy(hashed(301, (B, 60))) > 0).float().cuda(), "audio": x}
+def make():
+    det = dnet.get_network(); det.load_state_dict(onet.closed_form_state(onet.detector_spec(), seed=1))
+    jm = jnet.get_network(MyConfig()); jm.load_state_dict(onet.closed_form_state(onet.joint_spec(), seed=2))
+    return agent.DetectorAgent(det, lr=1e-3), agent.DenoiserAgent(jm, lr=1e-3)
+os.environ["SOS_FORCE_BUCKETS"] = "1"
+d1, j1 = make()
+assert d1.bucketer is not None and d1.bucketer.collective
+os.environ["SOS_FORCE_BUCKETS"] = "0"
+d2, j2 = make()
+assert d2.bucketer is None
+for _ in range(2):
+    agent.train_concurrent([(j1, bj), (d1, bd)])
+    agent.train_concurrent([(j2, bj), (d2, bd)])
+torch.cuda.synchronize()
+n = 0
+for a, b in ((d1, d2), (j1, j2)):
+    for (k, p), (_, q) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
+        assert torch.equal(p, q), k
+        n += 1
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_PATH_OK", n)
+"""
+
+
+def test_bucketed_all_reduce_path_on_rccl_world_of_one():
+    """The multi-GPU gradient path (GradBucketer: flat buckets, async all_reduce on the RCCL stream issued from the
+    two model streams, wait, Adam on the bucket views) with backend 'nccl' in a world of one, where the all-reduce
+    is the identity: parameters after two steps are bit-identical to the single-process path."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SOS_ROOT=root, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, r.stdout[-3000:]
