@@ -54,6 +54,18 @@ __device__ __forceinline__ void load8(const View& v, long long pix, int c8, floa
 
 // U pixels (pix, pix + step, ...) of one 8-channel group: all loads are issued before the first conversion, so a
 // thread keeps U (2U in hi|hi|lo mode) 16-byte requests in flight.  Pixels past the end are clamped (callers skip them).
+typedef unsigned bn_u32x4 __attribute__((ext_vector_type(4)));
+// streaming accesses (every byte is touched once per pass and the tensors are far larger than L2): the
+// non-temporal hint is worth 5-8 % of the HBM rate of these kernels (bn_bwd 4.7 -> 5.1 TB/s)
+__device__ __forceinline__ uint4 ld16(const bf16_t* p) {
+    const bn_u32x4 v = __builtin_nontemporal_load((const bn_u32x4*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st16(bf16_t* p, const uint4 v) {
+    const bn_u32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, (bn_u32x4*)p);
+}
+
 template <int BN_U>
 __device__ __forceinline__ void load8u(const View& v, long long pix, long long step, int c8, float (&f)[BN_U][8]) {
     uint4 h[BN_U], l[BN_U];
@@ -61,7 +73,7 @@ __device__ __forceinline__ void load8u(const View& v, long long pix, long long s
     for (int u = 0; u < BN_U; ++u) {
         const long long pp = pix + u * step < v.npix ? pix + u * step : v.npix - 1;
         const bf16_t* p = v.ptr + pp * v.row + v.c_off + c8;
-        h[u] = *(const uint4*)p;
+        h[u] = ld16(p);
         if (v.x3) l[u] = *(const uint4*)(p + 2 * v.third);
     }
 #pragma unroll
@@ -86,6 +98,10 @@ __device__ __forceinline__ void load8u(const View& v, long long pix, long long s
 __device__ __forceinline__ void store8(const View& v, long long pix, int c8, const float (&f)[8]) {
     bf16_t* p = v.ptr + pix * v.row + v.c_off + c8;
     unsigned hw[4], lw[4];
+    if (!v.x3) {        // v_cvt_pk_bf16_f32: one instruction per pair instead of the integer rounding sequence
+        st16(p, make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])));
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const bf16_t h0 = f2bf(f[2 * i]), h1 = f2bf(f[2 * i + 1]);
@@ -93,7 +109,7 @@ __device__ __forceinline__ void store8(const View& v, long long pix, int c8, con
         if (v.x3) lw[i] = (unsigned)f2bf(f[2 * i] - bf2f(h0)) | ((unsigned)f2bf(f[2 * i + 1] - bf2f(h1)) << 16);
     }
     const uint4 hv = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-    *(uint4*)p = hv;
+    st16(p, hv);
     if (v.x3) {
         *(uint4*)(p + v.third) = hv;
         *(uint4*)(p + 2 * v.third) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
