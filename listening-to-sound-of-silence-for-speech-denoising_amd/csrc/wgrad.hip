@@ -215,7 +215,10 @@ struct WgStage {
 // MT MFMAs and every G fragment WG_PAIRS of them.  Operands: WgStage<2> (32-channel sub-images, 64-byte
 // pixel pitch: conflict free for the transpose reads); with double buffering the DMA instructions of the
 // next tile are issued one per k-step by the "light" waves while the MFMAs of the current tile run.
-template <int MT, int NTB>
+// BAL (25 taps, NTB = 1): 25 pairs on 8 waves would give wave 0 a fourth pair (12 accumulator tiles, its SIMD 21 MFMAs
+// per k-step against 18 on the others).  Instead every wave owns three pairs and the 25th tap is split by m-tile
+// over the waves 0..MT-1 (three different SIMDs): 10 accumulator tiles, at most 19 MFMAs per SIMD and k-step.
+template <int MT, int NTB, bool BAL = false>
 __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -229,6 +232,8 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     const int m0 = blockIdx.y * (MT * 32), n0 = blockIdx.z * (NTB * 32);
     const int taps = p.kh * p.kw;
     const int npairs = taps * NTB;
+    constexpr int NP = BAL ? 3 : WG_PAIRS;                      // full (tap, n-tile) pairs per wave
+    const bool hasx = BAL && wave < MT;                          // this wave also owns m-tile `wave` of the last tap
     const int g4 = lane >> 4, s16 = lane & 15;
     const int chan_off = (16 * (g4 & 1) + 4 * (s16 & 3)) * 2;    // byte offset of this lane's 4-channel run
     const int krow = 8 * (g4 >> 1) + (s16 >> 2);                 // pixel (k) inside a 16-pixel k-step; +4 for 2nd read
@@ -237,26 +242,29 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     const WgStage<2, NTB> st(p, smem, tid, MT, NTB, m0, n0);
     const int ninstr = st.ninstr;
 
-    f32x16 acc[MT][WG_PAIRS];
+    f32x16 acc[MT][NP], accx;
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int t = 0; t < WG_PAIRS; ++t)
+        for (int t = 0; t < NP; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][t][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accx[e] = 0.f;
 
     // per-wave offsets of its pairs inside the X image (tap shift + n-tile sub-image)
-    unsigned toff[WG_PAIRS];
+    unsigned toff[NP];
 #pragma unroll
-    for (int u = 0; u < WG_PAIRS; ++u) {
+    for (int u = 0; u < NP; ++u) {
         const int pr = min(wave + WG_WAVES * u, npairs - 1);
         const int tap = pr / NTB, nt = pr - tap * NTB;
         const int ta = tap / p.kw, tb = tap - ta * p.kw;
         toff[u] = (unsigned)((ta * p.PW + tb) * 64 + nt * ximg);
     }
+    const unsigned toffx = (unsigned)((((taps - 1) / p.kw) * p.PW + (taps - 1) % p.kw) * 64);   // BAL: the last tap
     // While a tile is multiplied, the next one is fetched by the "light" waves: those that own one (tap, n-tile)
     // pair fewer than the others (25 taps on 8 waves: wave 0 has 4 pairs, waves 1..7 have 3).
-    int heavy = npairs & (WG_WAVES - 1);
+    int heavy = BAL ? 0 : (npairs & (WG_WAVES - 1));
     if ((WG_WAVES - heavy) * 16 < ninstr) heavy = 0;
     const int nlight = WG_WAVES - heavy, lw = wave - heavy;       // lw < 0: this wave issues no DMA in the k-loop
 
@@ -293,19 +301,28 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             // for its own fragments, so the first MFMAs start while the later fragments are still in flight.
             // The waits name their registers so that every consumer is ordered behind them.
             // (the two 64-bit halves of an operand are assembled into one 128-bit value first: no register moves)
-            u32x4 av[MT], bv[WG_PAIRS];
+            u32x4 av[MT], bv[NP], avx, bvx;
             auto rd2 = [&](const unsigned a0addr, const unsigned a1addr) {
                 const uint2 lo = lds_tr(a0addr), hi = lds_tr(a1addr);
                 return u32x4{lo.x, lo.y, hi.x, hi.y};
             };
+            if constexpr (BAL) {                   // issued first: LDS returns in order, so the counted waits below do not change
+                if (hasx) {
+                    const unsigned gax = ga + (unsigned)wave * 16384u;
+                    const uint2 lo = lds_tr(gax), hi = lds_tr_off<256>(gax);
+                    avx = u32x4{lo.x, lo.y, hi.x, hi.y};
+                    bvx = rd2(xlane0 + (xk + toffx), xlane1 + (xk + toffx));
+                }
+            }
             { const uint2 lo = lds_tr(ga), hi = lds_tr_off<256>(ga); av[0] = u32x4{lo.x, lo.y, hi.x, hi.y}; }
             bv[0] = rd2(xlane0 + (xk + toff[0]), xlane1 + (xk + toff[0]));
             if constexpr (MT >= 2) { const uint2 lo = lds_tr_off<16384>(ga), hi = lds_tr_off<16384 + 256>(ga); av[1] = u32x4{lo.x, lo.y, hi.x, hi.y}; }
             if constexpr (MT >= 3) { const uint2 lo = lds_tr_off<32768>(ga), hi = lds_tr_off<32768 + 256>(ga); av[2] = u32x4{lo.x, lo.y, hi.x, hi.y}; }
 #pragma unroll
-            for (int u = 1; u < WG_PAIRS; ++u) bv[u] = rd2(xlane0 + (xk + toff[u]), xlane1 + (xk + toff[u]));
-            constexpr int REST = 2 * (WG_PAIRS - 1);              // reads behind pair 0 / m-tile a
+            for (int u = 1; u < NP; ++u) bv[u] = rd2(xlane0 + (xk + toff[u]), xlane1 + (xk + toff[u]));
+            constexpr int REST = 2 * (NP - 1);              // reads behind pair 0 / m-tile a
             asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(ent), "+v"(av[0]), "+v"(bv[0]) : "n"(REST + 2 * (MT - 1)));
+            if constexpr (BAL) { if (hasx) asm volatile("" : "+v"(avx), "+v"(bvx)); }   // ordered behind the wait above
             if (dma) st.issue(di, ent, onext, cur ^ 1);
             const bool on0 = wave < npairs;
             {
@@ -321,16 +338,24 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
                 }
             }
 #pragma unroll
-            for (int u = 1; u < WG_PAIRS; ++u) {
-                if (u == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bv[1]));
-                if (u == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bv[2]));
-                if (u == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[3]));
-                if (wave + WG_WAVES * u < npairs) {
+            for (int u = 1; u < NP; ++u) {
+                if constexpr (NP == 4) {
+                    if (u == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bv[1]));
+                    if (u == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bv[2]));
+                    if (u == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[3]));
+                } else {
+                    if (u == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bv[1]));
+                    if (u == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[2]));
+                }
+                if (BAL || wave + WG_WAVES * u < npairs) {
                     const bf16x8 bfr = __builtin_bit_cast(bf16x8, bv[u]);
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
                         acc[a][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[a]), bfr, acc[a][u], 0, 0, 0);
                 }
+            }
+            if constexpr (BAL) {
+                if (hasx) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, avx), __builtin_bit_cast(bf16x8, bvx), accx, 0, 0, 0);
             }
         }
         if (p.dbuf) {
@@ -343,7 +368,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     // ---- write this split's partial tiles: D[row = m][col = n], row = (reg&3)+8*(reg>>2)+4*(lane>>5), col = lane&31
     float* out = p.partial + (size_t)split * taps * p.Mp * p.Np;
 #pragma unroll
-    for (int u = 0; u < WG_PAIRS; ++u) {
+    for (int u = 0; u < NP; ++u) {
         const int pr = wave + WG_WAVES * u;
         if (pr >= npairs) continue;
         const int tap = pr / NTB, nt = pr - tap * NTB;
@@ -355,6 +380,16 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.Mp) out[((size_t)tap * p.Mp + m) * p.Np + n] = acc[a][u][r];
+            }
+        }
+    }
+    if constexpr (BAL) {
+        const int n = n0 + (lane & 31);
+        if (hasx && n < p.Np) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.Mp) out[((size_t)(taps - 1) * p.Mp + m) * p.Np + n] = accx[r];
             }
         }
     }
@@ -659,6 +694,8 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     if (!attr_done) {       // every instantiation may use the full 160 KB of LDS
         SOS_WG_ATTR(1, 1) SOS_WG_ATTR(1, 2) SOS_WG_ATTR(1, 4) SOS_WG_ATTR(2, 1) SOS_WG_ATTR(2, 2) SOS_WG_ATTR(2, 4)
         SOS_WG_ATTR(3, 1) SOS_WG_ATTR(3, 2) SOS_WG_ATTR(3, 4)
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<3, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)wgrad16_kernel<3, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)wgrad16_kernel<3, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
@@ -667,8 +704,13 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
         if (taps == 25) hipLaunchKernelGGL((wgrad16_kernel<3, 3, 3>), grid, dim3(WG_THREADS), lds, s, p);
         else hipLaunchKernelGGL((wgrad16_kernel<3, 3, 1>), grid, dim3(WG_THREADS), lds, s, p);
     } else {
+        const bool bal = taps == 25 && ntb == 1 && mt >= 2 && !getenv("SOS_WGRAD_NOBAL");
+        if (bal && mt == 3) hipLaunchKernelGGL((wgrad_kernel<3, 1, true>), grid, dim3(WG_THREADS), lds, s, p);
+        else if (bal && mt == 2) hipLaunchKernelGGL((wgrad_kernel<2, 1, true>), grid, dim3(WG_THREADS), lds, s, p);
+        else {
         SOS_WG_CASE(1, 1) SOS_WG_CASE(1, 2) SOS_WG_CASE(1, 4) SOS_WG_CASE(2, 1) SOS_WG_CASE(2, 2) SOS_WG_CASE(2, 4)
         SOS_WG_CASE(3, 1) SOS_WG_CASE(3, 2) SOS_WG_CASE(3, 4)
+        }
     }
 #undef SOS_WG_CASE
 #undef SOS_WG_ATTR
