@@ -32,9 +32,21 @@ static int check_view(const sos_view* v, const char* what) {
     return SOS_OK;
 }
 
+typedef unsigned bn_u32x4 __attribute__((ext_vector_type(4)));
+// streaming accesses (every byte is touched once per pass and the tensors are far larger than L2): the
+// non-temporal hint is worth 5-8 % of the HBM rate of these kernels (bn_bwd 4.7 -> 5.1 TB/s)
+__device__ __forceinline__ uint4 ld16(const bf16_t* p) {
+    const bn_u32x4 v = __builtin_nontemporal_load((const bn_u32x4*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st16(bf16_t* p, const uint4 v) {
+    const bn_u32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, (bn_u32x4*)p);
+}
+
 __device__ __forceinline__ void load8(const View& v, long long pix, int c8, float (&f)[8]) {
     const bf16_t* p = v.ptr + pix * v.row + v.c_off + c8;
-    const uint4 h = *(const uint4*)p;
+    const uint4 h = ld16(p);
     const unsigned hw[4] = {h.x, h.y, h.z, h.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -54,18 +66,6 @@ __device__ __forceinline__ void load8(const View& v, long long pix, int c8, floa
 
 // U pixels (pix, pix + step, ...) of one 8-channel group: all loads are issued before the first conversion, so a
 // thread keeps U (2U in hi|hi|lo mode) 16-byte requests in flight.  Pixels past the end are clamped (callers skip them).
-typedef unsigned bn_u32x4 __attribute__((ext_vector_type(4)));
-// streaming accesses (every byte is touched once per pass and the tensors are far larger than L2): the
-// non-temporal hint is worth 5-8 % of the HBM rate of these kernels (bn_bwd 4.7 -> 5.1 TB/s)
-__device__ __forceinline__ uint4 ld16(const bf16_t* p) {
-    const bn_u32x4 v = __builtin_nontemporal_load((const bn_u32x4*)p);
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void st16(bf16_t* p, const uint4 v) {
-    const bn_u32x4 w = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(w, (bn_u32x4*)p);
-}
-
 template <int BN_U>
 __device__ __forceinline__ void load8u(const View& v, long long pix, long long step, int c8, float (&f)[BN_U][8]) {
     uint4 h[BN_U], l[BN_U];
