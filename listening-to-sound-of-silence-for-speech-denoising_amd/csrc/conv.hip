@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
     constexpr int BROWS = NT * 32;
     constexpr int BPIECES = BROWS * CPR;
     constexpr int NBREG = (BPIECES + 255) / 256;
-    constexpr int BBYTES = BROWS * BSTRIDE;
+    // double-buffered variants fill the slab by LDS-DMA in whole 1 KB instructions: a buffer is rounded up to that
+    constexpr int BBYTES = SB ? BROWS * BSTRIDE : (BROWS * (CPR + 1) + 63) / 64 * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
     const int boff0 = p.npix * PSTRIDE;          // weight slab buffers follow the patch
@@ -313,6 +314,38 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
         }
     }
     const long long tap_stride = (long long)p.cout_pad * p.ktot;
+    // Weight slab by LDS-DMA (double-buffered variants): the slab image in LDS is piece-linear (row * RPB + piece, the
+    // last piece of a row being the 16-byte pad), so one DMA instruction fills 1 KB = 64 consecutive pieces; the
+    // per-lane source offsets are tap invariant, the tap / chunk enters as the scalar offset.  No data registers, no
+    // ds_write_b128 (13 LDS cycles each): 96->96 5x5 1.29 -> 1.23 ms.  (SB variants keep the register path: their
+    // single buffer can only be refilled behind a barrier, where a DMA's latency would be exposed.)
+    constexpr int RPB = CPR + 1;
+    constexpr int WQ = BROWS * RPB;
+    constexpr int WINSTR = (WQ + 63) / 64;
+    constexpr int WPW = (WINSTR + 3) / 4;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    unsigned wvoff[WPW];
+    {
+        const int rmax = p.cout_pad - 1 - n0;
+#pragma unroll
+        for (int u = 0; u < WPW; ++u) {
+            const int q = (wv + 4 * u) * 64 + lane;
+            const int row = q / RPB, c = q - row * RPB;
+            // pad slots and the tail of the last instruction re-read a valid piece (their LDS bytes are never read)
+            wvoff[u] = (unsigned)(((n0 + min(row, rmax)) * p.ktot + min(c, CPR - 1) * 8) * 2);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.wgt, 0, (unsigned)((long long)p.kh * p.kw * p.cout_pad * p.ktot * 2), 0x00020000);
+    auto dma_slab = [&](const int buf, const unsigned soff) {
+#pragma unroll
+        for (int u = 0; u < WPW; ++u) {
+            const int i = wv + 4 * u;
+            if (i < WINSTR)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(smem + boff0 + buf * BBYTES + i * 1024), 16, wvoff[u],
+                                                         soff, 0, 0);
+        }
+    };
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -340,7 +373,8 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
                                  (unsigned)(cbase * 2));
         }
         // ---- weight slab of tap 0 straight into buffer 0
-        {
+        if constexpr (!SB) dma_slab(0, (unsigned)(cc * KC * 2));
+        else {
             const bf16_t* wsrc = p.wgt + ((long long)n0 * p.ktot + (long long)cc * KC);
 #pragma unroll
             for (int u = 0; u < NBREG; ++u) {
@@ -370,8 +404,10 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
             // (named scalars, not an array: with the scheduling barriers below an array is left in
             // scratch memory, which makes the "prefetch" synchronous)
             uint4 br0, br1, br2, br3, br4, br5, br6, br7;
+            constexpr bool WD = !SB;               // next tap's slab by LDS-DMA (lands while the MFMAs run)
+            if constexpr (WD) { if (tap + 1 < ntaps) dma_slab(cur ^ 1, (unsigned)(((long long)(tap + 1) * tap_stride + cc * KC) * 2)); }
             if (tap + 1 < ntaps && !CDBG(64)) wtap += tap_stride;
-#define SOS_BLOAD(i) if constexpr (NBREG > i) { if (!CDBG(8)) br##i = *(const uint4*)(wtap + bsrc[i]); else br##i = make_uint4(0,0,0,0); }
+#define SOS_BLOAD(i) if constexpr (NBREG > i && !WD) { if (!CDBG(8)) br##i = *(const uint4*)(wtap + bsrc[i]); else br##i = make_uint4(0,0,0,0); }
             SOS_BLOAD(0) SOS_BLOAD(1) SOS_BLOAD(2) SOS_BLOAD(3) SOS_BLOAD(4) SOS_BLOAD(5) SOS_BLOAD(6) SOS_BLOAD(7)
 #undef SOS_BLOAD
             // hipcc otherwise sinks these loads to the end of the tap (right before their use) and
@@ -409,12 +445,13 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
             }
             if (SB) __syncthreads();                      // every wave is done with the (single) slab buffer
 #define SOS_BSTORE(i)                                                                      \
-    if constexpr (NBREG > i) {                                                               \
+    if constexpr (NBREG > i && !WD) {                                                               \
         if (!CDBG(8) && ((i + 1) * 256 <= BPIECES || tid + i * 256 < BPIECES))              \
             *(uint4*)(smem + boff0 + (SB ? 0 : (cur ^ 1)) * BBYTES + bdst[i]) = br##i;       \
     }
             SOS_BSTORE(0) SOS_BSTORE(1) SOS_BSTORE(2) SOS_BSTORE(3) SOS_BSTORE(4) SOS_BSTORE(5) SOS_BSTORE(6) SOS_BSTORE(7)
 #undef SOS_BSTORE
+            if constexpr (WD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tap's slab has landed
             if (!CDBG(16)) __syncthreads();
         };
         const int ntaps_run = CDBG(2) ? 0 : ntaps;
@@ -821,7 +858,8 @@ static size_t lds_bytes(int npix, int nt, int ks) {           // ks >= 100: sing
     const bool single = ks >= 100;
     if (single) ks -= 100;
     const size_t row = (size_t)ks * 32 + 16;
-    return (size_t)npix * row + (single ? 1 : 2) * (size_t)nt * 32 * row + (size_t)npix * 4;
+    const size_t slab = single ? (size_t)nt * 32 * row : ((size_t)nt * 32 * (2 * ks + 1) + 63) / 64 * 1024;   // BBYTES of the kernel
+    return (size_t)npix * row + (single ? 1 : 2) * slab + (size_t)npix * 4;
 }
 
 // the 16-row kernel (conv16_kernel) handles: one bf16 channel segment of 16 or 48 channels, bf16 NHWC output,
