@@ -634,8 +634,11 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
     constexpr int PSTRIDE = KC * 2, BSTRIDE = KC * 2, CPR = 2 * KS;
     constexpr int BW = KS;                        // K-blocks of 32 channels per two-tap window
     constexpr int ROWS = NT16 * 16;
-    constexpr int TAPBYTES = ROWS * BSTRIDE, WBYTES = 2 * TAPBYTES;
+    constexpr int TAPBYTES = ROWS * BSTRIDE;
     constexpr int TPIECES = ROWS * CPR, WPIECES = 2 * TPIECES;
+    // the double-buffered variant fills the window slab by LDS-DMA (whole 1 KB instructions; the slab image is piece-linear)
+    constexpr int WINSTR = (WPIECES + 63) / 64, WPW = (WINSTR + 3) / 4;
+    constexpr int WBYTES = SB ? 2 * TAPBYTES : WINSTR * 1024;
     constexpr int NBREG = (WPIECES + 255) / 256;
     constexpr int OROW = NT16 * 32 + 16;          // bytes per staged output pixel row
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -693,6 +696,29 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
         btap1[u] = tl != 0;
     }
     const long long tap_stride = (long long)p.cout_pad * p.ktot;
+    // LDS-DMA source offsets (bytes from p.wgt for window 0; a window adds 2 taps): piece (tap tl, row, c).  A tap
+    // past the last one lies beyond the buffer resource, where the hardware writes zeros: the odd window's zero half.
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    unsigned wvoff[WPW];
+#pragma unroll
+    for (int u = 0; u < WPW; ++u) {
+        const int idx = min((wv + 4 * u) * 64 + lane, WPIECES - 1);
+        const int tl = idx / TPIECES, rem = idx - tl * TPIECES;
+        const int row = rem / CPR, c = rem - row * CPR;
+        wvoff[u] = (unsigned)((tl * tap_stride + (long long)row * p.ktot + c * 8) * 2);
+    }
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.wgt, 0, (unsigned)((long long)p.kh * p.kw * tap_stride * 2), 0x00020000);
+    auto dma_window = [&](const int w, const int buf) {
+        const unsigned woff = (unsigned)((long long)w * 2 * tap_stride * 2);
+#pragma unroll
+        for (int u = 0; u < WPW; ++u) {
+            const int i = wv + 4 * u;
+            if (i < WINSTR)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(smem + boff0 + buf * WBYTES + i * 1024), 16,
+                                                         wvoff[u] + woff, 0, 0, 0);
+        }
+    };
 
     f32x4 acc[4][NT16];
 #pragma unroll
@@ -728,7 +754,8 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
         for (int u = 0; u < NBREG; ++u)
             if ((u + 1) * 256 <= WPIECES || tid + u * 256 < WPIECES) *(uint4*)(smem + boff0 + buf * WBYTES + bdst[u]) = r[u];
     };
-    {
+    if constexpr (!SB) dma_window(0, 0);
+    else {
         uint4 r0[NBREG];
         load_window(0, r0);
         store_window(0, r0);
@@ -739,7 +766,8 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
     for (int w = 0; w < nwin; ++w) {
         const int cur = SB ? 0 : (w & 1);
         uint4 rn[NBREG];
-        load_window(w + 1 < nwin ? w + 1 : w, rn);       // next window's slab (lands while the MFMAs run)
+        if constexpr (!SB) { if (w + 1 < nwin) dma_window(w + 1, cur ^ 1); }       // next window's slab (lands while the MFMAs run)
+        else load_window(w + 1 < nwin ? w + 1 : w, rn);
         __builtin_amdgcn_sched_barrier(0);
         const int t0 = 2 * w, t1 = min(2 * w + 1, ntaps - 1);
         const int toff0 = ((t0 / p.kw) * p.PW + (t0 % p.kw)) * PSTRIDE;
@@ -766,8 +794,12 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
                     acc[pt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cb][nt], fb[cb][pt], acc[pt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (SB) __syncthreads();                          // every wave is done with the (single) slab buffer
-        store_window(SB ? 0 : cur ^ 1, rn);
+        if constexpr (SB) {
+            __syncthreads();                              // every wave is done with the (single) slab buffer
+            store_window(0, rn);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
     }
 
@@ -872,7 +904,8 @@ static int nt16_for(const sos_conv_desc* d) {
 }
 static size_t lds_bytes16(int npix, int nt16, int ks, bool single) {
     const size_t row = (size_t)ks * 32;            // unpadded pitches
-    return (size_t)npix * row + (single ? 1 : 2) * (size_t)2 * nt16 * 16 * row + (size_t)npix * 4;
+    const size_t slab = single ? (size_t)2 * nt16 * 16 * row : ((size_t)2 * nt16 * 16 * 2 * ks + 63) / 64 * 1024;   // WBYTES
+    return (size_t)npix * row + (single ? 1 : 2) * slab + (size_t)npix * 4;
 }
 
 // One tiling choice: NC residue classes x (1<<lth) x (1<<ltw) pixels, 16*ks channels per chunk (ks == 0: the
