@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
             // scratch memory, which makes the "prefetch" synchronous)
             uint4 br0, br1, br2, br3, br4, br5, br6, br7;
             constexpr bool WD = !SB;               // next tap's slab by LDS-DMA (lands while the MFMAs run)
-            if constexpr (WD) { if (tap + 1 < ntaps) dma_slab(cur ^ 1, (unsigned)(((long long)(tap + 1) * tap_stride + cc * KC) * 2)); }
+            if constexpr (WD) { if (tap + 1 < ntaps && !CDBG(8)) dma_slab(cur ^ 1, (unsigned)(((long long)(tap + 1) * tap_stride + cc * KC) * 2)); }
             if (tap + 1 < ntaps && !CDBG(64)) wtap += tap_stride;
 #define SOS_BLOAD(i) if constexpr (NBREG > i && !WD) { if (!CDBG(8)) br##i = *(const uint4*)(wtap + bsrc[i]); else br##i = make_uint4(0,0,0,0); }
             SOS_BLOAD(0) SOS_BLOAD(1) SOS_BLOAD(2) SOS_BLOAD(3) SOS_BLOAD(4) SOS_BLOAD(5) SOS_BLOAD(6) SOS_BLOAD(7)
