@@ -276,6 +276,17 @@ int sos_resample_f32(const float* x, int64_t n_in, double ratio, const float* wi
  * the last i with k0[i] <= t.  Returns the number of segments (<= capacity) or a negative error. */
 int sos_resample_time_segments(double ratio, int64_t n_out, int64_t* k0, double* s0, double* d, int capacity);
 
+/* ---- 8f-1  audio-visual variant, video branch: Conv3dBlock M1/networks.py:54-77, make_video_branch :110-118
+ * (configuration :87-89), fusion :135-142.  A Conv3d with temporal stride 1 runs on sos_conv2d_fwd over a
+ * time-stacked input (temporal taps on the contraction axis).
+ * sos_time_stack: in bf16 [B*T][HW][nseg*in_cs] (C real channels per third) -> out [B*T][HW][nseg*out_cs] with
+ *   out channel dt*C + c = frame t + dt - (kt-1)/2, zeros outside the clip and in the padding (out_cs >= kt*C).
+ * sos_spatial_mean: torch.mean(f_v, dim=(-2,-1)) of N images into out[n*out_row + third*out_third + out_c_off + c]. */
+int sos_time_stack(const void* in, int64_t B, int T, int64_t HW, int C, int in_cs, int nseg, int kt, void* out,
+                   int out_cs, sos_stream_t stream);
+int sos_spatial_mean(const void* in, int64_t N, int64_t HW, int C, int in_cs, int nseg, void* out, int64_t out_row,
+                     int out_third, int out_c_off, sos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,8 @@ SIGNATURES = {
     "sos_pcm_to_mono_f32": [_P, _I, _I, _L, _P, _P],
     "sos_resample_f32": [_P, _L, _D, _P, _I, _I, _P, _L, _P],
     "sos_resample_time_segments": [_D, _L, _P, _P, _P, _I],
+    "sos_time_stack": [_P, _L, _I, _L, _I, _I, _I, _I, _P, _I, _P],
+    "sos_spatial_mean": [_P, _L, _L, _I, _I, _I, _P, _L, _I, _I, _P],
 }
 
 _lib = None

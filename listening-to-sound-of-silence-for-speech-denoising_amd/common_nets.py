@@ -34,6 +34,74 @@ def make_encoder(kernel_sizes, dilations, nf, outf):
     return nn.Sequential(*blocks)
 
 
+class Conv3dBlock(nn.Module):
+    """Parameter container of the reference's Conv3dBlock (M1/networks.py:54-77): block.0 = Conv3d(bias=False,
+    padding (k-1)//2 per axis, stride), block.1 = BatchNorm3d, block.2 = ReLU."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride):
+        super().__init__()
+        pad = tuple((k - 1) // 2 for k in kernel_size)
+        self.block = nn.Sequential(nn.Conv3d(in_channels, out_channels, kernel_size, stride, pad, bias=False),
+                                   nn.BatchNorm3d(out_channels), nn.ReLU())
+
+    def forward(self, x):
+        raise RuntimeError("Conv3dBlock is executed by its parent network through libsos_hip")
+
+
+VIDEO_KERNEL_SIZES = [(5, 7, 7), (5, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3), (1, 3, 3)]   # M1/networks.py:87
+VIDEO_STRIDES = [(1, 2, 2), (1, 1, 1), (1, 2, 2), (1, 2, 2), (1, 2, 2), (1, 3, 3), (1, 3, 3)]         # M1/networks.py:88
+
+
+def make_video_branch(kernel_sizes, strides, nf=256, outf=256):
+    """make_video_branch (M1/networks.py:110-118)."""
+    blocks = [Conv3dBlock(3 if i == 0 else nf, nf, k, s) for i, (k, s) in enumerate(zip(kernel_sizes, strides))]
+    blocks.append(Conv3dBlock(nf, outf, (1, 1, 1), (1, 1, 1)))
+    return nn.Sequential(*blocks)
+
+
+def video_plan(enc, x3):
+    """Per Conv3dBlock: the (O, I, kt, kh, kw) weight as a 2-D conv weight over the time-stacked input
+    (contraction index dt*I + i, csrc/video.hip), packed like every other conv weight; eval BatchNorm3d folded."""
+    plan = []
+    for blk in enc:
+        conv, bn = blk.block[0], blk.block[1]
+        kt, kh, kw = conv.kernel_size
+        if conv.stride[0] != 1 or conv.stride[1] != conv.stride[2] or conv.dilation != (1, 1, 1):
+            raise NotImplementedError("video branch: temporal stride 1, square spatial stride, no dilation")
+        O, I = conv.out_channels, conv.in_channels
+        w2 = conv.weight.detach().permute(0, 2, 1, 3, 4).reshape(O, kt * I, kh, kw)
+        cin_store = E.pad_to(kt * I, 16)
+        w = E.pack_weight(w2, cin_store, x3)
+        scale, shift = E.fold_bn(bn, w.shape[1])
+        plan.append(dict(w=w, scale=scale, shift=shift, kt=kt, kh=kh, kw=kw, stride=conv.stride[1], cin=I, cout=O,
+                         cin_store=cin_store, pad=(conv.padding[1], conv.padding[2])))
+    return plan
+
+
+def run_video_branch(plan, frames, B, T, feat, feat_row, feat_third, feat_c_off, x3):
+    """frames: Act [B*T, H, W, 16] (3 real channels).  Every block = time stack (kt > 1) + one 2-D conv with the
+    folded BN + ReLU epilogue; the last block's output is averaged over (H, W) into the feature matrix
+    feat[b][t][feat_c_off + c] (torch.mean(f_v, dim=(-2,-1)) + the channel concat, M1/networks.py:136,141)."""
+    dev = frames.t.device
+    cur, C = frames, 3
+    for lp in plan:
+        H, W = cur.H, cur.W
+        if lp["kt"] > 1 or cur.cs != lp["cin_store"]:
+            st = E.Act(B * T, H, W, lp["cin_store"], x3, dev)
+            L.check(L.lib().sos_time_stack(L.ptr(cur.t), B, T, H * W, C, cur.cs, cur.nseg, lp["kt"], L.ptr(st.t),
+                                           st.cs, L.stream_ptr()), "sos_time_stack")
+            cur = st
+        s = lp["stride"]
+        Ho = (H + 2 * lp["pad"][0] - lp["kh"]) // s + 1
+        Wo = (W + 2 * lp["pad"][1] - lp["kw"]) // s + 1
+        dst = E.Act(B * T, Ho, Wo, E.pad_to(lp["cout"], 16), x3, dev)
+        E.conv_to_act(cur, 0, lp["cin_store"], lp["w"], lp["kh"], lp["kw"], lp["cout"], lp["scale"], lp["shift"],
+                      L.ACT_RELU, dst, cout_store=dst.cs, stride=s, pad=lp["pad"], Ho=Ho, Wo=Wo)
+        cur, C = dst, lp["cout"]
+    L.check(L.lib().sos_spatial_mean(L.ptr(cur.t), B * T, cur.H * cur.W, C, cur.cs, cur.nseg, L.ptr(feat), feat_row,
+                                     feat_third, feat_c_off, L.stream_ptr()), "sos_spatial_mean")
+
+
 def encoder_plan(enc, x3):
     """Packed weights + folded eval BN for every block of an encoder stack."""
     plan = []

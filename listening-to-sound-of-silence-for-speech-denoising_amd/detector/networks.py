@@ -10,9 +10,10 @@ from .. import engine as E
 from .. import train_ops as TO
 
 
-def get_network():
-    """M1/networks.py:8-9."""
-    return AudioVisualNet()
+def get_network(video=False):
+    """M1/networks.py:8-9.  video=True: the audio-visual variant (the reference's commented-out video branch, :87-89,
+    :135-142, on its live Conv3dBlock / make_video_branch classes); inference only."""
+    return AudioVisualNet(video=video)
 
 
 class _TrainFn(torch.autograd.Function):
@@ -35,13 +36,16 @@ class _TrainFn(torch.autograd.Function):
 class AudioVisualNet(nn.Module):
     """M1/networks.py:80-155 (audio-only: the video branch is commented out in the reference)."""
 
-    def __init__(self, freq_bins=256, time_bins=178, nf=96):
+    def __init__(self, freq_bins=256, time_bins=178, nf=96, video=False):
         super().__init__()
         audio_kernel_sizes = [(1, 7), (7, 1)] + [(5, 5)] * 9
         audio_dilations = [(1, 1), (1, 1), (1, 1), (2, 1), (4, 1), (8, 1), (16, 1), (32, 1), (1, 1), (2, 2), (4, 4)]
         self.encoder_audio = CN.make_encoder(audio_kernel_sizes, audio_dilations, nf=48, outf=8)
-        self.lstm = nn.LSTM(input_size=8 * freq_bins, hidden_size=100, bidirectional=True)
+        self.video_feat = 256 if video else 0
+        self.lstm = nn.LSTM(input_size=8 * freq_bins + self.video_feat, hidden_size=100, bidirectional=True)
         self.fc1 = nn.Sequential(nn.Linear(200, 100), nn.ReLU(True), nn.Linear(100, 1))
+        if video:       # registered after fc1, like assigning it to the reference module after construction
+            self.encoder_video = CN.make_video_branch(CN.VIDEO_KERNEL_SIZES, CN.VIDEO_STRIDES, nf=128, outf=256)
         self.freq_bins = freq_bins
         self._cache = E.PlanCache()
         self._tcache = E.PlanCache()
@@ -50,7 +54,8 @@ class AudioVisualNet(nn.Module):
         x3 = E.is_x3()
         return dict(x3=x3,
                     enc=CN.encoder_plan(self.encoder_audio, x3),
-                    lstm=CN.lstm_plan(self.lstm, 8 * self.freq_bins, x3),
+                    vid=CN.video_plan(self.encoder_video, x3) if self.video_feat else None,
+                    lstm=CN.lstm_plan(self.lstm, 8 * self.freq_bins + self.video_feat, x3),
                     fc0=CN.linear_plan(self.fc1[0], E.pad_to(200, 16), x3),
                     fc2=CN.linear_plan(self.fc1[2], E.pad_to(100, 16), x3))
 
@@ -105,10 +110,20 @@ class AudioVisualNet(nn.Module):
         TO.encoder_backward(plan["enc"], tape["enc"], dy, grads, "encoder_audio", x3)
         return grads
 
-    def forward(self, s, v_num_frames=60):
-        L.require_cuda(s)
+    def forward(self, s, v_num_frames=60, v=None):
+        """s (B,2,F,T) -> logits (B, v_num_frames).  Audio-visual variant: v (B,3,Tv,H,W) video frames; the audio
+        features are resized to Tv frames (M1/networks.py:138) and v_num_frames is ignored."""
+        L.require_cuda(s, v)
         if s.dim() != 4 or s.shape[1] != 2 or s.shape[2] != self.freq_bins:
             raise ValueError(f"expected (B, 2, {self.freq_bins}, T) input, got {tuple(s.shape)}")
+        if self.video_feat:
+            if v is None or v.dim() != 5 or v.shape[0] != s.shape[0] or v.shape[1] != 3:
+                raise ValueError("the audio-visual variant needs video frames v of shape (B, 3, Tv, H, W)")
+            if self.training:
+                raise NotImplementedError("the video branch is built for inference only (no Conv3d backward kernels)")
+            v_num_frames = v.shape[2]
+        elif v is not None:
+            raise ValueError("this network was built without the video branch (get_network(video=True))")
         if self.training:
             return _TrainFn.apply(self, s.contiguous().float(), int(v_num_frames), *self.parameters())
         plan = self._cache.get(self, self._build_plan)
@@ -118,10 +133,14 @@ class AudioVisualNet(nn.Module):
         n = int(v_num_frames)
         a = E.pack_input(s, x3)
         nseg = 3 if x3 else 1
-        nfeat = 8 * F
+        nfeat = 8 * F + self.video_feat
         feat = torch.empty((B, n, nseg * nfeat), dtype=torch.bfloat16, device=dev)
         gather = CN.nearest_index(T, n, dev)
         CN.run_encoder(plan["enc"], a, feat, nseg * nfeat, nfeat, 0, x3, w_gather=gather, T_out=n)
+        if self.video_feat:
+            # frames as a batch of B*Tv images; the video features land next to the audio ones (channel concat)
+            frames = E.pack_input(v.float().permute(0, 2, 1, 3, 4).reshape(B * n, 3, v.shape[3], v.shape[4]), x3)
+            CN.run_video_branch(plan["vid"], frames, B, n, feat, nseg * nfeat, nfeat, 8 * F, x3)
         h = CN.run_lstm(plan["lstm"], (feat, B, 1, n, nfeat, nseg), B, n, x3, dev)
         f0, f2 = plan["fc0"], plan["fc2"]
         m = E.Act(B, 1, n, E.pad_to(f0["cout"], 16), x3, dev)

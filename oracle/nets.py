@@ -121,6 +121,37 @@ def joint_spec():
 
 
 # ------------------------------------------------------------- closed-form weights
+# ---- audio-visual variant: the video branch the reference keeps as commented-out configuration
+# (M1/networks.py:87-89 kernel sizes / strides, nf=128, outf=256) on its live classes Conv3dBlock (:54-77) and
+# make_video_branch (:110-118); fusion per the commented lines of forward (:135-142).
+VID_KERNELS = [(5, 7, 7), (5, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3), (1, 3, 3)]
+VID_STRIDES = [(1, 2, 2), (1, 1, 1), (1, 2, 2), (1, 2, 2), (1, 2, 2), (1, 3, 3), (1, 3, 3)]
+
+
+def _vid_spec(prefix, kernels, nf, outf):
+    out = []
+    cin = 3
+    for i, k in enumerate(kernels):
+        out.append((f"{prefix}.{i}.block.0.weight", (nf, cin, k[0], k[1], k[2]), "conv"))
+        out += _bn_spec(f"{prefix}.{i}.block.1", nf)
+        cin = nf
+    i = len(kernels)
+    out.append((f"{prefix}.{i}.block.0.weight", (outf, nf, 1, 1, 1), "conv"))
+    out += _bn_spec(f"{prefix}.{i}.block.1", outf)
+    return out
+
+
+def audiovisual_spec(freq_bins=256, nf=48, nf_v=128, outf_v=256):
+    """Registration order of the resurrected module: encoder_video is assigned after __init__ (so it follows fc1),
+    the LSTM takes 8*freq_bins + outf_v features."""
+    spec = _enc_spec("encoder_audio", DET_KERNELS, nf, 8)
+    spec += _lstm_spec("lstm", 8 * freq_bins + outf_v, 100)
+    spec += [("fc1.0.weight", (100, 200), "lin"), ("fc1.0.bias", (100,), "bias"),
+             ("fc1.2.weight", (1, 100), "lin"), ("fc1.2.bias", (1,), "bias")]
+    spec += _vid_spec("encoder_video", VID_KERNELS, nf_v, outf_v)
+    return spec
+
+
 def _hash_uniform(tensor_idx, n):
     """Deterministic, platform independent U(-1,1): splitmix64 finaliser on (idx, i)."""
     with np.errstate(over="ignore"):
@@ -142,7 +173,7 @@ def closed_form_state(spec, seed=0):
         n = int(np.prod(shape)) if len(shape) else 1
         u = _hash_uniform(idx + 1000 * seed, n)
         if kind == "conv":
-            fan_in = shape[1] * shape[2] * shape[3]
+            fan_in = int(np.prod(shape[1:]))
             v = u * np.sqrt(6.0 / fan_in)
         elif kind == "convT":
             # effective fan-in of the k3/s2 transposed conv is cin*k*k/4
@@ -265,6 +296,44 @@ def detector_forward(sd, s, v_num_frames=60, training=False, stats_out=None, dil
     m = torch.relu(linear(m, sd, "fc1.0"))
     m = linear(m, sd, "fc1.2")
     return m.squeeze(2)
+
+
+def conv3d_block(x, sd, prefix, stride):
+    """Conv3dBlock (M1/networks.py:54-77), eval mode: Conv3d(pad (k-1)//2 per axis, no bias) -> BatchNorm3d -> ReLU."""
+    w = sd[prefix + ".block.0.weight"]
+    pad = tuple((k - 1) // 2 for k in w.shape[2:])
+    y = F.conv3d(x, w, None, stride, pad)
+    bn = prefix + ".block.1"
+    inv = torch.rsqrt(sd[bn + ".running_var"] + BN_EPS) * sd[bn + ".weight"]
+    y = (y - sd[bn + ".running_mean"][None, :, None, None, None]) * inv[None, :, None, None, None] \
+        + sd[bn + ".bias"][None, :, None, None, None]
+    return torch.relu(y)
+
+
+def video_forward(sd, v, prefix="encoder_video", strides=None, taps=None):
+    """make_video_branch (M1/networks.py:110-118): v (B,3,T,H,W) -> (B,256,T,h,w).  `taps` collects block outputs."""
+    strides = VID_STRIDES if strides is None else strides
+    for i, st in enumerate(strides):
+        v = conv3d_block(v, sd, f"{prefix}.{i}", st)
+        if taps is not None:
+            taps.append(v)
+    v = conv3d_block(v, sd, f"{prefix}.{len(strides)}", (1, 1, 1))
+    if taps is not None:
+        taps.append(v)
+    return v
+
+
+def audiovisual_forward(sd, s, v):
+    """AudioVisualNet.forward with the commented fusion lines live (M1/networks.py:130-155): spatial mean of the
+    video features, audio features resized to the video frame count, channel concat, BiLSTM, FC head."""
+    f_s = encoder(s, sd, "encoder_audio", DET_DILATIONS, False)
+    f_s = f_s.reshape(f_s.shape[0], -1, f_s.shape[3])
+    f_v = video_forward(sd, v).mean(dim=(-2, -1))          # (B, 256, T2)
+    f_s = nearest_resize_last(f_s, f_v.shape[2])
+    m = torch.cat([f_s, f_v], dim=1).permute(2, 0, 1)
+    m = lstm_bidir(m, sd, "lstm").permute(1, 0, 2)
+    m = torch.relu(linear(m, sd, "fc1.0"))
+    return linear(m, sd, "fc1.2").squeeze(2)
 
 
 # ------------------------------------------------------------------------ denoiser

@@ -1,0 +1,111 @@
+"""Audio-visual variant: oracle vs the golden vectors produced by the reference's live
+Conv3dBlock / make_video_branch classes (tests/golden/make_goldens_av.py), and the HIP inference path vs both.
+Tolerances: oracle 1e-5; HIP bf16x3 1e-3 (north_star), plain bf16 5e-2 on the video features / logits."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as onet
+from util import hashed, rel_err, spec_input
+
+
+def video_input(idx, B, T, H, W):
+    """Same closed form as tests/golden/make_goldens_av.py."""
+    t = np.arange(T)[:, None, None]
+    y = np.arange(H)[None, :, None]
+    x = np.arange(W)[None, None, :]
+    base = 0.5 + 0.25 * np.sin(0.13 * x + 0.3 * t) * np.cos(0.09 * y - 0.2 * t)
+    u = hashed(idx, (B, 3, T, H, W))
+    v = base[None, None] * np.array([1.0, 0.8, 0.6])[None, :, None, None, None] + 0.2 * u
+    return torch.from_numpy(np.clip(v, 0.0, 1.0).astype(np.float32))
+
+
+def _inputs(g):
+    si, vi = g["s_idx"], g["v_idx"]
+    return spec_input(int(si[0]), int(si[1]), int(si[2])), video_input(int(vi[0]), int(vi[1]), int(vi[2]), int(vi[3]), int(vi[4]))
+
+
+def test_oracle_matches_reference_goldens(golden):
+    g = golden("audiovisual")
+    s, v = _inputs(g)
+    sd = onet.closed_form_state(onet.audiovisual_spec(), seed=5)
+    taps = []
+    with torch.no_grad():
+        f_v = onet.video_forward(sd, v, taps=taps).mean(dim=(-2, -1))
+        out = onet.audiovisual_forward(sd, s, v)
+    assert len(taps) == 8
+    for i, t in enumerate(taps):
+        assert tuple(t.shape) == tuple(g[f"shape{i}"])
+        assert rel_err(t[0, ::16, ::3], g[f"tap{i}"]) < 1e-5, i
+    assert rel_err(f_v, g["f_v"]) < 1e-5 and rel_err(out, g["logits"]) < 1e-5
+    assert out.shape == (1, 12)
+
+
+def test_state_dict_layout_of_the_variant():
+    from sos_amd.detector import networks as dnet
+    net = dnet.get_network(video=True)
+    sd = onet.closed_form_state(onet.audiovisual_spec(), seed=5)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    assert all(tuple(v.shape) == tuple(sd[k].shape) for k, v in net.state_dict().items())
+    net.load_state_dict(sd, strict=True)
+    assert net.lstm.input_size == 8 * 256 + 256
+    n_video = sum(p.numel() for p in net.encoder_video.parameters())
+    assert 2_700_000 < n_video < 2_850_000                      # 2.78 M parameters
+    audio_only = dnet.get_network()
+    assert not hasattr(audio_only, "encoder_video") and audio_only.lstm.input_size == 2048
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_hip_audiovisual_forward_matches_goldens(golden, precision):
+    import sos_amd
+    from sos_amd.detector import networks as dnet
+    g = golden("audiovisual")
+    s, v = _inputs(g)
+    net = dnet.get_network(video=True)
+    net.load_state_dict(onet.closed_form_state(onet.audiovisual_spec(), seed=5), strict=True)
+    net = net.cuda().eval()
+    sos_amd.set_precision(precision)
+    try:
+        with torch.no_grad():
+            out = net(s.cuda(), v=v.cuda())
+            out_b2 = net(torch.cat([s, s * 0.5]).cuda(), v=torch.cat([v, v.flip(2)]).cuda())
+    finally:
+        sos_amd.set_precision("bf16")
+    e = rel_err(out.cpu(), g["logits"])
+    print(precision, "audio-visual logits rel err", e)
+    assert out.shape == (1, 12) and e < (1e-3 if precision == "bf16x3" else 5e-2)
+    # clips of a batch are independent: the first clip of a batch of two equals the single-clip run
+    assert out_b2.shape == (2, 12) and rel_err(out_b2[0].cpu(), out[0].cpu()) < (2e-4 if precision == "bf16x3" else 2e-2)
+    with pytest.raises(ValueError):
+        net(s.cuda())                                    # the variant needs frames
+    with pytest.raises(NotImplementedError):
+        net.train()(s.cuda(), v=v.cuda())                # inference only
+    with pytest.raises(ValueError):
+        dnet.get_network().cuda().eval()(s.cuda(), v=v.cuda())
+
+
+@pytest.mark.gpu
+def test_hip_video_features_match_oracle_blockwise(golden):
+    """Block by block (bf16x3): every Conv3dBlock output of the HIP path against the oracle on the same input."""
+    import sos_amd
+    from sos_amd import _lib as L, common_nets as CN, engine as E
+    from sos_amd.detector import networks as dnet
+    g = golden("audiovisual")
+    _, v = _inputs(g)
+    sd = onet.closed_form_state(onet.audiovisual_spec(), seed=5)
+    net = dnet.get_network(video=True)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    B, Tv = v.shape[0], v.shape[2]
+    sos_amd.set_precision("bf16x3")
+    try:
+        plan = CN.video_plan(net.encoder_video, True)
+        feat = torch.zeros((B, Tv, 3 * 256), dtype=torch.bfloat16, device="cuda")
+        frames = E.pack_input(v.cuda().permute(0, 2, 1, 3, 4).reshape(B * Tv, 3, v.shape[3], v.shape[4]), True)
+        CN.run_video_branch(plan, frames, B, Tv, feat, 3 * 256, 256, 0, True)
+    finally:
+        sos_amd.set_precision("bf16")
+    f = feat.float().cpu().reshape(B, Tv, 3, 256)
+    fv = (f[:, :, 0] + f[:, :, 2]).permute(0, 2, 1)                     # hi + lo -> (B, 256, Tv)
+    assert rel_err(fv, g["f_v"]) < 1e-3
