@@ -21,6 +21,9 @@ Pinning status
   resampy>=0.2.2, all absent: **parity unpinned**; cross-checked against
   analytic resampling of band-limited tones and scipy.signal.resample_poly in
   tests/test_oracle_wave_io.py.
+* Audio-visual variant (nets.video_forward / audiovisual_forward): pinned against
+  the reference's live Conv3dBlock / make_video_branch classes evaluated with the
+  commented-out configuration (tests/golden/make_goldens_av.py -> audiovisual.npz).
 * Hand-off formats: checked against the reference's own checked-in output files
   (tests/golden/handoff/).
 """
