@@ -11,6 +11,10 @@ python bench.py --mode infer --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 
 python tools/conv_bench.py > $O/conv_bench.txt 2>&1
 python tools/wgrad_bench.py > $O/wgrad_bench.txt 2>&1
 python tools/lstm_bench.py > $O/lstm_bench.txt 2>&1
+python tools/bn_bench.py > $O/bn_bench.txt 2>&1
+python tools/wave_io_bench.py > $O/wave_io_bench.txt 2>&1
+python tools/latency_bench.py > $O/latency_bench.txt 2>&1
+python tools/av_bench.py > $O/av_bench.txt 2>&1
 export SOS_CONV_TUNE_FROZEN=1
 rocprofv3 --kernel-trace --stats -d $O/prof_train -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_train.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_infer -o t -- python bench.py --mode infer --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_infer.log 2>&1
