@@ -286,6 +286,12 @@ int sos_time_stack(const void* in, int64_t B, int T, int64_t HW, int C, int in_c
                    int out_cs, sos_stream_t stream);
 int sos_spatial_mean(const void* in, int64_t N, int64_t HW, int C, int in_cs, int nseg, void* out, int64_t out_row,
                      int out_third, int out_c_off, sos_stream_t stream);
+/* their transposes (autograd of the variant): gradient of the stacked tensor folded back onto the frames, and the
+ * gradient of the spatial mean broadcast over the HW pixels (hi|hi|lo thirds re-split in bf16x3 mode). */
+int sos_time_unstack(const void* d_stacked, int64_t B, int T, int64_t HW, int C, int st_cs, int nseg, int kt,
+                     void* d_in, int in_cs, sos_stream_t stream);
+int sos_spatial_mean_bwd(const void* dfeat, int64_t N, int64_t HW, int C, int64_t f_row, int f_third, int f_c_off,
+                         int nseg, void* dy, int cs, sos_stream_t stream);
 
 #ifdef __cplusplus
 }

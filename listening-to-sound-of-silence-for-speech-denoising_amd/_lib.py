@@ -90,6 +90,8 @@ SIGNATURES = {
     "sos_resample_time_segments": [_D, _L, _P, _P, _P, _I],
     "sos_time_stack": [_P, _L, _I, _L, _I, _I, _I, _I, _P, _I, _P],
     "sos_spatial_mean": [_P, _L, _L, _I, _I, _I, _P, _L, _I, _I, _P],
+    "sos_time_unstack": [_P, _L, _I, _L, _I, _I, _I, _I, _P, _I, _P],
+    "sos_spatial_mean_bwd": [_P, _L, _L, _I, _L, _I, _I, _I, _P, _I, _P],
 }
 
 _lib = None

@@ -281,7 +281,10 @@ class DetectorAgent(BaseAgent):
     def forward(self, data):
         label = data["label"].to(self.device)
         audio = data["audio"].to(self.device)
-        output = self.net(audio) if label.shape[1] == 60 else self.net(audio, label.shape[1])
+        if "frames" in data:            # audio-visual variant: batch dict carries the video frames (B,3,Tv,H,W)
+            output = self.net(audio, v=data["frames"].to(self.device))
+        else:
+            output = self.net(audio) if label.shape[1] == 60 else self.net(audio, label.shape[1])
         return output, {"bce": bce_with_logits_loss(output, label)}
 
 

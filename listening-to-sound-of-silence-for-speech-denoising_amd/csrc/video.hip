@@ -86,3 +86,83 @@ extern "C" int sos_spatial_mean(const void* in, int64_t N, int64_t HW, int C, in
                        out_third, out_c_off);
     return sos_check_launch("sos_spatial_mean");
 }
+
+// ---- backward of the two glue kernels (training of the variant)
+// d_in[bt][pix][c] = sum_dt d_st[bt - (dt - pt)][pix][dt*C + c] over the frames of the same clip (the transpose of
+// time_stack).  Gradients carry hi|hi|lo thirds in bf16x3 mode: terms are summed as hi + lo and re-split.
+__global__ void time_unstack_kernel(const bf16_t* __restrict__ dst_, int T, long long HW, int C, int st_cs, int nseg, int kt,
+                                    bf16_t* __restrict__ din, int in_cs, long long total) {
+    const int pt = (kt - 1) / 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % in_cs);
+        long long r = i / in_cs;
+        const long long pix = r % HW;
+        const long long bt = r / HW;
+        const int t = (int)(bt % T);
+        float acc = 0.f;
+        if (c < C) {
+            for (int dt = 0; dt < kt; ++dt) {
+                const int tf = t - dt + pt;                       // frame whose stacked copy holds this frame at tap dt
+                if (tf < 0 || tf >= T) continue;
+                const bf16_t* px = dst_ + ((bt - dt + pt) * HW + pix) * ((long long)nseg * st_cs) + dt * C + c;
+                acc += bf2f(px[0]);
+                if (nseg == 3) acc += bf2f(px[2 * st_cs]);
+            }
+        }
+        bf16_t* o = din + (bt * HW + pix) * ((long long)nseg * in_cs) + c;
+        const bf16_t hi = f2bf(acc);
+        o[0] = hi;
+        if (nseg == 3) { o[in_cs] = hi; o[2 * in_cs] = f2bf(acc - bf2f(hi)); }
+    }
+}
+
+extern "C" int sos_time_unstack(const void* d_stacked, int64_t B, int T, int64_t HW, int C, int st_cs, int nseg, int kt,
+                                void* d_in, int in_cs, sos_stream_t stream) {
+    if (!d_stacked || !d_in || B < 1 || T < 1 || HW < 1 || C < 1 || C > in_cs || (nseg != 1 && nseg != 3) || kt < 1 ||
+        !(kt & 1) || st_cs < kt * C) {
+        sos_set_error("sos_time_unstack: bad args");
+        return SOS_EINVAL;
+    }
+    const long long total = (long long)B * T * HW * in_cs;
+    long long grid = (total + 255) / 256;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(time_unstack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d_stacked, T,
+                       (long long)HW, C, st_cs, nseg, kt, (bf16_t*)d_in, in_cs, total);
+    return sos_check_launch("sos_time_unstack");
+}
+
+// dy[n][pix][c] = dfeat[n * f_row + f_c_off + c] / HW  (dfeat thirds f_third apart in bf16x3 mode); channels >= C zero
+__global__ void spatial_mean_bwd_kernel(const bf16_t* __restrict__ dfeat, long long N, long long HW, int C, long long f_row,
+                                        int f_third, int f_c_off, int nseg, bf16_t* __restrict__ dy, int cs) {
+    const long long total = N * HW * cs;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cs);
+        const long long r = i / cs;
+        const long long n = r / HW;
+        float v = 0.f;
+        if (c < C) {
+            const bf16_t* f = dfeat + n * f_row + f_c_off + c;
+            v = bf2f(f[0]);
+            if (nseg == 3) v += bf2f(f[2 * f_third]);
+            v /= (float)HW;
+        }
+        bf16_t* o = dy + r * ((long long)nseg * cs) + c;
+        const bf16_t hi = f2bf(v);
+        o[0] = hi;
+        if (nseg == 3) { o[cs] = hi; o[2 * cs] = f2bf(v - bf2f(hi)); }
+    }
+}
+
+extern "C" int sos_spatial_mean_bwd(const void* dfeat, int64_t N, int64_t HW, int C, int64_t f_row, int f_third, int f_c_off,
+                                    int nseg, void* dy, int cs, sos_stream_t stream) {
+    if (!dfeat || !dy || N < 1 || HW < 1 || C < 1 || C > cs || (nseg != 1 && nseg != 3)) {
+        sos_set_error("sos_spatial_mean_bwd: bad args");
+        return SOS_EINVAL;
+    }
+    const long long total = (long long)N * HW * cs;
+    long long grid = (total + 255) / 256;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dfeat,
+                       (long long)N, (long long)HW, C, (long long)f_row, f_third, f_c_off, nseg, (bf16_t*)dy, cs);
+    return sos_check_launch("sos_spatial_mean_bwd");
+}

@@ -12,7 +12,7 @@ from .. import train_ops as TO
 
 def get_network(video=False):
     """M1/networks.py:8-9.  video=True: the audio-visual variant (the reference's commented-out video branch, :87-89,
-    :135-142, on its live Conv3dBlock / make_video_branch classes); inference only."""
+    :135-142, on its live Conv3dBlock / make_video_branch classes)."""
     return AudioVisualNet(video=video)
 
 
@@ -21,8 +21,8 @@ class _TrainFn(torch.autograd.Function):
     hand-written HIP backward; the parameters are passed so autograd routes their gradients."""
 
     @staticmethod
-    def forward(ctx, net, s, n, *params):
-        out, tape = net._forward_train(s, n)
+    def forward(ctx, net, s, n, v, *params):
+        out, tape = net._forward_train(s, n, v)
         ctx.net, ctx.tape = net, tape
         return out
 
@@ -30,7 +30,7 @@ class _TrainFn(torch.autograd.Function):
     def backward(ctx, g):
         grads = ctx.net._backward(ctx.tape, g)
         ctx.tape = None
-        return (None, None, None) + tuple(grads[name].reshape(p.shape) for name, p in ctx.net.named_parameters())
+        return (None, None, None, None) + tuple(grads[name].reshape(p.shape) for name, p in ctx.net.named_parameters())
 
 
 class AudioVisualNet(nn.Module):
@@ -63,22 +63,27 @@ class AudioVisualNet(nn.Module):
     def _build_train_plan(self):
         x3 = E.is_x3()
         return dict(x3=x3, enc=TO.encoder_train_plan(self.encoder_audio, x3),
-                    lstm=TO.lstm_train_plan(self.lstm, 8 * self.freq_bins, x3),
+                    vid=TO.video_train_plan(self.encoder_video, x3) if self.video_feat else None,
+                    lstm=TO.lstm_train_plan(self.lstm, 8 * self.freq_bins + self.video_feat, x3),
                     fc0=TO.linear_train_plan(self.fc1[0], E.pad_to(200, 16), x3),
                     fc2=TO.linear_train_plan(self.fc1[2], E.pad_to(100, 16), x3))
 
-    def _forward_train(self, s, n):
+    def _forward_train(self, s, n, v=None):
         plan = self._tcache.get(self, self._build_train_plan)
         x3 = plan["x3"]
         dev = s.device
         B, _, F, T = s.shape
         nseg = 3 if x3 else 1
-        nfeat = 8 * F
+        nfeat = 8 * F + self.video_feat
         a = E.pack_input(s, x3)
         feat = torch.empty((B, n, nseg * nfeat), dtype=torch.bfloat16, device=dev)
         gather = CN.nearest_index(T, n, dev)
         fspec = dict(t=feat, row=nseg * nfeat, third=nfeat, c_off=0, H=F, W=T, Wo=n, gather=gather, x3=x3)
         tape_enc = TO.encoder_forward_train(plan["enc"], a, fspec, x3)
+        tape_vid = None
+        if self.video_feat:
+            frames = E.pack_input(v.float().permute(0, 2, 1, 3, 4).reshape(B * n, 3, v.shape[3], v.shape[4]), x3)
+            tape_vid = TO.video_forward_train(plan["vid"], frames, B, n, feat, nseg * nfeat, nfeat, 8 * F, x3)
         h, tape_lstm = TO.lstm_forward_train(plan["lstm"], (feat, B, 1, n, nfeat, nseg), B, n, x3, dev)
         f0, f2 = plan["fc0"], plan["fc2"]
         m = E.Act(B, 1, n, E.pad_to(f0["cout"], 16), x3, dev, zero=True)
@@ -87,7 +92,7 @@ class AudioVisualNet(nn.Module):
         out = torch.empty((B, n), dtype=torch.float32, device=dev)
         E.conv(m, 0, f2["cin_store"], f2["w"], 1, 1, 1, f2["scale"], f2["shift"], L.ACT_NONE, out=out,
                out_dtype=L.DT_F32, sb=n, sh=0, sw=1, sc=1, Ho=1, Wo=n)
-        tape = dict(plan=plan, enc=tape_enc, lstm=tape_lstm, h=h, m=m, gather=gather, dims=(B, F, T, n), x3=x3)
+        tape = dict(plan=plan, enc=tape_enc, vid=tape_vid, lstm=tape_lstm, h=h, m=m, gather=gather, dims=(B, F, T, n), x3=x3)
         return out, tape
 
     def _backward(self, tape, g):
@@ -105,9 +110,12 @@ class AudioVisualNet(nn.Module):
         dfeat = TO.lstm_backward(plan["lstm"], tape["lstm"], dh, grads, "lstm", B, n, x3, dev)
         lo, hi = TO.gather_ranges(tape["gather"].cpu().numpy(), T)
         nseg = 3 if x3 else 1
-        dy = TO.feat_grad_to_nhwc(dfeat, nseg * 8 * F, 8 * F, 0, 8, B, F, T, n, x3,
+        nfeat = 8 * F + self.video_feat
+        dy = TO.feat_grad_to_nhwc(dfeat, nseg * nfeat, nfeat, 0, 8, B, F, T, n, x3,
                                   torch.from_numpy(lo).to(dev), torch.from_numpy(hi).to(dev))
         TO.encoder_backward(plan["enc"], tape["enc"], dy, grads, "encoder_audio", x3)
+        if self.video_feat:
+            TO.video_backward(plan["vid"], tape["vid"], dfeat, nseg * nfeat, nfeat, 8 * F, grads, "encoder_video", B, n, x3)
         return grads
 
     def forward(self, s, v_num_frames=60, v=None):
@@ -119,13 +127,12 @@ class AudioVisualNet(nn.Module):
         if self.video_feat:
             if v is None or v.dim() != 5 or v.shape[0] != s.shape[0] or v.shape[1] != 3:
                 raise ValueError("the audio-visual variant needs video frames v of shape (B, 3, Tv, H, W)")
-            if self.training:
-                raise NotImplementedError("the video branch is built for inference only (no Conv3d backward kernels)")
             v_num_frames = v.shape[2]
         elif v is not None:
             raise ValueError("this network was built without the video branch (get_network(video=True))")
         if self.training:
-            return _TrainFn.apply(self, s.contiguous().float(), int(v_num_frames), *self.parameters())
+            return _TrainFn.apply(self, s.contiguous().float(), int(v_num_frames),
+                                  v.contiguous().float() if v is not None else None, *self.parameters())
         plan = self._cache.get(self, self._build_plan)
         x3 = plan["x3"]
         dev = s.device

@@ -140,6 +140,149 @@ def encoder_backward(plan, tape, dy, grads, prefix, x3, need_input_grad=False):
     return dy
 
 
+# ------------------------------------------------------------------ video branch (Conv3dBlock stack) of the audio-visual variant
+def _phase_dgrad_weights(w2, s, pad, cout_cs, x3):
+    """Data gradient of a zero-padded stride-s conv as s*s stride-1 convs over dy, one per input phase (rh, rw):
+    dx[s*j + r] = sum_m w[k0 + s*m] dy[j + c - m], k0 = (r + pad) % s, c = (r + pad - k0) / s  (per axis), i.e. a
+    correlation with the flipped sub-kernel g[m'] = w[k0 + s*(M-1-m')] and left padding (M-1) - c.
+    Returns {(rh, rw): (packed (I, O, Mh, Mw) weight, Mh, Mw, pad_h, pad_w)} (phases without taps are skipped:
+    their gradient is zero)."""
+    O, I, kh, kw = w2.shape
+    wt = w2.detach().float().transpose(0, 1)                       # (I, O, kh, kw)
+
+    def axis(r, k, p):
+        k0 = (r + p) % s
+        taps = list(range(k0, k, s))
+        c = (r + p - k0) // s
+        return taps, c
+
+    phases = {}
+    for rh in range(s):
+        th, ch = axis(rh, kh, pad[0])
+        for rw in range(s):
+            tw, cw = axis(rw, kw, pad[1])
+            if not th or not tw:
+                continue
+            sub = wt[:, :, th[::-1]][:, :, :, tw[::-1]].contiguous()
+            phases[(rh, rw)] = (E.pack_weight(sub, cout_cs, x3), len(th), len(tw), len(th) - 1 - ch, len(tw) - 1 - cw)
+    return phases
+
+
+def video_train_plan(enc, x3):
+    plan = []
+    for blk in enc:
+        conv, bn = blk.block[0], blk.block[1]
+        kt, kh, kw = conv.kernel_size
+        O, I, s = conv.out_channels, conv.in_channels, conv.stride[1]
+        w2 = conv.weight.detach().permute(0, 2, 1, 3, 4).reshape(O, kt * I, kh, kw)
+        cin_store = E.pad_to(kt * I, 16)
+        pad = (conv.padding[1], conv.padding[2])
+        lp = dict(w=E.pack_weight(w2, cin_store, x3), conv=conv, bn=bn, kt=kt, kh=kh, kw=kw, stride=s, pad=pad, cin=I,
+                  cout=O, cin_store=cin_store)
+        cout_cs = E.pad_to(O, 16)
+        if s == 1:
+            lp["wd"] = dgrad_weight(w2, x3)
+        else:
+            lp["wd_phases"] = _phase_dgrad_weights(w2, s, pad, cout_cs, x3)
+        plan.append(lp)
+    return plan
+
+
+def video_forward_train(plan, frames, B, T, feat, feat_row, feat_third, feat_c_off, x3):
+    """Training forward of the Conv3dBlock stack: time stack -> conv (raw) -> BatchNorm3d with batch statistics over
+    (B, T, H, W) -> ReLU; the spatial mean of the last block goes into the BiLSTM feature matrix."""
+    dev = frames.t.device
+    tape = []
+    cur, C = frames, 3
+    for lp in plan:
+        H, W = cur.H, cur.W
+        st = cur
+        if lp["kt"] > 1 or cur.cs != lp["cin_store"]:
+            st = E.Act(B * T, H, W, lp["cin_store"], x3, dev)
+            L.check(L.lib().sos_time_stack(L.ptr(cur.t), B, T, H * W, C, cur.cs, cur.nseg, lp["kt"], L.ptr(st.t), st.cs,
+                                           L.stream_ptr()), "sos_time_stack")
+        s = lp["stride"]
+        Ho = (H + 2 * lp["pad"][0] - lp["kh"]) // s + 1
+        Wo = (W + 2 * lp["pad"][1] - lp["kw"]) // s + 1
+        cs = E.pad_to(lp["cout"], 16)
+        one, zero = ones_zeros(lp["w"].shape[1], dev)
+        raw = E.Act(B * T, Ho, Wo, cs, x3, dev)
+        E.conv_to_act(st, 0, lp["cin_store"], lp["w"], lp["kh"], lp["kw"], lp["cout"], one, zero, L.ACT_NONE, raw,
+                      cout_store=cs, stride=s, pad=lp["pad"], Ho=Ho, Wo=Wo)
+        y = E.Act(B * T, Ho, Wo, cs, x3, dev, zero=cs > E.pad_to(lp["cout"], 8))
+        saved = E.bn_train(raw, 0, lp["cout"], lp["bn"], L.ACT_RELU, None, y, 0)
+        tape.append(dict(src=cur, src_C=C, stacked=st, raw=raw, saved=saved))
+        cur, C = y, lp["cout"]
+    L.check(L.lib().sos_spatial_mean(L.ptr(cur.t), B * T, cur.H * cur.W, C, cur.cs, cur.nseg, L.ptr(feat), feat_row,
+                                     feat_third, feat_c_off, L.stream_ptr()), "sos_spatial_mean")
+    return dict(blocks=tape, out=cur)
+
+
+def video_backward(plan, tape, dfeat, f_row, f_third, f_c_off, grads, prefix, B, T, x3):
+    """BPTT side of the video branch: d(features) -> spatial-mean backward -> per block BN/ReLU backward, weight
+    gradient against the time-stacked input (reshaped to the Conv3d weight), data gradient (flipped conv, or one conv
+    per input phase for the strided blocks) folded back onto the frames."""
+    dev = dfeat.device
+    last = tape["out"]
+    C = plan[-1]["cout"]
+    dy = E.Act(last.B, last.H, last.W, last.cs, x3, dev)
+    L.check(L.lib().sos_spatial_mean_bwd(L.ptr(dfeat), B * T, last.H * last.W, C, f_row, f_third, f_c_off, dy.nseg,
+                                         L.ptr(dy.t), dy.cs, L.stream_ptr()), "sos_spatial_mean_bwd")
+    for i in range(len(plan) - 1, -1, -1):
+        lp, tp = plan[i], tape["blocks"][i]
+        raw, st = tp["raw"], tp["stacked"]
+        d_raw = E.Act(raw.B, raw.H, raw.W, raw.cs, x3, dev, zero=raw.cs > E.pad_to(lp["cout"], 8))
+        dgamma, dbeta, _ = bn_bwd(dy, 0, raw, 0, lp["cout"], tp["saved"], lp["bn"].weight, L.ACT_RELU, None, d_raw)
+        grads[f"{prefix}.{i}.block.1.weight"], grads[f"{prefix}.{i}.block.1.bias"] = dgamma, dbeta
+        kt, I, O = lp["kt"], lp["cin"], lp["cout"]
+        dw2 = torch.empty((O, kt * I, lp["kh"], lp["kw"]), dtype=torch.float32, device=dev)
+        if lp["stride"] >= 3:
+            # stride 3 (the two smallest feature maps): the wgrad kernel's pixel tile would need a 9x patch; gather the
+            # pixels each tap touches (a strided view of the zero-padded input, layout plumbing) and run 1x1 wgrads
+            sd_, (ph_, pw_) = lp["stride"], lp["pad"]
+            xp = torch.nn.functional.pad(st.t, (0, 0, pw_, pw_ + sd_, ph_, ph_ + sd_))
+            for a in range(lp["kh"]):
+                for b_ in range(lp["kw"]):
+                    sub = E.Act(st.B, raw.H, raw.W, st.cs, x3, dev)
+                    sub.t.copy_(xp[:, a:a + sd_ * raw.H:sd_, b_:b_ + sd_ * raw.W:sd_, :])
+                    dwa = torch.empty((O, kt * I, 1, 1), dtype=torch.float32, device=dev)
+                    E.wgrad(d_raw, 0, O, sub, 0, kt * I, 1, 1, dwa)
+                    dw2[:, :, a:a + 1, b_:b_ + 1] = dwa
+        elif lp["kh"] * lp["kw"] <= 32:
+            E.wgrad(d_raw, 0, O, st, 0, kt * I, lp["kh"], lp["kw"], dw2, stride=lp["stride"], pad=lp["pad"])
+        else:       # 7x7: more taps than one wgrad workgroup holds -> one kernel row (1 x kw taps) per call
+            for a in range(lp["kh"]):
+                dwa = torch.empty((O, kt * I, 1, lp["kw"]), dtype=torch.float32, device=dev)
+                E.wgrad(d_raw, 0, O, st, 0, kt * I, 1, lp["kw"], dwa, stride=lp["stride"], pad=(lp["pad"][0] - a, lp["pad"][1]))
+                dw2[:, :, a:a + 1] = dwa
+        grads[f"{prefix}.{i}.block.0.weight"] = dw2.reshape(O, kt, I, lp["kh"], lp["kw"]).permute(0, 2, 1, 3, 4).contiguous()
+        if i == 0:
+            break
+        d_st = E.Act(st.B, st.H, st.W, st.cs, x3, dev, zero=lp["stride"] > 1 or st.cs > E.pad_to(kt * I, 8))
+        if lp["stride"] == 1:
+            one, zero = ones_zeros(lp["wd"].shape[1], dev)
+            E.conv_to_act(d_raw, 0, d_raw.cs, lp["wd"], lp["kh"], lp["kw"], kt * I, one, zero, L.ACT_NONE, d_st,
+                          cout_store=st.cs, pad=(lp["kh"] - 1 - lp["pad"][0], lp["kw"] - 1 - lp["pad"][1]), Ho=st.H, Wo=st.W)
+        else:
+            s = lp["stride"]
+            row = d_st.nseg * d_st.cs
+            for (rh, rw), (w, Mh, Mw, ph, pw) in lp["wd_phases"].items():
+                Hp, Wp = (st.H - rh + s - 1) // s, (st.W - rw + s - 1) // s
+                if Hp < 1 or Wp < 1:
+                    continue
+                one, zero = ones_zeros(w.shape[1], dev)
+                E.conv(d_raw, 0, d_raw.cs, w, Mh, Mw, kt * I, one, zero, L.ACT_NONE, out=d_st.t, out_dtype=d_st.dtype_code,
+                       sb=d_st.H * d_st.W * row, sh=s * d_st.W * row, sw=s * row, sc=1, cout_store=st.cs, third=d_st.cs,
+                       pad=(ph, pw), Ho=Hp, Wo=Wp, out_elem_offset=(rh * d_st.W + rw) * row)
+        src = tp["src"]
+        if st is src:                                    # 1x1x1 block on an unstacked input
+            dy = d_st
+        else:
+            dy = E.Act(src.B, src.H, src.W, src.cs, x3, dev)
+            L.check(L.lib().sos_time_unstack(L.ptr(d_st.t), B, T, src.H * src.W, tp["src_C"], d_st.cs, d_st.nseg, kt,
+                                             L.ptr(dy.t), dy.cs, L.stream_ptr()), "sos_time_unstack")
+
+
 def gather_ranges(gather_np, W):
     """For the nearest-resize gather i -> gather[i] (monotonic): [lo[w], hi[w]) = the i with gather[i] == w."""
     lo = np.searchsorted(gather_np, np.arange(W), side="left").astype(np.int32)

@@ -298,37 +298,36 @@ def detector_forward(sd, s, v_num_frames=60, training=False, stats_out=None, dil
     return m.squeeze(2)
 
 
-def conv3d_block(x, sd, prefix, stride):
-    """Conv3dBlock (M1/networks.py:54-77), eval mode: Conv3d(pad (k-1)//2 per axis, no bias) -> BatchNorm3d -> ReLU."""
+def conv3d_block(x, sd, prefix, stride, training=False, stats_out=None):
+    """Conv3dBlock (M1/networks.py:54-77): Conv3d(pad (k-1)//2 per axis, no bias) -> BatchNorm3d -> ReLU.
+    BatchNorm3d over (B, T, H, W) is BatchNorm2d of the tensor viewed as (B, C, T*H, W)."""
     w = sd[prefix + ".block.0.weight"]
     pad = tuple((k - 1) // 2 for k in w.shape[2:])
     y = F.conv3d(x, w, None, stride, pad)
-    bn = prefix + ".block.1"
-    inv = torch.rsqrt(sd[bn + ".running_var"] + BN_EPS) * sd[bn + ".weight"]
-    y = (y - sd[bn + ".running_mean"][None, :, None, None, None]) * inv[None, :, None, None, None] \
-        + sd[bn + ".bias"][None, :, None, None, None]
-    return torch.relu(y)
+    shp = y.shape
+    y = batch_norm(y.reshape(shp[0], shp[1], shp[2] * shp[3], shp[4]), sd, prefix + ".block.1", training, stats_out)
+    return torch.relu(y.reshape(shp))
 
 
-def video_forward(sd, v, prefix="encoder_video", strides=None, taps=None):
+def video_forward(sd, v, prefix="encoder_video", strides=None, taps=None, training=False, stats_out=None):
     """make_video_branch (M1/networks.py:110-118): v (B,3,T,H,W) -> (B,256,T,h,w).  `taps` collects block outputs."""
     strides = VID_STRIDES if strides is None else strides
     for i, st in enumerate(strides):
-        v = conv3d_block(v, sd, f"{prefix}.{i}", st)
+        v = conv3d_block(v, sd, f"{prefix}.{i}", st, training, stats_out)
         if taps is not None:
             taps.append(v)
-    v = conv3d_block(v, sd, f"{prefix}.{len(strides)}", (1, 1, 1))
+    v = conv3d_block(v, sd, f"{prefix}.{len(strides)}", (1, 1, 1), training, stats_out)
     if taps is not None:
         taps.append(v)
     return v
 
 
-def audiovisual_forward(sd, s, v):
+def audiovisual_forward(sd, s, v, training=False, stats_out=None):
     """AudioVisualNet.forward with the commented fusion lines live (M1/networks.py:130-155): spatial mean of the
     video features, audio features resized to the video frame count, channel concat, BiLSTM, FC head."""
-    f_s = encoder(s, sd, "encoder_audio", DET_DILATIONS, False)
+    f_s = encoder(s, sd, "encoder_audio", DET_DILATIONS, training, stats_out)
     f_s = f_s.reshape(f_s.shape[0], -1, f_s.shape[3])
-    f_v = video_forward(sd, v).mean(dim=(-2, -1))          # (B, 256, T2)
+    f_v = video_forward(sd, v, training=training, stats_out=stats_out).mean(dim=(-2, -1))          # (B, 256, T2)
     f_s = nearest_resize_last(f_s, f_v.shape[2])
     m = torch.cat([f_s, f_v], dim=1).permute(2, 0, 1)
     m = lstm_bidir(m, sd, "lstm").permute(1, 0, 2)

@@ -1,6 +1,7 @@
 """Audio-visual variant: oracle vs the golden vectors produced by the reference's live
-Conv3dBlock / make_video_branch classes (tests/golden/make_goldens_av.py), and the HIP inference path vs both.
-Tolerances: oracle 1e-5; HIP bf16x3 1e-3 (north_star), plain bf16 5e-2 on the video features / logits."""
+Conv3dBlock / make_video_branch classes and their autograd (tests/golden/make_goldens_av.py), and the HIP inference
+and training paths vs both.  Tolerances: oracle 1e-5; HIP bf16x3 1e-3 (north_star), plain bf16 5e-2 on the video
+features / logits; gradients as for the audio networks (tests/test_gpu_train_nets.py)."""
 import numpy as np
 import pytest
 import torch
@@ -79,8 +80,6 @@ def test_hip_audiovisual_forward_matches_goldens(golden, precision):
     assert out_b2.shape == (2, 12) and rel_err(out_b2[0].cpu(), out[0].cpu()) < (2e-4 if precision == "bf16x3" else 2e-2)
     with pytest.raises(ValueError):
         net(s.cuda())                                    # the variant needs frames
-    with pytest.raises(NotImplementedError):
-        net.train()(s.cuda(), v=v.cuda())                # inference only
     with pytest.raises(ValueError):
         dnet.get_network().cuda().eval()(s.cuda(), v=v.cuda())
 
@@ -109,3 +108,57 @@ def test_hip_video_features_match_oracle_blockwise(golden):
     f = feat.float().cpu().reshape(B, Tv, 3, 256)
     fv = (f[:, :, 0] + f[:, :, 2]).permute(0, 2, 1)                     # hi + lo -> (B, 256, Tv)
     assert rel_err(fv, g["f_v"]) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_hip_audiovisual_train_step_matches_reference_autograd(golden, precision):
+    """Train-mode forward (BatchNorm3d batch statistics), BCE loss and every parameter gradient of the variant against
+    the reference modules' autograd (goldens).  Tolerances as for the audio networks (tests/test_gpu_train_nets.py)."""
+    import sos_amd
+    from sos_amd import agent
+    from sos_amd.detector import networks as dnet
+    from test_gpu_train_nets import _check_grads
+    g = golden("audiovisual")
+    i_s, i_v, i_l, B, T, Tv, HW = [int(x) for x in g["train_idx"]]
+    s = spec_input(i_s, B, T)
+    v = video_input(i_v, B, Tv, HW, HW)
+    label = torch.from_numpy((hashed(i_l, (B, Tv)) > 0).astype(np.float32))
+    sos_amd.set_precision(precision)
+    try:
+        net = dnet.get_network(video=True)
+        net.load_state_dict(onet.closed_form_state(onet.audiovisual_spec(), seed=5), strict=True)
+        net = net.cuda().train()
+        out = net(s.cuda(), v=v.cuda())
+        loss = agent.bce_with_logits_loss(out, label.cuda())
+        loss.backward()
+        x3 = precision == "bf16x3"
+        e = rel_err(out.detach().cpu(), g["train_logits"])
+        print(precision, "train logits rel err", e, "loss", float(loss), "ref", float(g["train_loss"]))
+        assert e < (1e-3 if x3 else 0.1)
+        assert abs(float(loss) / float(g["train_loss"]) - 1) < (1e-3 if x3 else 5e-2)
+        worst = _check_grads(list(net.named_parameters()), g["train_gradnorm"], g["train_gradhead"], 3e-2 if x3 else 0.4, precision)
+        print(precision, "worst grad err", worst)
+        sd = net.state_dict()
+        assert rel_err(sd["encoder_video.7.block.1.running_mean"].cpu(), g["train_rm7"]) < (1e-3 if x3 else 5e-2)
+        assert rel_err(sd["encoder_video.0.block.1.running_var"].cpu(), g["train_rv0"]) < (1e-3 if x3 else 5e-2)
+        assert int(sd["encoder_video.3.block.1.num_batches_tracked"]) == 1
+    finally:
+        sos_amd.set_precision("bf16")
+
+
+@pytest.mark.gpu
+def test_agent_trains_the_variant_and_reduces_the_loss():
+    """DetectorAgent on a batch dict with `frames`: two Adam steps on the same batch lower the BCE loss."""
+    import sos_amd
+    from sos_amd import agent
+    from sos_amd.detector import networks as dnet
+    sos_amd.set_precision("bf16")
+    torch.manual_seed(0)
+    B, T, Tv = 2, 89, 8
+    batch = {"audio": spec_input(720, B, T).cuda(), "frames": video_input(721, B, Tv, 48, 48).cuda(),
+             "label": torch.from_numpy((hashed(722, (B, Tv)) > 0).astype(np.float32)).cuda()}
+    ag = agent.DetectorAgent(dnet.get_network(video=True), lr=1e-3)
+    losses = [float(ag.train_func(batch)[1]["bce"]) for _ in range(4)]
+    print("audio-visual agent losses", losses)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
