@@ -293,6 +293,25 @@ int sos_time_unstack(const void* d_stacked, int64_t B, int T, int64_t HW, int C,
 int sos_spatial_mean_bwd(const void* dfeat, int64_t N, int64_t HW, int C, int64_t f_row, int f_third, int f_c_off,
                          int nseg, void* dy, int cs, sos_stream_t stream);
 
+/* ---- 8f-4  objective measures of M2/metrics.py, the per-sample / per-frame work (finalisation = host code in
+ * sos_amd/metrics.py): f32 device signals, frames start = f*skip of `winlength` samples under `window` (f64[winlength]).
+ * sos_metric_totals      : out3 = {sum ref^2, sum (ref-deg)^2, max |ref|}            (overall SNR :97, silence threshold :192)
+ * sos_metric_frame_energy: out[f] = {sum (w c)^2, sum (w c - w p)^2}                (metrics_ssnr* :119-127)
+ * sos_metric_compact     : keeps, in order, the samples with |clean| >= thr         (metrics_ssnr_exclude_silence :189-199)
+ * sos_metric_llr         : out[f] = log(a_p R_c a_p' / a_c R_c a_c'), order-P LPC   (llr :561-623, lpcoeff :626-681)
+ * sos_metric_wss         : out[f] = weighted spectral slope distance, crit_filter f32 [25][n_fft/2]   (wss :404-558)
+ * sos_metric_l1          : mean |lerp(output)(linspace(0, n_out-1, n_t)) - target|  (metrics_L1 :40-45) */
+int sos_metric_totals(const float* ref, const float* deg, int64_t n, double* out3, sos_stream_t stream);
+int sos_metric_frame_energy(const float* ref, const float* deg, int64_t n, int winlength, int skip, int64_t num_frames,
+                            const double* window, double* out, sos_stream_t stream);
+int sos_metric_compact(const float* clean, const float* proc, int64_t n, float thr, float* out_clean, float* out_proc,
+                       int64_t* count, sos_stream_t stream);
+int sos_metric_llr(const float* ref, const float* deg, int64_t n, int winlength, int skip, int64_t num_frames,
+                   const double* window, int P, float* out, sos_stream_t stream);
+int sos_metric_wss(const float* ref, const float* deg, int64_t n, int winlength, int skip, int64_t num_frames,
+                   const double* window, int n_fft, const float* crit_filter, double eps, float* out, sos_stream_t stream);
+int sos_metric_l1(const float* output, int64_t n_out, const float* target, int64_t n_t, double* result, sos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

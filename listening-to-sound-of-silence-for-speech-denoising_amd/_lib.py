@@ -90,6 +90,12 @@ SIGNATURES = {
     "sos_resample_time_segments": [_D, _L, _P, _P, _P, _I],
     "sos_time_stack": [_P, _L, _I, _L, _I, _I, _I, _I, _P, _I, _P],
     "sos_spatial_mean": [_P, _L, _L, _I, _I, _I, _P, _L, _I, _I, _P],
+    "sos_metric_totals": [_P, _P, _L, _P, _P],
+    "sos_metric_frame_energy": [_P, _P, _L, _I, _I, _L, _P, _P, _P],
+    "sos_metric_compact": [_P, _P, _L, _F, _P, _P, _P, _P],
+    "sos_metric_llr": [_P, _P, _L, _I, _I, _L, _P, _I, _P, _P],
+    "sos_metric_wss": [_P, _P, _L, _I, _I, _L, _P, _I, _P, _D, _P, _P],
+    "sos_metric_l1": [_P, _L, _P, _L, _P, _P],
     "sos_time_unstack": [_P, _L, _I, _L, _I, _I, _I, _I, _P, _I, _P],
     "sos_spatial_mean_bwd": [_P, _L, _L, _I, _L, _I, _I, _I, _P, _I, _P],
 }

@@ -24,6 +24,8 @@ Pinning status
 * Audio-visual variant (nets.video_forward / audiovisual_forward): pinned against
   the reference's live Conv3dBlock / make_video_branch classes evaluated with the
   commented-out configuration (tests/golden/make_goldens_av.py -> audiovisual.npz).
+* Objective measures (oracle/metrics.py): pinned against the imported M2/metrics.py
+  functions (tests/golden/make_goldens_metrics.py -> metrics.npz); PESQ / STOI not restated.
 * Hand-off formats: checked against the reference's own checked-in output files
   (tests/golden/handoff/).
 """
