@@ -22,7 +22,7 @@ from operator import itemgetter
 import numpy as np
 import torch
 
-from . import audio_io, tools, transform
+from . import audio_io, metrics, tools, transform
 
 JSON_DUMP_PARAMS = dict(indent=4, sort_keys=False, ensure_ascii=False, separators=(',', ':'))   # M1/tools.py:36
 BITSTREAM_JSON_LABEL = 'bit_stream'            # M1/tools.py:54
@@ -220,12 +220,12 @@ def create_data_from_prediction(input_json, output_json=None, suffix="", noise_s
 # ------------------------------------------------------------------------------------------- JSON -> model 2
 def get_data_from_first_model(first_model_json_path, sr=DATA_REQUIRED_SR, snr=None, n_fft=510, hop_length=158,
                               win_length=400, unknown_clean_signal=True):
-    """M2/predict.py:255-374 for recordings without a clean reference: per file of pred_data.json load
-    `mixed_audio`, turn `recovered_prediction` into the sample mask, noise_sig = mixed * mask, STFT both.
-    Tensors stay in HBM: item['mixed'] / item['noise'] are (1, 2, 256, T) GPU tensors, item['mask'] a
-    (n_samples,) GPU tensor."""
-    if not unknown_clean_signal:
-        raise NotImplementedError("only the unknown_clean_signal=True path is built (no clean/full-noise files)")
+    """M2/predict.py:255-374: per file of pred_data.json load `mixed_audio`, turn `recovered_prediction` into the
+    sample mask, noise_sig = mixed * mask, STFT both.  With unknown_clean_signal=False the file entries also name
+    `clean_audio` and `full_noise` (written by the reference's create_data_from_pred.py with clean_audio=True): the
+    clean signal is silenced on the ground-truth silent intervals (:321) and both are transformed too.
+    Tensors stay in HBM: item['mixed'] / item['noise'] (/ 'clean' / 'full_noise') are (1, 2, 256, T) GPU tensors,
+    item['mask'] a (n_samples,) GPU tensor."""
     with open(first_model_json_path, 'r') as fp:
         obj = json.load(fp)
     snr = obj['snr']
@@ -243,22 +243,47 @@ def get_data_from_first_model(first_model_json_path, sr=DATA_REQUIRED_SR, snr=No
         bits = torch.tensor(vals, dtype=torch.uint8, device=mixed_sig.device).reshape(1, -1)
         mask, noise_sig = tools.bits_to_mask_batch(bits, float(sr) / data['framerate'], mixed_sig.numel(),
                                                    mixed_sig.reshape(1, -1))
-        data_list.append(OrderedDict([
-            ('id', os.path.splitext(os.path.basename(data['path']))[0]), ('path', data['path']),
-            ('mixed_audio_path', mixed_audio_path), ('bitstream', bitstream),
-            ('mixed', transform.stft_batch(mixed_sig.reshape(1, -1), n_fft, hop_length, win_length)),
-            ('noise', transform.stft_batch(noise_sig, n_fft, hop_length, win_length)),
-            ('mask', mask[0]), ('snr', snr), ('sr', sr)]))
+        item = OrderedDict([('id', os.path.splitext(os.path.basename(data['path']))[0]), ('path', data['path'])])
+        known = OrderedDict()
+        if not unknown_clean_signal:
+            clean_audio_path = os.path.join(get_parent_dir(first_model_json_path), data['clean_audio'])
+            full_noise_path = os.path.join(get_parent_dir(first_model_json_path), data['full_noise'])
+            clean_sig, _ = audio_io.load_device(clean_audio_path, sr=sr)
+            full_noise, _ = audio_io.load_device(full_noise_path, sr=sr)
+            gt = torch.tensor([0 if b == '0' else 1 for b in data[GT_BIT_STREAM_LABEL]], dtype=torch.uint8,
+                              device=clean_sig.device).reshape(1, -1)
+            gt_mask = tools.bits_to_mask_batch(gt, float(sr) / data['framerate'], clean_sig.numel())
+            clean_sig = clean_sig * (1 - gt_mask[0])             # silent intervals truly silent (M2/predict.py:321)
+            item['clean_audio_path'] = clean_audio_path
+            known['clean'] = transform.stft_batch(clean_sig.reshape(1, -1), n_fft, hop_length, win_length)
+            known['full_noise'] = transform.stft_batch(full_noise.reshape(1, -1), n_fft, hop_length, win_length)
+        item['mixed_audio_path'] = mixed_audio_path
+        if not unknown_clean_signal:
+            item['full_noise_path'] = full_noise_path
+        item['bitstream'] = bitstream
+        item['mixed'] = transform.stft_batch(mixed_sig.reshape(1, -1), n_fft, hop_length, win_length)
+        if 'clean' in known:
+            item['clean'] = known['clean']
+        item['noise'] = transform.stft_batch(noise_sig, n_fft, hop_length, win_length)
+        if 'full_noise' in known:
+            item['full_noise'] = known['full_noise']
+        item.update([('mask', mask[0]), ('snr', snr), ('sr', sr)])
+        data_list.append(item)
     info = OrderedDict([(k, obj[k]) for k in ('dataset_path', 'num_videos', 'data_total_frames', 'data_center_frames',
                                               'sigmoid_threshold')])
     return data_list, info
 
 
 @torch.no_grad()
-def denoise_files(net, data_list_info, outputs, snr=None, threshold="", save_individual_results=True, save_stat=True):
-    """M2/predict.py:377-576 (`evaluate`, unknown_clean_signal): net(mixed, noise) -> (pred_noise, mask);
-    mask applied to the mixed spectrogram; ISTFT of mixed / noise intervals / predicted noise / output written
-    as <outputs>/<snr suffix>/<id>/*.wav + stat.json, and <outputs>/eval_results<suffixes>.json."""
+def denoise_files(net, data_list_info, outputs, snr=None, threshold="", save_individual_results=True, save_stat=True,
+                  pesq_fn=None, stoi_fn=None):
+    """M2/predict.py:377-576 (`evaluate`): net(mixed, noise) -> (pred_noise, mask); mask applied to the mixed
+    spectrogram; ISTFT of mixed / noise intervals / predicted noise / output written as
+    <outputs>/<snr suffix>/<id>/*.wav + stat.json, and <outputs>/eval_results<suffixes>.json.  Items that carry a
+    `clean` spectrogram (unknown_clean_signal=False) also get the objective measures of the output resampled to
+    16 kHz against the clean signal (:455-460) and the ground-truth WAVE files; `pesq_fn(clean, output, sr)` /
+    `stoi_fn(clean, output, sr)` supply the two third-party scores (None entries otherwise) and the averages of the
+    available measures go to `denoise_statistics`."""
     data_list, data_info = data_list_info
     data_info = OrderedDict(data_info)
     data_info['snr'] = snr
@@ -268,9 +293,22 @@ def denoise_files(net, data_list_info, outputs, snr=None, threshold="", save_ind
         pred_noise_stft, crm = net(data['mixed'], data['noise'])
         out_stft = transform.batch_fast_icRM_sigmoid(data['mixed'], crm)
         sigs = transform.istft_batch(torch.cat([data['mixed'], data['noise'], pred_noise_stft, out_stft], dim=0))
-        info = OrderedDict([('id', str(data['id'])), ('path', str(data['path'])),
-                            ('mixed_audio_path', data['mixed_audio_path']), ('bitstream', data['bitstream']),
-                            ('sr', data['sr']), ('snr', data['snr'])])
+        known = 'clean' in data
+        info = OrderedDict([('id', str(data['id'])), ('path', str(data['path']))])
+        if known:
+            info['clean_audio_path'] = data['clean_audio_path']
+        info['mixed_audio_path'] = data['mixed_audio_path']
+        if known:
+            info['full_noise_path'] = data['full_noise_path']
+        info.update([('bitstream', data['bitstream']), ('sr', data['sr']), ('snr', data['snr'])])
+        gt_sigs = None
+        if known:
+            gt_sigs = transform.istft_batch(torch.cat([data['full_noise'], data['clean']], dim=0))
+            out16 = audio_io.resample_device(sigs[3].contiguous(), data['sr'], 16000)
+            clean16 = audio_io.resample_device(gt_sigs[1].contiguous(), data['sr'], 16000)
+            pesq = pesq_fn(clean16.cpu().numpy(), out16.cpu().numpy(), 16000) if pesq_fn is not None else None
+            stoi = stoi_fn(clean16.cpu().numpy(), out16.cpu().numpy(), 16000) if stoi_fn is not None else None
+            info.update(metrics.evaluate_metrics(out16, clean16, sr=16000, pesq=pesq, stoi=stoi))
         if save_individual_results:
             save_dir = os.path.join(os.path.abspath(outputs), convert_snr_to_suffix2(snr)[1:], str(data['id']))
             ensure_dir(save_dir)
@@ -279,10 +317,21 @@ def denoise_files(net, data_list_info, outputs, snr=None, threshold="", save_ind
                 p = os.path.join(save_dir, name + '.wav')
                 audio_io.write_wav(p, host[k], data['sr'])
                 info[name] = p
+            if known:
+                gh = gt_sigs.cpu().numpy()
+                for k, name in enumerate(('ground_truth_full_noise', 'ground_truth_clean_input')):
+                    p = os.path.join(save_dir, name + '.wav')
+                    audio_io.write_wav(p, gh[k][:host.shape[1]], data['sr'])
+                    info[name] = p
             with open(os.path.join(save_dir, 'stat.json'), 'w') as fp:
                 json.dump(info, fp, **JSON_DUMP_PARAMS)
         stat.append(info)
     if save_stat:
+        if stat and 'l1' in stat[0]:
+            keys = ('l1', 'stoi', 'csig', 'cbak', 'covl', 'pesq', 'ssnr_regular', 'ssnr_shift', 'ssnr_clip', 'ssnr_exsi', 'overall_snr')
+            data_info['denoise_statistics'] = OrderedDict(
+                ('avg_' + k, (sum(it[k] for it in stat) / len(stat)) if all(it[k] is not None for it in stat) else None)
+                for k in keys)
         data_info['files'] = stat
         ensure_dir(os.path.abspath(outputs))
         path = os.path.join(os.path.abspath(outputs), 'eval_results' + convert_threshold_to_suffix(threshold) +

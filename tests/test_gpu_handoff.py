@@ -135,3 +135,61 @@ def test_file_chain_through_handoff_formats(tmp_path):
             err = np.max(np.abs(y - want[name])) / np.max(np.abs(want[name]))
             print(info["id"], name, "rel err", err)
             assert err < 1e-3
+
+
+def test_known_clean_signal_path_reports_the_objective_measures(tmp_path):
+    """M2/predict.py with a clean reference (pred_data.json entries carrying clean_audio / full_noise): stat.json gets
+    the reference's metric keys in its order, the values equal the oracle measures of the written WAVE files, the
+    averages land in denoise_statistics."""
+    from oracle import metrics as om
+    from sos_amd import audio_io, handoff
+    from sos_amd.common import MyConfig
+    from sos_amd.denoiser import networks as jnet
+    root = tmp_path / "m1"
+    (root / "recovered").mkdir(parents=True)
+    rng = np.random.default_rng(9)
+    n, nfr = 14000 * 2, 60
+    t = np.arange(n) / 14000
+    clean = (0.3 * np.sin(2 * np.pi * 300 * t) * (0.2 + (np.sin(2 * np.pi * 1.3 * t) > -0.4)) + 0.003 * rng.standard_normal(n)).astype(np.float32)
+    noise = (0.05 * rng.standard_normal(n)).astype(np.float32)
+    for name, sig in (("c_clean", clean), ("c_full_noise", noise), ("c_mixed", clean + noise)):
+        audio_io.write_wav(str(root / "recovered" / (name + ".wav")), sig, 14000)
+    bits = "".join("1" if (i // 10) % 3 else "0" for i in range(nfr))
+    pd = dict(dataset_path="/a", num_videos=1, data_total_frames=60, data_center_frames=1, sigmoid_threshold=0.5, snr=10,
+              files=[dict(path="/a/c.wav", framerate=30, bit_stream="1" * nfr, recovered_prediction=bits,   # no forced-silent frames:
+                          # an all-zero clean frame has a singular LPC system (NaN LLR, in the reference too)
+                          mixed_audio="recovered/c_mixed.wav", clean_audio="recovered/c_clean.wav",
+                          full_noise="recovered/c_full_noise.wav")])
+    with open(root / "pred_data_snr10.json", "w") as fp:
+        json.dump(pd, fp)
+    jm = jnet.get_network(MyConfig())
+    jm.load_state_dict(onet.closed_form_state(onet.joint_spec(), seed=2))
+    jm = jm.cuda().eval()
+    dli = handoff.get_data_from_first_model(str(root / "pred_data_snr10.json"), sr=14000, unknown_clean_signal=False)
+    item = dli[0][0]
+    assert list(item)[:5] == ["id", "path", "clean_audio_path", "mixed_audio_path", "full_noise_path"]
+    assert {"clean", "full_noise", "mixed", "noise"} <= set(item)
+    out = str(tmp_path / "m2")
+    stat = handoff.denoise_files(jm, dli, out, snr=10, pesq_fn=lambda c, o, sr: 2.5)
+    info = stat[0]
+    assert list(info) == ["id", "path", "clean_audio_path", "mixed_audio_path", "full_noise_path", "bitstream", "sr", "snr",
+                          "l1", "stoi", "csig", "cbak", "covl", "pesq", "ssnr_regular", "ssnr_shift", "ssnr_clip", "ssnr_exsi",
+                          "overall_snr", "noisy_input", "noise_intervals", "predicted_full_noise", "denoised_output",
+                          "ground_truth_full_noise", "ground_truth_clean_input"]
+    assert info["pesq"] == 2.5 and info["stoi"] is None and 1 <= info["csig"] <= 5
+    assert os.path.dirname(info["denoised_output"]).endswith(os.path.join("snr10", "c"))
+    # the measures are those of the written files (oracle resampling + oracle measures)
+    _, y = scipy.io.wavfile.read(info["denoised_output"])
+    _, c = scipy.io.wavfile.read(info["ground_truth_clean_input"])
+    y16, c16 = owio.resample(y, 14000, 16000).astype(np.float32), owio.resample(c, 14000, 16000).astype(np.float32)
+    want = om.composite(c16, y16, 16000, eps=1e-20, pesq_raw=2.5)
+    assert abs(info["ssnr_clip"] - want["segSNR"]) < 1e-3 * abs(want["segSNR"]) + 1e-3
+    assert abs(info["overall_snr"] - want["overall_snr"]) < 1e-3 * abs(want["overall_snr"]) + 1e-3
+    assert abs(info["covl"] - want["covl"]) < 5e-3 and abs(info["cbak"] - want["cbak"]) < 5e-3
+    assert abs(info["ssnr_exsi"] - om.metrics_ssnr_exclude_silence(c16, y16, 16000, eps=1e-20)[1]) < 2e-2
+    assert abs(info["l1"] - om.metrics_L1(y16, c16)) < 1e-5
+    with open(os.path.join(out, "eval_results_snr10.json")) as fp:
+        ev = json.load(fp)
+    assert list(ev["denoise_statistics"]) == ["avg_l1", "avg_stoi", "avg_csig", "avg_cbak", "avg_covl", "avg_pesq", "avg_ssnr_regular",
+                                              "avg_ssnr_shift", "avg_ssnr_clip", "avg_ssnr_exsi", "avg_overall_snr"]
+    assert ev["denoise_statistics"]["avg_stoi"] is None and ev["denoise_statistics"]["avg_pesq"] == 2.5
