@@ -324,7 +324,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(ent), "+v"(av[0]), "+v"(bv[0]) : "n"(REST + 2 * (MT - 1)));
             if constexpr (BAL) { if (hasx) asm volatile("" : "+v"(avx), "+v"(bvx)); }   // ordered behind the wait above
             if (dma) st.issue(di, ent, onext, cur ^ 1);
-            const bool on0 = wave < npairs;
+            const bool on0 = BAL || wave < npairs;      // BAL: 25 pairs, every wave owns pair 0 (no per-MFMA branches)
             {
                 const bf16x8 bfr = __builtin_bit_cast(bf16x8, bv[0]);
                 if (on0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[0]), bfr, acc[0][0], 0, 0, 0);
