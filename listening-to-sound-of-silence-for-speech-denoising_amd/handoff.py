@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import audio_io, metrics, tools, transform
+from .dataset import add_signals
 
 JSON_DUMP_PARAMS = dict(indent=4, sort_keys=False, ensure_ascii=False, separators=(',', ':'))   # M1/tools.py:36
 BITSTREAM_JSON_LABEL = 'bit_stream'            # M1/tools.py:54
@@ -126,20 +127,57 @@ def _resolve(path, dataset_path, data_root):
 
 # ------------------------------------------------------------------------------------------- model 1 -> JSON
 @torch.no_grad()
-def detect_files(net, dataset_json, outputs, data_root=None, save_stat=True):
-    """Whole-file silent-interval detection of every file of a dataset JSON (`evaluate(..., clean_audio=False)`,
-    M1/predict.py:38-233 with the prediction-phase items of M1/tools.py:297-332 and M1/dataset.py:226-252):
-    one item per file, the whole recording at 14 kHz -> STFT -> net(s, v_num_frames=len(bits)) -> sigmoid ->
-    >= 0.5.  Returns the stat dict and writes <outputs>/eval_results.json."""
+def add_noise_to_audio(audio, noise, snr, start_pos=0, norm=0.5):
+    """M1/tools.py:846-869 with an explicit start position: crop (zero-pad) the noise to the audio, mix at `snr` dB,
+    peak-normalise to `norm` (add_signals, M1/tools.py = M2/tools.py:217-276).  numpy in, numpy out."""
+    crop = np.asarray(noise)[start_pos:start_pos + len(audio)]
+    if len(crop) < len(audio):
+        crop = np.concatenate((crop, np.zeros(len(audio) - len(crop), dtype=crop.dtype)))
+    return add_signals(np.asarray(audio), [crop], snr=snr, norm=norm)
+
+
+def detect_files(net, dataset_json, outputs, data_root=None, save_stat=True, noise_files=None, snr=None, seed=0):
+    """Whole-file silent-interval detection of every file of a dataset JSON (`evaluate`, M1/predict.py:38-233 with
+    the prediction-phase items of M1/tools.py:297-332 and M1/dataset.py:226-252): one item per file, the whole
+    recording at 14 kHz -> STFT -> net(s, v_num_frames=len(bits)) -> sigmoid -> >= 0.5.  Returns the stat dict and
+    writes <outputs>/eval_results<suffix>.json.
+    `noise_files` + `snr` select the clean-recordings branch (clean_audio=True): the recording is silenced on its
+    labelled silent intervals, a crop of a noise file is mixed in at `snr` dB (peak 0.5) before detection, and the
+    crop + its bookkeeping go to <outputs>/noise_snr<snr>/ (M1/predict.py:82-104) for create_data_from_prediction.
+    The reference draws noise file and crop from Python's `random` stream; here a seeded numpy generator does
+    (the draws themselves are not reproducible across the two)."""
     with open(dataset_json, 'r') as fp:
         ds = json.load(fp)
     net.eval()
     stat = []
+    clean_audio = noise_files is not None
+    if clean_audio and snr is None:
+        raise ValueError("the clean-recordings branch needs an snr")
+    suffix = convert_snr_to_suffix2(snr) if clean_audio else ''
+    rng = np.random.default_rng(seed)
+    noise_entries = OrderedDict()
     for data_id, f in enumerate(ds['files']):
         bits_full = f[BITSTREAM_JSON_LABEL]
         i1, i2 = _trim_unknown(bits_full)
         label = [str(int(b)) for b in bits_full[i1:i2]]
         snd, _ = audio_io.load_device(_resolve(f['audio_path'], ds.get('dataset_path'), data_root), sr=DATA_REQUIRED_SR)
+        if clean_audio:
+            gt = torch.tensor([int(b) for b in label], dtype=torch.uint8, device=snd.device).reshape(1, -1)
+            gmask = tools.bits_to_mask_batch(gt, float(DATA_REQUIRED_SR) / f['framerate'], snd.numel())
+            audio = (snd * (1 - gmask[0])).cpu().numpy()            # M1/dataset.py:247-249
+            noise, _ = audio_io.load(noise_files[int(rng.integers(len(noise_files)))], sr=DATA_REQUIRED_SR)
+            need = int(np.ceil(f['duration'])) * DATA_REQUIRED_SR
+            start = int(rng.integers(0, max(len(noise) - need, 0) + 1))
+            crop = noise[start:start + need]                        # M1/dataset.py:141-142
+            mixed, _, _ = add_noise_to_audio(audio, crop, snr, start_pos=int(i1 / f['framerate'] * DATA_REQUIRED_SR))
+            snd = torch.from_numpy(np.ascontiguousarray(mixed, dtype=np.float32)).to(snd.device)
+            base = os.path.basename(f['path'])
+            noise_name = base.split('.mp4')[0].split('.wav')[0] + '_noise.wav'
+            noise_dir = os.path.join(os.path.abspath(outputs), 'noise' + suffix)
+            ensure_dir(noise_dir)
+            audio_io.write_wav(os.path.join(noise_dir, noise_name), crop.astype(np.float32), DATA_REQUIRED_SR)
+            noise_entries[base] = OrderedDict([('audio', base.split('.mp4')[0].split('.wav')[0] + '.wav'),
+                                               ('noise', noise_name), ('snr', snr)])
         S = transform.stft_batch(snd.reshape(1, -1))
         logits = net(s=S, v_num_frames=len(label))
         pred, conf = tools.threshold_bits(logits, SIGMOID_THRESHOLD)
@@ -152,23 +190,28 @@ def detect_files(net, dataset_json, outputs, data_root=None, save_stat=True):
             ('confidence', [str(c) for c in conf[0].cpu().numpy()])]))
     stat_dict = OrderedDict([
         ('data_total_frames', CLIP_FRAMES), ('data_center_frames', SILENT_CONSECUTIVE_FRAMES),
-        ('sigmoid_threshold', SIGMOID_THRESHOLD), ('snr', None),
+        ('sigmoid_threshold', SIGMOID_THRESHOLD), ('snr', snr if clean_audio else None),
         ('prediction_statistics', OrderedDict([('all', show_metrics([b for it in stat for b in it['label']],
                                                                     [b for it in stat for b in it['pred_label']]))]))])
     stat_dict['data'] = sorted(stat, key=lambda x: np.mean([float(c) for c in x['confidence']]), reverse=True)
+    if clean_audio:
+        with open(os.path.join(os.path.abspath(outputs), 'noise' + suffix, suffix[1:] + '.json'), 'w') as fp:
+            json.dump(OrderedDict([('snrs', [snr]), ('files', noise_entries)]), fp, **JSON_DUMP_PARAMS)
     if save_stat:
         ensure_dir(os.path.abspath(outputs))
-        with open(os.path.join(os.path.abspath(outputs), 'eval_results.json'), 'w') as fp:
+        with open(os.path.join(os.path.abspath(outputs), 'eval_results' + suffix + '.json'), 'w') as fp:
             json.dump(stat_dict, fp, **JSON_DUMP_PARAMS)
     return stat_dict
 
 
 def create_data_from_prediction(input_json, output_json=None, suffix="", noise_snr=None, save_results=True,
-                                data_root=None):
-    """eval_results.json -> pred_data.json (`create_data_from_prediction_newtarget_bceloss_no_voting(...,
-    clean_audio=False)`, M1/create_data_from_pred.py:38-271): per file the ground-truth, predicted and
-    `recovered_prediction` bit streams; with save_results the 14 kHz signal is written to
-    recovered<suffix>/<name>_mixed.wav next to the JSON and referenced as `mixed_audio`."""
+                                data_root=None, clean_audio=False):
+    """eval_results.json -> pred_data.json (`create_data_from_prediction_newtarget_bceloss_no_voting`,
+    M1/create_data_from_pred.py:38-271): per file the ground-truth, predicted and `recovered_prediction` bit
+    streams; with save_results the 14 kHz signal is written to recovered<suffix>/<name>_mixed.wav next to the JSON and
+    referenced as `mixed_audio`.  clean_audio=True (:158-190): the recording is mixed with the noise crop that
+    detect_files stored (noise<nsuffix>/<nsuffix[1:]>.json) at its SNR, and `<name>_mixed / _clean / _full_noise.wav`
+    are written and referenced (`mixed_audio`, `clean_audio`, `full_noise`, `audio_path`)."""
     suffix = suffix or ""
     if output_json is None:
         output_json = os.path.join(get_parent_dir(input_json), 'pred_data.json')
@@ -206,8 +249,24 @@ def create_data_from_prediction(input_json, output_json=None, suffix="", noise_s
             snd, _ = audio_io.load(_resolve(wav_path, src_root, data_root), sr=DATA_REQUIRED_SR)
             filename = os.path.basename(wav_path).split('.wav')[0]
             mixed_path = os.path.join(save_dir, filename + '_mixed.wav')
-            audio_io.write_wav(mixed_path, snd, DATA_REQUIRED_SR)
-            item['mixed_audio'] = os.path.join(os.path.basename(save_dir), os.path.basename(mixed_path))
+            rel = lambda q: os.path.join(os.path.basename(save_dir), os.path.basename(q))     # noqa: E731
+            if clean_audio:
+                noise_dir = os.path.join(get_parent_dir(output_json), 'noise' + nsuffix)
+                with open(os.path.join(noise_dir, nsuffix[1:] + '.json'), 'r') as fpn:
+                    noise_files = json.load(fpn)['files']
+                entry = noise_files[os.path.basename(item['path'])]
+                noise, _ = audio_io.load(os.path.join(noise_dir, entry['noise']), sr=DATA_REQUIRED_SR)
+                mixed, clean, full_noise = add_noise_to_audio(snd, noise, entry['snr'], start_pos=0, norm=0.5)
+                clean_path = os.path.join(save_dir, filename + '_clean.wav')
+                full_noise_path = os.path.join(save_dir, filename + '_full_noise.wav')
+                audio_io.write_wav(mixed_path, mixed.astype(np.float32), DATA_REQUIRED_SR)
+                audio_io.write_wav(clean_path, clean.astype(np.float32), DATA_REQUIRED_SR)
+                audio_io.write_wav(full_noise_path, full_noise[0].astype(np.float32), DATA_REQUIRED_SR)
+                item['mixed_audio'], item['clean_audio'], item['full_noise'] = rel(mixed_path), rel(clean_path), rel(full_noise_path)
+                item['audio_path'] = clean_path
+            else:
+                audio_io.write_wav(mixed_path, snd, DATA_REQUIRED_SR)
+                item['mixed_audio'] = rel(mixed_path)
     hierarchy = OrderedDict([
         ('dataset_path', ds_path), ('num_videos', len(groups)), ('data_total_frames', obj['data_total_frames']),
         ('data_center_frames', obj['data_center_frames']), ('sigmoid_threshold', obj['sigmoid_threshold']),

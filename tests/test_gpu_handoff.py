@@ -193,3 +193,47 @@ def test_known_clean_signal_path_reports_the_objective_measures(tmp_path):
     assert list(ev["denoise_statistics"]) == ["avg_l1", "avg_stoi", "avg_csig", "avg_cbak", "avg_covl", "avg_pesq", "avg_ssnr_regular",
                                               "avg_ssnr_shift", "avg_ssnr_clip", "avg_ssnr_exsi", "avg_overall_snr"]
     assert ev["denoise_statistics"]["avg_stoi"] is None and ev["denoise_statistics"]["avg_pesq"] == 2.5
+
+
+def test_clean_recordings_branch_end_to_end(tmp_path):
+    """clean_audio=True end to end: detect_files mixes a stored noise crop into the (silenced) clean recording,
+    create_data_from_prediction writes <name>_mixed / _clean / _full_noise.wav with mixed = clean + full_noise at the
+    requested SNR and peak 0.5, and the model-2 stage reports the objective measures against the clean signal."""
+    from sos_amd import handoff
+    from sos_amd.common import MyConfig
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+    root = str(tmp_path / "ds")
+    files = _make_dataset(root)
+    rng = np.random.default_rng(21)
+    noise_path = os.path.join(root, "noise.wav")
+    scipy.io.wavfile.write(noise_path, 14000, (0.1 * rng.standard_normal(14000 * 6)).astype(np.float32))
+    det = dnet.get_network(); det.load_state_dict(onet.closed_form_state(onet.detector_spec(), seed=1))
+    jm = jnet.get_network(MyConfig()); jm.load_state_dict(onet.closed_form_state(onet.joint_spec(), seed=2))
+    det, jm = det.cuda().eval(), jm.cuda().eval()
+    out1 = str(tmp_path / "m1")
+    st = handoff.detect_files(det, os.path.join(root, "dataset.json"), out1, data_root=root, noise_files=[noise_path], snr=7)
+    assert st["snr"] == 7 and os.path.exists(os.path.join(out1, "eval_results_snr7.json"))
+    with open(os.path.join(out1, "noise_snr7", "snr7.json")) as fp:
+        nj = json.load(fp)
+    assert nj["snrs"] == [7] and set(nj["files"]) == {os.path.basename(f["path"]) for f in files}
+    assert all(os.path.exists(os.path.join(out1, "noise_snr7", v["noise"])) and v["snr"] == 7 for v in nj["files"].values())
+    pred_json = handoff.create_data_from_prediction(os.path.join(out1, "eval_results_snr7.json"), noise_snr=7, data_root=root,
+                                                    clean_audio=True)
+    assert os.path.basename(pred_json) == "pred_data_snr7.json"
+    with open(pred_json) as fp:
+        pd = json.load(fp)
+    assert pd["snr"] == 7
+    for pf in pd["files"]:
+        assert {"mixed_audio", "clean_audio", "full_noise", "audio_path"} <= set(pf) and pf["mixed_audio"].startswith("recovered_snr7/")
+        sig = {k: scipy.io.wavfile.read(os.path.join(out1, pf[k]))[1].astype(np.float64) for k in ("mixed_audio", "clean_audio", "full_noise")}
+        assert np.max(np.abs(sig["mixed_audio"] - sig["clean_audio"] - sig["full_noise"])) < 1e-6
+        assert abs(np.max(np.abs(sig["mixed_audio"])) - 0.5) < 1e-6
+        got_snr = 10 * np.log10(np.mean(sig["clean_audio"] ** 2) / np.mean(sig["full_noise"] ** 2))
+        assert abs(got_snr - 7) < 0.2                                  # the noise crop may be zero-padded at the tail
+    dli = handoff.get_data_from_first_model(pred_json, sr=14000, unknown_clean_signal=False)
+    stat = handoff.denoise_files(jm, dli, str(tmp_path / "m2"), snr=7)
+    assert len(stat) == 2 and all(np.isfinite(s["ssnr_regular"]) and s["pesq"] is None and "ground_truth_clean_input" in s for s in stat)
+    with open(os.path.join(str(tmp_path / "m2"), "eval_results_snr7.json")) as fp:
+        ev = json.load(fp)
+    assert ev["snr"] == 7 and ev["denoise_statistics"]["avg_l1"] > 0
