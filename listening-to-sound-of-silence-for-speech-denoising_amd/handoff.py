@@ -9,10 +9,12 @@ with the reference's scripts on the README's real-recording path (`--unknown_cle
                                                                      predicted_full_noise,denoised_output}.wav, stat.json, eval_results.json
 
 Same keys, key order, value types and JSON formatting as the reference writes (checked against the reference's
-own checked-in outputs in tests/golden/handoff/).  The synthetic-noise branch (clean_audio=True: needs the
-authors' noise corpora) and the PNG plots (cv2 / matplotlib) are not built; the `waveform` / `spectrum` keys are
-therefore absent from stat.json.  All signal work (decode, resample, STFT, networks, masks, ISTFT) runs on the GPU
-through audio_io / transform / tools; this module is the host-side bookkeeping around it."""
+own checked-in outputs in tests/golden/handoff/).  Both branches of the scripts are covered: real recordings
+(`--unknown_clean_signal true`) and clean recordings mixed with noise at an SNR (clean_audio=True: noise bookkeeping,
+`_mixed / _clean / _full_noise` WAVE files, objective measures in stat.json).  The PNG plots (cv2 / matplotlib) are
+not built; the `waveform` / `spectrum` keys are therefore absent from stat.json.  All signal work (decode, resample,
+STFT, networks, masks, ISTFT, measures) runs on the GPU through audio_io / transform / tools / metrics; this module is
+the host-side bookkeeping around it."""
 import json
 import os
 from collections import OrderedDict
