@@ -237,3 +237,35 @@ def test_clean_recordings_branch_end_to_end(tmp_path):
     with open(os.path.join(str(tmp_path / "m2"), "eval_results_snr7.json")) as fp:
         ev = json.load(fp)
     assert ev["snr"] == 7 and ev["denoise_statistics"]["avg_l1"] > 0
+
+
+def test_file_backed_dataloader_emits_the_reference_batch_dicts(tmp_path):
+    """get_dataloader(dataset_json=, noise_files=): clips cut from recordings as the reference cuts them, batch dicts of
+    M1/dataset.py:348-352 / M2/dataset.py:311-320 whose tensors are the oracle transforms of the mixed clips."""
+    from sos_amd import dataset
+    root = str(tmp_path / "ds")
+    files = _make_dataset(root)                                  # 3.2 s (44.1 kHz stereo) and 2.5 s (14 kHz mono)
+    rng = np.random.default_rng(3)
+    noise_path = os.path.join(root, "noise.wav")
+    scipy.io.wavfile.write(noise_path, 14000, (0.1 * rng.standard_normal(14000 * 5)).astype(np.float32))
+    dl = dataset.get_dataloader(dataset.PHASE_TESTING, batch_size=4, dataset_json=os.path.join(root, "dataset.json"),
+                                noise_files=[noise_path], data_root=root, model="denoiser", snr_idx=5)
+    batches = list(dl)
+    # 2 s windows every second: floor((3.2 - 2) / 1) + 1 = 2 clips of the first file, 1 of the second
+    assert len(dl) == 1 and len(batches) == 1 and batches[0]["mixed"].shape == (3, 2, 256, 178)
+    b = batches[0]
+    assert set(b) >= {"mixed", "clean", "noise", "full_noise", "mask", "start", "bitstream"} and b["start"] == [0, 14000, 0]
+    raw = b["_raw"]
+    assert raw["snr"] == [7, 7, 7] and all(abs(np.max(np.abs(m)) - 0.5) < 1e-6 for m in raw["mixed"])
+    for i in range(3):
+        bits = [int(c) for c in b["bitstream"][i]]
+        mask = ofe.convert_bitstreammask_to_audiomask(raw["mixed"][i], 14000 / 30.0, bits)
+        assert np.allclose(raw["clean"][i] * mask, 0)            # silenced before mixing
+        for key, sig in (("mixed", raw["mixed"][i]), ("noise", raw["mixed"][i] * mask), ("full_noise", raw["full_noise"][i])):
+            S = ofe.fast_stft(sig).transpose(2, 0, 1)
+            assert np.max(np.abs(b[key][i].cpu().numpy() - S)) < 1e-4 * np.max(np.abs(S)) + 1e-6, key
+    det = dataset.get_dataloader(dataset.PHASE_TRAINING, batch_size=8, dataset_json=os.path.join(root, "dataset.json"),
+                                 noise_files=[noise_path], data_root=root, model="detector")
+    db = next(iter(det))
+    # 60-frame windows every 30 frames: 96 frames -> 2 windows, 75 frames -> 1
+    assert db["audio"].shape == (3, 2, 256, 178) and db["label"].shape == (3, 60) and set(db["label"].unique().tolist()) <= {0.0, 1.0}
