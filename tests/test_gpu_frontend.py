@@ -112,3 +112,25 @@ def test_threshold_bits():
     bits, conf = tools.threshold_bits(lg)
     assert bits.cpu().tolist() == [[0, 0, 1, 1, 1]]
     assert rel_err(conf.cpu().numpy(), torch.sigmoid(lg.cpu()).numpy()) < 1e-6
+
+
+def test_bits_to_mask_randomised_bit_exact():
+    """Integer work is bit-exact: 40 seeded random cases over frame counts, sample rates / frame rates (non-integer
+    samples per frame) and signal lengths that do not match the bit stream, incl. isolated single bits and tails."""
+    from sos_amd import tools
+    rng = np.random.default_rng(2024)
+    ratios = [14000 / 30.0, 16000 / 25.0, 44100 / 29.97, 8000 / 24.0, 14000 / 60.0, 22050 / 30.0]
+    for case in range(40):
+        nfr = int(rng.integers(1, 700))
+        ratio = ratios[case % len(ratios)]
+        p_flip = [0.02, 0.2, 0.5][case % 3]
+        bits = np.zeros(nfr, dtype=np.uint8)
+        cur = int(rng.integers(0, 2))
+        for i in range(nfr):                       # runs with occasional isolated frames
+            if rng.random() < p_flip:
+                cur ^= 1
+            bits[i] = cur
+        n = max(8, int(nfr * ratio) + int(rng.integers(-300, 300)))
+        want = ofe.convert_bitstreammask_to_audiomask(np.zeros(n, np.float32), ratio, list(bits))
+        got = tools.bits_to_mask_batch(torch.from_numpy(bits[None]).cuda(), ratio, n)[0].cpu().numpy()
+        assert np.array_equal(got, want), (case, nfr, ratio, n)
