@@ -48,6 +48,7 @@ struct WgParams {
     int bufbytes;             // bytes of one LDS operand buffer (multiple of 1 KB)
     int dbuf;                 // two operand buffers: the next tile is fetched while this one is multiplied
     int dbg;                  // SOS_WGRAD_DBG ablation mask (0 in production)
+    int ny, nz, xcdmap;       // m-groups / n-groups of the 1-D grid (wgrad_kernel), XCD-aware id mapping on/off
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -228,8 +229,23 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int split = blockIdx.x;
-    const int m0 = blockIdx.y * (MT * 32), n0 = blockIdx.z * (NTB * 32);
+    // 1-D grid, XCD aware: workgroups go to the 8 XCDs round robin by their linear id, and every XCD has its own L2.
+    // The (m-group, n-group) workgroups of ONE pixel split read the same G / X tiles at the same time, so they are
+    // given ids that are congruent mod 8: the tile is fetched from HBM once per XCD instead of once per workgroup
+    // (96->96: G was read three times, 2.55 GB -> 1.43 GB per launch).
+    // (used when the splits are a multiple of 8 and an XCD's 32 CUs hold all its workgroups at once: p.xcdmap)
+    const int nyz = p.ny * p.nz;
+    const int lin = blockIdx.x;
+    int split, yz;
+    if (p.xcdmap) {
+        const int xcd = lin & 7, slot = lin >> 3;
+        yz = slot % nyz;
+        split = (slot / nyz) * 8 + xcd;
+    } else {
+        split = lin % p.ksplit;
+        yz = lin / p.ksplit;
+    }
+    const int m0 = (yz / p.nz) * (MT * 32), n0 = (yz % p.nz) * (NTB * 32);
     const int taps = p.kh * p.kw;
     const int npairs = taps * NTB;
     constexpr int NP = BAL ? 3 : WG_PAIRS;                      // full (tap, n-tile) pairs per wave
@@ -702,7 +718,23 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     if (ksplit > p.nsteps) ksplit = p.nsteps;                            // never an empty split
     p.ksplit = ksplit;
     p.steps_per_split = (p.nsteps + ksplit - 1) / ksplit;
-    dim3 grid((unsigned)ksplit, (unsigned)mgroups, (unsigned)((ntiles_n + ntb - 1) / ntb));
+    p.ny = mgroups; p.nz = (ntiles_n + ntb - 1) / ntb;
+    p.xcdmap = 0;
+    if (!use16 && d->ksplit <= 0 && p.ny * p.nz > 1 && p.ny * p.nz <= 16 && !getenv("SOS_WGRAD_NOXCD")) {
+        // one workgroup per CU: an XCD (32 CUs) takes floor(32 / groups) splits, all groups of a split on one XCD
+        const int per_xcd = 32 / (p.ny * p.nz);
+        int ks8 = 8 * per_xcd;
+        if (ks8 > p.nsteps) ks8 = p.nsteps / 8 * 8;
+        const int cap = wg_max_split(d) / 8 * 8;
+        if (ks8 > cap) ks8 = cap;
+        if (ks8 >= 8 && ks8 * 100 >= ksplit * 93) {        // only if (almost) as many workgroups as one per CU remain
+            ksplit = ks8;
+            p.ksplit = ksplit;
+            p.steps_per_split = (p.nsteps + ksplit - 1) / ksplit;
+            p.xcdmap = 1;
+        }
+    }
+    dim3 grid((unsigned)(ksplit * p.ny * p.nz), 1, 1);                       // see the id mapping in wgrad_kernel
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
     if (use16) grid = dim3((unsigned)ksplit, 1, 1);
