@@ -719,15 +719,15 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + in_b * p.in_cs), 0, (unsigned)(p.H * p.W * p.in_cs) * 2u, 0x00020000);
     build_pixel_table(p, pixtab, tid, hin0, win0, rw0);
     __syncthreads();
-    stage_patch_dma<CPR, false>(p, patch, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc,
+    if (!CDBG(1)) stage_patch_dma<CPR, false>(p, patch, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc,
                                 (unsigned)(p.cin_off * 2));
-    dma_window(0, 0);
+    if (!CDBG(8)) dma_window(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's patch pieces have landed
     __syncthreads();
 
     for (int w = 0; w < nwin; ++w) {
         const int cur = SB ? 0 : (w & 1);
-        if constexpr (!SB) { if (w + 1 < nwin) dma_window(w + 1, cur ^ 1); }       // next window's slab (lands while the MFMAs run)
+        if constexpr (!SB) { if (w + 1 < nwin && !CDBG(8)) dma_window(w + 1, cur ^ 1); }       // next window's slab (lands while the MFMAs run)
         __builtin_amdgcn_sched_barrier(0);
         const int t0 = 2 * w, t1 = min(2 * w + 1, ntaps - 1);
         const int toff0 = ((t0 / p.kw) * p.PW + (t0 % p.kw)) * PSTRIDE;
@@ -758,12 +758,13 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
             // single buffer: refilled behind a barrier; the DMA's latency is covered by the two other workgroups of the
             // CU, and the LDS pipe is spared the ds_write_b128s of a register path (48->48 5x5: 0.356 -> 0.340 ms)
             __syncthreads();
-            if (w + 1 < nwin) dma_window(w + 1, 0);
+            if (w + 1 < nwin && !CDBG(8)) dma_window(w + 1, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
+    if (CDBG(4)) return;
     // ---- epilogue: D[m = cout][n = pixel]: lane = pixel + 16 * (cout / 4), register = cout % 4
     const float slope = (p.act == SOS_ACT_PRELU && p.slope) ? p.slope[0] : 0.f;
     const bool partial = ROWS > p.cout, sig = p.act == SOS_ACT_SIGMOID;
