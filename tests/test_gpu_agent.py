@@ -204,3 +204,28 @@ def test_detector_learns_the_synthetic_task():
     base = float(max(test["label"].mean(), 1 - test["label"].mean()))
     print("detector losses", [round(x, 3) for x in losses[::5]], "val accuracy", acc, "majority", base)
     assert np.mean(losses[-5:]) < 0.8 * np.mean(losses[:5]) and acc > base + 0.02
+
+
+def test_denoiser_learns_the_synthetic_task():
+    """60 Adam steps on fresh synthetic batches lower both MSE terms of the two-stage denoiser, and the masked output of
+    a held-out batch ends up closer to the clean spectrogram than the noisy input is."""
+    import sos_amd
+    from sos_amd import agent, transform
+    from sos_amd.common import MyConfig
+    from sos_amd.dataset import make_batch
+    from sos_amd.denoiser import networks as jnet
+    sos_amd.set_precision("bf16")
+    torch.manual_seed(0)
+    ag = agent.DenoiserAgent(jnet.get_network(MyConfig()), lr=1e-3)
+    l1, l2 = [], []
+    for it in range(60):
+        _, ls = ag.train_func(make_batch("denoiser", 7000 + 8 * it, 8))
+        l1.append(float(ls["stage1"].detach())); l2.append(float(ls["stage2"].detach()))
+    test = make_batch("denoiser", 95000, 16)
+    (n_pred, crm), _ = ag.val_func(test)
+    rec = transform.batch_fast_icRM_sigmoid(test["mixed"], crm)
+    err_out = float(((rec - test["clean"]) ** 2).mean())
+    err_in = float(((test["mixed"] - test["clean"]) ** 2).mean())
+    print("denoiser stage1", [round(x, 4) for x in l1[::10]], "stage2", [round(x, 4) for x in l2[::10]], "val MSE out/in", err_out, err_in)
+    assert np.mean(l1[-5:]) < 0.8 * np.mean(l1[:5]) and np.mean(l2[-5:]) < 0.8 * np.mean(l2[:5])
+    assert err_out < err_in
