@@ -34,6 +34,10 @@ enum { SOS_DT_BF16 = 0, SOS_DT_BF16X3 = 1, SOS_DT_F32 = 2 };
 
 int sos_abi_version(void);
 const char* sos_last_error(void);
+/* The package builds this ABI twice from the same sources: libsos_hip.so computes on bfloat16 storage ("bf16"),
+ * libsos_hip_f16.so on IEEE half ("fp16", same MFMA rate, 11 instead of 8 significand bits).  Wherever this header
+ * says "bf16" for an activation / packed-weight buffer it means "the library's 16-bit storage type". */
+const char* sos_storage_dtype(void);
 
 /* ---- a1  fast_stft: M1/transform.py:188-193 (librosa.stft(data,510,158,400),
  * hann-periodic window centred in n_fft, center=True, reflect pad) fused with
@@ -83,7 +87,8 @@ int sos_threshold_bits(const float* logits, int64_t n, float threshold, uint8_t*
  * [B][H][W][cs] (channels >= C zero filled; SOS_DT_BF16X3 writes hi|hi|lo thirds
  * of width cs/3). */
 int sos_pack_nchw_to_nhwc(const float* in, int64_t B, int C, int64_t H, int64_t W, void* out, int cs,
-                          int dtype, sos_stream_t stream);
+                          int dtype, const float* mul /* optional device scalar multiplied in (loss scale) */,
+                          sos_stream_t stream);
 
 /* ---- a6,a8,a9 (+ a7/a10/a11 heads): Conv2d (zero or reflect pad, stride,
  * dilation) / ConvTranspose2d phases / Linear, fused with folded BatchNorm or bias
@@ -212,6 +217,7 @@ typedef struct sos_wgrad_desc {
     float* dw;
     int32_t accumulate;     /* 0: dw = result, 1: dw += result */
     float scale;
+    const float* scale_dev; /* optional device scalar multiplied into `scale` (1 / loss scale of the fp16 mode) */
 } sos_wgrad_desc;
 int64_t sos_wgrad_workspace_bytes(const sos_wgrad_desc* desc);
 int sos_conv2d_wgrad(const sos_wgrad_desc* desc, sos_stream_t stream);
@@ -223,13 +229,16 @@ int sos_conv2d_wgrad(const sos_wgrad_desc* desc, sos_stream_t stream);
  * (or the bias gradient), dslope[0] (PReLU) and dx = grad of the raw conv output. */
 int sos_bn_bwd(const sos_view* dy, const sos_view* x, const float* scale, const float* shift, const float* mean,
                const float* invstd, const float* gamma, int act, const float* slope, float* partial, float* coef,
-               float* dgamma, float* dbeta, float* dslope, const sos_view* dx, sos_stream_t stream);
+               float* dgamma, float* dbeta, float* dslope, const sos_view* dx,
+               const float* out_scale /* optional device scalar: dgamma, dbeta, dslope are multiplied by it */,
+               sos_stream_t stream);
 /* dz = dy * act'(y) from the stored OUTPUT y (Linear+ReLU / Linear+Sigmoid heads). */
 int sos_act_bwd_from_y(const sos_view* dy, const sos_view* y, int act, const sos_view* dz, sos_stream_t stream);
 /* f32 strided gradient (x sigmoid'(y) if act == SOS_ACT_SIGMOID) -> bf16 rows: element (o,t,c) read at
  * g[o*so + t*st + c*sc], written to row o*inner+t, channel c of `out`. */
 int sos_pack_grad_f32(const float* g, const float* y, int act, int64_t outer, int64_t inner, int C, int64_t so,
-                      int64_t st, int64_t sc, const sos_view* out, sos_stream_t stream);
+                      int64_t st, int64_t sc, const sos_view* out, const float* mul /* optional device scalar */,
+                      sos_stream_t stream);
 /* gradient of the LSTM feature matrix back to NHWC (inverse of the feature form of sos_bn_act_apply):
  * out[b][h][w][c] = sum_{i in [lo[w],hi[w])} feat[b][i][(feat.c_off+c)*H + h]  (lo/hi NULL: i == w). */
 int sos_feat_to_nhwc(const sos_view* feat, int B, int H, int W, int Wo, const int32_t* lo, const int32_t* hi,
@@ -246,6 +255,16 @@ int sos_mse_loss(const float* a, const float* b, int64_t n, float upstream, floa
                  sos_stream_t stream);
 int sos_bce_logits_loss(const float* x, const float* y, int64_t n, float upstream, float* loss, float* grad,
                         float* partial, sos_stream_t stream);
+/* ---- loss scale of the fp16 storage mode (the reference trains in fp32, M2/agent.py:101-106; half precision needs
+ * the gradients of the activations moved into its exponent range).  The scale is a power of two chosen ON THE DEVICE
+ * from the gradient entering the hand-written backward, so no host synchronisation: sos_amax_f32 folds max|g| into
+ * *amax (caller zeroes it; several tensors may be folded), sos_loss_scale writes scale2 = {S, 1/S} with
+ * S = 2^floor(log2(target / amax)) clamped to [2^-40, 2^40] (S = 1 when amax is 0 or not finite).  The backward multiplies S in
+ * where f32 gradients become 16-bit (sos_pack_grad_f32 / sos_pack_nchw_to_nhwc `mul`) and 1/S where parameter
+ * gradients leave (sos_wgrad_desc.scale_dev, sos_bn_bwd out_scale, sos_scale_f32): exact, the pass is linear. */
+int sos_amax_f32(const float* x, int64_t n, float* amax, sos_stream_t stream);
+int sos_loss_scale(const float* amax, float target, float* scale2, sos_stream_t stream);
+int sos_scale_f32(float* x, int64_t n, const float* s /* device scalar */, sos_stream_t stream);
 int sos_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int64_t step, float grad_scale, sos_stream_t stream);
 

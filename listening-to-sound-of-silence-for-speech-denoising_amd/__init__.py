@@ -22,10 +22,15 @@ def set_precision(mode):
                  BASELINE.json dtype).
     'bf16x3': every activation and weight carried as a (hi, lo) bf16 pair and contracted as
               hi*hi + hi*lo + lo*hi on the same MFMA kernel (~fp32 accuracy, 3x the MACs);
-              used to separate algorithmic from precision error in parity tests."""
+              used to separate algorithmic from precision error in parity tests.
+    'fp16'  : IEEE half activations/weights on the same MFMA kernels at the same rate (libsos_hip_f16.so, the
+              -DSOS_F16 build of the same sources): 11 significand bits instead of 8, i.e. ~8x less rounding
+              noise than 'bf16' at equal cost; training keeps the activation gradients in half's exponent
+              range with a power-of-two loss scale chosen on the device (engine.GradScale).
+    A forward pass and its backward pass must run in the same mode."""
     global _PRECISION
-    if mode not in ("bf16", "bf16x3"):
-        raise ValueError("precision must be 'bf16' or 'bf16x3'")
+    if mode not in ("bf16", "bf16x3", "fp16"):
+        raise ValueError("precision must be 'bf16', 'bf16x3' or 'fp16'")
     _PRECISION = mode
 
 

@@ -3,7 +3,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SOS_HIP_LIB", os.path.join(_HERE, "libsos_hip.so"))     # override: A/B timing of two builds
+# the two builds of the same sources (csrc/Makefile): storage type bfloat16 / IEEE half.  SOS_HIP_LIB overrides the
+# bf16 one (A/B timing of two builds)
+LIB_PATH = os.environ.get("SOS_HIP_LIB", os.path.join(_HERE, "libsos_hip.so"))
+LIB_PATH_F16 = os.environ.get("SOS_HIP_LIB_F16", os.path.join(_HERE, "libsos_hip_f16.so"))
 
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
@@ -45,7 +48,7 @@ class WgradDesc(C.Structure):
                 ("x_off", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
                 ("stride", C.c_int32), ("dil_h", C.c_int32), ("dil_w", C.c_int32), ("pad_top", C.c_int32),
                 ("pad_left", C.c_int32), ("pad_mode", C.c_int32), ("ksplit", C.c_int32), ("partial", C.c_void_p),
-                ("dw", C.c_void_p), ("accumulate", C.c_int32), ("scale", C.c_float)]
+                ("dw", C.c_void_p), ("accumulate", C.c_int32), ("scale", C.c_float), ("scale_dev", C.c_void_p)]
 
 
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
@@ -60,7 +63,8 @@ SIGNATURES = {
     "sos_crm_target_f32": [_P, _P, _P, _L, _L, _F, _F, _P],
     "sos_bits_to_mask": [_P, _L, _L, _D, _L, _P, _P, _P, _P],
     "sos_threshold_bits": [_P, _L, _F, _P, _P, _P],
-    "sos_pack_nchw_to_nhwc": [_P, _L, _I, _L, _L, _P, _I, _I, _P],
+    "sos_storage_dtype": [],
+    "sos_pack_nchw_to_nhwc": [_P, _L, _I, _L, _L, _P, _I, _I, _P, _P],
     "sos_conv2d_fwd": [C.POINTER(ConvDesc), _P],
     "sos_conv2d_tune": [C.POINTER(ConvDesc), _I, _I, C.POINTER(C.c_float), _P],
     "sos_conv2d_tune_save": [C.c_char_p],
@@ -69,9 +73,9 @@ SIGNATURES = {
     "sos_lstm_pack_bytes": [_I, _I],
     "sos_lstm_pack_whh": [_P, _I, _P, _P, _P, _P, _P],
     "sos_lstm_bidir_fwd": [_P, _P, _P, _L, _L, _I, _P, _I, _I, _L, _P, _P, _P],
-    "sos_bn_bwd": [C.POINTER(View), C.POINTER(View), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(View), _P],
+    "sos_bn_bwd": [C.POINTER(View), C.POINTER(View), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(View), _P, _P],
     "sos_act_bwd_from_y": [C.POINTER(View), C.POINTER(View), _I, C.POINTER(View), _P],
-    "sos_pack_grad_f32": [_P, _P, _I, _L, _L, _I, _L, _L, _L, C.POINTER(View), _P],
+    "sos_pack_grad_f32": [_P, _P, _I, _L, _L, _I, _L, _L, _L, C.POINTER(View), _P, _P],
     "sos_feat_to_nhwc": [C.POINTER(View), _I, _I, _I, _I, _P, _P, C.POINTER(View), _P],
     "sos_reflect_fold": [C.POINTER(View), _I, _I, _I, C.POINTER(View), _I, _P],
     "sos_copy_crop": [C.POINTER(View), _I, _I, C.POINTER(View), _I, _I, _P],
@@ -79,6 +83,9 @@ SIGNATURES = {
     "sos_mse_loss": [_P, _P, _L, _F, _P, _P, _P, _P],
     "sos_bce_logits_loss": [_P, _P, _L, _F, _P, _P, _P, _P],
     "sos_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P],
+    "sos_amax_f32": [_P, _L, _P, _P],
+    "sos_loss_scale": [_P, _F, _P, _P],
+    "sos_scale_f32": [_P, _L, _P, _P],
     "sos_bn_stats_blocks": [_L],
     "sos_bn_stats": [C.POINTER(View), _P, _P],
     "sos_bn_finalize": [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -100,27 +107,38 @@ SIGNATURES = {
     "sos_spatial_mean_bwd": [_P, _L, _L, _I, _L, _I, _I, _I, _P, _I, _P],
 }
 
-_lib = None
+_libs = {}
+
+
+def _load(path, want_dtype):
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+    import torch  # noqa: F401  -- load torch's bundled HIP runtime FIRST so libsos_hip binds to the same one
+    h = C.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(h, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = C.c_int64 if name in ("sos_wgrad_workspace_bytes", "sos_lstm_pack_bytes", "sos_conv2d_tile_count") else C.c_int
+    h.sos_last_error.restype = C.c_char_p
+    h.sos_last_error.argtypes = []
+    h.sos_storage_dtype.restype = C.c_char_p
+    got = h.sos_storage_dtype().decode()
+    if got != want_dtype:
+        raise ImportError(f"{path} computes on {got} storage, expected {want_dtype}")
+    return h
 
 
 def lib():
-    """Load libsos_hip.so or fail loudly (there is no fallback path)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
-        import torch  # noqa: F401  -- load torch's bundled HIP runtime FIRST so libsos_hip binds to the same one
-        h = C.CDLL(LIB_PATH)
-        for name, argtypes in SIGNATURES.items():
-            fn = getattr(h, name)          # AttributeError if the symbol is not exported
-            fn.argtypes = argtypes
-            fn.restype = C.c_int64 if name in ("sos_wgrad_workspace_bytes", "sos_lstm_pack_bytes", "sos_conv2d_tile_count") else C.c_int
-        h.sos_last_error.restype = C.c_char_p
-        h.sos_last_error.argtypes = []
-        _lib = h
-    return _lib
+    """The library of the current precision mode (libsos_hip.so: 'bf16' / 'bf16x3'; libsos_hip_f16.so: 'fp16'), loaded
+    on first use, or a loud failure (there is no fallback path)."""
+    from . import get_precision
+    which = "fp16" if get_precision() == "fp16" else "bf16"
+    h = _libs.get(which)
+    if h is None:
+        h = _libs[which] = _load(LIB_PATH_F16 if which == "fp16" else LIB_PATH, which)
+    return h
 
 
 def check(rc, what=""):

@@ -50,16 +50,16 @@ __device__ __forceinline__ void load8(const View& v, long long pix, int c8, floa
     const unsigned hw[4] = {h.x, h.y, h.z, h.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        f[2 * i] = __uint_as_float(hw[i] << 16);
-        f[2 * i + 1] = __uint_as_float(hw[i] & 0xffff0000u);
+        f[2 * i] = sos_lo2f(hw[i]);
+        f[2 * i + 1] = sos_hi2f(hw[i]);
     }
     if (v.x3) {
         const uint4 l = *(const uint4*)(p + 2 * v.third);
         const unsigned lw[4] = {l.x, l.y, l.z, l.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f[2 * i] += __uint_as_float(lw[i] << 16);
-            f[2 * i + 1] += __uint_as_float(lw[i] & 0xffff0000u);
+            f[2 * i] += sos_lo2f(lw[i]);
+            f[2 * i + 1] += sos_hi2f(lw[i]);
         }
     }
 }
@@ -81,15 +81,15 @@ __device__ __forceinline__ void load8u(const View& v, long long pix, long long s
         const unsigned hw[4] = {h[u].x, h[u].y, h[u].z, h[u].w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f[u][2 * i] = __uint_as_float(hw[i] << 16);
-            f[u][2 * i + 1] = __uint_as_float(hw[i] & 0xffff0000u);
+            f[u][2 * i] = sos_lo2f(hw[i]);
+            f[u][2 * i + 1] = sos_hi2f(hw[i]);
         }
         if (v.x3) {
             const unsigned lw[4] = {l[u].x, l[u].y, l[u].z, l[u].w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                f[u][2 * i] += __uint_as_float(lw[i] << 16);
-                f[u][2 * i + 1] += __uint_as_float(lw[i] & 0xffff0000u);
+                f[u][2 * i] += sos_lo2f(lw[i]);
+                f[u][2 * i + 1] += sos_hi2f(lw[i]);
             }
         }
     }
@@ -391,7 +391,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(View dy, View x, con
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ s3out,
-                                       float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc) {
+                                       float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc,
+                                       const float* __restrict__ out_scale) {
     __shared__ double r1[256], r2[256], r3[256];
     const int c = blockIdx.x, tid = threadIdx.x;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -408,9 +409,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     }
     if (tid != 0) return;
     s1 = r1[0]; s2 = r2[0]; s3 = r3[0];
-    if (dgamma) dgamma[c] = (float)s2;
-    if (dbeta) dbeta[c] = (float)s1;
-    if (s3out) s3out[c] = (float)s3;            // per-channel PReLU slope partials, summed by the next kernel
+    // parameter gradients leave in the caller's units: out_scale = 1 / (loss scale the activation gradients carry);
+    // dx below stays in the scaled units
+    const double os = out_scale ? (double)out_scale[0] : 1.0;
+    if (dgamma) dgamma[c] = (float)(s2 * os);
+    if (dbeta) dbeta[c] = (float)(s1 * os);
+    if (s3out) s3out[c] = (float)(s3 * os);     // per-channel PReLU slope partials, summed by the next kernel
     if (invstd) {
         const double a = (double)(gamma ? gamma[c] : 1.f) * (double)invstd[c];
         ca[c] = (float)a;
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View x, cons
 extern "C" int sos_bn_bwd(const sos_view* dy, const sos_view* x, const float* scale, const float* shift,
                           const float* mean, const float* invstd, const float* gamma, int act, const float* slope,
                           float* partial, float* coef /* [4][C] */, float* dgamma, float* dbeta, float* dslope,
-                          const sos_view* dx, sos_stream_t stream) {
+                          const sos_view* dx, const float* out_scale, sos_stream_t stream) {
     int rc = check_view(dy, "sos_bn_bwd");
     if (!rc) rc = check_view(x, "sos_bn_bwd");
     if (!rc) rc = check_view(dx, "sos_bn_bwd");
@@ -498,7 +502,7 @@ extern "C" int sos_bn_bwd(const sos_view* dy, const sos_view* x, const float* sc
     // (nblk*3*C) partial buffer?  No -- keep it simple: the slope partials go to the tail of `coef`
     // (caller sizes coef as [4][C]).
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, partial, nblk, C, (double)x->npix, gamma, invstd,
-                       dgamma, dbeta, dslope ? coef + 3 * C : nullptr, coef, coef + C, coef + 2 * C);
+                       dgamma, dbeta, dslope ? coef + 3 * C : nullptr, coef, coef + C, coef + 2 * C, out_scale);
     if (dslope) hipLaunchKernelGGL(slope_sum_kernel, dim3(1), dim3(256), 0, s, coef + 3 * C, C, dslope);
     const int PLh = 256 / ((C + 7) / 8);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((x->npix + PLh - 1) / PLh * 256)), dim3(256), 0, s, to_view(dy),
@@ -546,8 +550,9 @@ extern "C" int sos_act_bwd_from_y(const sos_view* dy, const sos_view* y, int act
 // out row (o*inner + t), channel c.
 __global__ __launch_bounds__(256) void pack_grad_kernel(const float* __restrict__ g, const float* __restrict__ y, int act,
                                                         long long outer, long long inner, int C, long long so,
-                                                        long long st, long long sc, View out) {
+                                                        long long st, long long sc, View out, const float* __restrict__ mul_p) {
     const long long total = outer * inner * C;
+    const float mul = mul_p ? mul_p[0] : 1.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         // t fastest so that reads along the (usually unit-stride) inner axis coalesce
         const long long t = i % inner;
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(256) void pack_grad_kernel(const float* __restrict_
         const int c = (int)(r % C);
         const long long o = r / C;
         const long long src = o * so + t * st + c * sc;
-        float v = g[src];
+        float v = g[src] * mul;
         if (act == SOS_ACT_SIGMOID) { const float yy = y[src]; v *= yy * (1.f - yy); }
         bf16_t* dst = out.ptr + (o * inner + t) * out.row + out.c_off + c;
         const bf16_t hi = f2bf(v);
@@ -565,14 +570,14 @@ __global__ __launch_bounds__(256) void pack_grad_kernel(const float* __restrict_
 }
 
 extern "C" int sos_pack_grad_f32(const float* g, const float* y, int act, int64_t outer, int64_t inner, int C,
-                                 int64_t so, int64_t st, int64_t sc, const sos_view* out, sos_stream_t stream) {
+                                 int64_t so, int64_t st, int64_t sc, const sos_view* out, const float* mul, sos_stream_t stream) {
     if (!g || !out || !out->ptr || outer < 1 || inner < 1 || C < 1 || (act == SOS_ACT_SIGMOID && !y)) {
         sos_set_error("sos_pack_grad_f32: bad args");
         return SOS_EINVAL;
     }
     const long long total = outer * inner * C;
     hipLaunchKernelGGL(pack_grad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g, y, act, outer, inner, C,
-                       so, st, sc, to_view(out));
+                       so, st, sc, to_view(out), mul);
     return sos_check_launch("sos_pack_grad_f32");
 }
 

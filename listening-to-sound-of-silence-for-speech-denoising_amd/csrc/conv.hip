@@ -20,12 +20,13 @@
 #include "sos_common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <algorithm>
 #include <map>
 #include <type_traits>
 #include <vector>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef sos_half_t bf16x8 __attribute__((ext_vector_type(8)));   // 8 storage-type (bf16, or fp16 in the SOS_F16 build) MFMA operands
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Ablation switches (SOS_CONV_DBG bit mask: 1 patch staging, 2 tap loop, 4 epilogue, 8 weight-slab
@@ -151,8 +152,8 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
                 const unsigned hw[4] = {hv.x, hv.y, hv.z, hv.w}, lw[4] = {lv.x, lv.y, lv.z, lv.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float v0 = __uint_as_float(hw[i] << 16) + __uint_as_float(lw[i] << 16);
-                    const float v1 = __uint_as_float(hw[i] & 0xffff0000u) + __uint_as_float(lw[i] & 0xffff0000u);
+                    const float v0 = sos_lo2f(hw[i]) + sos_lo2f(lw[i]);
+                    const float v1 = sos_hi2f(hw[i]) + sos_hi2f(lw[i]);
                     s[2 * i] += v0; q[2 * i] = fmaf(v0, v0, q[2 * i]);
                     s[2 * i + 1] += v1; q[2 * i + 1] = fmaf(v1, v1, q[2 * i + 1]);
                 }
@@ -214,10 +215,10 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
                 unsigned rh[4], rl[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float a0 = __uint_as_float(nh[e] << 16) + __uint_as_float(nl[e] << 16) +
-                                     __uint_as_float(ph[e] << 16) + __uint_as_float(pl[e] << 16);
-                    const float a1 = __uint_as_float(nh[e] & 0xffff0000u) + __uint_as_float(nl[e] & 0xffff0000u) +
-                                     __uint_as_float(ph[e] & 0xffff0000u) + __uint_as_float(pl[e] & 0xffff0000u);
+                    const float a0 = sos_lo2f(nh[e]) + sos_lo2f(nl[e]) +
+                                     sos_lo2f(ph[e]) + sos_lo2f(pl[e]);
+                    const float a1 = sos_hi2f(nh[e]) + sos_hi2f(nl[e]) +
+                                     sos_hi2f(ph[e]) + sos_hi2f(pl[e]);
                     const bf16_t h0 = f2bf(a0), h1 = f2bf(a1);
                     rh[e] = (unsigned)h0 | ((unsigned)h1 << 16);
                     rl[e] = (unsigned)f2bf(a0 - bf2f(h0)) | ((unsigned)f2bf(a1 - bf2f(h1)) << 16);
@@ -438,8 +439,8 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[cb][nt], af[cb][0], acc[0][nt], 0, 0, 0);
-                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[cb][nt], af[cb][1], acc[1][nt], 0, 0, 0);
+                    acc[0][nt] = SOS_MFMA_32x32x16(wfr[cb][nt], af[cb][0], acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = SOS_MFMA_32x32x16(wfr[cb][nt], af[cb][1], acc[1][nt], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
             for (int nt = 0; nt < NT16; ++nt)
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt)
-                    acc[pt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cb][nt], fb[cb][pt], acc[pt][nt], 0, 0, 0);
+                    acc[pt][nt] = SOS_MFMA_16x16x32(fa[cb][nt], fb[cb][pt], acc[pt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (SB) {
@@ -810,16 +811,17 @@ typedef void (*conv_kernel_t)(ConvParams);
 
 template <int NT, int KS, bool SB>
 static int launch_one(const ConvParams& p, dim3 grid, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;
+    static sos_device_once attr_once;           // one per instantiation
     conv_kernel_t k = conv_mfma_kernel<NT, KS, SB>;
-    if (!attr_set) {
+    const int arc = sos_per_device_once(attr_once, [k] {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         if (e != hipSuccess) {
             sos_set_error("sos_conv2d_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return SOS_ELAUNCH;
+            return (int)SOS_ELAUNCH;
         }
-        attr_set = true;
-    }
+        return (int)SOS_OK;
+    });
+    if (arc) return arc;
     hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, p);
     return sos_check_launch("sos_conv2d_fwd");
 }
@@ -954,9 +956,27 @@ static ShapeKey shape_key(const sos_conv_desc* d) {
     return k;
 }
 
+// The tiling table: shape -> tiling.  The only mutable global of the library; every access goes through the two
+// helpers below under one mutex (nn.DataParallel calls the entry points from one host thread per replica).
+static std::mutex& tuned_mutex() {
+    static std::mutex mu;
+    return mu;
+}
 static std::map<ShapeKey, ConvCfg>& tuned_cache() {
     static std::map<ShapeKey, ConvCfg> m;
     return m;
+}
+static bool tuned_lookup(const ShapeKey& k, ConvCfg* out) {
+    std::lock_guard<std::mutex> g(tuned_mutex());
+    auto it = tuned_cache().find(k);
+    if (it == tuned_cache().end()) return false;
+    *out = it->second;
+    return true;
+}
+static void tuned_store(const ShapeKey& k, const ConvCfg& c, bool overwrite) {
+    std::lock_guard<std::mutex> g(tuned_mutex());
+    if (overwrite) tuned_cache()[k] = c;
+    else tuned_cache().emplace(k, c);
 }
 
 static int validate(const sos_conv_desc* d) {
@@ -1029,15 +1049,15 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
         if (nt16 == NTV && ks16 == KSV) k = single ? conv16_kernel<NTV, KSV, true> : conv16_kernel<NTV, KSV, false>;
         SOS_C16(1, 1) SOS_C16(1, 3) SOS_C16(3, 1) SOS_C16(3, 3)
 #undef SOS_C16
-        static bool attr16 = false;
-        if (!attr16) {
+        static sos_device_once attr16;
+        (void)sos_per_device_once(attr16, [] {
 #define SOS_C16A(NTV, KSV)                                                                                                        \
             (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);  \
             (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
             SOS_C16A(1, 1) SOS_C16A(1, 3) SOS_C16A(3, 1) SOS_C16A(3, 3)
 #undef SOS_C16A
-            attr16 = true;
-        }
+            return (int)SOS_OK;
+        });
         hipLaunchKernelGGL(k, dim3((unsigned)nblk, 1), dim3(256), lds16, s, p);
         return sos_check_launch("sos_conv2d_fwd(16)");
     }
@@ -1068,8 +1088,8 @@ extern "C" int64_t sos_conv2d_tile_count(const sos_conv_desc* d) {
     if (validate(d)) return -1;
     static const char* force = getenv("SOS_CONV_FORCE_CFG");
     if (!force) {
-        auto it = tuned_cache().find(shape_key(d));
-        if (it != tuned_cache().end()) return tiles_of(d, it->second);
+        ConvCfg c;
+        if (tuned_lookup(shape_key(d), &c)) return tiles_of(d, c);
     }
     std::vector<ConvCfg> cfgs = enumerate_cfgs(d);
     if (cfgs.empty()) { sos_set_error("sos_conv2d_tile_count: no tile fits LDS"); return -1; }
@@ -1081,10 +1101,9 @@ extern "C" int sos_conv2d_fwd(const sos_conv_desc* d, sos_stream_t stream) {
     if (rc) return rc;
     // SOS_CONV_FORCE_CFG=k (testing): use the k-th candidate tiling (mod count) instead of the tuned one
     static const char* force = getenv("SOS_CONV_FORCE_CFG");
-    auto& cache = tuned_cache();
     if (!force) {
-        auto it = cache.find(shape_key(d));
-        if (it != cache.end()) return launch_cfg(d, it->second, (hipStream_t)stream);
+        ConvCfg c;
+        if (tuned_lookup(shape_key(d), &c)) return launch_cfg(d, c, (hipStream_t)stream);
     }
     std::vector<ConvCfg> cfgs = enumerate_cfgs(d);
     if (cfgs.empty()) {
@@ -1105,9 +1124,8 @@ extern "C" int sos_conv2d_tune(const sos_conv_desc* d, int max_candidates, int i
                                sos_stream_t stream) {
     int rc = validate(d);
     if (rc) return rc;
-    auto& cache = tuned_cache();
     const ShapeKey key = shape_key(d);
-    if (cache.count(key)) { if (best_ms) *best_ms = -1.f; return SOS_OK; }
+    { ConvCfg c; if (tuned_lookup(key, &c)) { if (best_ms) *best_ms = -1.f; return SOS_OK; } }
     std::vector<ConvCfg> cfgs = enumerate_cfgs(d);
     if (cfgs.empty()) { sos_set_error("sos_conv2d_tune: no tile fits LDS"); return SOS_ENOSPC; }
     if (max_candidates < 1) max_candidates = 1;
@@ -1135,27 +1153,65 @@ extern "C" int sos_conv2d_tune(const sos_conv_desc* d, int max_candidates, int i
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc) return rc;
-    cache[key] = cfgs[besti];
+    tuned_store(key, cfgs[besti], false);       // first writer wins: concurrent tuners of one shape agree afterwards
     if (best_ms) *best_ms = best;
     return SOS_OK;
 }
 
-// Persist / restore the tuned tilings (text file: 19 shape ints + 4 config ints per line; ks == 0: 16-row kernel) so that
-// profiling and benchmark runs do not have to repeat the tuning launches.
+// Persist / restore the tiling table.  Text file: a header line `sos_conv_tune <format> abi <sos_abi_version> nkey 19`,
+// then 19 shape ints + 4 tiling ints per line (ks == 0 / -1: 16-row kernel).  The package ships a table for the
+// BASELINE shapes (tune_table_gfx950.txt) so that every process -- and every rank of a data-parallel job -- runs the
+// SAME tilings, hence the same summation order; timing-based autotuning is opt-in.
+#define SOS_TUNE_FORMAT 2
+extern "C" int sos_abi_version(void);
+
+// the sos_conv_desc fields enumerate_cfgs() / nt16_for() read, rebuilt from a shape key
+static sos_conv_desc desc_of_key(const ShapeKey& k) {
+    sos_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.B = k.v[0]; d.H = k.v[1]; d.W = k.v[2]; d.Wl = k.v[3]; d.cin = k.v[4]; d.in_nseg = k.v[5]; d.cout_pad = k.v[6];
+    d.kh = k.v[7]; d.kw = k.v[8]; d.stride = k.v[9]; d.dil_h = k.v[10]; d.dil_w = k.v[11]; d.Ho = k.v[12]; d.Wo = k.v[13];
+    d.out_dtype = k.v[14]; d.out_sc = k.v[15] ? 1 : 2; d.pad_mode = k.v[16]; d.cout = k.v[18];
+    return d;
+}
+
 extern "C" int sos_conv2d_tune_save(const char* path) {
-    FILE* f = fopen(path, "w");
-    if (!f) { sos_set_error("sos_conv2d_tune_save: cannot open %s", path); return SOS_EINVAL; }
-    for (const auto& kv : tuned_cache()) {
-        for (int i = 0; i < 19; ++i) fprintf(f, "%d ", kv.first.v[i]);
-        fprintf(f, "%d %d %d %d\n", kv.second.NC, kv.second.lth, kv.second.ltw, kv.second.ks);
+    if (!path) { sos_set_error("sos_conv2d_tune_save: null path"); return SOS_EINVAL; }
+    // written to a temporary and renamed: a reader (another rank) never sees a half-written table
+    char tmp[4096];
+    snprintf(tmp, sizeof(tmp), "%s.tmp.%ld", path, (long)getpid());
+    FILE* f = fopen(tmp, "w");
+    if (!f) { sos_set_error("sos_conv2d_tune_save: cannot open %s", tmp); return SOS_EINVAL; }
+    fprintf(f, "sos_conv_tune %d abi %d nkey 19\n", SOS_TUNE_FORMAT, sos_abi_version());
+    {
+        std::lock_guard<std::mutex> g(tuned_mutex());
+        for (const auto& kv : tuned_cache()) {
+            for (int i = 0; i < 19; ++i) fprintf(f, "%d ", kv.first.v[i]);
+            fprintf(f, "%d %d %d %d\n", kv.second.NC, kv.second.lth, kv.second.ltw, kv.second.ks);
+        }
     }
-    fclose(f);
+    if (fclose(f) != 0 || rename(tmp, path) != 0) {
+        remove(tmp);
+        sos_set_error("sos_conv2d_tune_save: cannot write %s", path);
+        return SOS_EINVAL;
+    }
     return SOS_OK;
 }
 
+// Returns the number of entries accepted (0: no file), or a negative error for a file of another format / ABI.
+// An entry is accepted only if its tiling is one enumerate_cfgs() would offer for that shape with this build (LDS
+// fit, NC vs dilation, 16-row eligibility): a stale or foreign table can never select an invalid launch.
 extern "C" int sos_conv2d_tune_load(const char* path) {
+    if (!path) { sos_set_error("sos_conv2d_tune_load: null path"); return SOS_EINVAL; }
     FILE* f = fopen(path, "r");
     if (!f) return 0;                    // nothing cached yet
+    int fmt = -1, abi = -1, nkey = -1;
+    if (fscanf(f, " sos_conv_tune %d abi %d nkey %d", &fmt, &abi, &nkey) != 3 || fmt != SOS_TUNE_FORMAT ||
+        abi != sos_abi_version() || nkey != 19) {
+        fclose(f);
+        sos_set_error("sos_conv2d_tune_load: %s was written by another build (format %d abi %d)", path, fmt, abi);
+        return SOS_EINVAL;
+    }
     int n = 0;
     for (;;) {
         ShapeKey k;
@@ -1164,13 +1220,15 @@ extern "C" int sos_conv2d_tune_load(const char* path) {
         for (int i = 0; i < 19 && ok; ++i) ok = fscanf(f, "%d", &k.v[i]) == 1;
         if (!ok || fscanf(f, "%d %d %d %d", &c.NC, &c.lth, &c.ltw, &c.ks) != 4) break;
         c.cost = 0;
-        {
-            const int k = c.ks >= 1000 ? c.ks % 1000 : c.ks, ntv = c.ks / 1000;
-            if (c.NC < 1 || c.lth < 0 || c.ltw < 0 || c.lth + c.ltw > 8 || c.ks < -1 || (k > 8 && (k < 101 || k > 104)) || ntv > 4 ||
-                (c.ks >= 1000 && k < 1))
-                continue;
-        }
-        tuned_cache()[k] = c;
+        const sos_conv_desc d = desc_of_key(k);
+        if (d.cin < 16 || d.cin % 16 || d.cout_pad < 32 || d.cout_pad % 32 || d.kh < 1 || d.kw < 1 || d.kh * d.kw > 64 ||
+            d.stride < 1 || d.dil_h < 1 || d.dil_w < 1 || d.Ho < 1 || d.Wo < 1 || d.in_nseg < 1 || d.cout < 1)
+            continue;
+        bool legal = false;
+        for (const ConvCfg& e : enumerate_cfgs(&d))
+            if (e.NC == c.NC && e.lth == c.lth && e.ltw == c.ltw && e.ks == c.ks) { legal = true; break; }
+        if (!legal) continue;
+        tuned_store(k, c, true);
         ++n;
     }
     fclose(f);

@@ -341,8 +341,9 @@ extern "C" int sos_threshold_bits(const float* logits, int64_t n, float threshol
 
 // ----------------------------------------------------------------- NCHW f32 -> NHWC bf16 pack
 __global__ void pack_kernel(const float* __restrict__ in, int C, int64_t HW, int64_t total, bf16_t* __restrict__ out,
-                            int cs, int x3) {
+                            int cs, int x3, const float* __restrict__ mul_p) {
     const int third = x3 ? cs / 3 : cs;
+    const float mul = mul_p ? mul_p[0] : 1.f;
     if (!x3 && (cs & 7) == 0) {          // common case: a pixel's channel run as whole 16-byte stores
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
             const int64_t b = i / HW, r = i - b * HW;
@@ -353,7 +354,7 @@ __global__ void pack_kernel(const float* __restrict__ in, int C, int64_t HW, int
                 for (int e = 0; e < 4; ++e) {
                     const int c = c0 + 2 * e;
                     const float v0 = c < C ? ip[(int64_t)c * HW] : 0.f, v1 = c + 1 < C ? ip[(int64_t)(c + 1) * HW] : 0.f;
-                    w4[e] = pack2bf(v0, v1);
+                    w4[e] = pack2bf(v0 * mul, v1 * mul);
                 }
                 *(uint4*)(out + i * cs + c0) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
             }
@@ -364,7 +365,7 @@ __global__ void pack_kernel(const float* __restrict__ in, int C, int64_t HW, int
         const int64_t b = i / HW, r = i - b * HW;
         bf16_t* o = out + i * cs;
         for (int c = 0; c < third; ++c) {
-            float v = c < C ? in[(b * C + c) * HW + r] : 0.f;
+            float v = c < C ? in[(b * C + c) * HW + r] * mul : 0.f;
             const bf16_t hi = f2bf(v);
             o[c] = hi;
             if (x3) {
@@ -376,7 +377,7 @@ __global__ void pack_kernel(const float* __restrict__ in, int C, int64_t HW, int
 }
 
 extern "C" int sos_pack_nchw_to_nhwc(const float* in, int64_t B, int C, int64_t H, int64_t W, void* out, int cs,
-                                     int dtype, sos_stream_t stream) {
+                                     int dtype, const float* mul, sos_stream_t stream) {
     const int x3 = dtype == SOS_DT_BF16X3;
     if (!in || !out || B < 1 || C < 1 || (dtype != SOS_DT_BF16 && !x3) || (x3 && cs % 3) || (x3 ? cs / 3 : cs) < C) {
         sos_set_error("sos_pack_nchw_to_nhwc: bad args");
@@ -384,6 +385,6 @@ extern "C" int sos_pack_nchw_to_nhwc(const float* in, int64_t B, int C, int64_t 
     }
     const int64_t total = B * H * W;
     hipLaunchKernelGGL(pack_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, in, C, H * W, total,
-                       (bf16_t*)out, cs, x3);
+                       (bf16_t*)out, cs, x3, mul);
     return sos_check_launch("sos_pack_nchw_to_nhwc");
 }

@@ -21,7 +21,7 @@
 // passes hi*hi + hi*lo + lo*hi.
 #include "sos_common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef sos_half_t bf16x8 __attribute__((ext_vector_type(8)));   // 8 storage-type (bf16, or fp16 in the SOS_F16 build) MFMA operands
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LM_NB 16              // clips per workgroup (MFMA N)
@@ -199,11 +199,11 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
             for (int kk = 0; kk < 8; ++kk) {
                 if (kk < KF) {
                     if (X3) {
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w0[kk]), frag(hf[kk]), acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w0[kk]), frag(hl[kk]), acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w1[kk]), frag(hf[kk]), acc, 0, 0, 0);
+                        acc = SOS_MFMA_16x16x32(frag(w0[kk]), frag(hf[kk]), acc, 0, 0, 0);
+                        acc = SOS_MFMA_16x16x32(frag(w0[kk]), frag(hl[kk]), acc, 0, 0, 0);
+                        acc = SOS_MFMA_16x16x32(frag(w1[kk]), frag(hf[kk]), acc, 0, 0, 0);
                     } else {
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag((ti & 1) ? w1[kk] : w0[kk]), frag(hf[kk]), acc, 0, 0, 0);
+                        acc = SOS_MFMA_16x16x32(frag((ti & 1) ? w1[kk] : w0[kk]), frag(hf[kk]), acc, 0, 0, 0);
                     }
                 }
             }
@@ -387,11 +387,11 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_bwd_kernel(const bf16_t* __re
                     const int kk = k0 + u;
                     if (kk < KB) {
                         const uint4 d0 = *(const uint4*)(dg + n * GP + kk * 64 + g4 * 16);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w[u]), frag(d0), acc, 0, 0, 0);
+                        acc = SOS_MFMA_16x16x32(frag(w[u]), frag(d0), acc, 0, 0, 0);
                         if (wl) {
                             const uint4 d1 = *(const uint4*)(dg + LM_NB * GP + n * GP + kk * 64 + g4 * 16);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(w[u]), frag(d1), acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(l[u]), frag(d0), acc, 0, 0, 0);
+                            acc = SOS_MFMA_16x16x32(frag(w[u]), frag(d1), acc, 0, 0, 0);
+                            acc = SOS_MFMA_16x16x32(frag(l[u]), frag(d0), acc, 0, 0, 0);
                         }
                     }
                 }
@@ -420,8 +420,11 @@ extern "C" int sos_lstm_bidir_bwd(const void* dh_out, int dh_cs, int dh_dtype, i
     }
     const size_t lds = (size_t)2 * (wtk_lo ? 2 : 1) * LM_NB * (lm_kb(H) * 64 + 16);
     if (lds > 160 * 1024) { sos_set_error("sos_lstm_bidir_bwd: LDS"); return SOS_ENOSPC; }
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static sos_device_once attr_once;
+    (void)sos_per_device_once(attr_once, [] {
+        (void)hipFuncSetAttribute((const void*)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return SOS_OK;
+    });
     dim3 grid((unsigned)((B + LM_NB - 1) / LM_NB), 2);
     hipLaunchKernelGGL(lstm_bwd_kernel, grid, dim3(LM_THREADS), lds, (hipStream_t)stream, (const bf16_t*)dh_out, dh_cs,
                        dh_dtype == SOS_DT_BF16X3 ? 1 : 0, (long long)dh_third, gates, csave, (const uint4*)wtk_hi,

@@ -78,6 +78,54 @@ extern "C" int sos_bce_logits_loss(const float* x, const float* y, int64_t n, fl
     return sos_check_launch("sos_bce_logits_loss");
 }
 
+// ---- loss scale of the fp16 storage mode (sos_hip.h): max|g| folded with an integer atomic max on the bit patterns of
+// the non-negative floats (order independent -> deterministic), then S = 2^floor(log2(target/amax)).
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long n, float* __restrict__ amax) {
+    __shared__ float red[256];
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax((unsigned*)amax, __float_as_uint(red[0]));
+}
+__global__ void loss_scale_kernel(const float* __restrict__ amax, float target, float* __restrict__ scale2) {
+    const float a = amax[0];
+    float S = 1.f;
+    if (a > 0.f && a < 3.0e38f) {
+        int e = (int)floorf(log2f(target / a));
+        e = e < -40 ? -40 : (e > 40 ? 40 : e);
+        S = exp2f((float)e);
+    }
+    scale2[0] = S;
+    scale2[1] = 1.f / S;
+}
+__global__ void scale_kernel(float* __restrict__ x, long long n, const float* __restrict__ s) {
+    const float k = s[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] *= k;
+}
+
+extern "C" int sos_amax_f32(const float* x, int64_t n, float* amax, sos_stream_t stream) {
+    if (!x || !amax || n < 1) { sos_set_error("sos_amax_f32: bad args"); return SOS_EINVAL; }
+    hipLaunchKernelGGL(amax_kernel, dim3(loss_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, amax);
+    return sos_check_launch("sos_amax_f32");
+}
+extern "C" int sos_loss_scale(const float* amax, float target, float* scale2, sos_stream_t stream) {
+    if (!amax || !scale2 || !(target > 0.f)) { sos_set_error("sos_loss_scale: bad args"); return SOS_EINVAL; }
+    hipLaunchKernelGGL(loss_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, amax, target, scale2);
+    return sos_check_launch("sos_loss_scale");
+}
+extern "C" int sos_scale_f32(float* x, int64_t n, const float* s, sos_stream_t stream) {
+    if (!x || !s || n < 1) { sos_set_error("sos_scale_f32: bad args"); return SOS_EINVAL; }
+    long long gb = (n + 255) / 256;
+    if (gb > 2048) gb = 2048;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, x, (long long)n, s);
+    return sos_check_launch("sos_scale_f32");
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
                             float bc1, float bc2_sqrt, float gscale) {

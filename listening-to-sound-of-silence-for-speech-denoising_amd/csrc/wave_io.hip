@@ -169,14 +169,15 @@ extern "C" int sos_resample_f32(const float* x, int64_t n_in, double ratio, cons
     int64_t n_valid = (int64_t)((double)n_in * ratio);      // resampy's output length; the rest is librosa's padding
     if (n_valid > n_out) n_valid = n_out;
     const size_t lds = (size_t)(nwin + 1) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            sos_set_error("sos_resample_f32: cannot raise the dynamic LDS limit");
-            return SOS_ELAUNCH;
-        }
-        attr_set = true;
-    }
+    static sos_device_once attr_once;
+    if (sos_per_device_once(attr_once, [] {
+            if (hipFuncSetAttribute((const void*)resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                sos_set_error("sos_resample_f32: cannot raise the dynamic LDS limit");
+                return (int)SOS_ELAUNCH;
+            }
+            return (int)SOS_OK;
+        }))
+        return SOS_ELAUNCH;
     RsSegs seg;
     if (rs_build_segments(1.0 / ratio, n_valid > 0 ? n_valid : 1, &seg) != 0) {
         sos_set_error("sos_resample_f32: time register needs more than %d segments", RS_MAXSEG);

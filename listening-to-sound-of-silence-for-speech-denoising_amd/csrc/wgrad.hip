@@ -18,7 +18,7 @@
 #include "sos_common.h"
 #include <stdlib.h>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef sos_half_t bf16x8 __attribute__((ext_vector_type(8)));   // 8 storage-type (bf16, or fp16 in the SOS_F16 build) MFMA operands
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -343,14 +343,14 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             const bool on0 = BAL || wave < npairs;      // BAL: 25 pairs, every wave owns pair 0 (no per-MFMA branches)
             {
                 const bf16x8 bfr = __builtin_bit_cast(bf16x8, bv[0]);
-                if (on0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[0]), bfr, acc[0][0], 0, 0, 0);
+                if (on0) acc[0][0] = SOS_MFMA_32x32x16(__builtin_bit_cast(bf16x8, av[0]), bfr, acc[0][0], 0, 0, 0);
                 if constexpr (MT >= 2) {
                     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(av[1]) : "n"(REST + 2 * (MT - 2)));
-                    if (on0) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[1]), bfr, acc[1][0], 0, 0, 0);
+                    if (on0) acc[1][0] = SOS_MFMA_32x32x16(__builtin_bit_cast(bf16x8, av[1]), bfr, acc[1][0], 0, 0, 0);
                 }
                 if constexpr (MT >= 3) {
                     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(av[2]) : "n"(REST));
-                    if (on0) acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[2]), bfr, acc[2][0], 0, 0, 0);
+                    if (on0) acc[2][0] = SOS_MFMA_32x32x16(__builtin_bit_cast(bf16x8, av[2]), bfr, acc[2][0], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -367,11 +367,11 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
                     const bf16x8 bfr = __builtin_bit_cast(bf16x8, bv[u]);
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
-                        acc[a][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[a]), bfr, acc[a][u], 0, 0, 0);
+                        acc[a][u] = SOS_MFMA_32x32x16(__builtin_bit_cast(bf16x8, av[a]), bfr, acc[a][u], 0, 0, 0);
                 }
             }
             if constexpr (BAL) {
-                if (hasx) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, avx), __builtin_bit_cast(bf16x8, bvx), accx, 0, 0, 0);
+                if (hasx) accx = SOS_MFMA_32x32x16(__builtin_bit_cast(bf16x8, avx), __builtin_bit_cast(bf16x8, bvx), accx, 0, 0, 0);
             }
         }
         if (p.dbuf) {
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
                 for (int n = 0; n < N16; ++n) {
 #pragma unroll
                     for (int a = 0; a < M16; ++a)
-                        acc[f][a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[a]),
+                        acc[f][a][n] = SOS_MFMA_16x16x32(__builtin_bit_cast(bf16x8, av[a]),
                                                                                __builtin_bit_cast(bf16x8, bv[f][n]), acc[f][a][n], 0, 0, 0);
                 }
             }
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
                 if constexpr (N16 == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ae), "+v"(be[0]), "+v"(be[1]), "+v"(be[2]));
 #pragma unroll
                 for (int n = 0; n < N16; ++n)
-                    acce[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ae), __builtin_bit_cast(bf16x8, be[n]),
+                    acce[n] = SOS_MFMA_16x16x32(__builtin_bit_cast(bf16x8, ae), __builtin_bit_cast(bf16x8, be[n]),
                                                                       acce[n], 0, 0, 0);
             }
         }
@@ -578,8 +578,10 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
 // in flight per thread); the four partial sums are added in a fixed order (deterministic).  Only the single
 // write per element is strided (by taps).  (One thread per element walking all <= 256 splits ran at 0.6 TB/s.)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int ksplit, int taps, int M, int N,
-                                                           int Mp, int Np, float* __restrict__ dw, int accumulate, float scale) {
+                                                           int Mp, int Np, float* __restrict__ dw, int accumulate, float scale_h,
+                                                           const float* __restrict__ scale_dev) {
     __shared__ float part[4][64];
+    const float scale = scale_dev ? scale_h * scale_dev[0] : scale_h;
     const long long total = (long long)taps * M * N;
     const size_t sstride = (size_t)taps * Mp * Np;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -736,21 +738,21 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     }
     dim3 grid((unsigned)(ksplit * p.ny * p.nz), 1, 1);                       // see the id mapping in wgrad_kernel
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_done = false;
+    static sos_device_once attr_once;
     if (use16) grid = dim3((unsigned)ksplit, 1, 1);
 #define SOS_WG_ATTR(MTV, NTBV) \
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<MTV, NTBV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #define SOS_WG_CASE(MTV, NTBV) \
     if (mt == MTV && ntb == NTBV) hipLaunchKernelGGL((wgrad_kernel<MTV, NTBV>), grid, dim3(WG_THREADS), lds, s, p);
-    if (!attr_done) {       // every instantiation may use the full 160 KB of LDS
+    (void)sos_per_device_once(attr_once, [] {       // every instantiation may use the full 160 KB of LDS
         SOS_WG_ATTR(1, 1) SOS_WG_ATTR(1, 2) SOS_WG_ATTR(1, 4) SOS_WG_ATTR(2, 1) SOS_WG_ATTR(2, 2) SOS_WG_ATTR(2, 4)
         SOS_WG_ATTR(3, 1) SOS_WG_ATTR(3, 2) SOS_WG_ATTR(3, 4)
         (void)hipFuncSetAttribute((const void*)wgrad_kernel<3, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)wgrad16_kernel<3, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)wgrad16_kernel<3, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+        return (int)SOS_OK;
+    });
     if (use16) {
         if (taps == 25) hipLaunchKernelGGL((wgrad16_kernel<3, 3, 3>), grid, dim3(WG_THREADS), lds, s, p);
         else hipLaunchKernelGGL((wgrad16_kernel<3, 3, 1>), grid, dim3(WG_THREADS), lds, s, p);
@@ -771,6 +773,6 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     long long gb = (total + 63) / 64;
     if (gb > 8192) gb = 8192;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, d->partial, ksplit, taps, d->M, d->N,
-                       p.Mp, p.Np, d->dw, d->accumulate, d->scale);
+                       p.Mp, p.Np, d->dw, d->accumulate, d->scale, d->scale_dev);
     return sos_check_launch("sos_conv2d_wgrad(reduce)");
 }

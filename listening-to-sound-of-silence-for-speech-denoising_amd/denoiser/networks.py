@@ -274,7 +274,7 @@ class ContextAggNet(nn.Module):
         B, _, F, T = x.shape
         nseg = 3 if x3 else 1
         nfeat = 12 * F
-        feat = torch.empty((B, T, nseg * nfeat), dtype=torch.bfloat16, device=dev)
+        feat = torch.empty((B, T, nseg * nfeat), dtype=E.act_dtype(), device=dev)
         CN.run_encoder(plan["enc_x"], E.pack_input(x, x3), feat, nseg * nfeat, nfeat, 0, x3)
         CN.run_encoder(plan["enc_n"], E.pack_input(n, x3), feat, nseg * nfeat, nfeat, 8, x3)
         h = CN.run_lstm(plan["lstm"], (feat, B, 1, T, nfeat, nseg), B, T, x3, dev)
@@ -303,7 +303,7 @@ class ContextAggNet(nn.Module):
         B, _, F, T = x.shape
         nseg = 3 if x3 else 1
         nfeat = 12 * F
-        feat = torch.empty((B, T, nseg * nfeat), dtype=torch.bfloat16, device=dev)
+        feat = torch.empty((B, T, nseg * nfeat), dtype=E.act_dtype(), device=dev)
         fs = dict(t=feat, row=nseg * nfeat, third=nfeat, H=F, W=T, Wo=T, gather=None, x3=x3)
         tx = TO.encoder_forward_train(plan["enc_x"], E.pack_input(x, x3), dict(fs, c_off=0), x3)
         tn = TO.encoder_forward_train(plan["enc_n"], E.pack_input(n, x3), dict(fs, c_off=8), x3)
@@ -388,6 +388,12 @@ class JointModel(nn.Module):
         return (n_pred, out), dict(plan=plan, t1=t1, t2=t2, x3=x3)
 
     def _backward(self, tape, g_npred, g_out):
+        g_npred = g_npred.contiguous().float() if g_npred is not None else None
+        g_out = g_out.contiguous().float() if g_out is not None else None
+        with E.backward_scale(g_npred, g_out):      # fp16 mode: one loss scale for both entering gradients
+            return self._backward_scaled(tape, g_npred, g_out)
+
+    def _backward_scaled(self, tape, g_npred, g_out):
         plan, x3 = tape["plan"], tape["x3"]
         factory = getattr(self, "grad_sink_factory", None)
         grads = factory() if factory is not None else {}
@@ -397,7 +403,7 @@ class JointModel(nn.Module):
             g_out = torch.zeros((B, 2, F, T), dtype=torch.float32, device=dev)
         d_np = self.stage2.backward(plan["s2"], tape["t2"], g_out, grads, x3)          # Act [B,F,T,16]
         if g_npred is not None:
-            direct = E.pack_input(g_npred.contiguous().float(), x3)                    # loss gradient on n_pred
+            direct = E.pack_input(g_npred, x3, mul=E.cur_gs().mul)                     # loss gradient on n_pred
             TO.reflect_fold(direct, F, T, 0, d_np, 0, 2, accumulate=True)              # pad 0: plain add
         self.stage1.backward(plan["s1"], tape["t1"], d_np, grads, x3)
         return grads

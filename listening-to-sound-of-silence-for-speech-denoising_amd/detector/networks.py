@@ -76,7 +76,7 @@ class AudioVisualNet(nn.Module):
         nseg = 3 if x3 else 1
         nfeat = 8 * F + self.video_feat
         a = E.pack_input(s, x3)
-        feat = torch.empty((B, n, nseg * nfeat), dtype=torch.bfloat16, device=dev)
+        feat = torch.empty((B, n, nseg * nfeat), dtype=E.act_dtype(), device=dev)
         gather = CN.nearest_index(T, n, dev)
         fspec = dict(t=feat, row=nseg * nfeat, third=nfeat, c_off=0, H=F, W=T, Wo=n, gather=gather, x3=x3)
         tape_enc = TO.encoder_forward_train(plan["enc"], a, fspec, x3)
@@ -96,13 +96,18 @@ class AudioVisualNet(nn.Module):
         return out, tape
 
     def _backward(self, tape, g):
+        g = g.contiguous().float()
+        with E.backward_scale(g):           # fp16 mode: loss scale for this pass (a no-op in the bf16 modes)
+            return self._backward_scaled(tape, g)
+
+    def _backward_scaled(self, tape, g):
         plan, x3 = tape["plan"], tape["x3"]
         B, F, T, n = tape["dims"]
         dev = g.device
         factory = getattr(self, "grad_sink_factory", None)
         grads = factory() if factory is not None else {}
         dz2 = E.Act(B, 1, n, 16, x3, dev, zero=True)
-        TO.pack_grad(g.contiguous().float(), None, L.ACT_NONE, B, n, 1, n, 1, 1, dz2)
+        TO.pack_grad(g, None, L.ACT_NONE, B, n, 1, n, 1, 1, dz2)
         d_m = TO.linear_backward(plan["fc2"], tape["m"], dz2, grads, "fc1.2", x3, dev)
         dz0 = E.Act(B, 1, n, tape["m"].cs, x3, dev, zero=True)
         TO.act_bwd_from_y(d_m, tape["m"], L.ACT_RELU, dz0, plan["fc0"]["cout"])
@@ -141,7 +146,7 @@ class AudioVisualNet(nn.Module):
         a = E.pack_input(s, x3)
         nseg = 3 if x3 else 1
         nfeat = 8 * F + self.video_feat
-        feat = torch.empty((B, n, nseg * nfeat), dtype=torch.bfloat16, device=dev)
+        feat = torch.empty((B, n, nseg * nfeat), dtype=E.act_dtype(), device=dev)
         gather = CN.nearest_index(T, n, dev)
         CN.run_encoder(plan["enc"], a, feat, nseg * nfeat, nfeat, 0, x3, w_gather=gather, T_out=n)
         if self.video_feat:

@@ -38,27 +38,40 @@ class LaunchProfiler:
 
 PROFILER = None
 
-# Autotune conv tilings the first time a launch shape is seen (sos_conv2d_tune synchronises, so it
-# is skipped while a stream capture is in progress).  SOS_CONV_TUNE=0 disables it.
+# Conv tilings.  By default every process loads the SHIPPED table (tune_table_gfx950.txt, measured once on an MI355X for
+# the BASELINE shapes) and uses the deterministic cost-model pick for any other shape: two processes -- or two ranks of
+# one data-parallel job -- therefore run identical tilings, i.e. identical summation orders and bit-identical results.
+# SOS_CONV_TUNE=1 opts into timing-based autotuning of shapes the table does not hold (sos_conv2d_tune synchronises, so
+# it is skipped while a stream capture is in progress); SOS_CONV_TUNE_CACHE=<file> replaces the shipped table and, with
+# autotuning on, receives the tuned table at exit (rank 0 only, written atomically).  tools/make_tune_table.py
+# regenerates the shipped file.
 import os as _os
-AUTOTUNE = _os.environ.get("SOS_CONV_TUNE", "1") != "0"
+import threading as _threading
+AUTOTUNE = _os.environ.get("SOS_CONV_TUNE", "0") == "1"
+SHIPPED_TUNE_TABLE = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tune_table_gfx950.txt")
 _tuned = set()
-# SOS_CONV_TUNE_CACHE=<file>: tuned tilings are loaded from / saved to this file, so that a second
-# process (e.g. a rocprofv3 run) starts with the tuned configuration and launches no tuning kernels.
+_tune_lock = _threading.Lock()
 _TUNE_CACHE = _os.environ.get("SOS_CONV_TUNE_CACHE")
-_cache_loaded = False
+_cache_loaded = set()          # precision-mode libraries whose table has been loaded
 
 
 def _load_tune_cache():
-    global _cache_loaded, AUTOTUNE
-    if _cache_loaded or not _TUNE_CACHE:
+    which = "fp16" if get_precision() == "fp16" else "bf16"
+    if which in _cache_loaded:
         return
-    _cache_loaded = True
-    n = L.lib().sos_conv2d_tune_load(_TUNE_CACHE.encode())
-    if n > 0 and _os.environ.get("SOS_CONV_TUNE_FROZEN", "0") == "1":
-        AUTOTUNE = False                      # profile runs: use the cached tilings only
-    import atexit
-    atexit.register(lambda: L.lib().sos_conv2d_tune_save(_TUNE_CACHE.encode()))
+    with _tune_lock:
+        if which in _cache_loaded:
+            return
+        path = _TUNE_CACHE or SHIPPED_TUNE_TABLE
+        if _os.environ.get("SOS_CONV_TUNE_TABLE", "1") != "0":      # =0: cost-model picks only (A/B of the table itself)
+            n = L.lib().sos_conv2d_tune_load(path.encode())
+            if n < 0:
+                raise RuntimeError("sos_conv2d_tune_load: " + (L.lib().sos_last_error() or b"").decode())
+        if AUTOTUNE and _TUNE_CACHE and int(_os.environ.get("RANK", "0")) == 0:
+            import atexit
+            h = L.lib()
+            atexit.register(lambda: h.sos_conv2d_tune_save((_TUNE_CACHE + ("" if which == "bf16" else ".f16")).encode()))
+        _cache_loaded.add(which)
 
 
 def pad_to(x, m):
@@ -73,7 +86,7 @@ class Act:
         self.B, self.H, self.W, self.cs, self.x3 = B, H, W, cs, x3
         self.nseg = 3 if x3 else 1
         alloc = torch.zeros if zero else torch.empty
-        self.t = alloc((B, H, W, self.nseg * cs), dtype=torch.bfloat16, device=device)
+        self.t = alloc((B, H, W, self.nseg * cs), dtype=act_dtype(), device=device)
 
     @property
     def dtype_code(self):
@@ -84,15 +97,76 @@ def is_x3():
     return get_precision() == "bf16x3"
 
 
-def pack_input(x, x3=None):
-    """f32 NCHW module input -> Act with cs = 16 (sos_pack_nchw_to_nhwc)."""
+def act_dtype():
+    """torch dtype of the 16-bit storage buffers of the current precision mode (torch only allocates them)."""
+    return torch.float16 if get_precision() == "fp16" else torch.bfloat16
+
+
+class GradScale:
+    """Loss scale of the fp16 mode for ONE backward pass (include/sos_hip.h, sos_loss_scale): a device pair {S, 1/S}
+    chosen from max|g| of the gradients entering the hand-written backward, no host synchronisation.  `mul` is
+    multiplied in where f32 gradients become 16-bit, `inv` where parameter gradients leave.  In the bf16 modes both
+    are None (bf16 has f32's exponent range)."""
+
+    TARGET = 256.0          # the entering gradients are scaled to max|g| in [256, 512): 2^7 of headroom, 2^-32 of floor
+
+    def __init__(self, *grads):
+        self.mul = self.inv = None
+        if get_precision() != "fp16":
+            return
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return
+        dev = gs[0].device
+        buf = torch.zeros(3, dtype=torch.float32, device=dev)
+        for g in gs:
+            L.check(L.lib().sos_amax_f32(L.ptr(g), g.numel(), L.ptr(buf), L.stream_ptr()), "sos_amax_f32")
+        L.check(L.lib().sos_loss_scale(L.ptr(buf), self.TARGET, L.ptr(buf[1:]), L.stream_ptr()), "sos_loss_scale")
+        self.buf, self.mul, self.inv = buf, buf[1:2], buf[2:3]
+
+    def unscale(self, t):
+        """In-place 1/S on a small f32 tensor (bias gradients)."""
+        if self.inv is not None:
+            L.check(L.lib().sos_scale_f32(L.ptr(t), t.numel(), L.ptr(self.inv), L.stream_ptr()), "sos_scale_f32")
+        return t
+
+
+NO_SCALE = GradScale.__new__(GradScale)
+NO_SCALE.mul = NO_SCALE.inv = None
+_TLS = _threading.local()
+
+
+class backward_scale:
+    """`with backward_scale(g1, g2, ...):` -- the hand-written backward of one network runs inside; wgrad / bn_bwd /
+    colsum / pack_grad pick the pass's GradScale up through cur_gs() (thread local: DataParallel-style callers run one
+    backward per host thread)."""
+
+    def __init__(self, *grads):
+        self.gs = GradScale(*grads)
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, "gs", NO_SCALE)
+        _TLS.gs = self.gs
+        return self.gs
+
+    def __exit__(self, *exc):
+        _TLS.gs = self.prev
+        return False
+
+
+def cur_gs():
+    return getattr(_TLS, "gs", NO_SCALE)
+
+
+def pack_input(x, x3=None, mul=None):
+    """f32 NCHW module input -> Act with cs = 16 (sos_pack_nchw_to_nhwc); `mul`: optional device scalar (loss scale)."""
     L.require_cuda(x)
     x3 = is_x3() if x3 is None else x3
     x = x.contiguous().float()
     B, Cc, H, W = x.shape
     a = Act(B, H, W, pad_to(Cc, 16), x3, x.device)
     L.check(L.lib().sos_pack_nchw_to_nhwc(L.ptr(x), B, Cc, H, W, L.ptr(a.t), a.nseg * a.cs, a.dtype_code,
-                                          L.stream_ptr()), "sos_pack_nchw_to_nhwc")
+                                          L.ptr(mul), L.stream_ptr()), "sos_pack_nchw_to_nhwc")
     return a
 
 
@@ -109,10 +183,10 @@ def pack_weight(w, cin_store, x3, in_perm=None):
     Op = pad_to(O, 32)
     full = torch.zeros((kh * kw, Op, cin_store), dtype=torch.float32, device=w.device)
     full[:, :O, :I] = wp
-    hi = full.to(torch.bfloat16)
+    hi = full.to(act_dtype())
     if not x3:
         return hi.contiguous()
-    lo = (full - hi.float()).to(torch.bfloat16)
+    lo = (full - hi.float()).to(act_dtype())
     return torch.cat([hi, lo, hi], dim=2).contiguous()
 
 
@@ -171,6 +245,7 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
         key = (B, H, W, d.Wl, cin, d.in_nseg, d.cout_pad, cout, kh, kw, stride, dil, Ho, Wo, out_dtype, sc == 1, pad_mode,
                w_gather is not None)
         if key not in _tuned and not torch.cuda.is_current_stream_capturing():
+            _tuned.add(key)
             if accumulate:
                 # the tuner launches the kernel many times: never let it accumulate into the real
                 # gradient buffer -- tune a non-accumulating copy of the descriptor on scratch output
@@ -182,7 +257,6 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
                 d.out, d.accumulate = real_out, 1
             else:
                 L.check(L.lib().sos_conv2d_tune(C.byref(d), 8, 3, None, L.stream_ptr()), "sos_conv2d_tune")
-            _tuned.add(key)
     end = None
     if PROFILER is not None:
         sig = ("conv", kh, kw, dil[0], dil[1], stride, d.in_nseg * cin, cout, B, Ho, Wo)
@@ -333,12 +407,13 @@ _wg_ws = {}
 
 
 def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0, 0), pad_mode=L.PAD_ZERO,
-          accumulate=False, scale=1.0):
+          accumulate=False, scale=1.0, gs=None):
     """dw[m][n][a][b] (+)= scale * sum_p G[p][m] X[p*stride + (a,b)*dil - pad][n] (sos_conv2d_wgrad).
     g, x: Act.  In bf16x3 mode the product (g_hi+g_lo)(x_hi+x_lo) is taken as hi*hi + hi*lo + lo*hi
     with three accumulating passes over the thirds."""
     import ctypes
     dev = g.t.device
+    gs = cur_gs() if gs is None else gs
     passes = [(0, 0)] if not g.x3 else [(0, 0), (0, 2), (2, 0)]
     first = True
     for gt, xt in passes:
@@ -357,6 +432,7 @@ def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0,
         d.dw = dw.data_ptr()
         d.accumulate = 1 if (accumulate or not first) else 0
         d.scale = scale
+        d.scale_dev = gs.inv.data_ptr() if gs.inv is not None else None
         end = None
         if PROFILER is not None:
             sig = ("wgrad", kh, kw, dil[0], dil[1], stride, M, N, g.B, g.H, g.W)

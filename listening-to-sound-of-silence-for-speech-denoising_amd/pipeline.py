@@ -67,8 +67,8 @@ class GraphedDenoiser:
     of ~190 host-side launches -- what bounds small-batch / streaming latency.  Shapes are exact (the reference
     pads nothing: M2/predict.py:377-447), the `max_graphs` most recently used graphs are kept.  Capture happens
     after two eager warm-up runs on a side stream (conv autotuning, weight packing and table uploads must not
-    happen inside a capture).  Weights are read at replay time from the buffers packed at capture time: call
-    `reset()` after loading new weights."""
+    happen inside a capture).  Weights are read at replay time from the buffers packed at capture time, so the
+    cache key carries the precision mode and the parameters' version counters (new weights -> new capture)."""
 
     def __init__(self, detector, denoiser, sr=SR, fps=FPS, max_graphs=16):
         self.detector, self.denoiser, self.sr, self.fps, self.max_graphs = detector, denoiser, sr, fps, max_graphs
@@ -95,7 +95,10 @@ class GraphedDenoiser:
     def __call__(self, mixed, clone=True):
         if mixed.dim() != 2 or not mixed.is_cuda or mixed.dtype != torch.float32:
             raise ValueError("GraphedDenoiser expects a float32 (B, N) GPU tensor")
-        key = (tuple(mixed.shape), mixed.device.index)
+        # precision mode and weight versions are part of the key: a graph replays the buffers packed at capture time
+        from . import get_precision
+        wv = tuple(t._version for m in (self.detector, self.denoiser) for t in list(m.parameters()) + list(m.buffers()))
+        key = (tuple(mixed.shape), mixed.device.index, get_precision(), hash(wv))
         entry = self._graphs.get(key)
         if entry is None:
             if len(self._graphs) >= self.max_graphs:

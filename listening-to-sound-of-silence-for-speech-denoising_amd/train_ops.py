@@ -36,13 +36,16 @@ def colsum(act, c_off, C):
     # finalize with count = 1: "mean" is the plain sum
     L.check(L.lib().sos_bn_finalize(L.ptr(partial), nblk, C, 1, None, None, 1.0, 0.0, None, None, None, L.ptr(scratch[0]),
                                     L.ptr(scratch[1]), L.ptr(out), None, L.stream_ptr()), "sos_bn_finalize(colsum)")
-    return out
+    return E.cur_gs().unscale(out)          # parameter gradients leave in the caller's units (fp16 loss scale)
 
 
-def pack_grad(g, y, act, outer, inner, C, so, st, sc, dst, c_off=0):
+def pack_grad(g, y, act, outer, inner, C, so, st, sc, dst, c_off=0, scaled=False):
+    """f32 gradient -> 16-bit rows.  scaled=False: `g` is in the caller's units and the pass's loss scale is multiplied
+    in here; scaled=True: `g` was derived from already scaled gradients (the LSTM's dgates)."""
     v = E.view(dst, c_off, C)
+    mul = None if scaled else E.cur_gs().mul
     L.check(L.lib().sos_pack_grad_f32(L.ptr(g), L.ptr(y), act, outer, inner, C, so, st, sc, ctypes.byref(v),
-                                      L.stream_ptr()), "sos_pack_grad_f32")
+                                      L.ptr(mul), L.stream_ptr()), "sos_pack_grad_f32")
 
 
 def bn_bwd(dy, dy_off, raw, raw_off, C, saved, gamma, act, slope, dx, dx_off=0):
@@ -59,7 +62,7 @@ def bn_bwd(dy, dy_off, raw, raw_off, C, saved, gamma, act, slope, dx, dx_off=0):
     L.check(L.lib().sos_bn_bwd(ctypes.byref(dyv), ctypes.byref(xv), L.ptr(saved["scale"]), L.ptr(saved["shift"]),
                                L.ptr(saved.get("mean")), L.ptr(saved.get("invstd")), L.ptr(gamma), act, L.ptr(slope),
                                L.ptr(partial), L.ptr(coef), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dslope), ctypes.byref(dxv),
-                               L.stream_ptr()), "sos_bn_bwd")
+                               L.ptr(E.cur_gs().inv), L.stream_ptr()), "sos_bn_bwd")
     return dgamma, dbeta, dslope
 
 
@@ -336,7 +339,7 @@ def lstm_backward(lp, tape, dh, grads, prefix, B, T, x3, dev):
                                        L.ptr(tape["csave"]), L.ptr(lp["wpk"]["bh"]), L.ptr(lp["wpk"]["bl"]), B, T, H, L.ptr(dgates), L.stream_ptr()),
             "sos_lstm_bidir_bwd")
     dga = E.Act(B, 1, T, E.pad_to(8 * H, 16), x3, dev, zero=(8 * H) % 16 != 0)
-    pack_grad(dgates, None, L.ACT_NONE, B, T, 8 * H, T * 8 * H, 8 * H, 1, dga)
+    pack_grad(dgates, None, L.ACT_NONE, B, T, 8 * H, T * 8 * H, 8 * H, 1, dga, scaled=True)
     # biases: both b_ih and b_hh receive sum over (b,t) of the gate grads
     inv = lp["inv"]                                # gate-interleaved rows -> torch's (gate, unit) order
     db = colsum(dga, 0, 8 * H)[inv]
@@ -363,7 +366,7 @@ def lstm_backward(lp, tape, dh, grads, prefix, B, T, x3, dev):
         grads[f"{prefix}.weight_hh_l0{sfx}"] = dwhh[inv[:4 * H], d * H:(d + 1) * H]
     # input gradient
     nseg = 3 if x3 else 1
-    dfeat = torch.empty((B, T, nseg * I), dtype=torch.bfloat16, device=dev)
+    dfeat = torch.empty((B, T, nseg * I), dtype=E.act_dtype(), device=dev)
     one, zero = ones_zeros(lp["wd"].shape[1], dev)
     E.conv(dga, 0, dga.cs, lp["wd"], 1, 1, I, one, zero, L.ACT_NONE, out=dfeat,
            out_dtype=L.DT_BF16X3 if x3 else L.DT_BF16, sb=T * nseg * I, sh=0, sw=nseg * I, sc=1, third=I, Ho=1, Wo=T)

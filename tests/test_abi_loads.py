@@ -11,17 +11,48 @@ from oracle import nets as onet
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_library_exports_every_declared_symbol():
+@pytest.mark.parametrize("precision,storage", [("bf16", b"bf16"), ("bf16x3", b"bf16"), ("fp16", b"fp16")])
+def test_library_exports_every_declared_symbol(precision, storage):
+    """Both builds of the C ABI (libsos_hip.so: bfloat16 storage, libsos_hip_f16.so: IEEE half) export every symbol the
+    header declares, and the ctypes table binds exactly those."""
+    import sos_amd
     from sos_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "sos_hip.h")).read()
     declared = set(re.findall(r"\b(sos_[a-z0-9_]+)\s*\(", hdr))
     declared.discard("sos_stream_t")
     assert declared, "header parse failed"
-    h = _lib.lib()
+    sos_amd.set_precision(precision)
+    try:
+        h = _lib.lib()
+    finally:
+        sos_amd.set_precision("bf16")
     for name in declared:
         assert hasattr(h, name), f"{name} declared in sos_hip.h but not exported"
     assert set(_lib.SIGNATURES) | {"sos_last_error"} == declared
-    assert h.sos_abi_version() == 1
+    assert h.sos_abi_version() == 2
+    assert h.sos_storage_dtype() == storage
+
+
+def test_tune_table_load_rejects_foreign_and_illegal_entries(tmp_path):
+    """sos_conv2d_tune_load (host only, no GPU): a table of another format / ABI is an error, an entry whose tiling the
+    build would not offer for that shape is dropped, a legal one is accepted; the shipped table loads completely."""
+    from sos_amd import _lib, engine
+    h = _lib.lib()
+    bad = tmp_path / "old.txt"
+    bad.write_text("64 256 178 178 96 1 96 5 5 1 1 1 256 178 0 1 0 0 96 1 4 4 6\n")      # round-1 format: no header
+    assert h.sos_conv2d_tune_load(str(bad).encode()) < 0
+    shape = "64 256 178 178 96 1 96 5 5 1 1 1 256 178 0 1 0 0 96"
+    mixed = tmp_path / "mixed.txt"
+    mixed.write_text("sos_conv_tune 2 abi 2 nkey 19\n"
+                     f"{shape} 1 4 4 6\n"            # legal: 16x16 pixels, 6 k-steps per chunk
+                     f"{shape} 1 4 4 7\n"            # 7 does not divide cin/16
+                     f"{shape} 4 2 4 6\n"            # 4 residue classes need dil_w >= 4
+                     f"{shape} 1 8 8 6\n")           # 2^16 pixels per workgroup
+    assert h.sos_conv2d_tune_load(str(mixed).encode()) == 1
+    assert h.sos_conv2d_tune_load(str(tmp_path / "missing.txt").encode()) == 0
+    if os.path.exists(engine.SHIPPED_TUNE_TABLE):
+        lines = [ln for ln in open(engine.SHIPPED_TUNE_TABLE).read().splitlines()[1:] if ln.strip()]
+        assert h.sos_conv2d_tune_load(engine.SHIPPED_TUNE_TABLE.encode()) == len(lines) > 0
 
 
 def test_state_dict_keys_match_reference_layout():

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 # tolerance on ||a-b||_inf / ||b||_inf per tensor: bf16x3 carries ~16 mantissa bits end to end
 # (north_star bar 1e-3); plain bf16 carries 8 and is checked against its own, looser bound.
-TOL = {"bf16x3": 1e-3, "bf16": 6e-2}
+TOL = {"bf16x3": 1e-3, "bf16": 6e-2, "fp16": 5e-3}
 
 
 def _nets():
@@ -25,7 +25,7 @@ def _nets():
     return det.cuda().eval(), jm.cuda().eval()
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
 def test_eval_forward_matches_reference_goldens(golden, precision):
     g = golden("networks")
     sos_amd.set_precision(precision)

@@ -40,7 +40,7 @@ def _check_grads(named_params, gradnorm, gradhead, tol, label):
     return worst
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
 def test_detector_train_step_matches_reference_autograd(golden, precision):
     from sos_amd.detector import networks as dnet
     g = golden("networks")
@@ -77,7 +77,7 @@ def test_detector_train_step_matches_reference_autograd(golden, precision):
         sos_amd.set_precision("bf16")
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
 def test_denoiser_train_step_matches_reference_autograd(golden, precision):
     from sos_amd.denoiser import networks as jnet
     from sos_amd.common import MyConfig

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Regenerates the shipped conv tiling table (sos_amd/tune_table_gfx950.txt) on an MI355X: runs the BASELINE workloads
+once with timing-based autotuning on, so that every launch shape they contain gets its measured-best tiling, and writes
+the table to gpurun_out/tune_table_gfx950.txt (copy it into the package and commit it).
+
+    gpurun -- python tools/make_tune_table.py
+
+Every later process loads the committed table and never times anything: all processes (and all ranks of a
+data-parallel job) then run identical tilings, i.e. identical summation orders (engine.py, conv.hip)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "gpurun_out", "tune_table_gfx950.txt")
+os.makedirs(os.path.dirname(OUT), exist_ok=True)
+os.environ["SOS_CONV_TUNE"] = "1"
+os.environ["SOS_CONV_TUNE_CACHE"] = OUT
+if os.path.exists(OUT):
+    os.remove(OUT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import sos_amd  # noqa: E402
+from sos_amd import agent, pipeline, tools, transform  # noqa: E402
+from sos_amd.common import MyConfig  # noqa: E402
+from sos_amd.dataset import synth_batch  # noqa: E402
+from sos_amd.denoiser import networks as jnet  # noqa: E402
+from sos_amd.detector import networks as dnet  # noqa: E402
+
+
+def workloads(B):
+    torch.manual_seed(0)
+    det = dnet.get_network().cuda()
+    jm = jnet.get_network(MyConfig()).cuda()
+    raw = synth_batch(0, min(B, 8))
+    rep = (B + len(raw["mixed"]) - 1) // len(raw["mixed"])
+    tile = lambda a: torch.from_numpy(np.tile(a, (rep, 1))[:B]).cuda().contiguous()   # noqa: E731
+    mixed, clean, full_noise, bits = tile(raw["mixed"]), tile(raw["clean"]), tile(raw["full_noise"]), tile(raw["bits"])
+    mask, noise_sig = tools.bits_to_mask_batch(bits, 14000 / 30.0, 28000, mixed)
+    S = transform.stft_batch(torch.cat([mixed, clean * (1 - mask), noise_sig, full_noise]))
+    bj = {"mixed": S[:B].contiguous(), "clean": S[B:2 * B].contiguous(), "noise": S[2 * B:3 * B].contiguous(),
+          "full_noise": S[3 * B:].contiguous()}
+    bd = {"audio": bj["mixed"], "label": bits.float()}
+    pipeline.denoise(det.eval(), jm.eval(), mixed)                       # inference shapes
+    agent.DetectorAgent(det.train(), lr=1e-3).train_func(bd)             # training shapes (forward, dgrad)
+    agent.DenoiserAgent(jm.train(), lr=1e-3).train_func(bj)
+    torch.cuda.synchronize()
+
+
+def main():
+    # the table is shared by both builds (same kernels, same shapes): tune on the bf16 one; bf16x3 has its own
+    # (three-segment) shapes
+    for prec, batches in (("bf16", (64, 32, 16, 8, 4, 2, 1)), ("bf16x3", (64, 2, 1))):
+        sos_amd.set_precision(prec)
+        for B in batches:
+            workloads(B)
+            print("tuned", prec, "B =", B, flush=True)
+    from sos_amd import _lib
+    sos_amd.set_precision("bf16")
+    _lib.lib().sos_conv2d_tune_save(OUT.encode())
+    print("wrote", OUT, sum(1 for _ in open(OUT)) - 1, "entries")
+
+
+if __name__ == "__main__":
+    main()
