@@ -260,11 +260,27 @@ def main():
     lo_o, l_o = onet.detector_loss({k: v.clone() for k, v in sd1.items()}, {"audio": x, "label": label}, True, st1)
     assert rel_err(lo_o.detach(), lo.detach()) < 5e-5
     assert abs(float(l_o["bce"]) - float(bce)) < 1e-5
+    # condition scale of every PReLU slope gradient: d_slope = sum_{z<0} dy*z is a heavily cancelling sum of ~1e6
+    # signed terms; sum_{z<0} |dy*z| is the magnitude a relative perturbation of the terms is amplified by (the tests
+    # bound |d_slope - reference| by a fraction of it)
+    slope_scale, hooks = {}, []
+    for mname, mod in jm.named_modules():
+        if isinstance(mod, torch.nn.PReLU):
+            def fwd_hook(m, inp, outp, mname=mname):
+                z = inp[0].detach()
+                outp.register_hook(lambda dy, z=z, mname=mname: slope_scale.__setitem__(
+                    mname + ".weight", float((dy.double() * z.double()).abs()[z < 0].sum())))
+            hooks.append(mod.register_forward_hook(fwd_hook))
     n_pred, out = jm(x, n)
     rec = ref_tf.batch_fast_icRM_sigmoid(x, out)
     l1 = torch.nn.MSELoss()(n_pred, full_noise)
     l2 = torch.nn.MSELoss()(rec, clean)
     (l1 + l2).backward()
+    for h in hooks:
+        h.remove()
+    nets["train_jm_slope_scale"] = np.array([slope_scale.get(k, np.nan) for k, _ in jm.named_parameters()])
+    print("PReLU slope gradients vs their condition scale:",
+          [(k, round(float(p.grad), 4), round(slope_scale[k], 3)) for k, p in jm.named_parameters() if k in slope_scale])
     st2 = {}
     (np_o, out_o), ls = onet.denoiser_losses({k: v.clone() for k, v in sd2.items()},
                                              {"mixed": x, "noise": n, "clean": clean, "full_noise": full_noise}, True, st2)

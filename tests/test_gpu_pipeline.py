@@ -25,7 +25,14 @@ def _oracle_chain(sd1, sd2, wave, n_frames):
     return lo[0].numpy(), bits, mask, ofe.fast_istft(rec)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+# per precision mode: logit band around the threshold inside which a frame decision may flip, waveform bound
+# (||a-b||_inf / ||b||_inf), fidelity floor (SI-SDR of the HIP waveform w.r.t. the oracle's, dB), SI-SDR-vs-clean
+# bound where the score is > -25 dB / below.  fp16 is the timed mode: it has to hold the north_star's 0.05 dB where
+# the metric is conditioned at all.
+_PIPE_BOUNDS = {"bf16x3": (2e-4, 1e-3, 70.0, 0.05, 0.05), "fp16": (3e-3, 1e-2, 40.0, 0.05, 0.1), "bf16": (2e-2, 1e-1, 20.0, 0.1, 0.5)}
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
 def test_pipeline_matches_oracle_and_si_sdr(precision):
     from sos_amd import pipeline
     from sos_amd.common import MyConfig
@@ -50,12 +57,12 @@ def test_pipeline_matches_oracle_and_si_sdr(precision):
         r = pipeline.denoise(det, jm, torch.from_numpy(raw["mixed"]).cuda(), return_all=True)
     finally:
         sos_amd.set_precision("bf16")
-    x3 = precision == "bf16x3"
+    band, err_tol, fid_min, sdr_hi, sdr_lo = _PIPE_BOUNDS[precision]
     for i in range(len(raw["mixed"])):
         lo, bits, mask, y = _oracle_chain(sd1, sd2, raw["mixed"][i], n_frames)
         bits_gpu = r["bits"][i].cpu().numpy()
         # frames whose logit is within the forward tolerance of the threshold may legitimately flip
-        unsure = np.abs(lo) < (2e-4 if x3 else 2e-2) * max(1.0, np.abs(lo).max())
+        unsure = np.abs(lo) < band * max(1.0, np.abs(lo).max())
         assert np.array_equal(bits_gpu[~unsure], bits[~unsure])
         assert 0 < bits.sum() < len(bits)
         if np.array_equal(bits_gpu, bits):
@@ -68,22 +75,17 @@ def test_pipeline_matches_oracle_and_si_sdr(precision):
             print(precision, "clip", i, "waveform rel err", err, "SI-SDR", ofe.si_sdr(y, raw["clean"][i]), "delta dB", d_sdr)
             # bf16x3 is the parity mode (north_star 1e-3); plain bf16 carries 0.5-2e-2 per-layer rounding noise whose sum
             # depends on the summation order of the conv tilings the autotuner picks (observed 1.6e-2 .. 5.9e-2 here)
-            assert err < (1e-3 if x3 else 1e-1)
+            assert err < err_tol
             # fidelity of the HIP waveform w.r.t. the oracle's waveform, as an SI-SDR (dB)
             fid = ofe.si_sdr(out, y)
-            assert fid > (70.0 if x3 else 20.0), fid
+            assert fid > fid_min, fid
             # north_star: SI-SDR (vs clean) within 0.05 dB of the reference path.  The weights here are
             # untrained, so the output is nearly uncorrelated with `clean` (SI-SDR -20 .. -40 dB) and the
             # metric is ill-conditioned below ~-25 dB (a 3 % waveform change moves a -39 dB score by 0.2 dB):
             # the 0.05 dB bar is enforced for bf16x3 (observed 2e-5 .. 5e-4 dB); plain bf16 gets 0.1 dB where the score is
             # > -25 dB (observed 0.045 dB with one tiling choice: too close to 0.05 for a bound that has to hold for
             # whatever tilings the autotuner picks) and 0.5 dB below.
-            if x3:
-                assert d_sdr < 0.05
-            elif ofe.si_sdr(y, raw["clean"][i]) > -25.0:
-                assert d_sdr < 0.1
-            else:
-                assert d_sdr < 0.5
+            assert d_sdr < (sdr_hi if ofe.si_sdr(y, raw["clean"][i]) > -25.0 else sdr_lo)
 
 
 def test_ragged_batch_matches_per_clip_and_oracle():
@@ -164,28 +166,34 @@ def test_graph_replay_equals_eager_launches():
 def test_si_sdr_parity_with_briefly_trained_weights():
     """north_star at a well-conditioned operating point: both networks are trained for a few dozen steps on synthetic
     clips (on the HIP path), then the end-to-end chain is run on held-out clips by the HIP pipeline and by the oracle
-    with the SAME trained weights.  SI-SDR vs the clean signal: |HIP - oracle| <= 0.05 dB in bf16x3 AND in plain bf16
-    (observed <= 0.001 dB in both).  The output must also be an actual improvement over the noisy input."""
+    with the SAME trained weights.  SI-SDR vs the clean signal: |HIP - oracle| <= 0.05 dB in bf16x3, in fp16 (the timed
+    mode) AND in plain bf16 (observed <= 0.001 dB in all).  The output must also be an actual improvement over the noisy
+    input.  The training itself runs in fp16 (loss-scaled half gradients): it has to learn."""
     from sos_amd import agent, pipeline
     from sos_amd.common import MyConfig
     from sos_amd.dataset import make_batch, synth_batch
     from sos_amd.denoiser import networks as jnet
     from sos_amd.detector import networks as dnet
-    sos_amd.set_precision("bf16")
-    torch.manual_seed(0)
-    ad = agent.DetectorAgent(dnet.get_network(), lr=1e-3)
-    aj = agent.DenoiserAgent(jnet.get_network(MyConfig()), lr=1e-3)
-    for it in range(40):
-        ad.train_func(make_batch("detector", 5000 + 16 * it, 16))
-    for it in range(60):
-        aj.train_func(make_batch("denoiser", 7000 + 8 * it, 8))
+    sos_amd.set_precision("fp16")
+    try:
+        torch.manual_seed(0)
+        ad = agent.DetectorAgent(dnet.get_network(), lr=1e-3)
+        aj = agent.DenoiserAgent(jnet.get_network(MyConfig()), lr=1e-3)
+        for it in range(40):
+            ad.train_func(make_batch("detector", 5000 + 16 * it, 16))
+        for it in range(100):
+            _, losses = aj.train_func(make_batch("denoiser", 7000 + 8 * it, 8))
+            if it % 20 == 0 or it == 99:
+                print("fp16 denoiser step", it, {k: round(float(v), 4) for k, v in losses.items()})
+    finally:
+        sos_amd.set_precision("bf16")
     det, jm = ad.net.eval(), aj.net.eval()
     sd1 = {k: v.detach().float().cpu() for k, v in det.state_dict().items()}
     sd2 = {k: v.detach().float().cpu() for k, v in jm.state_dict().items()}
     raw = synth_batch(123456, 3)
     n_frames = pipeline.n_video_frames(raw["mixed"].shape[1])
     res = {}
-    for precision in ("bf16x3", "bf16"):
+    for precision in ("bf16x3", "fp16", "bf16"):
         sos_amd.set_precision(precision)
         try:
             res[precision] = pipeline.denoise(det, jm, torch.from_numpy(raw["mixed"]).cuda(), return_all=True)
@@ -196,7 +204,7 @@ def test_si_sdr_parity_with_briefly_trained_weights():
         lo, bits, mask, y = _oracle_chain(sd1, sd2, raw["mixed"][i], n_frames)
         s_or = ofe.si_sdr(y, raw["clean"][i])
         s_in = ofe.si_sdr(raw["mixed"][i][:len(y)], raw["clean"][i])
-        for precision, tol in (("bf16x3", 0.05), ("bf16", 0.05)):
+        for precision, tol in (("bf16x3", 0.05), ("fp16", 0.05), ("bf16", 0.05)):
             r = res[precision]
             if not np.array_equal(r["bits"][i].cpu().numpy(), bits):
                 continue                                    # a frame decision within rounding of the threshold flipped

@@ -12,10 +12,21 @@ from util import rel_err, silent_gate, spec_input
 
 pytestmark = pytest.mark.gpu
 
+# whole-network gradient-norm bounds of the timed fp16 mode (observed worst 0.10 / median 7e-3 on the denoiser)
+DET_TOL_FP16, JM_TOL_FP16 = 0.1, 0.15
 
-def _check_grads(named_params, gradnorm, gradhead, tol, label):
+
+# Bound on |d_slope - reference| as a fraction of the slope gradient's CONDITION SCALE (tests/golden/make_goldens.py:
+# sum_{z<0} |dy*z| from the reference's own autograd, 130..470 here against gradients of 0.01..1, i.e. condition numbers
+# of 2e2..2e4): d_slope = sum_{z<0} dy*z over ~1e6 signed terms cancels almost completely, so a relative perturbation
+# eps of the terms moves it by ~eps * scale.  Observed: bf16x3 3e-4, fp16 1.7e-3, bf16 5e-3 of the scale.
+SLOPE_TOL = {"bf16x3": 1e-3, "fp16": 5e-3, "bf16": 2e-2}
+
+
+def _check_grads(named_params, gradnorm, gradhead, tol, label, slope_scale=None):
     worst = 0.0
     bad = []
+    errs = []
     for i, (name, p) in enumerate(named_params):
         assert p.grad is not None, name
         g = p.grad.detach().float().cpu().reshape(-1).numpy()
@@ -23,21 +34,19 @@ def _check_grads(named_params, gradnorm, gradhead, tol, label):
         e_norm = abs(gn - gradnorm[i]) / (gradnorm[i] + 1e-12)
         head = np.pad(g[:8], (0, max(0, 8 - len(g))))
         e_head = np.max(np.abs(head - gradhead[i])) / (np.max(np.abs(gradhead[i])) + 1e-3 * gradnorm[i] + 1e-12)
-        if g.size == 1:
-            # single shared PReLU slope: d_slope = sum_{z<0} dy*z over ~1e6 signed terms cancels almost
-            # completely, so it inherits the ReLU/PReLU gating sensitivity described below; the kernel
-            # itself matches torch to 1e-6 on a single block (tools/probe/down_bwd.py)
-            # (plain bf16 storage of dy and z adds ~4e-3 relative noise per term: the sum's noise is then of
-            # the order of the Cauchy-Schwarz scale * 4e-3, i.e. up to O(1) absolute here)
-            # observed in plain bf16, depending on the tilings the autotuner picks: +0.58 against a reference of -0.47
-            ok = abs(float(g[0]) - float(gradhead[i][0])) < ((0.05 + 0.05 * abs(float(gradhead[i][0]))) if tol < 0.1 else 3.0)
-            e_norm = e_head = 0.0 if ok else 1e9
-        worst = max(worst, e_norm, e_head)
+        if g.size == 1 and slope_scale is not None and np.isfinite(slope_scale[i]):
+            # single shared PReLU slope: bounded against its condition scale (see SLOPE_TOL)
+            e_s = abs(float(g[0]) - float(gradhead[i][0])) / float(slope_scale[i])
+            print(f"  {label} {name:44s} d_slope {float(g[0]):+.4f} ref {float(gradhead[i][0]):+.4f} err/scale {e_s:.2e}")
+            assert e_s < SLOPE_TOL[label], (name, float(g[0]), float(gradhead[i][0]), float(slope_scale[i]))
+            continue
+        errs.append(e_norm)
+        worst = max(worst, e_norm, e_head / 10)
         if not (e_norm < tol and e_head < 10 * tol):
             bad.append((name, e_norm, e_head))
             print(f"  {label} {name:44s} |g| {gn:10.4e} ref {gradnorm[i]:10.4e} e_norm {e_norm:8.2e} e_head {e_head:8.2e}")
     assert not bad, bad
-    return worst
+    return worst, float(np.median(errs))
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
@@ -62,17 +71,18 @@ def test_detector_train_step_matches_reference_autograd(golden, precision):
         # tools/probe/det_bwd_debug.py).  Norms stay within a few 1e-3 with the tuned tilings; other (equally valid)
         # conv tilings change the summation order and moved single tensors to 1.3e-2 (test_gpu_forced_tilings.py),
         # so the bound leaves room for whatever tiling the autotuner picks on a given box.
-        tol = 2e-2 if precision == "bf16x3" else 0.25
+        tol = {"bf16x3": 2e-2, "fp16": DET_TOL_FP16, "bf16": 0.25}[precision]
         e_lo = rel_err(logits, g["train_det_logits"])
         print(precision, "train logits rel err", e_lo, "loss", float(loss), "ref", float(g["train_bce"]))
-        assert e_lo < (1e-3 if precision == "bf16x3" else 0.1)
-        worst = _check_grads(list(det.named_parameters()), g["train_det_gradnorm"], g["train_det_gradhead"], tol, precision)
-        print(precision, "worst grad err", worst)
+        assert e_lo < {"bf16x3": 1e-3, "fp16": 2e-2, "bf16": 0.1}[precision]
+        worst, med = _check_grads(list(det.named_parameters()), g["train_det_gradnorm"], g["train_det_gradhead"], tol, precision)
+        print(precision, "worst grad err", worst, "median", med)
+        assert med < {"bf16x3": 2e-3, "fp16": 2e-2, "bf16": 8e-2}[precision]
         # running statistics were updated like torch's
         rv = [v.detach().cpu().numpy().reshape(-1)[:4] for k, v in det.state_dict().items() if k.endswith("running_var")]
         want = g["train_det_running_var_head"]
         for a, b in zip(rv, want):
-            assert rel_err(np.pad(a, (0, 4 - len(a))), b) < (1e-3 if precision == "bf16x3" else 5e-2)
+            assert rel_err(np.pad(a, (0, 4 - len(a))), b) < {"bf16x3": 1e-3, "fp16": 1e-2, "bf16": 5e-2}[precision]
     finally:
         sos_amd.set_precision("bf16")
 
@@ -102,12 +112,15 @@ def test_denoiser_train_step_matches_reference_autograd(golden, precision):
         x3 = precision == "bf16x3"
         e1, e2 = rel_err(n_pred, g["train_n_pred"]), rel_err(out, g["train_mask"])
         print(precision, "train n_pred/mask rel err", e1, e2, "losses", float(l1), float(l2), "ref", float(g["train_l1"]), float(g["train_l2"]))
-        assert max(e1, e2) < (1e-3 if x3 else 0.1)
-        assert abs(float(l1) / float(g["train_l1"]) - 1) < (1e-3 if x3 else 5e-2)
-        assert abs(float(l2) / float(g["train_l2"]) - 1) < (1e-3 if x3 else 5e-2)
-        worst = _check_grads(list(jm.named_parameters()), g["train_jm_gradnorm"], g["train_jm_gradhead"],
-                             3e-2 if x3 else 0.4, precision)      # see the note on conditioning above
-        print(precision, "worst grad err", worst)
+        assert max(e1, e2) < {"bf16x3": 1e-3, "fp16": 1.5e-2, "bf16": 0.1}[precision]
+        ltol = {"bf16x3": 1e-3, "fp16": 5e-3, "bf16": 5e-2}[precision]
+        assert abs(float(l1) / float(g["train_l1"]) - 1) < ltol
+        assert abs(float(l2) / float(g["train_l2"]) - 1) < ltol
+        worst, med = _check_grads(list(jm.named_parameters()), g["train_jm_gradnorm"], g["train_jm_gradhead"],
+                                  {"bf16x3": 3e-2, "fp16": JM_TOL_FP16, "bf16": 0.4}[precision], precision,
+                                  g["train_jm_slope_scale"])      # see the note on conditioning above
+        print(precision, "worst grad err", worst, "median", med)
+        assert med < {"bf16x3": 2e-3, "fp16": 1.5e-2, "bf16": 5e-2}[precision]
     finally:
         sos_amd.set_precision("bf16")
 
