@@ -78,6 +78,13 @@ int sos_bits_to_mask(const uint8_t* bits, int64_t batch, int64_t n_frames, doubl
                      int64_t n_samples, float* mask, const float* sig, float* masked,
                      sos_stream_t stream);
 
+/* ---- a16  add_signals / add_noise_to_audio: M2/tools.py:217-303.  Per clip b: every noise k is rescaled so that
+ * energy(signal) / energy(noise) = 10^(snr_db[b]/10) (left alone when signal or noise is silent), mixed = signal +
+ * sum_k noise_k, then mixed, signal and the noises are divided by max|mixed| / norm (norm == 0: no normalisation).
+ * signal f32 [B][n], noises f32 [B][n_noises][n] (n_noises <= 8), snr_db f32 [B] (device); outputs same shapes. */
+int sos_add_signals_f32(const float* signal, const float* noises, const float* snr_db, int64_t batch, int n_noises,
+                        int64_t n, float norm, float* mixed, float* signal_out, float* noises_out, sos_stream_t stream);
+
 /* ---- a14  detector post-processing: M1/predict.py:117-119,
  * bit = sigmoid(logit) >= 0.5 (1 = non-silent).  conf (optional) = sigmoid. */
 int sos_threshold_bits(const float* logits, int64_t n, float threshold, uint8_t* bits, float* conf,

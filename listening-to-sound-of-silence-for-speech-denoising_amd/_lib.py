@@ -63,6 +63,7 @@ SIGNATURES = {
     "sos_crm_target_f32": [_P, _P, _P, _L, _L, _F, _F, _P],
     "sos_bits_to_mask": [_P, _L, _L, _D, _L, _P, _P, _P, _P],
     "sos_threshold_bits": [_P, _L, _F, _P, _P, _P],
+    "sos_add_signals_f32": [_P, _P, _P, _L, _I, _L, _F, _P, _P, _P, _P],
     "sos_storage_dtype": [],
     "sos_pack_nchw_to_nhwc": [_P, _L, _I, _L, _L, _P, _I, _I, _P, _P],
     "sos_conv2d_fwd": [C.POINTER(ConvDesc), _P],

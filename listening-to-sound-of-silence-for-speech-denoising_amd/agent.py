@@ -45,6 +45,15 @@ class TrainClock(object):
 
 
 # ------------------------------------------------------------------------------------ fused losses
+def _scale_by(grad, g):
+    """grad * g for the 0-dim upstream gradient `g` of a scalar loss (sos_scale_f32 on a copy: a second backward through
+    a retained graph must see the unscaled gradient again)."""
+    out = grad.clone()
+    g = g.detach().reshape(1).to(device=grad.device, dtype=torch.float32)
+    L.check(L.lib().sos_scale_f32(L.ptr(out), out.numel(), L.ptr(g), L.stream_ptr()), "sos_scale_f32")
+    return out
+
+
 class _MSE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -61,7 +70,7 @@ class _MSE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None
+        return _scale_by(grad, g), None
 
 
 class _BCE(torch.autograd.Function):
@@ -80,7 +89,7 @@ class _BCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None
+        return _scale_by(grad, g), None
 
 
 def mse_loss(a, b):
@@ -192,6 +201,16 @@ class GradSink(dict):
         super().__setitem__(k, self.bucketer.ready(k, v) if self.bucketer is not None else v)
 
 
+def broadcast_module_state(net, src=0, group=None):
+    """Same initial weights and buffers on every rank: rank `src`'s (nn.DataParallel replicates module 0's parameters
+    and buffers onto the other GPUs every step, M1/agent.py:157-159; with one process per GPU once at start is enough,
+    the averaged gradients keep the replicas identical and BatchNorm statistics stay per rank)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    for t in list(net.parameters()) + list(net.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
 # ------------------------------------------------------------------------------------------ agents
 class BaseAgent(object):
     """M1/agent.py:25-150 without tensorboard / path plumbing."""
@@ -202,9 +221,7 @@ class BaseAgent(object):
         self.clock = TrainClock()
         self.model_dir = model_dir
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        if self.world > 1:      # same initial weights and buffers on every rank (rank 0's, like DataParallel)
-            for t in list(self.net.parameters()) + list(self.net.buffers()):
-                dist.broadcast(t.data, src=0)
+        broadcast_module_state(self.net)
         self.optimizer = FusedAdam(self.net.parameters(), lr)
         self.optimizer.grad_scale = 1.0 / self.world
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, lr_step_size)
@@ -229,6 +246,9 @@ class BaseAgent(object):
         ck = torch.load(path, map_location=self.device)
         self.net.load_state_dict(ck["model_state_dict"])
         self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        for st in self.optimizer.state.values():     # map_location moved the step counters to the GPU: int(step) would
+            if torch.is_tensor(st.get("step")):      # then synchronise once per parameter and step
+                st["step"] = st["step"].detach().cpu()
         self.scheduler.load_state_dict(ck["scheduler_state_dict"])
         self.clock.restore_checkpoint(ck["clock"])
 

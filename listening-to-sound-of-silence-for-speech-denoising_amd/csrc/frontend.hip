@@ -269,6 +269,79 @@ extern "C" int sos_crm_target_f32(const float* clean, const float* mix, float* o
     return sos_check_launch("sos_crm_target_f32");
 }
 
+// ---------------------------------------------------------- a16: mix speech and noise at an SNR
+// One workgroup per clip.  Pass 1: energies of the signal and of each noise (f64 sums: the clip is 28 000 .. 1e6
+// samples); pass 2: each noise is rescaled so that E_signal / E_noise = 10^(snr/10) (left as it is when the signal or
+// the noise is silent) and added, the peak of the sum is taken; pass 3: mixed, signal and noises are divided by
+// peak / norm (norm == 0 or a silent sum: no normalisation).  M2/tools.py:217-276.
+__global__ __launch_bounds__(256) void add_signals_kernel(const float* __restrict__ sig, const float* __restrict__ noi,
+                                                          const float* __restrict__ snr_db, int K, long long n, float norm,
+                                                          float* __restrict__ mixed, float* __restrict__ sig_out,
+                                                          float* __restrict__ noi_out) {
+    __shared__ double red[256];
+    __shared__ float gain[9];                 // [k < 8] noise gains, [8] final 1/scale
+    const long long b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float* s = sig + b * n;
+    auto block_sum = [&](double v) {
+        red[tid] = v;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) red[tid] += red[tid + st];
+            __syncthreads();
+        }
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    double e = 0.0;
+    for (long long i = tid; i < n; i += 256) e += (double)s[i] * (double)s[i];
+    const double e_sig = block_sum(e);
+    const double target = e_sig / pow(10.0, (double)snr_db[b] / 10.0);        // wanted noise energy
+    for (int k = 0; k < K; ++k) {
+        const float* nz = noi + (b * K + k) * n;
+        double en = 0.0;
+        for (long long i = tid; i < n; i += 256) en += (double)nz[i] * (double)nz[i];
+        en = block_sum(en);
+        if (tid == 0) gain[k] = (e_sig == 0.0 || en == 0.0) ? 1.f : (float)(sqrt(target) / sqrt(en));
+    }
+    __syncthreads();
+    float peak = 0.f;
+    for (long long i = tid; i < n; i += 256) {
+        float m = s[i];
+        for (int k = 0; k < K; ++k) m += noi[(b * K + k) * n + i] * gain[k];
+        mixed[b * n + i] = m;
+        peak = fmaxf(peak, fabsf(m));
+    }
+    red[tid] = (double)peak;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) red[tid] = fmax(red[tid], red[tid + st]);
+        __syncthreads();
+    }
+    if (tid == 0) gain[8] = (norm != 0.f && red[0] != 0.0) ? (float)((double)norm / red[0]) : 1.f;
+    __syncthreads();
+    const float inv = gain[8];
+    for (long long i = tid; i < n; i += 256) {
+        mixed[b * n + i] *= inv;
+        sig_out[b * n + i] = s[i] * inv;
+        for (int k = 0; k < K; ++k) noi_out[(b * K + k) * n + i] = noi[(b * K + k) * n + i] * gain[k] * inv;
+    }
+}
+
+extern "C" int sos_add_signals_f32(const float* signal, const float* noises, const float* snr_db, int64_t batch, int n_noises,
+                                   int64_t n, float norm, float* mixed, float* signal_out, float* noises_out,
+                                   sos_stream_t stream) {
+    if (!signal || !noises || !snr_db || !mixed || !signal_out || !noises_out || batch < 1 || n < 1 || n_noises < 1 ||
+        n_noises > 8) {
+        sos_set_error("sos_add_signals_f32: bad args (1..8 noises per clip)");
+        return SOS_EINVAL;
+    }
+    hipLaunchKernelGGL(add_signals_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, signal, noises, snr_db,
+                       n_noises, (long long)n, norm, mixed, signal_out, noises_out);
+    return sos_check_launch("sos_add_signals_f32");
+}
+
 // --------------------------------------------------------------------- bits -> sample mask
 // Pre-flip mask value of sample j: 1 if j lies in [int(i*r), int((i+1)*r - 1)) of a silent
 // frame i (bit 0), else 0.  All index arithmetic in IEEE double with explicit (un-fused)

@@ -25,33 +25,6 @@ SNRS = [-10, -7, -3, 0, 3, 7, 10]
 PHASE_TRAINING, PHASE_TESTING, PHASE_PREDICTION = 'training', 'testing', 'pred'
 
 
-def power_of_signal(signal):
-    return np.sum(np.abs(signal ** 2))
-
-
-def add_signals(signal, noises, snr, norm=0.5):
-    """M2/tools.py:217-276 (same return triple: mixed, clean, [noises])."""
-    if not isinstance(noises, list):
-        noises = [noises]
-    signal_power = power_of_signal(signal)
-    pn = signal_power / np.power(10, snr / 10)
-    new_noises = []
-    ret_signal = np.copy(signal)
-    for noise in noises:
-        if signal_power == 0:
-            new_noise = noise
-        else:
-            ratio = np.sqrt(power_of_signal(noise)) / np.sqrt(pn)
-            new_noise = noise if ratio == 0 else noise / ratio
-        new_noises.append(new_noise)
-        ret_signal = ret_signal + new_noise
-    if norm:
-        scale = np.max(np.abs(ret_signal)) / norm
-        if scale != 0:
-            return ret_signal / scale, signal / scale, [x / scale for x in new_noises]
-    return ret_signal, signal, new_noises
-
-
 def synth_bits(rng, n_frames, p_silent=0.3, min_run=5):
     """Per-video-frame labels, 1 = non-silent, runs of at least `min_run` frames."""
     bits = []
@@ -61,47 +34,75 @@ def synth_bits(rng, n_frames, p_silent=0.3, min_run=5):
     return np.array(bits[:n_frames], dtype=np.uint8)
 
 
-def synth_clip(i, n_samples=int(DATA_REQUIRED_SR * CLIP_SECONDS), sr=DATA_REQUIRED_SR, fps=FPS, snr=None):
-    """Returns dict(mixed, clean, full_noise: f32 [n], bits: u8 [n_frames], snr)."""
+def _synth_raw(i, n_samples, sr, fps, snr):
+    """Host-side draws of clip i (seeded): un-gated "speech", coloured noise, per-video-frame labels, SNR."""
     rng = np.random.default_rng(1234 + i)
     n_frames = int(round(n_samples / sr * fps))
     bits = synth_bits(rng, n_frames)
-    env = np.repeat(bits.astype(np.float32), int(np.ceil(sr / fps)))[:n_samples]
-    env = np.pad(env, (0, n_samples - len(env)))
-    # band-limited "speech": white noise through a 2-pole resonator-ish smoothing
+    # band-limited "speech": white noise through a short smoothing window
     s = rng.standard_normal(n_samples).astype(np.float32)
-    s = np.convolve(s, np.hanning(9) / np.hanning(9).sum(), mode="same").astype(np.float32) * env
+    s = np.convolve(s, np.hanning(9) / np.hanning(9).sum(), mode="same").astype(np.float32)
     z = rng.standard_normal(n_samples).astype(np.float32)
     a = 0.85                                   # 1-pole low-pass colouring
     noise = lfilter([1 - a], [1, -a], z).astype(np.float32)
-    snr = SNRS[i % len(SNRS)] if snr is None else snr
-    mixed, clean, noises = add_signals(s, [noise], snr, norm=0.5)
-    return dict(mixed=mixed.astype(np.float32), clean=clean.astype(np.float32),
-                full_noise=noises[0].astype(np.float32), bits=bits, snr=snr)
+    return s, noise, bits, (SNRS[i % len(SNRS)] if snr is None else snr)
 
 
-def synth_batch(start, batch, **kw):
-    clips = [synth_clip(start + i, **kw) for i in range(batch)]
-    out = {k: np.stack([c[k] for c in clips]) for k in ("mixed", "clean", "full_noise", "bits")}
-    out["snr"] = [c["snr"] for c in clips]
-    return out
+def synth_batch(start, batch, n_samples=int(DATA_REQUIRED_SR * CLIP_SECONDS), sr=DATA_REQUIRED_SR, fps=FPS, snr=None,
+                device="cuda"):
+    """`batch` synthetic clips start .. start+batch-1 -> dict of host arrays mixed / clean / full_noise (B, n) f32,
+    bits (B, n_frames) u8, snr list.  The draws are host numpy (seeded per clip); the speech is gated with the SAME
+    per-sample mask the pipeline derives from the bits (sos_bits_to_mask: silent samples are exactly zero, so
+    mixed == clean + full_noise sample for sample, M2/dataset.py:183 then :217), and the mix at the SNR + peak
+    normalisation is sos_add_signals_f32."""
+    draws = [_synth_raw(start + i, n_samples, sr, fps, snr) for i in range(batch)]
+    bits = np.stack([d[2] for d in draws])
+    sp = torch.from_numpy(np.stack([d[0] for d in draws])).to(device)
+    nz = torch.from_numpy(np.stack([d[1] for d in draws])).to(device)
+    mask = tools.bits_to_mask_batch(torch.from_numpy(bits).to(device), float(sr) / fps, n_samples)
+    snrs = [d[3] for d in draws]
+    mixed, clean, noise = tools.add_signals_batch(sp * (1 - mask), nz, snrs, norm=0.5)
+    return dict(mixed=mixed.cpu().numpy(), clean=clean.cpu().numpy(), full_noise=noise.cpu().numpy(), bits=bits, snr=snrs)
+
+
+def synth_clip(i, **kw):
+    """One synthetic clip: dict(mixed, clean, full_noise: f32 [n], bits: u8 [n_frames], snr)."""
+    b = synth_batch(i, 1, **kw)
+    return dict(mixed=b["mixed"][0], clean=b["clean"][0], full_noise=b["full_noise"][0], bits=b["bits"][0], snr=b["snr"][0])
+
+
+def shard_indices(n_items, rank, world_size):
+    """The item indices rank `rank` of `world_size` processes owns: every rank gets ceil(n / world) of them (the tail
+    wraps around, like torch's DistributedSampler, so that all ranks run the same number of steps and the gradient
+    all-reduce never waits for a missing partner)."""
+    if not 0 <= rank < world_size:
+        raise ValueError("rank must be in [0, world_size)")
+    per = (n_items + world_size - 1) // world_size
+    return [(rank + k * world_size) % n_items for k in range(per)] if n_items else []
 
 
 class _SyntheticLoader:
-    def __init__(self, model, phase, batch_size, n_batches, device):
+    """Global batch b of the epoch = clips [b*G, (b+1)*G) with G = batch_size * world_size; rank r takes the r-th
+    slice of `batch_size` clips (disjoint across ranks, identical for every world size)."""
+
+    def __init__(self, model, phase, batch_size, n_batches, device, rank=0, world_size=1):
         self.model, self.phase, self.batch_size, self.n_batches, self.device = model, phase, batch_size, n_batches, device
+        self.rank, self.world_size = rank, world_size
 
     def __len__(self):
         return self.n_batches
 
-    def __iter__(self):
+    def starts(self):
         off = {PHASE_TRAINING: 0, PHASE_TESTING: 10 ** 6, PHASE_PREDICTION: 2 * 10 ** 6}[self.phase]
-        for b in range(self.n_batches):
-            yield make_batch(self.model, off + b * self.batch_size, self.batch_size, self.device)
+        return [off + (b * self.world_size + self.rank) * self.batch_size for b in range(self.n_batches)]
+
+    def __iter__(self):
+        for st in self.starts():
+            yield make_batch(self.model, st, self.batch_size, self.device)
 
 
 def make_batch(model, start, batch_size, device="cuda"):
-    return batch_from_raw(model, synth_batch(start, batch_size), list(range(start, start + batch_size)), device)
+    return batch_from_raw(model, synth_batch(start, batch_size, device=device), list(range(start, start + batch_size)), device)
 
 
 def batch_from_raw(model, raw, starts, device="cuda"):
@@ -116,8 +117,9 @@ def batch_from_raw(model, raw, starts, device="cuda"):
         return {"label": bits.float(), "audio": transform.stft_batch(mixed)}
     clean = torch.from_numpy(raw["clean"]).to(device)
     full_noise = torch.from_numpy(raw["full_noise"]).to(device)
+    # the clean clip was silenced on its silent intervals BEFORE mixing (M2/dataset.py:183 then :217: synth_batch and
+    # _FileLoader do that), so mixed == clean + full_noise and nothing is re-gated here
     mask, noise_sig = tools.bits_to_mask_batch(bits, DATA_REQUIRED_SR / FPS, n, mixed)   # M2/dataset.py:193,229
-    clean = clean * (1 - mask)                                                          # silent intervals truly silent
     S = transform.stft_batch(torch.cat([mixed, clean, noise_sig, full_noise], dim=0))
     B = batch_size
     mixed_s, clean_s, noise_s, full_s = S[:B], S[B:2 * B], S[2 * B:3 * B], S[3 * B:]
@@ -138,7 +140,8 @@ class _FileLoader:
     peak 0.5 (M2/dataset.py:155-208).  Files are decoded and resampled once (GPU) and kept in host memory; draws
     come from a seeded numpy generator (the reference uses unseeded worker RNGs)."""
 
-    def __init__(self, model, phase, batch_size, dataset_json, noise_files, snr_idx, data_root, device, seed):
+    def __init__(self, model, phase, batch_size, dataset_json, noise_files, snr_idx, data_root, device, seed, rank=0,
+                 world_size=1):
         import json
         import os
         from . import audio_io
@@ -153,9 +156,7 @@ class _FileLoader:
             y, _ = audio_io.load(fix(f["audio_path"]), sr=DATA_REQUIRED_SR)
             self.audio.append(y)
             bits, fps = f["bit_stream"], float(f["framerate"])
-            runs = [(k, len(list(g))) for k, g in __import__("itertools").groupby(bits)]
-            i1 = runs[0][1] if runs and runs[0][0] == "2" else 0
-            i2 = len(bits) - (runs[-1][1] if len(runs) > 1 and runs[-1][0] == "2" else 0)
+            i1, i2 = tools.trim_unknown_frames(bits)       # the reference's truncate(): same rule as the hand-off
             lab = bits[i1:i2]
             if model == "detector":
                 nfr = int(round(CLIP_SECONDS * FPS))
@@ -176,11 +177,16 @@ class _FileLoader:
             raise RuntimeError("no clips of %g s in %s (or no noise files)" % (CLIP_SECONDS, dataset_json))
         if any(len(nz) < n_clip for nz in self.noises):
             raise ValueError("noise files must be at least one clip long")
-        self.rng = np.random.default_rng(seed)
+        # the shuffle is drawn from `seed` alone (every rank computes the same permutation, then takes its own shard of
+        # it); the noise / SNR draws come from a per-rank stream
+        self.order_rng = np.random.default_rng(seed)
+        self.rng = np.random.default_rng([seed, rank])
         self.n_clip = n_clip
+        self.rank, self.world_size = rank, world_size
 
     def __len__(self):
-        return (len(self.items) + self.batch_size - 1) // self.batch_size
+        per_rank = (len(self.items) + self.world_size - 1) // self.world_size
+        return (per_rank + self.batch_size - 1) // self.batch_size
 
     def _clip(self, item):
         fi, a, b, bits, fps = item
@@ -194,7 +200,8 @@ class _FileLoader:
     def __iter__(self):
         order = np.arange(len(self.items))
         if self.phase == PHASE_TRAINING:
-            self.rng.shuffle(order)
+            self.order_rng.shuffle(order)
+        order = order[shard_indices(len(order), self.rank, self.world_size)]
         for s0 in range(0, len(order), self.batch_size):
             idx = order[s0:s0 + self.batch_size]
             clips = [self._clip(self.items[k]) for k in idx]
@@ -202,25 +209,35 @@ class _FileLoader:
             bits = np.stack([c[1] for c in clips])
             # silent intervals truly silent before mixing (M2/dataset.py:160-183): the sample mask comes from the GPU kernel
             mask = tools.bits_to_mask_batch(torch.from_numpy(bits).to(self.device), DATA_REQUIRED_SR / FPS, self.n_clip).cpu().numpy()
-            raw = dict(mixed=[], clean=[], full_noise=[], bits=bits, snr=[])
-            for a, m in zip(audio, mask):
-                snr = SNRS[self.snr_idx] if self.snr_idx is not None else SNRS[int(self.rng.integers(len(SNRS)))]
+            snrs, crops = [], []
+            for _ in idx:
+                snrs.append(SNRS[self.snr_idx] if self.snr_idx is not None else SNRS[int(self.rng.integers(len(SNRS)))])
                 nz = self.noises[int(self.rng.integers(len(self.noises)))]
                 st = int(self.rng.integers(0, len(nz) - self.n_clip + 1))
-                mixed, clean, fn = add_signals(a * (1 - m), [nz[st:st + self.n_clip]], snr, norm=0.5)
-                raw["mixed"].append(mixed); raw["clean"].append(clean); raw["full_noise"].append(fn[0]); raw["snr"].append(snr)
-            for k in ("mixed", "clean", "full_noise"):
-                raw[k] = np.stack(raw[k]).astype(np.float32)
+                crops.append(nz[st:st + self.n_clip].astype(np.float32))
+            mixed, clean, fn = tools.add_signals_batch(torch.from_numpy(audio * (1 - mask)).to(self.device),
+                                                       torch.from_numpy(np.stack(crops)).to(self.device), snrs, norm=0.5)
+            raw = dict(mixed=mixed.cpu().numpy(), clean=clean.cpu().numpy(), full_noise=fn.cpu().numpy(), bits=bits, snr=snrs)
             batch = batch_from_raw(self.model, raw, [self.items[k][1] for k in idx], self.device)
             batch["_raw"] = raw
             yield batch
 
 
 def get_dataloader(phase, batch_size=4, num_workers=4, snr_idx=None, dataset_json=None, clean_audio=True,
-                   model="denoiser", n_batches=8, device="cuda", noise_files=None, data_root=None, seed=0):
+                   model="denoiser", n_batches=8, device="cuda", noise_files=None, data_root=None, seed=0, rank=None,
+                   world_size=None):
     """Reference signature + `model` ('detector' -> M1 schema, 'denoiser' -> M2 schema).  With `dataset_json` and
-    `noise_files` the clips come from real recordings (see _FileLoader); otherwise they are synthesised."""
+    `noise_files` the clips come from real recordings (see _FileLoader); otherwise they are synthesised.
+    `batch_size` is PER RANK; `rank` / `world_size` (default: torch.distributed's, else 0 / 1) shard the clips so that
+    the ranks of a data-parallel job see disjoint data (the reference's single-process DataParallel scatters one
+    loader's batch over the GPUs, M2/dataset.py:44-50 + M2/agent.py:151)."""
     assert phase in (PHASE_TRAINING, PHASE_TESTING, PHASE_PREDICTION)
+    if rank is None or world_size is None:
+        import torch.distributed as dist
+        on = dist.is_available() and dist.is_initialized()
+        rank = (dist.get_rank() if on else 0) if rank is None else rank
+        world_size = (dist.get_world_size() if on else 1) if world_size is None else world_size
     if dataset_json is not None and noise_files:
-        return _FileLoader(model, phase, batch_size, dataset_json, noise_files, snr_idx, data_root, device, seed)
-    return _SyntheticLoader(model, phase, batch_size, n_batches, device)
+        return _FileLoader(model, phase, batch_size, dataset_json, noise_files, snr_idx, data_root, device, seed, rank,
+                           world_size)
+    return _SyntheticLoader(model, phase, batch_size, n_batches, device, rank, world_size)

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import audio_io, metrics, tools, transform
-from .dataset import add_signals
+from .tools import add_signals
 
 JSON_DUMP_PARAMS = dict(indent=4, sort_keys=False, ensure_ascii=False, separators=(',', ':'))   # M1/tools.py:36
 BITSTREAM_JSON_LABEL = 'bit_stream'            # M1/tools.py:54
@@ -111,13 +111,7 @@ def show_metrics(y_true, y_score):
         ('roc_auc', nan_to_null(auc)), ('mcc', nan_to_null(float(mcc)))])
 
 
-def _trim_unknown(bits):
-    """M1/tools.py:270-274,306-311: leading / trailing runs of '2' (unlabelled frames) are cut; streams
-    without two such runs are used whole."""
-    runs = [len(list(g)) for k, g in groupby(bits) if k == '2']
-    if len(runs) >= 2:
-        return runs[0], len(bits) - runs[1]
-    return 0, len(bits)
+_trim_unknown = tools.trim_unknown_frames
 
 
 def _resolve(path, dataset_path, data_root):

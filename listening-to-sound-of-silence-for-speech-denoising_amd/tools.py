@@ -55,3 +55,47 @@ def threshold_bits(logits, threshold=0.5):
     L.check(L.lib().sos_threshold_bits(L.ptr(lg), lg.numel(), float(threshold), L.ptr(bits), L.ptr(conf),
                                        L.stream_ptr()), "sos_threshold_bits")
     return bits, conf
+
+
+def add_signals_batch(signal, noises, snr, norm=0.5):
+    """Batched, on-device `add_signals`: signal f32 (B, n), noises f32 (B, K, n) or (B, n), snr scalar / sequence / tensor
+    of B values (dB) -> (mixed (B, n), signal (B, n), noises like the input), GPU tensors."""
+    L.require_cuda(signal, noises)
+    signal = signal.contiguous().float()
+    squeeze = noises.dim() == 2
+    nz = (noises[:, None] if squeeze else noises).contiguous().float()
+    B, n = signal.shape
+    if nz.shape[0] != B or nz.shape[2] != n or not 1 <= nz.shape[1] <= 8:
+        raise ValueError("noises must be (B, K <= 8, n) matching signal (B, n)")
+    snr_t = torch.as_tensor(snr, dtype=torch.float32).reshape(-1)
+    snr_t = (snr_t.expand(B) if snr_t.numel() == 1 else snr_t).contiguous().to(signal.device)
+    if snr_t.numel() != B:
+        raise ValueError("snr must be a scalar or one value per clip")
+    mixed, s_out, n_out = torch.empty_like(signal), torch.empty_like(signal), torch.empty_like(nz)
+    L.check(L.lib().sos_add_signals_f32(L.ptr(signal), L.ptr(nz), L.ptr(snr_t), B, nz.shape[1], n, float(norm or 0.0),
+                                        L.ptr(mixed), L.ptr(s_out), L.ptr(n_out), L.stream_ptr()), "sos_add_signals_f32")
+    return mixed, s_out, (n_out[:, 0] if squeeze else n_out)
+
+
+def add_signals(signal, noises, snr, norm=0.5):
+    """M2/tools.py:217-276 with its arguments and its return triple (mixed, signal, [noises]): numpy in, numpy out, the
+    arithmetic in sos_add_signals_f32."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("sos_amd.tools needs an MI355X: there is no CPU fallback")
+    single = not isinstance(noises, (list, tuple))
+    stack = np.stack([np.asarray(x, dtype=np.float32) for x in ([noises] if single else noises)])
+    sig = torch.from_numpy(np.ascontiguousarray(signal, dtype=np.float32)).cuda()[None]
+    m, s, nz = add_signals_batch(sig, torch.from_numpy(stack).cuda()[None], float(snr), norm)
+    dt = np.asarray(signal).dtype if np.issubdtype(np.asarray(signal).dtype, np.floating) else np.float32
+    return m[0].cpu().numpy().astype(dt), s[0].cpu().numpy().astype(dt), [x.cpu().numpy().astype(dt) for x in nz[0]]
+
+
+def trim_unknown_frames(bits):
+    """M1/tools.py:270-274,306-311 (`truncate`): the first two runs of '2' (unlabelled frames) bound the labelled part
+    of a bit-stream; a stream without two such runs is used whole.  Returns (first, end) frame indices.  One helper
+    for the file data loader and the on-disk hand-off."""
+    from itertools import groupby
+    runs = [len(list(g)) for k, g in groupby(bits) if k == '2']
+    if len(runs) >= 2:
+        return runs[0], len(bits) - runs[1]
+    return 0, len(bits)

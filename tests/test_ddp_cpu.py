@@ -21,7 +21,20 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from sos_amd.agent import GradBucketer, GradSink
+    from sos_amd.agent import GradBucketer, GradSink, broadcast_module_state
+    from sos_amd.dataset import get_dataloader
+    # rank 0's initial weights and buffers win (DataParallel replicates module 0)
+    torch.manual_seed(100 + rank)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.BatchNorm1d(3))
+    net[1].running_mean.fill_(float(rank + 1))
+    broadcast_module_state(net)
+    torch.manual_seed(100)
+    want_net = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.BatchNorm1d(3))
+    same = all(torch.equal(a, b) for a, b in zip(net.parameters(), want_net.parameters())) and \
+        torch.equal(net[1].running_mean, torch.ones(3))
+    # the loader shards by torch.distributed's rank / world size by default: disjoint clips, same number of steps
+    ld = get_dataloader("training", batch_size=4, n_batches=3, model="detector")
+    starts = ld.starts()
     torch.manual_seed(0)
     params = [("a.weight", torch.nn.Parameter(torch.zeros(7, 5))), ("a.bias", torch.nn.Parameter(torch.zeros(7))),
               ("b.weight", torch.nn.Parameter(torch.zeros(300, 40))), ("c.slope", torch.nn.Parameter(torch.zeros(1)))]
@@ -31,11 +44,13 @@ def _worker(rank, world, port, q):
     for name, p in reversed(params):
         sink[name] = torch.full(p.shape, float(rank + 1)) * (1 + len(name))
     bk.finalize()
-    ok = True
+    ok = same
     for name, p in params:
         want = (1 + 2) * (1 + len(name)) * torch.ones(p.shape)          # SUM over ranks 1 and 2
         ok = ok and p.grad is not None and torch.equal(p.grad, want) and p.grad.shape == p.shape
-    q.put((rank, ok))
+        # the optimizer's grad_scale = 1/world turns the sum into the data-parallel AVERAGE (the kernel multiplies it in)
+        ok = ok and torch.allclose(p.grad * (1.0 / bk.world), 1.5 * (1 + len(name)) * torch.ones(p.shape))
+    q.put((rank, ok, starts))
     dist.destroy_process_group()
 
 
@@ -49,4 +64,18 @@ def test_grad_bucketer_allreduce_two_ranks():
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    res = sorted(res)
+    assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True)]
+    s0, s1 = res[0][2], res[1][2]
+    clips = lambda starts: {c for st in starts for c in range(st, st + 4)}       # noqa: E731
+    assert len(s0) == len(s1) == 3 and not (clips(s0) & clips(s1)) and clips(s0) | clips(s1) == set(range(24))
+
+
+def test_shard_indices_cover_every_item_once_per_epoch():
+    from sos_amd.dataset import shard_indices
+    for n, world in ((10, 1), (10, 3), (7, 8), (64, 8), (0, 2)):
+        shards = [shard_indices(n, r, world) for r in range(world)]
+        assert len({len(s) for s in shards}) == 1                      # same number of steps on every rank
+        seen = [i for s in shards for i in s]
+        assert set(seen) == set(range(n))                              # nothing dropped (the tail wraps around)
+        assert len(seen) - n < world or n == 0

@@ -134,3 +134,32 @@ def test_bits_to_mask_randomised_bit_exact():
         want = ofe.convert_bitstreammask_to_audiomask(np.zeros(n, np.float32), ratio, list(bits))
         got = tools.bits_to_mask_batch(torch.from_numpy(bits[None]).cuda(), ratio, n)[0].cpu().numpy()
         assert np.array_equal(got, want), (case, nfr, ratio, n)
+
+
+def test_add_signals_golden_and_edge_cases(golden):
+    """a16 (M2/tools.py:217-276): the PRODUCT functions (tools.add_signals = numpy API, tools.add_signals_batch = device
+    API, both sos_add_signals_f32) against vectors produced by the imported reference, plus its edge cases: a list of
+    noises, a silent signal, a silent noise, norm=None."""
+    from sos_amd import tools
+    g = golden("addsignals")
+    for snr in (-10, 0, 7):
+        m, c, n = tools.add_signals(g["sig"], [g["noi"]], snr, 0.5)
+        assert isinstance(n, list) and m.dtype == np.float32
+        # the reference sums float32 energies pairwise in float32, the kernel in f64: 1e-7-level differences of the gains
+        assert np.allclose(m, g[f"mixed_{snr}"], atol=3e-7) and np.allclose(c, g[f"clean_{snr}"], atol=3e-7)
+        assert np.allclose(n[0], g[f"noise_{snr}"], atol=3e-7)
+        assert abs(np.max(np.abs(m)) - 0.5) < 1e-6
+        assert np.allclose(m, c + n[0], atol=1e-6)
+    # batched, different SNR per clip, against the oracle restatement
+    sig = np.stack([g["sig"], g["noi"][::-1] * 0.3, np.zeros_like(g["sig"])])
+    noi = np.stack([g["noi"], g["sig"], g["noi"]])
+    snrs = [3.0, -7.0, 0.0]
+    M, C, N = tools.add_signals_batch(torch.from_numpy(sig).cuda(), torch.from_numpy(noi).cuda(), snrs)
+    for i in range(3):
+        m, c, n = ofe.add_signals(sig[i], noi[i], snrs[i], 0.5)
+        assert np.allclose(M[i].cpu().numpy(), m, atol=3e-7) and np.allclose(C[i].cpu().numpy(), c, atol=3e-7)
+        assert np.allclose(N[i].cpu().numpy(), n, atol=3e-7)
+    # two noises, no normalisation; silent noise left alone
+    m, c, n = tools.add_signals(g["sig"], [g["noi"], np.zeros_like(g["noi"])], 5, None)
+    m2, c2, n2 = ofe.add_signals(g["sig"], g["noi"], 5, None)
+    assert np.allclose(m, m2, atol=3e-6) and np.array_equal(c, g["sig"]) and not n[1].any()
