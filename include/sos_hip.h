@@ -46,15 +46,22 @@ const char* sos_storage_dtype(void);
  * T = 1 + n_samples/hop.  window f32 [win_length], twiddle f32 [n_fft][2] (cos,sin). */
 int sos_stft_f32(const float* wave, int64_t batch, int64_t n_samples, int64_t wave_stride,
                  const float* window, const float* twiddle, int n_fft, int hop, int win_length,
-                 float* out, int64_t n_frames, sos_stream_t stream);
+                 float* out, int64_t n_frames,
+                 const int32_t* clip_samples /* optional device [B], ragged batch: clip b has clip_samples[b] <= n_samples
+                    samples (reflected at ITS end) and 1 + clip_samples[b]/hop frames; rows keep the pitch n_frames */,
+                 sos_stream_t stream);
 
 /* ---- a2  fast_istft: M1/transform.py:196-202 (librosa.istft(S,158,400)): irDFT,
  * window, overlap-add, divide by window-sum-square, trim n_fft/2 both ends.
  * spec f32 [B][2][F][T]; inv_wss f32 [n_fft + hop*(T-1)] = 1/wss where wss > tiny
- * else 1; out f32 [B][out_stride], hop*(T-1) samples written. */
+ * else 1, or NULL: the kernel sums the window squares of the (<= 3) frames covering a sample itself;
+ * out f32 [B][out_stride], hop*(T-1) samples written. */
 int sos_istft_f32(const float* spec, int64_t batch, int64_t n_frames, const float* window,
                   const float* twiddle, const float* inv_wss, int n_fft, int hop, int win_length,
-                  float* out, int64_t out_stride, sos_stream_t stream);
+                  float* out, int64_t out_stride,
+                  const int32_t* clip_frames /* optional device [B], ragged batch: clip b has clip_frames[b] <= n_frames
+                     frames -> hop*(clip_frames[b]-1) samples; inv_wss must then be NULL */,
+                  sos_stream_t stream);
 
 /* ---- a4/a5  batch_fast_icRM_sigmoid: M1/transform.py:156-169 (and the numpy
  * twin fast_icRM_sigmoid :141-153): M = (1/a)(log(c/(1-c+1e-8)+1e-10)+b), rec = M*Y
@@ -76,6 +83,8 @@ int sos_crm_target_f32(const float* clean, const float* mix, float* out, int64_t
  * Integer index rule evaluated in IEEE double exactly like the Python. */
 int sos_bits_to_mask(const uint8_t* bits, int64_t batch, int64_t n_frames, double ratio,
                      int64_t n_samples, float* mask, const float* sig, float* masked,
+                     const int32_t* clip_frames, const int32_t* clip_samples /* optional device [B] each, ragged batch:
+                        clip b has clip_frames[b] bits and clip_samples[b] samples; row pitches stay n_frames / n_samples */,
                      sos_stream_t stream);
 
 /* ---- a16  add_signals / add_noise_to_audio: M2/tools.py:217-303.  Per clip b: every noise k is rescaled so that
@@ -135,6 +144,15 @@ typedef struct sos_conv_desc {
      * tile < sos_conv2d_tile_count(desc); feed to sos_bn_finalize(partial = stats, nblk = tile count). */
     float* stats;
     int32_t stats_c;
+    /* optional RAGGED batch (BASELINE configs[3]: clips of different lengths in one launch; the reference runs each
+     * file at its own length, M2/predict.py:405-447): the buffers keep the geometry above with W / Wl / Wo = the
+     * batch's maxima, image b uses only its first wl_tab[b] logical input columns (zero / reflect borders are taken
+     * at ITS end) and produces wo_tab[b] output columns; the rest of its output columns are left untouched.  Device
+     * int32 [B] each, both or neither.  w_gather_stride: distance in ints between the images' w_gather tables
+     * (0: one table for all). */
+    const int32_t* wl_tab;
+    const int32_t* wo_tab;
+    int32_t w_gather_stride;
 } sos_conv_desc;
 
 int sos_conv2d_fwd(const sos_conv_desc* desc /* host pointer */, sos_stream_t stream);
@@ -169,7 +187,10 @@ int sos_lstm_pack_whh(const float* whh, int H, void* fwd_hi, void* fwd_lo, void*
 int sos_lstm_bidir_fwd(const float* xproj, const void* wpk_hi, const void* wpk_lo /* optional */, int64_t B, int64_t T,
                        int H, void* out_bf16, int out_cs, int out_dtype, int64_t out_third,
                        float* save_gates /* optional f32, ceil16(B)*T*2*4H: post-activation i,f,g,o */,
-                       float* save_c /* optional f32, ceil16(B)*T*2*H: cell state */, sos_stream_t stream);
+                       float* save_c /* optional f32, ceil16(B)*T*2*H: cell state */,
+                       const int32_t* lengths /* optional device [B]: clip b has lengths[b] <= T frames (ragged batch:
+                          its reverse pass starts at frame lengths[b]-1; rows past it are neither read nor written) */,
+                       sos_stream_t stream);
 /* save_gates / save_c are consumed only by sos_lstm_bidir_bwd; their layout is the forward kernel's MFMA lane order
  * [16-clip group][t][dir][4-unit tile][clip][unit][i,f,g,o] (one coalesced store per tile and step). */
 

@@ -32,6 +32,7 @@ class ConvDesc(C.Structure):
         ("scale", C.c_void_p), ("shift", C.c_void_p),
         ("act", C.c_int32), ("act_param", C.c_void_p), ("accumulate", C.c_int32),
         ("stats", C.c_void_p), ("stats_c", C.c_int32),
+        ("wl_tab", C.c_void_p), ("wo_tab", C.c_void_p), ("w_gather_stride", C.c_int32),
     ]
 
 
@@ -56,12 +57,12 @@ _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 # name -> argtypes, exactly the prototypes of include/sos_hip.h
 SIGNATURES = {
     "sos_abi_version": [],
-    "sos_stft_f32": [_P, _L, _L, _L, _P, _P, _I, _I, _I, _P, _L, _P],
-    "sos_istft_f32": [_P, _L, _L, _P, _P, _P, _I, _I, _I, _P, _L, _P],
+    "sos_stft_f32": [_P, _L, _L, _L, _P, _P, _I, _I, _I, _P, _L, _P, _P],
+    "sos_istft_f32": [_P, _L, _L, _P, _P, _P, _I, _I, _I, _P, _L, _P, _P],
     "sos_crm_apply_f32": [_P, _P, _P, _L, _L, _F, _F, _P],
     "sos_crm_apply_bwd_f32": [_P, _P, _P, _P, _L, _L, _F, _P],
     "sos_crm_target_f32": [_P, _P, _P, _L, _L, _F, _F, _P],
-    "sos_bits_to_mask": [_P, _L, _L, _D, _L, _P, _P, _P, _P],
+    "sos_bits_to_mask": [_P, _L, _L, _D, _L, _P, _P, _P, _P, _P, _P],
     "sos_threshold_bits": [_P, _L, _F, _P, _P, _P],
     "sos_add_signals_f32": [_P, _P, _P, _L, _I, _L, _F, _P, _P, _P, _P],
     "sos_storage_dtype": [],
@@ -73,7 +74,7 @@ SIGNATURES = {
     "sos_conv2d_tile_count": [C.POINTER(ConvDesc)],
     "sos_lstm_pack_bytes": [_I, _I],
     "sos_lstm_pack_whh": [_P, _I, _P, _P, _P, _P, _P],
-    "sos_lstm_bidir_fwd": [_P, _P, _P, _L, _L, _I, _P, _I, _I, _L, _P, _P, _P],
+    "sos_lstm_bidir_fwd": [_P, _P, _P, _L, _L, _I, _P, _I, _I, _L, _P, _P, _P, _P],
     "sos_bn_bwd": [C.POINTER(View), C.POINTER(View), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(View), _P, _P],
     "sos_act_bwd_from_y": [C.POINTER(View), C.POINTER(View), _I, C.POINTER(View), _P],
     "sos_pack_grad_f32": [_P, _P, _I, _L, _L, _I, _L, _L, _L, C.POINTER(View), _P, _P],

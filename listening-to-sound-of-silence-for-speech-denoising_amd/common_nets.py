@@ -116,12 +116,15 @@ def encoder_plan(enc, x3):
     return plan
 
 
-def run_encoder(plan, a, feat, feat_row, feat_third, feat_c_off, x3, w_gather=None, T_out=None):
+def run_encoder(plan, a, feat, feat_row, feat_third, feat_c_off, x3, w_gather=None, T_out=None, rag=None, rag_out=None):
     """Run blocks 0..n-2 NHWC->NHWC (ping-pong) and the final 1x1 block straight into the LSTM
     feature matrix feat[b][t][c*F + f] (the reference's view(B,-1,T).permute(2,0,1),
     M1/networks.py:132,142 / M2/networks.py:84-87), optionally through a nearest-resize column
-    gather (F.interpolate, M1/networks.py:133)."""
+    gather (F.interpolate, M1/networks.py:133).  rag: engine.Ragged of a variable-length batch (every conv then
+    takes the clips' own widths); rag_out: (per-clip output widths table, gather stride) of the last block when it
+    resizes (w_gather is then a (B, T_out) table of per-clip nearest indices)."""
     B, H, W = a.B, a.H, a.W
+    rk = rag.kw(0) if rag is not None else {}
     cur = a
     bufs = [None, None]
     for i, lp in enumerate(plan[:-1]):
@@ -131,13 +134,15 @@ def run_encoder(plan, a, feat, feat_row, feat_third, feat_c_off, x3, w_gather=No
             dst = E.Act(B, H, W, cs, x3, a.t.device)
             bufs[i & 1] = dst
         E.conv_to_act(cur, 0, lp["cin_store"], lp["w"], lp["kh"], lp["kw"], lp["cout"], lp["scale"], lp["shift"],
-                      L.ACT_RELU, dst, cout_store=cs, dil=lp["dil"], pad=lp["pad"], Ho=H, Wo=W)
+                      L.ACT_RELU, dst, cout_store=cs, dil=lp["dil"], pad=lp["pad"], Ho=H, Wo=W, **rk)
         cur = dst
     lp = plan[-1]
     Wo = W if T_out is None else T_out
+    if rag is not None and rag_out is not None:       # logical input columns = output columns = the clip's frame count
+        rk = dict(wl_tab=rag_out[0], wo_tab=rag_out[0], wg_stride=rag_out[1])
     E.conv(cur, 0, lp["cin_store"], lp["w"], 1, 1, lp["cout"], lp["scale"], lp["shift"], L.ACT_RELU,
            out=feat, out_dtype=L.DT_BF16X3 if x3 else L.DT_BF16, sb=Wo * feat_row, sh=1, sw=feat_row, sc=H,
-           c_off=feat_c_off, third=feat_third, Ho=H, Wo=Wo, w_gather=w_gather)
+           c_off=feat_c_off, third=feat_third, Ho=H, Wo=Wo, w_gather=w_gather, **rk)
 
 
 def lstm_plan(lstm, cin_store, x3):
@@ -150,14 +155,15 @@ def lstm_plan(lstm, cin_store, x3):
                 shift=E.pad_vec(bias, w.shape[1]), wpk=E.lstm_pack(lstm, x3), H=H, cin_store=cin_store)
 
 
-def run_lstm(lp, feat_dims, B, T, x3, device):
-    """Input projection (1x1 conv on MFMA) + recurrent kernel -> Act [B,1,T,pad16(2H)]."""
+def run_lstm(lp, feat_dims, B, T, x3, device, lengths=None):
+    """Input projection (1x1 conv on MFMA) + recurrent kernel -> Act [B,1,T,pad16(2H)].  lengths: int32 device (B,)
+    frames per clip of a ragged batch."""
     H = lp["H"]
     xproj = torch.empty((B, T, 8 * H), dtype=torch.float32, device=device)
     E.conv(None, 0, lp["cin_store"], lp["w"], 1, 1, 8 * H, lp["scale"], lp["shift"], L.ACT_NONE,
            out=xproj, out_dtype=L.DT_F32, sb=T * 8 * H, sh=0, sw=8 * H, sc=1, Ho=1, Wo=T, in_dims=feat_dims)
     h = E.Act(B, 1, T, E.pad_to(2 * H, 16), x3, device, zero=True)
-    E.lstm(xproj, lp["wpk"], B, T, H, h)
+    E.lstm(xproj, lp["wpk"], B, T, H, h, lengths=lengths)
     return h
 
 
@@ -180,3 +186,17 @@ def nearest_index(in_size, out_size, device):
         idx = np.minimum(np.floor(np.arange(out_size, dtype=np.float32) * scale).astype(np.int64), in_size - 1)
         _nearest_tables[key] = torch.from_numpy(idx.astype(np.int32)).to(device)
     return _nearest_tables[key]
+
+
+def nearest_index_ragged(rag, n_max, device):
+    """(B, n_max) int32: row b = nearest_index(rag.T[b], rag.n_vframes[b]) padded with zeros (never read: the conv's
+    per-clip logical width stops at n_vframes[b]); cached on the Ragged object."""
+    key = ("nearest", n_max)
+    t = rag._tabs.get(key)
+    if t is None:
+        rows = np.zeros((len(rag.T), n_max), dtype=np.int32)
+        for b, (Tc, nc) in enumerate(zip(rag.T, rag.n_vframes)):
+            scale = np.float32(Tc) / np.float32(nc)
+            rows[b, :nc] = np.minimum(np.floor(np.arange(nc, dtype=np.float32) * scale).astype(np.int64), Tc - 1)
+        t = rag._tabs[key] = torch.from_numpy(rows).to(device)
+    return t

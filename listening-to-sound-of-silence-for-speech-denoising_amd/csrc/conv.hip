@@ -53,6 +53,11 @@ struct ConvParams {
     int out_dtype, c_off, act, accum;
     float* stats;           // optional fused BatchNorm partial sums [tile][2][stats_c]
     int stats_c;
+    // ragged batches (variable-length clips stored in buffers of the batch's maximum width): per-image logical input
+    // width / valid output width, and the per-image stride of the column-gather table
+    const int* wl_tab;
+    const int* wo_tab;
+    int wg_stride;
     long long sb, sh, sw, sc, third;
     // tiling
     int NC, logTH, logTW, PH, PW;
@@ -71,7 +76,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // Byte offset (inside its image) of every pixel of the workgroup's input patch, or ~0 for a pixel that
 // is zero padding.  Built once per tile; every channel chunk's staging pass reuses it.
-__device__ __forceinline__ void build_pixel_table(const ConvParams& p, unsigned* tab, int tid, int hin0, int win0, int rw0) {
+__device__ __forceinline__ void build_pixel_table(const ConvParams& p, unsigned* tab, int tid, int hin0, int win0, int rw0,
+                                                  const int Wl, const int* __restrict__ wgather) {
     const bool reflect = p.pad_mode == SOS_PAD_REFLECT;
     for (int pix = tid; pix < p.npix; pix += 256) {
         const int rr = pix / p.PW, c = pix - rr * p.PW;
@@ -80,11 +86,11 @@ __device__ __forceinline__ void build_pixel_table(const ConvParams& p, unsigned*
         int h = hin0 + r * p.dh;
         int w = win0 + cls * p.stride + c * p.dw;
         bool ok = (rw0 + cls) < p.dw || cls == 0;
-        if (reflect) { h = reflect_index(h, p.H); w = reflect_index(w, p.Wl); }
-        ok = ok && h >= 0 && h < p.H && w >= 0 && w < p.Wl;
+        if (reflect) { h = reflect_index(h, p.H); w = reflect_index(w, Wl); }
+        ok = ok && h >= 0 && h < p.H && w >= 0 && w < Wl;
         unsigned off = 0xffffffffu;
         if (ok) {
-            if (p.wgather) w = p.wgather[w];
+            if (wgather) w = wgather[w];
             off = (unsigned)((h * p.W + w) * p.in_cs) * 2u;
         }
         tab[pix] = off;
@@ -119,7 +125,8 @@ __device__ __forceinline__ void stage_patch_dma(const ConvParams& p, char* patch
 // run (and consecutive pixels of a tile row are adjacent in memory when dil_w == 1).  PPX = 16-byte pieces per pixel.
 template <int PPX, int OROW>
 __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* smem, const int tid, const int b, const int n0,
-                                                  const int ho_base, const int wo_base, const int rw0, const bool x3) {
+                                                  const int ho_base, const int wo_base, const int rw0, const bool x3,
+                                                  const int Wo) {
     const int TH = 1 << p.logTH, TW = 1 << p.logTW;
     char* ost_hi = smem;
     char* ost_lo = smem + 256 * OROW;
@@ -132,7 +139,7 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
         const int cls = m >> (p.logTW + p.logTH);
         const int ho = ho_base + i * p.dh;
         const int wo = wo_base + cls + j * p.dw;
-        otab[m] = (ho < p.Ho && wo < p.Wo && (cls == 0 || rw0 + cls < p.dw)) ? ho * (int)p.sh + wo * (int)p.sw : -1;
+        otab[m] = (ho < p.Ho && wo < Wo && (cls == 0 || rw0 + cls < p.dw)) ? ho * (int)p.sh + wo * (int)p.sw : -1;
     }
     __syncthreads();
     if (p.stats) {
@@ -199,7 +206,7 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
         const int cls = m >> (p.logTW + p.logTH);
         const int ho = ho_base + i * p.dh;
         const int wo = wo_base + cls + j * p.dw;
-        if (!(ho < p.Ho && wo < p.Wo && (cls == 0 || rw0 + cls < p.dw))) continue;
+        if (!(ho < p.Ho && wo < Wo && (cls == 0 || rw0 + cls < p.dw))) continue;
         const int o = ho * ish + wo * isw + q * 8;
         uint4 hv = *(const uint4*)(ost_hi + m * OROW + q * 16);
         if (co + 8 <= p.cout_store) {
@@ -289,6 +296,13 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
     const int wo_base = rw0 + tj * TW * p.dw;
     const int hin0 = ho_base * p.stride - p.pad_t;
     const int win0 = wo_base * p.stride - p.pad_l;
+    // ragged batch: this image's own logical input width / valid output width; a tile past its end has nothing to do
+    int Wl = p.Wl, Wo = p.Wo;
+    if (p.wl_tab) {
+        Wl = p.wl_tab[b]; Wo = p.wo_tab[b];
+        if (wo_base >= Wo) return;
+    }
+    const int* wgather = p.wgather ? p.wgather + (long long)b * p.wg_stride : nullptr;
 
     // ---- per-lane pixel operand base addresses (tap (0,0), k-step 0)
     int abase[2];
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
     const long long in_b = (long long)b * p.H * p.W;
     const __amdgpu_buffer_rsrc_t in_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + in_b * p.in_cs), 0, (unsigned)(p.H * p.W * p.in_cs) * 2u, 0x00020000);
-    build_pixel_table(p, pixtab, tid, hin0, win0, rw0);
+    build_pixel_table(p, pixtab, tid, hin0, win0, rw0, Wl, wgather);
 
     for (int cc = 0; cc < p.nchunks; ++cc) {
         __syncthreads();   // everyone is done reading the previous chunk's patch / weight buffers
@@ -489,7 +503,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
         const int ho = ho_base + i * p.dh;
         const int wo = wo_base + cls + j * p.dw;
         mrow[mt] = m * OROW;
-        pix_ok[mt] = ho < p.Ho && wo < p.Wo && (cls == 0 || rw0 + cls < p.dw);
+        pix_ok[mt] = ho < p.Ho && wo < Wo && (cls == 0 || rw0 + cls < p.dw);
         obase[mt] = (long long)b * p.sb + (long long)ho * p.sh + (long long)wo * p.sw;
     }
     // Common case (bf16 NHWC output, ReLU / PReLU / linear): the activation is the branch-free
@@ -613,7 +627,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
     }
     }
     if (!staged) return;
-    store_staged_tile<NT * 4, OROW>(p, smem, tid, b, n0, ho_base, wo_base, rw0, x3);
+    store_staged_tile<NT * 4, OROW>(p, smem, tid, b, n0, ho_base, wo_base, rw0, x3, Wo);
 #endif
 }
 
@@ -664,6 +678,12 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
     const int rw0 = gw * p.NC;
     const int ho_base = rh + ti * TH * p.dh, wo_base = rw0 + tj * TW * p.dw;
     const int hin0 = ho_base * p.stride - p.pad_t, win0 = wo_base * p.stride - p.pad_l;
+    int Wl = p.Wl, Wo = p.Wo;                     // ragged batch: per-image widths (see conv_mfma_kernel)
+    if (p.wl_tab) {
+        Wl = p.wl_tab[b]; Wo = p.wo_tab[b];
+        if (wo_base >= Wo) return;
+    }
+    const int* wgather = p.wgather ? p.wgather + (long long)b * p.wg_stride : nullptr;
 
     // per-lane pixel operand base (tap (0,0)) of the wave's four 16-pixel column tiles
     int pbase[4];
@@ -718,7 +738,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
     const long long in_b = (long long)b * p.H * p.W;
     const __amdgpu_buffer_rsrc_t in_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + in_b * p.in_cs), 0, (unsigned)(p.H * p.W * p.in_cs) * 2u, 0x00020000);
-    build_pixel_table(p, pixtab, tid, hin0, win0, rw0);
+    build_pixel_table(p, pixtab, tid, hin0, win0, rw0, Wl, wgather);
     __syncthreads();
     if (!CDBG(1)) stage_patch_dma<CPR, false>(p, patch, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc,
                                 (unsigned)(p.cin_off * 2));
@@ -800,7 +820,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
             *(uint2*)(smem + m * OROW + co * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
         }
     }
-    store_staged_tile<NT16 * 2, OROW>(p, smem, tid, b, 0, ho_base, wo_base, rw0, false);
+    store_staged_tile<NT16 * 2, OROW>(p, smem, tid, b, 0, ho_base, wo_base, rw0, false, Wo);
 #endif
 }
 
@@ -997,6 +1017,10 @@ static int validate(const sos_conv_desc* d) {
         sos_set_error("sos_conv2d_fwd: fused statistics need a dense bf16 NHWC output without accumulation");
         return SOS_EINVAL;
     }
+    if ((d->wl_tab == nullptr) != (d->wo_tab == nullptr) || (d->wl_tab && d->stats)) {
+        sos_set_error("sos_conv2d_fwd: ragged batches need both wl_tab and wo_tab and no fused statistics");
+        return SOS_EINVAL;
+    }
     if ((uint64_t)d->H * d->W * d->in_cs * 2 >= 0xfff00000ull) {
         sos_set_error("sos_conv2d_fwd: one input image exceeds 4 GB");
         return SOS_ENOSPC;
@@ -1017,6 +1041,7 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     p.stride = d->stride; p.dh = d->dil_h; p.dw = d->dil_w; p.pad_t = d->pad_top; p.pad_l = d->pad_left;
     p.pad_mode = d->pad_mode; p.Ho = d->Ho; p.Wo = d->Wo; p.out_dtype = d->out_dtype; p.c_off = d->out_c_off;
     p.stats = d->stats; p.stats_c = d->stats_c;
+    p.wl_tab = d->wl_tab; p.wo_tab = d->wo_tab; p.wg_stride = d->w_gather_stride;
     p.act = d->act; p.accum = d->accumulate; p.sb = d->out_sb; p.sh = d->out_sh; p.sw = d->out_sw; p.sc = d->out_sc; p.third = d->out_third;
     // c.ks encodes: k-steps per chunk (% 100), + 100 single slab buffer, + 1000 * n-tiles per workgroup (0: default)
     const int nt = c.ks >= 1000 ? c.ks / 1000 : nt_for(d);

@@ -18,7 +18,8 @@
 __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wave, int64_t n_samples,
                                                    int64_t wave_stride, const float* __restrict__ window,
                                                    const float* __restrict__ twiddle, int n_fft, int hop,
-                                                   int win, float* __restrict__ out, int64_t T) {
+                                                   int win, float* __restrict__ out, int64_t T,
+                                                   const int* __restrict__ n_tab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xw = (float*)smem;                                  // [win][STFT_FT]
     float2* tw = (float2*)(smem + (size_t)win * STFT_FT * 4);  // [n_fft]
@@ -28,13 +29,21 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav
     const int nbins = n_fft / 2 + 1;
     const int lpad = (n_fft - win) / 2;
     const float* wv = wave + b * wave_stride;
+    // ragged batch: clip b has n_tab[b] <= n_samples samples, i.e. Tc <= T frames, and is reflected at ITS end; the
+    // output keeps the row pitch T
+    int64_t Tc = T;
+    if (n_tab) {
+        n_samples = n_tab[b];
+        Tc = 1 + n_samples / hop;
+        if (t0 >= Tc) return;
+    }
 
     for (int k = tid; k < n_fft; k += 256) tw[k] = make_float2(twiddle[2 * k], twiddle[2 * k + 1]);
     for (int idx = tid; idx < win * STFT_FT; idx += 256) {
         const int tt = idx / win, n = idx - tt * win;
         const int64_t t = t0 + tt;
         float v = 0.f;
-        if (t < T) {
+        if (t < Tc) {
             int64_t i = t * hop + n + lpad - n_fft / 2;       // index into the un-padded clip
             if (i < 0) i = -i;
             if (i >= n_samples) i = 2 * (n_samples - 1) - i;
@@ -67,14 +76,14 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav
         float* oim = out + ((b * 2 + 1) * nbins + f) * T + t0;
 #pragma unroll
         for (int i = 0; i < STFT_FT; ++i) {
-            if (t0 + i < T) { ore[i] = re[i]; oim[i] = im[i]; }
+            if (t0 + i < Tc) { ore[i] = re[i]; oim[i] = im[i]; }
         }
     }
 }
 
 extern "C" int sos_stft_f32(const float* wave, int64_t batch, int64_t n_samples, int64_t wave_stride,
                             const float* window, const float* twiddle, int n_fft, int hop, int win_length,
-                            float* out, int64_t n_frames, sos_stream_t stream) {
+                            float* out, int64_t n_frames, const int32_t* clip_samples, sos_stream_t stream) {
     if (!wave || !window || !twiddle || !out) { sos_set_error("sos_stft_f32: null pointer"); return SOS_EINVAL; }
     if (n_fft < 2 || (n_fft & 1) || win_length > n_fft || hop < 1 || n_samples <= n_fft / 2 ||
         n_frames != 1 + n_samples / hop || batch < 1 || batch > 65535) {
@@ -86,7 +95,7 @@ extern "C" int sos_stft_f32(const float* wave, int64_t batch, int64_t n_samples,
     if (lds > 64 * 1024) { sos_set_error("sos_stft_f32: window too long for LDS staging"); return SOS_ENOSPC; }
     dim3 grid((unsigned)((n_frames + STFT_FT - 1) / STFT_FT), (unsigned)batch);
     hipLaunchKernelGGL(stft_kernel, grid, dim3(256), lds, (hipStream_t)stream, wave, n_samples, wave_stride,
-                       window, twiddle, n_fft, hop, win_length, out, n_frames);
+                       window, twiddle, n_fft, hop, win_length, out, n_frames, clip_samples);
     return sos_check_launch("sos_stft_f32");
 }
 
@@ -102,7 +111,8 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ sp
                                                     const float* __restrict__ window,
                                                     const float* __restrict__ twiddle,
                                                     const float* __restrict__ inv_wss, int n_fft, int hop, int win,
-                                                    float* __restrict__ out, int64_t out_stride, int64_t n_out) {
+                                                    float* __restrict__ out, int64_t out_stride, int64_t n_out,
+                                                    const int* __restrict__ t_tab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nbins = n_fft / 2 + 1;
     float2* tw = (float2*)smem;                               // [n_fft]
@@ -113,6 +123,13 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ sp
     const int64_t j0 = (int64_t)blockIdx.x * 256;
     const int lpad = (n_fft - win) / 2;
     const int half = n_fft / 2;
+    // ragged batch: clip b has t_tab[b] <= T frames (the spectrogram keeps the row pitch T) and hop*(Tc-1) output samples
+    const int64_t Tp = T;
+    if (t_tab) {
+        T = t_tab[b];
+        n_out = (int64_t)hop * (T - 1);
+        if (j0 >= n_out) return;
+    }
     // frames overlapping [j0+half, j0+half+255]: n = p - t*hop in [lpad, lpad+win)
     int64_t tlo = (j0 + half - lpad - win + 1 + hop - 1);
     tlo = tlo <= 0 ? 0 : tlo / hop;
@@ -125,8 +142,8 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ sp
         const int fr = idx / nbins, f = idx - fr * nbins;
         float r = 0.f, i = 0.f;
         if (fr < nfr) {
-            r = spec[((b * 2 + 0) * nbins + f) * T + tlo + fr];
-            i = spec[((b * 2 + 1) * nbins + f) * T + tlo + fr];
+            r = spec[((b * 2 + 0) * nbins + f) * Tp + tlo + fr];
+            i = spec[((b * 2 + 1) * nbins + f) * Tp + tlo + fr];
         }
         sre[idx] = r;
         sim[idx] = i;
@@ -138,7 +155,7 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ sp
     const int64_t p = j + half;
     int64_t tmax = (p - lpad) / hop;
     if (tmax > T - 1) tmax = T - 1;
-    float y = 0.f;
+    float y = 0.f, wss = 0.f;
     const float invn = 1.0f / (float)n_fft;
     for (int s = 0; s < 3; ++s) {
         const int64_t t = tmax - s;
@@ -158,15 +175,20 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ sp
             k += n;
             if (k >= n_fft) k -= n_fft;
         }
-        y = fmaf(window[n - lpad], (acc + 2.f * acc2) * invn, y);
+        const float wn = window[n - lpad];
+        y = fmaf(wn, (acc + 2.f * acc2) * invn, y);
+        wss = fmaf(wn, wn, wss);               // librosa.filters.window_sumsquare over the same (<= 3) frames
     }
-    out[b * out_stride + j] = y * inv_wss[p];
+    // divide by the window-sum-square where it exceeds tiny (librosa.istft); a caller-provided table takes precedence
+    const float inv = inv_wss ? inv_wss[p] : (wss > 1.17549435e-38f ? 1.0f / wss : 1.0f);
+    out[b * out_stride + j] = y * inv;
 }
 
 extern "C" int sos_istft_f32(const float* spec, int64_t batch, int64_t n_frames, const float* window,
                              const float* twiddle, const float* inv_wss, int n_fft, int hop, int win_length,
-                             float* out, int64_t out_stride, sos_stream_t stream) {
-    if (!spec || !window || !twiddle || !inv_wss || !out) { sos_set_error("sos_istft_f32: null pointer"); return SOS_EINVAL; }
+                             float* out, int64_t out_stride, const int32_t* clip_frames, sos_stream_t stream) {
+    if (!spec || !window || !twiddle || !out) { sos_set_error("sos_istft_f32: null pointer"); return SOS_EINVAL; }
+    if (clip_frames && inv_wss) { sos_set_error("sos_istft_f32: a ragged batch computes the window-sum-square in the kernel (inv_wss must be NULL)"); return SOS_EINVAL; }
     const int64_t n_out = (int64_t)hop * (n_frames - 1);
     if (n_fft < 2 || (n_fft & 1) || win_length > n_fft || hop < 1 || n_frames < 2 || batch < 1 || batch > 65535 ||
         out_stride < n_out || (255 + win_length) / hop + 2 > ISTFT_MAXFR || (win_length + hop - 1) / hop > 3) {
@@ -178,7 +200,7 @@ extern "C" int sos_istft_f32(const float* spec, int64_t batch, int64_t n_frames,
     const size_t lds = (size_t)n_fft * 8 + (size_t)ISTFT_MAXFR * nbins * 8;
     dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)batch);
     hipLaunchKernelGGL(istft_kernel, grid, dim3(256), lds, (hipStream_t)stream, spec, n_frames, window, twiddle,
-                       inv_wss, n_fft, hop, win_length, out, out_stride, n_out);
+                       inv_wss, n_fft, hop, win_length, out, out_stride, n_out, clip_frames);
     return sos_check_launch("sos_istft_f32");
 }
 
@@ -359,11 +381,14 @@ __device__ __forceinline__ int premask(const uint8_t* bits, int64_t n_frames, do
 
 __global__ void bits_to_mask_kernel(const uint8_t* __restrict__ bits, int64_t n_frames, double ratio,
                                     int64_t n_samples, float* __restrict__ mask, const float* __restrict__ sig,
-                                    float* __restrict__ masked) {
+                                    float* __restrict__ masked, const int* __restrict__ fr_tab,
+                                    const int* __restrict__ ns_tab) {
     const int64_t b = blockIdx.y;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t pitch_s = n_samples, pitch_f = n_frames;       // ragged batch: row pitches stay the batch maxima
+    if (fr_tab) { n_frames = fr_tab[b]; n_samples = ns_tab[b]; }
     if (j >= n_samples) return;
-    const uint8_t* bb = bits + b * n_frames;
+    const uint8_t* bb = bits + b * pitch_f;
     const int v = premask(bb, n_frames, ratio, j);
     // length of the ORIGINAL run containing j (capped): the reference flips every run shorter
     // than 5 samples in one pass over the original runs (groupby never sees its own writes).
@@ -377,21 +402,21 @@ __global__ void bits_to_mask_kernel(const uint8_t* __restrict__ bits, int64_t n_
         ++len;
     }
     const float m = (float)(len < 5 ? 1 - v : v);
-    mask[b * n_samples + j] = m;
-    if (masked) masked[b * n_samples + j] = sig[b * n_samples + j] * m;
+    mask[b * pitch_s + j] = m;
+    if (masked) masked[b * pitch_s + j] = sig[b * pitch_s + j] * m;
 }
 
 extern "C" int sos_bits_to_mask(const uint8_t* bits, int64_t batch, int64_t n_frames, double ratio,
                                 int64_t n_samples, float* mask, const float* sig, float* masked,
-                                sos_stream_t stream) {
+                                const int32_t* clip_frames, const int32_t* clip_samples, sos_stream_t stream) {
     if (!bits || !mask || batch < 1 || batch > 65535 || n_frames < 1 || n_samples < 1 || !(ratio > 1.0) ||
-        (masked && !sig)) {
+        (masked && !sig) || ((clip_frames == nullptr) != (clip_samples == nullptr))) {
         sos_set_error("sos_bits_to_mask: bad args");
         return SOS_EINVAL;
     }
     dim3 grid((unsigned)((n_samples + 255) / 256), (unsigned)batch);
     hipLaunchKernelGGL(bits_to_mask_kernel, grid, dim3(256), 0, (hipStream_t)stream, bits, n_frames, ratio,
-                       n_samples, mask, sig, masked);
+                       n_samples, mask, sig, masked, clip_frames, clip_samples);
     return sos_check_launch("sos_bits_to_mask");
 }
 

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
                                                                const uint4* __restrict__ wl, int B, int T, int H,
                                                                bf16_t* __restrict__ out, int out_cs, int out_x3,
                                                                long long third, float* __restrict__ save_gates,
-                                                               float* __restrict__ save_c, int dbg) {
+                                                               float* __restrict__ save_c, int dbg,
+                                                               const int* __restrict__ t_tab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KF = (H + 31) / 32, NT = H >> 2, G = 4 * H;
     const int HP = KF * 64 + 16;                         // bytes of one clip's h row (bf16, k padded to 32, +16: banks)
@@ -118,6 +119,16 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
     const int n = lane & 15, g4 = lane >> 4;
     const int b = b0 + n;
     const bool live = b < B;
+    // ragged batch: clip b has t_tab[b] <= T frames (rows past them are padding).  Every clip starts at step 0 from the
+    // zero state -- the reverse direction at ITS last frame -- and simply goes idle (computes, stores nothing) after its
+    // last step; the group runs to its longest clip.
+    const int Tc = (t_tab && live) ? t_tab[b] : T;
+    int Tg = T;
+    if (t_tab) {
+        Tg = 1;
+        for (int c = 0; c < LM_NB; ++c)
+            if (b0 + c < B) Tg = max(Tg, t_tab[b0 + c]);
+    }
     for (int i = tid; i < 2 * P * LM_NB * HP / 4; i += LM_THREADS) ((unsigned*)smem)[i] = 0u;
     float creg[LM_FT];
 #pragma unroll
@@ -133,9 +144,9 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
             if (kk < KF) w[kk] = base[((size_t)(LDBG(4) ? 0 : tile) * KF + kk) * 64];
     };
     auto load_x = [&](const int ti, const int step) {
-        const int t = dir == 0 ? step : T - 1 - step;
+        const int t = dir == 0 ? step : Tc - 1 - step;
         const float* xp = xproj + (((size_t)b * T + t) * 2 + dir) * G + ((wave + LM_WAVES * ti) * 4 + g4) * 4;
-        if (live && step < T && !LDBG(2)) {
+        if (live && step < Tc && !LDBG(2)) {
             const float4 x4 = *(const float4*)xp;          // gate-interleaved projection: one 16-byte load
             xc[ti] = f32x4{x4.x, x4.y, x4.z, x4.w};
         }
@@ -148,8 +159,9 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
     if (!X3 && cnt > 0) load_frags(w0, whd, wave);
     __syncthreads();
 
-    for (int step = 0; step < T; ++step) {
-        const int t = dir == 0 ? step : T - 1 - step;
+    for (int step = 0; step < Tg; ++step) {
+        const int t = dir == 0 ? step : Tc - 1 - step;
+        const bool act = live && step < Tc;              // this lane's clip still has frames
         const char* hb = smem + (size_t)(step & 1) * P * LM_NB * HP;
         char* hn = smem + (size_t)((step + 1) & 1) * P * LM_NB * HP;
         // B fragments: h_{t-1}[k][clip], lane = clip + 16 * (k / 8)
@@ -164,11 +176,12 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
         // h_{t-1} (this step's B operand) is also the previous step's OUTPUT: flush its rows to global here, as
         // whole 16-byte pieces of a clip's [dir*H, dir*H + H) run (H % 8 == 0; otherwise element stores below)
         if (step > 0 && (H & 7) == 0 && !LDBG(1)) {
-            const int tp = dir == 0 ? step - 1 : T - step;
             const int ppr = H >> 3;                      // pieces per clip row
             for (int i = tid; i < LM_NB * ppr; i += LM_THREADS) {
                 const int c = i / ppr, q = i - c * ppr;
-                if (b0 + c < B) {
+                const int Tcc = (t_tab && b0 + c < B) ? t_tab[b0 + c] : T;
+                const int tp = dir == 0 ? step - 1 : Tcc - step;
+                if (b0 + c < B && step <= Tcc) {
                     bf16_t* o = out + ((size_t)(b0 + c) * T + tp) * out_cs + dir * H + q * 8;
                     const uint4 hv = *(const uint4*)(hb + c * HP + q * 16);
                     *(uint4*)o = hv;
@@ -217,7 +230,7 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
             if (X3 || out_x3) lo = f2bf(h - bf2f(hi));
             if (X3) *(bf16_t*)(hn + LM_NB * HP + n * HP + j * 2) = lo;
             if (!LDBG(1)) {
-                if (live && (H & 7)) {
+                if (act && (H & 7)) {
                     bf16_t* o = out + row * out_cs + dir * H + j;
                     o[0] = hi;
                     if (out_x3) { o[third] = hi; o[2 * third] = lo; }
@@ -234,13 +247,14 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
         }
         __syncthreads();
     }
-    if ((H & 7) == 0 && !LDBG(1)) {                      // the last step's output
-        const char* hb = smem + (size_t)(T & 1) * P * LM_NB * HP;
-        const int tp = dir == 0 ? T - 1 : 0;
+    if ((H & 7) == 0 && !LDBG(1)) {                      // the last step's output (clips as long as the group)
+        const char* hb = smem + (size_t)(Tg & 1) * P * LM_NB * HP;
+        const int tp = dir == 0 ? Tg - 1 : 0;
         const int ppr = H >> 3;
         for (int i = tid; i < LM_NB * ppr; i += LM_THREADS) {
             const int c = i / ppr, q = i - c * ppr;
-            if (b0 + c < B) {
+            const int Tcc = (t_tab && b0 + c < B) ? t_tab[b0 + c] : T;
+            if (b0 + c < B && Tcc == Tg) {
                 bf16_t* o = out + ((size_t)(b0 + c) * T + tp) * out_cs + dir * H + q * 8;
                 const uint4 hv = *(const uint4*)(hb + c * HP + q * 16);
                 *(uint4*)o = hv;
@@ -252,11 +266,15 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
 
 extern "C" int sos_lstm_bidir_fwd(const float* xproj, const void* wpk_hi, const void* wpk_lo, int64_t B, int64_t T, int H,
                                   void* out_bf16, int out_cs, int out_dtype, int64_t out_third, float* save_gates,
-                                  float* save_c, sos_stream_t stream) {
+                                  float* save_c, const int32_t* lengths, sos_stream_t stream) {
     if (!xproj || !wpk_hi || !out_bf16 || B < 1 || T < 1 || H < 4 || H > 256 || (H & 3) || out_cs < 2 * H ||
         (out_dtype != SOS_DT_BF16 && out_dtype != SOS_DT_BF16X3) || ((save_gates == nullptr) != (save_c == nullptr)) ||
         ((out_dtype == SOS_DT_BF16X3) != (wpk_lo != nullptr)) || (out_cs & 7) || (out_third & 7)) {
         sos_set_error("sos_lstm_bidir_fwd: bad args (B=%lld T=%lld H=%d)", (long long)B, (long long)T, H);
+        return SOS_EINVAL;
+    }
+    if (lengths && save_gates) {
+        sos_set_error("sos_lstm_bidir_fwd: per-clip lengths are an inference feature (no saved activations)");
         return SOS_EINVAL;
     }
     dim3 grid((unsigned)((B + LM_NB - 1) / LM_NB), 2);
@@ -268,11 +286,11 @@ extern "C" int sos_lstm_bidir_fwd(const float* xproj, const void* wpk_hi, const 
     if (wpk_lo)
         hipLaunchKernelGGL(lstm_fwd_kernel<true>, grid, dim3(LM_THREADS), lds, (hipStream_t)stream, xproj, (const uint4*)wpk_hi,
                            (const uint4*)wpk_lo, (int)B, (int)T, H, (bf16_t*)out_bf16, out_cs,
-                           out_dtype == SOS_DT_BF16X3 ? 1 : 0, (long long)out_third, save_gates, save_c, dbg);
+                           out_dtype == SOS_DT_BF16X3 ? 1 : 0, (long long)out_third, save_gates, save_c, dbg, lengths);
     else
         hipLaunchKernelGGL(lstm_fwd_kernel<false>, grid, dim3(LM_THREADS), lds, (hipStream_t)stream, xproj, (const uint4*)wpk_hi,
                            (const uint4*)wpk_lo, (int)B, (int)T, H, (bf16_t*)out_bf16, out_cs,
-                           out_dtype == SOS_DT_BF16X3 ? 1 : 0, (long long)out_third, save_gates, save_c, dbg);
+                           out_dtype == SOS_DT_BF16X3 ? 1 : 0, (long long)out_third, save_gates, save_c, dbg, lengths);
     return sos_check_launch("sos_lstm_bidir_fwd");
 }
 

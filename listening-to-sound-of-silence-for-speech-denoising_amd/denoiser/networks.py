@@ -90,13 +90,14 @@ def _up_plan(blk, x3):
                 slope=prelu.weight.detach().float())
 
 
-def _run_down(lp, src, cin_off, dst, c_off, Ho, Wo):
+def _run_down(lp, src, cin_off, dst, c_off, Ho, Wo, rk=None):
+    """rk: ragged-batch keywords (engine.Ragged.kw): the clips' own input / output widths."""
     E.conv_to_act(src, cin_off, lp["cin_store"], lp["w"], lp["k"], lp["k"], lp["cout"], lp["scale"], lp["shift"],
                   lp["act"], dst, c_off=c_off, cout_store=lp["cout"], stride=lp["stride"], dil=(lp["dil"], lp["dil"]),
-                  pad=(lp["pad"], lp["pad"]), pad_mode=L.PAD_REFLECT, slope=lp["slope"], Ho=Ho, Wo=Wo)
+                  pad=(lp["pad"], lp["pad"]), pad_mode=L.PAD_REFLECT, slope=lp["slope"], Ho=Ho, Wo=Wo, **(rk or {}))
 
 
-def _run_up(lp, src, dst, c_off):
+def _run_up(lp, src, dst, c_off, rag=None, lsrc=0, ldst=0):
     """Four output-parity phases of the transposed conv, each a small stride-1 conv written to the
     interleaved positions of `dst` (cropped to dst's size == the reference's nearest-resize fix-up
     F.interpolate(out, skip.size()) which drops the surplus last row/column, M2/networks.py:199-203)."""
@@ -106,10 +107,14 @@ def _run_up(lp, src, dst, c_off):
         Wo = min(src.W, (dst.W - pw + 1) // 2)
         if Ho <= 0 or Wo <= 0:
             continue
+        rk = {}
+        if rag is not None:     # per clip: its own source width, and the crop to ITS skip connection's width
+            ws, wd = rag.widths(lsrc), rag.widths(ldst)
+            rk = dict(wl_tab=rag.tab(ws), wo_tab=rag.tab([min(a, (b - pw + 1) // 2) for a, b in zip(ws, wd)]))
         E.conv(src, 0, lp["cin_store"], w, 1 + ph, 1 + pw, lp["cout"], lp["scale"], lp["shift"], L.ACT_PRELU,
                out=dst.t, out_dtype=dst.dtype_code, sb=dst.H * dst.W * row, sh=2 * dst.W * row, sw=2 * row, sc=1,
                c_off=c_off, cout_store=lp["cout"], third=dst.cs, slope=lp["slope"], Ho=Ho, Wo=Wo,
-               out_elem_offset=(ph * dst.W + pw) * row)
+               out_elem_offset=(ph * dst.W + pw) * row, **rk)
 
 
 class InpaintNet(nn.Module):
@@ -145,9 +150,11 @@ class InpaintNet(nn.Module):
             up1_0=_down_plan(self.up1[0], x3, perm_up1), up1_1=_up_plan(self.up1[1], x3),
             up2_0=_down_plan(self.up2[0], x3), up2_1=_down_plan(self.up2[1], x3))
 
-    def run(self, plan, x, y, x3):
+    def run(self, plan, x, y, x3, rag=None):
         """forward(x, y) of M2/networks.py:192-205: x = noise-interval STFT, y = mixed STFT,
-        both f32 (B,2,F,T); returns f32 (B,2,F,T)."""
+        both f32 (B,2,F,T); returns f32 (B,2,F,T).  rag: engine.Ragged of a variable-length batch (T = the longest
+        clip; every block takes the clips' own widths at its resolution level, so reflect borders, stride-2 sizes and
+        the crop after the transposed convs are each clip's own)."""
         dev = x.device
         B, _, H, W = x.shape
         H1, W1 = (H + 1) // 2, (W + 1) // 2          # after the 5x5 stride-2 reflect-padded convs
@@ -157,24 +164,26 @@ class InpaintNet(nn.Module):
         U2 = E.Act(B, H, W, 128, x3, dev)            # [up1.1 out | down3]
         X = E.Act(B, H1, W1, 384, x3, dev)           # [down2 | down4 | mid.8 out]
         t128 = E.Act(B, H1, W1, 128, x3, dev)
-        _run_down(plan["down1"], ax, 0, d1, 0, H, W)
-        _run_down(plan["down2_0"], d1, 0, t128, 0, H1, W1)
-        _run_down(plan["down2_1"], t128, 0, X, 0, H1, W1)
-        _run_down(plan["down3"], ay, 0, U2, 64, H, W)
-        _run_down(plan["down4_0"], U2, 64, t128, 0, H1, W1)
-        _run_down(plan["down4_1"], t128, 0, X, 128, H1, W1)
+        k = (lambda a, b=None: rag.kw(a, b)) if rag is not None else (lambda a, b=None: None)
+        _run_down(plan["down1"], ax, 0, d1, 0, H, W, k(0))
+        _run_down(plan["down2_0"], d1, 0, t128, 0, H1, W1, k(0, 1))
+        _run_down(plan["down2_1"], t128, 0, X, 0, H1, W1, k(1))
+        _run_down(plan["down3"], ay, 0, U2, 64, H, W, k(0))
+        _run_down(plan["down4_0"], U2, 64, t128, 0, H1, W1, k(0, 1))
+        _run_down(plan["down4_1"], t128, 0, X, 128, H1, W1, k(1))
         m = [E.Act(B, H2, W2, 256, x3, dev), E.Act(B, H2, W2, 256, x3, dev)]
-        _run_down(plan["mid"][0], X, 0, m[0], 0, H2, W2)
+        _run_down(plan["mid"][0], X, 0, m[0], 0, H2, W2, k(1, 2))
         for i in range(1, 8):
-            _run_down(plan["mid"][i], m[(i - 1) & 1], 0, m[i & 1], 0, H2, W2)
-        _run_up(plan["mid8"], m[1], X, 256)
-        _run_down(plan["up1_0"], X, 128, t128, 0, H1, W1)
-        _run_up(plan["up1_1"], t128, U2, 0)
-        _run_down(plan["up2_0"], U2, 0, d1, 0, H, W)
+            _run_down(plan["mid"][i], m[(i - 1) & 1], 0, m[i & 1], 0, H2, W2, k(2))
+        _run_up(plan["mid8"], m[1], X, 256, rag, 2, 1)
+        _run_down(plan["up1_0"], X, 128, t128, 0, H1, W1, k(1))
+        _run_up(plan["up1_1"], t128, U2, 0, rag, 1, 0)
+        _run_down(plan["up2_0"], U2, 0, d1, 0, H, W, k(0))
         lp = plan["up2_1"]
         out = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
         E.conv(d1, 0, lp["cin_store"], lp["w"], 3, 3, 2, lp["scale"], lp["shift"], L.ACT_NONE, out=out,
-               out_dtype=L.DT_F32, sb=2 * H * W, sh=W, sw=1, sc=H * W, pad=(1, 1), pad_mode=L.PAD_REFLECT, Ho=H, Wo=W)
+               out_dtype=L.DT_F32, sb=2 * H * W, sh=W, sw=1, sc=H * W, pad=(1, 1), pad_mode=L.PAD_REFLECT, Ho=H, Wo=W,
+               **(k(0) or {}))
         return out
 
     # ------------------------------------------------------------------ training path
@@ -268,16 +277,19 @@ class ContextAggNet(nn.Module):
                     fc0=CN.linear_plan(self.fc[0], 400, x3), fc2=CN.linear_plan(self.fc[2], E.pad_to(600, 16), x3),
                     fc4=CN.linear_plan(self.fc[4], E.pad_to(600, 16), x3))
 
-    def run(self, plan, x, n, x3):
-        """forward(x, n) of M2/networks.py:82-94 -> sigmoid mask f32 (B,2,F,T)."""
+    def run(self, plan, x, n, x3, rag=None):
+        """forward(x, n) of M2/networks.py:82-94 -> sigmoid mask f32 (B,2,F,T).  rag: engine.Ragged of a variable-length
+        batch."""
         dev = x.device
         B, _, F, T = x.shape
         nseg = 3 if x3 else 1
         nfeat = 12 * F
-        feat = torch.empty((B, T, nseg * nfeat), dtype=E.act_dtype(), device=dev)
-        CN.run_encoder(plan["enc_x"], E.pack_input(x, x3), feat, nseg * nfeat, nfeat, 0, x3)
-        CN.run_encoder(plan["enc_n"], E.pack_input(n, x3), feat, nseg * nfeat, nfeat, 8, x3)
-        h = CN.run_lstm(plan["lstm"], (feat, B, 1, T, nfeat, nseg), B, T, x3, dev)
+        # ragged: rows of frames past a clip's end stay zero (finite) -- the FC head runs over all rows
+        feat = (torch.empty if rag is None else torch.zeros)((B, T, nseg * nfeat), dtype=E.act_dtype(), device=dev)
+        lengths = rag.level(0) if rag is not None else None
+        CN.run_encoder(plan["enc_x"], E.pack_input(x, x3), feat, nseg * nfeat, nfeat, 0, x3, rag=rag)
+        CN.run_encoder(plan["enc_n"], E.pack_input(n, x3), feat, nseg * nfeat, nfeat, 8, x3, rag=rag)
+        h = CN.run_lstm(plan["lstm"], (feat, B, 1, T, nfeat, nseg), B, T, x3, dev, lengths=lengths)
         f0, f2, f4 = plan["fc0"], plan["fc2"], plan["fc4"]
         a0 = E.Act(B, 1, T, E.pad_to(600, 16), x3, dev)
         a1 = E.Act(B, 1, T, E.pad_to(600, 16), x3, dev)
@@ -408,16 +420,21 @@ class JointModel(nn.Module):
         self.stage1.backward(plan["s1"], tape["t1"], d_np, grads, x3)
         return grads
 
-    def forward(self, x, n):
+    def forward(self, x, n, rag=None):
+        """rag (eval only): engine.Ragged with the clips' own frame counts of a variable-length batch; x, n are then
+        (B,2,F,max T) and only the first rag.T[b] columns of clip b's outputs are valid -- each clip computed exactly as
+        if it were run alone at its own length (M2/predict.py:405-412 runs one file at a time)."""
         L.require_cuda(x, n)
         if x.dim() != 4 or x.shape[1] != 2 or x.shape != n.shape:
             raise ValueError(f"expected two (B, 2, F, T) inputs, got {tuple(x.shape)} and {tuple(n.shape)}")
+        if rag is not None and (self.training or len(rag.T) != x.shape[0] or max(rag.T) != x.shape[3]):
+            raise ValueError("ragged batches are an inference feature; rag must describe this batch")
         if self.training:
             return _JointTrainFn.apply(self, x.contiguous().float(), n.contiguous().float(), *self.parameters())
         plan = self._cache.get(self, self._build_plan)
         x3 = plan["x3"]
         x = x.contiguous().float()
         n = n.contiguous().float()
-        n_pred = self.stage1.run(plan["s1"], n, x, x3)
-        out = self.stage2.run(plan["s2"], x, n_pred, x3)
+        n_pred = self.stage1.run(plan["s1"], n, x, x3, rag)
+        out = self.stage2.run(plan["s2"], x, n_pred, x3, rag)
         return n_pred, out

@@ -123,9 +123,12 @@ class AudioVisualNet(nn.Module):
             TO.video_backward(plan["vid"], tape["vid"], dfeat, nseg * nfeat, nfeat, 8 * F, grads, "encoder_video", B, n, x3)
         return grads
 
-    def forward(self, s, v_num_frames=60, v=None):
+    def forward(self, s, v_num_frames=60, v=None, rag=None):
         """s (B,2,F,T) -> logits (B, v_num_frames).  Audio-visual variant: v (B,3,Tv,H,W) video frames; the audio
-        features are resized to Tv frames (M1/networks.py:138) and v_num_frames is ignored."""
+        features are resized to Tv frames (M1/networks.py:138) and v_num_frames is ignored.
+        rag (eval only): engine.Ragged with the clips' own STFT frame counts (rag.T) and video-frame counts
+        (rag.n_vframes) of a variable-length batch; s is then (B,2,F,max T), the logits (B, max n) with clip b's first
+        rag.n_vframes[b] entries valid -- each clip computed exactly as if it were run alone at its own length."""
         L.require_cuda(s, v)
         if s.dim() != 4 or s.shape[1] != 2 or s.shape[2] != self.freq_bins:
             raise ValueError(f"expected (B, 2, {self.freq_bins}, T) input, got {tuple(s.shape)}")
@@ -135,6 +138,8 @@ class AudioVisualNet(nn.Module):
             v_num_frames = v.shape[2]
         elif v is not None:
             raise ValueError("this network was built without the video branch (get_network(video=True))")
+        if rag is not None and (self.training or self.video_feat):
+            raise ValueError("ragged batches are an inference feature of the audio-only network")
         if self.training:
             return _TrainFn.apply(self, s.contiguous().float(), int(v_num_frames),
                                   v.contiguous().float() if v is not None else None, *self.parameters())
@@ -146,14 +151,24 @@ class AudioVisualNet(nn.Module):
         a = E.pack_input(s, x3)
         nseg = 3 if x3 else 1
         nfeat = 8 * F + self.video_feat
-        feat = torch.empty((B, n, nseg * nfeat), dtype=E.act_dtype(), device=dev)
-        gather = CN.nearest_index(T, n, dev)
-        CN.run_encoder(plan["enc"], a, feat, nseg * nfeat, nfeat, 0, x3, w_gather=gather, T_out=n)
+        lengths = None
+        if rag is None:
+            feat = torch.empty((B, n, nseg * nfeat), dtype=E.act_dtype(), device=dev)
+            gather = CN.nearest_index(T, n, dev)
+            CN.run_encoder(plan["enc"], a, feat, nseg * nfeat, nfeat, 0, x3, w_gather=gather, T_out=n)
+        else:
+            if len(rag.T) != B or max(rag.T) != T or max(rag.n_vframes) != n:
+                raise ValueError("rag does not describe this batch")
+            feat = torch.zeros((B, n, nseg * nfeat), dtype=E.act_dtype(), device=dev)      # padding rows stay finite
+            gather = CN.nearest_index_ragged(rag, n, dev)                                  # (B, n): per-clip T_c -> n_c
+            lengths = rag.tab(rag.n_vframes)
+            CN.run_encoder(plan["enc"], a, feat, nseg * nfeat, nfeat, 0, x3, w_gather=gather, T_out=n, rag=rag,
+                           rag_out=(lengths, n))
         if self.video_feat:
             # frames as a batch of B*Tv images; the video features land next to the audio ones (channel concat)
             frames = E.pack_input(v.float().permute(0, 2, 1, 3, 4).reshape(B * n, 3, v.shape[3], v.shape[4]), x3)
             CN.run_video_branch(plan["vid"], frames, B, n, feat, nseg * nfeat, nfeat, 8 * F, x3)
-        h = CN.run_lstm(plan["lstm"], (feat, B, 1, n, nfeat, nseg), B, n, x3, dev)
+        h = CN.run_lstm(plan["lstm"], (feat, B, 1, n, nfeat, nseg), B, n, x3, dev, lengths=lengths)
         f0, f2 = plan["fc0"], plan["fc2"]
         m = E.Act(B, 1, n, E.pad_to(f0["cout"], 16), x3, dev)
         E.conv_to_act(h, 0, f0["cin_store"], f0["w"], 1, 1, f0["cout"], f0["scale"], f0["shift"], L.ACT_RELU, m,

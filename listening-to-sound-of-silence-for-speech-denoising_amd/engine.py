@@ -205,7 +205,8 @@ def fold_bn(bn, cout_pad):
 
 def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dtype, sb, sh, sw, sc,
          Ho, Wo, c_off=0, cout_store=None, third=0, stride=1, dil=(1, 1), pad=(0, 0), pad_mode=L.PAD_ZERO,
-         slope=None, w_gather=None, out_elem_offset=0, in_dims=None, accumulate=False, stats_c=0):
+         slope=None, w_gather=None, out_elem_offset=0, in_dims=None, accumulate=False, stats_c=0, wl_tab=None,
+         wo_tab=None, wg_stride=0):
     """Fill a sos_conv_desc and enqueue sos_conv2d_fwd.  `src` is an Act (or a (tensor,B,H,W,cs,nseg)
     view described by in_dims).  stats_c > 0: also return the fused BatchNorm partial sums of the first stats_c
     output channels as (partial [tiles][2][stats_c], tiles) for sos_bn_finalize."""
@@ -240,6 +241,8 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
     d.act = act
     d.act_param = slope.data_ptr() if slope is not None else None
     d.accumulate = 1 if accumulate else 0
+    if wl_tab is not None:                # ragged batch: per-image logical input width / valid output width (sos_hip.h)
+        d.wl_tab, d.wo_tab, d.w_gather_stride = wl_tab.data_ptr(), wo_tab.data_ptr(), wg_stride
     _load_tune_cache()
     if AUTOTUNE:
         key = (B, H, W, d.Wl, cin, d.in_nseg, d.cout_pad, cout, kh, kw, stride, dil, Ho, Wo, out_dtype, sc == 1, pad_mode,
@@ -309,11 +312,45 @@ def lstm_pack(lstm_mod, x3):
     return pk
 
 
-def lstm(xproj, wpk, B, T, H, out_act, save_gates=None, save_c=None):
-    """Recurrent part (sos_lstm_bidir_fwd); wpk from lstm_pack; out_act: Act [B,1,T,cs>=2H] pre-zeroed."""
+def lstm(xproj, wpk, B, T, H, out_act, save_gates=None, save_c=None, lengths=None):
+    """Recurrent part (sos_lstm_bidir_fwd); wpk from lstm_pack; out_act: Act [B,1,T,cs>=2H] pre-zeroed; lengths:
+    optional int32 device [B] (ragged batch)."""
     L.check(L.lib().sos_lstm_bidir_fwd(L.ptr(xproj), L.ptr(wpk["fh"]), L.ptr(wpk["fl"]), B, T, H, L.ptr(out_act.t),
                                        out_act.nseg * out_act.cs, out_act.dtype_code, out_act.cs,
-                                       L.ptr(save_gates), L.ptr(save_c), L.stream_ptr()), "sos_lstm_bidir_fwd")
+                                       L.ptr(save_gates), L.ptr(save_c), L.ptr(lengths), L.stream_ptr()), "sos_lstm_bidir_fwd")
+
+
+class Ragged:
+    """Per-clip widths of a ragged batch (BASELINE configs[3]: clips of different lengths in one launch; buffers are
+    sized for the longest clip, every kernel takes the clips' own widths from small device tables).  `T` = STFT frames
+    per clip; level(k) = width after k stride-2 blocks ((w + 1) // 2 each, M2/networks.py:158-176)."""
+
+    def __init__(self, T, device, n_vframes=None, n_samples=None):
+        self.T = [int(t) for t in T]
+        self.device = device
+        self.n_vframes = None if n_vframes is None else [int(n) for n in n_vframes]
+        self.n_samples = None if n_samples is None else [int(n) for n in n_samples]
+        self._tabs = {}
+
+    def widths(self, level):
+        w = self.T
+        for _ in range(level):
+            w = [(x + 1) // 2 for x in w]
+        return w
+
+    def tab(self, widths):
+        key = tuple(int(x) for x in widths)
+        t = self._tabs.get(key)
+        if t is None:
+            t = self._tabs[key] = torch.tensor(key, dtype=torch.int32, device=self.device)
+        return t
+
+    def level(self, k):
+        return self.tab(self.widths(k))
+
+    def kw(self, lin, lout=None):
+        """conv keyword arguments for a layer reading level `lin` and writing level `lout`."""
+        return dict(wl_tab=self.level(lin), wo_tab=self.level(lin if lout is None else lout))
 
 
 class PlanCache:

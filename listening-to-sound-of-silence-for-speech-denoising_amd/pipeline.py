@@ -39,26 +39,60 @@ def denoise(detector, denoiser, mixed, sr=SR, fps=FPS, bits=None, return_all=Fal
     return out
 
 
+def _denoise_group(detector, denoiser, clips, sr, fps):
+    """One launch sequence for clips of DIFFERENT lengths: buffers sized for the longest clip, every kernel takes the
+    clips' own sample / frame / video-frame counts from device tables (engine.Ragged), so each clip is computed exactly
+    as if it were run alone: reflect padding of the STFT at its own end, zero / reflect conv borders at its own last
+    frame, its own stride-2 sizes and transposed-conv crops, BiLSTM reverse pass from its own last frame, overlap-add
+    normalisation of its own frame count."""
+    from . import engine as E
+    dev = clips[0].device
+    ns = [int(c.numel()) for c in clips]
+    B, Nmax = len(clips), max(ns)
+    wave = torch.zeros((B, Nmax), dtype=torch.float32, device=dev)
+    for b, c in enumerate(clips):
+        wave[b, :ns[b]] = c
+    T = [1 + n // transform.HOP_LENGTH for n in ns]
+    nv = [n_video_frames(n, sr, fps) for n in ns]
+    rag = E.Ragged(T, dev, n_vframes=nv, n_samples=ns)
+    t_ns, t_nv = rag.tab(ns), rag.tab(nv)
+    S_mixed = transform.stft_batch(wave, clip_samples=t_ns)
+    logits = detector(s=S_mixed, v_num_frames=max(nv), rag=rag)
+    bits, _ = tools.threshold_bits(logits, SIGMOID_THRESHOLD)
+    mask, noise_sig = tools.bits_to_mask_batch(bits, float(sr) / fps, Nmax, wave, clip_frames=t_nv, clip_samples=t_ns)
+    S_noise = transform.stft_batch(noise_sig, clip_samples=t_ns)
+    n_pred, crm = denoiser(S_mixed, S_noise, rag=rag)
+    S_out = transform.batch_fast_icRM_sigmoid(S_mixed, crm)
+    out = transform.istft_batch(S_out, clip_frames=rag.level(0))
+    return [out[b, :transform.HOP_LENGTH * (T[b] - 1)] for b in range(B)], dict(logits=logits, bits=bits, rag=rag)
+
+
 @torch.no_grad()
-def denoise_ragged(detector, denoiser, clips, sr=SR, fps=FPS, max_batch=64):
+def denoise_ragged(detector, denoiser, clips, sr=SR, fps=FPS, max_batch=256, max_columns=65536, return_all=False):
     """Variable-length inference (BASELINE configs[3]): `clips` = list of 1-D f32 GPU tensors of ANY lengths.
     The reference denoises one file at a time at its own length (M2/predict.py:377-447: no padding, so reflect
-    padding, frame count and video-frame count follow the clip); clips of equal length are bucketed into one
-    batch (<= max_batch; same result as one by one up to the summation order of the tuned conv tilings) and the
-    outputs come back in input order, each hop*(T-1) samples long."""
-    order = {}
-    for i, c in enumerate(clips):
+    padding, frame count and video-frame count follow the clip).  Here clips of different lengths share launches:
+    they are sorted by length (the BiLSTM kernel steps 16 clips in lockstep, so neighbours should be similar) and cut
+    into groups of <= max_batch clips and <= max_columns (clips x frames of the longest) spectrogram columns -- the
+    memory budget of a launch sequence, ~0.5 MB of live activations per column -- and every group runs as ONE batch
+    with per-clip geometry (_denoise_group).  Outputs come back in input order, each hop*(T-1) samples long."""
+    for c in clips:
         if c.dim() != 1:
             raise ValueError("denoise_ragged expects 1-D waveforms")
-        order.setdefault(int(c.numel()), []).append(i)
-    outs = [None] * len(clips)
-    for n, idx in sorted(order.items()):
-        for j in range(0, len(idx), max_batch):
-            part = idx[j:j + max_batch]
-            y = denoise(detector, denoiser, torch.stack([clips[i] for i in part]).contiguous(), sr, fps)
-            for k, i in enumerate(part):
-                outs[i] = y[k]
-    return outs
+    order = sorted(range(len(clips)), key=lambda i: -int(clips[i].numel()))
+    outs, extra = [None] * len(clips), [None] * len(clips)
+    j = 0
+    while j < len(order):
+        t_long = 1 + int(clips[order[j]].numel()) // transform.HOP_LENGTH        # the group's longest clip comes first
+        nb = max(1, min(max_batch, max_columns // t_long, len(order) - j))
+        part = order[j:j + nb]
+        ys, info = _denoise_group(detector, denoiser, [clips[i].contiguous().float() for i in part], sr, fps)
+        for k, i in enumerate(part):
+            outs[i] = ys[k]
+            if return_all:
+                extra[i] = dict(logits=info["logits"][k, :info["rag"].n_vframes[k]], bits=info["bits"][k, :info["rag"].n_vframes[k]])
+        j += nb
+    return (outs, extra) if return_all else outs
 
 
 class GraphedDenoiser:
@@ -111,7 +145,8 @@ class GraphedDenoiser:
         return entry[2].clone() if clone else entry[2]
 
     def denoise_ragged(self, clips, max_batch=64):
-        """`denoise_ragged` with every equal-length bucket replayed from its graph."""
+        """Equal-length buckets of `clips`, each replayed from its graph (streams of fixed-size chunks: the shapes repeat,
+        so the graphs are reused; pipeline.denoise_ragged is the path for arbitrary mixed lengths)."""
         order = {}
         for i, c in enumerate(clips):
             if c.dim() != 1:

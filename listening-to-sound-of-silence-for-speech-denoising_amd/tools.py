@@ -5,9 +5,10 @@ import torch
 from . import _lib as L
 
 
-def bits_to_mask_batch(bits, ratio, n_samples, sig=None):
+def bits_to_mask_batch(bits, ratio, n_samples, sig=None, clip_frames=None, clip_samples=None):
     """bits uint8 (B, n_frames) on the GPU (1 = non-silent) -> mask f32 (B, n_samples)
-    (1 on silent samples) and, if `sig` is given, sig*mask (M2/predict.py:310,317)."""
+    (1 on silent samples) and, if `sig` is given, sig*mask (M2/predict.py:310,317).  clip_frames / clip_samples:
+    optional int32 device (B,) each, ragged batch (clip b uses its own frame and sample counts)."""
     L.require_cuda(bits, sig)
     bits = bits.contiguous()
     if bits.dtype != torch.uint8 or bits.dim() != 2:
@@ -21,7 +22,8 @@ def bits_to_mask_batch(bits, ratio, n_samples, sig=None):
             raise ValueError("sig must be float32 (B, n_samples)")
         masked = torch.empty_like(sig)
     L.check(L.lib().sos_bits_to_mask(L.ptr(bits), B, nfr, float(ratio), n_samples, L.ptr(mask), L.ptr(sig),
-                                     L.ptr(masked), L.stream_ptr()), "sos_bits_to_mask")
+                                     L.ptr(masked), L.ptr(clip_frames), L.ptr(clip_samples), L.stream_ptr()),
+            "sos_bits_to_mask")
     return (mask, masked) if sig is not None else mask
 
 

@@ -32,28 +32,10 @@ def _front_tables(device, n_fft, win_length):
     return _tables[key]
 
 
-def _inv_wss(device, n_frames, n_fft, hop, win_length):
-    """1 / window-sum-square (librosa filters.window_sumsquare), 1 where wss <= tiny."""
-    key = ("wss", str(device), n_frames, n_fft, hop, win_length)
-    if key not in _tables:
-        n = np.arange(win_length, dtype=np.float64)
-        w = np.zeros(n_fft)
-        lpad = (n_fft - win_length) // 2
-        w[lpad:lpad + win_length] = (0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)) ** 2
-        total = n_fft + hop * (n_frames - 1)
-        x = np.zeros(total)
-        for i in range(n_frames):
-            x[i * hop:i * hop + n_fft] += w
-        inv = np.ones(total)
-        nz = x > np.finfo(np.float32).tiny
-        inv[nz] = 1.0 / x[nz]
-        _tables[key] = torch.from_numpy(inv.astype(np.float32)).to(device)
-    return _tables[key]
-
-
-def stft_batch(wave, n_fft=N_FFT, hop_length=HOP_LENGTH, win_length=WIN_LENGTH):
+def stft_batch(wave, n_fft=N_FFT, hop_length=HOP_LENGTH, win_length=WIN_LENGTH, clip_samples=None):
     """wave f32 (B, N) on the GPU -> (B, 2, n_fft//2+1, 1+N//hop) f32 (a1, fused with the
-    [F,T,2] -> [2,F,T] transpose of M2/dataset.py:255)."""
+    [F,T,2] -> [2,F,T] transpose of M2/dataset.py:255).  clip_samples: optional int32 device (B,), ragged batch: clip b
+    has clip_samples[b] <= N samples (frames past its own 1 + n//hop are left unwritten)."""
     L.require_cuda(wave)
     if wave.dim() != 2 or wave.dtype != torch.float32:
         raise ValueError("stft_batch expects a float32 (B, N) tensor")
@@ -63,12 +45,13 @@ def stft_batch(wave, n_fft=N_FFT, hop_length=HOP_LENGTH, win_length=WIN_LENGTH):
     window, tw = _front_tables(wave.device, n_fft, win_length)
     out = torch.empty((B, 2, n_fft // 2 + 1, T), dtype=torch.float32, device=wave.device)
     L.check(L.lib().sos_stft_f32(L.ptr(wave), B, N, N, L.ptr(window), L.ptr(tw), n_fft, hop_length, win_length,
-                                 L.ptr(out), T, L.stream_ptr()), "sos_stft_f32")
+                                 L.ptr(out), T, L.ptr(clip_samples), L.stream_ptr()), "sos_stft_f32")
     return out
 
 
-def istft_batch(spec, hop_length=HOP_LENGTH, win_length=WIN_LENGTH):
-    """spec f32 (B, 2, F, T) on the GPU -> (B, hop*(T-1)) f32 (a2)."""
+def istft_batch(spec, hop_length=HOP_LENGTH, win_length=WIN_LENGTH, clip_frames=None):
+    """spec f32 (B, 2, F, T) on the GPU -> (B, hop*(T-1)) f32 (a2).  clip_frames: optional int32 device (B,), ragged
+    batch: clip b has clip_frames[b] <= T frames and gets hop*(clip_frames[b]-1) samples."""
     L.require_cuda(spec)
     if spec.dim() != 4 or spec.shape[1] != 2 or spec.dtype != torch.float32:
         raise ValueError("istft_batch expects a float32 (B, 2, F, T) tensor")
@@ -76,11 +59,11 @@ def istft_batch(spec, hop_length=HOP_LENGTH, win_length=WIN_LENGTH):
     B, _, F, T = spec.shape
     n_fft = 2 * (F - 1)
     window, tw = _front_tables(spec.device, n_fft, win_length)
-    inv = _inv_wss(spec.device, T, n_fft, hop_length, win_length)
+    # the window-sum-square normalisation is computed inside the kernel (the <= 3 frames covering a sample)
     n_out = hop_length * (T - 1)
     out = torch.empty((B, n_out), dtype=torch.float32, device=spec.device)
-    L.check(L.lib().sos_istft_f32(L.ptr(spec), B, T, L.ptr(window), L.ptr(tw), L.ptr(inv), n_fft, hop_length,
-                                  win_length, L.ptr(out), n_out, L.stream_ptr()), "sos_istft_f32")
+    L.check(L.lib().sos_istft_f32(L.ptr(spec), B, T, L.ptr(window), L.ptr(tw), None, n_fft, hop_length,
+                                  win_length, L.ptr(out), n_out, L.ptr(clip_frames), L.stream_ptr()), "sos_istft_f32")
     return out
 
 
