@@ -10,6 +10,8 @@ A "step" is one pass of the hot path over one batch of synthetic 2 s clips resid
                (independent) models on one HIP stream each;
                for N > 1 the gradients are averaged with bucketed RCCL all-reduces overlapped with backward
   --mode infer: STFT -> detector -> bits->mask -> STFT(noise) -> JointModel -> mask apply -> ISTFT
+  --mode infer-ragged (BASELINE.json configs[3]): the same chain over --batch (default 256) clips of DIFFERENT lengths,
+               U(1 s, 10 s) with seed 99, per-clip geometry inside the kernels (pipeline.denoise_ragged)
 Each rank processes its own batch (independent utterances): weak scaling.
 """
 import argparse
@@ -112,8 +114,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
-    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU per step (default 64; 256 for infer-ragged)")
+    ap.add_argument("--mode", default="train", choices=["train", "infer", "infer-ragged"])
     ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["bf16", "fp16", "bf16x3"],
                     help="16-bit storage type of activations/weights (MFMA rate is the same for bf16 and fp16); bf16x3 = "
                          "three-pass hi/lo split (3x the MACs, ~fp32 accuracy)")
@@ -139,6 +141,8 @@ def main():
     from sos_amd.denoiser import networks as jnet
     from sos_amd.detector import networks as dnet
 
+    if args.batch is None:
+        args.batch = 256 if args.mode == "infer-ragged" else 64
     sos_amd.set_precision(args.precision)
     torch.manual_seed(0)
     det = dnet.get_network().cuda().eval()
@@ -167,6 +171,16 @@ def main():
                 ag_jm.train_func(batch_jm)
             else:           # the two models are independent: one HIP stream each
                 agent.train_concurrent([(ag_jm, batch_jm), (ag_det, batch_det)])
+    elif args.mode == "infer-ragged":
+        # BASELINE configs[3]: lengths drawn uniformly from 1-10 s with seed 99, every rank its own draw
+        lens = [int(v) for v in np.random.default_rng(99 + rank).uniform(14000, 140000, B)]
+        pool = np.concatenate(list(synth_batch(2000 * rank, 20)["mixed"]))
+        pool_t = torch.from_numpy(np.ascontiguousarray(pool)).cuda()
+        ragged_clips = [pool_t[(4099 * i) % (len(pool) - 140000):][:n].contiguous() for i, n in enumerate(lens)]
+        audio_seconds = sum(lens) / 14000.0
+
+        def step():
+            return pipeline.denoise_ragged(det, jm, ragged_clips)
     else:
         def step():
             return pipeline.denoise(det, jm, mixed)
@@ -202,6 +216,8 @@ def main():
         ach = prof["flops"] / (prof["avg_ms"] * 1e-3) / 1e12
         train = args.mode == "train"
         gflop = GFLOP_PER_UTT_INFER * (3.0 if train else 1.0)      # algorithmic (reference) FLOPs: bf16x3's 3x MACs do not count
+        if args.mode == "infer-ragged":                            # FLOPs scale with the frames of a clip: 2 s = 178 frames
+            gflop *= sum(1 + n // 158 for n in lens) / (178.0 * B)
         # HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs, FETCH_SIZE doubled per the gfx950 correction); null when the signature has no PMC record
         traffic = None
@@ -212,19 +228,25 @@ def main():
         except Exception:
             pass
         line = {
-            "metric": "utterances/sec (2 s clips), " + ("training step: detector + denoiser forward/backward/Adam" if train
-                                                         else "inference pipeline STFT->detector->mask->denoiser->ISTFT"),
+            "metric": ("utterances/sec (variable-length clips 1-10 s), " if args.mode == "infer-ragged" else "utterances/sec (2 s clips), ") +
+                      ("training step: detector + denoiser forward/backward/Adam" if train
+                       else "inference pipeline STFT->detector->mask->denoiser->ISTFT"),
             "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": ("training (BASELINE configs[1])" if train else "inference") +
-                                   f", batch={B} clips/GPU of 2 s @14 kHz (28000 samples, STFT 510/158/400 -> 2x256x178), "
+            "config": {"workload": ("training (BASELINE configs[1])" if train else
+                                    "inference" if args.mode == "infer" else "variable-length inference (BASELINE configs[3])") +
+                                   (f", batch={B} clips/GPU of 2 s @14 kHz (28000 samples, STFT 510/158/400 -> 2x256x178), "
+                                    if args.mode != "infer-ragged" else
+                                    f", batch={B} clips/GPU, lengths U(1 s, 10 s) seed 99 @14 kHz ({audio_seconds:.0f} s of audio, "
+                                    f"{audio_seconds / 2.0:.0f} 2-s equivalents; STFT 510/158/400 -> 2x256xT, T = 89..887), clips of "
+                                    "different lengths share launches (per-clip geometry in the kernels, no padding of the data), ") +
                                    "detector + two-stage denoiser, random-init weights (manual_seed 0)"
                                    + (", detector BCE + denoiser 2xMSE, Adam lr 1e-3, per-rank BatchNorm" if train else ""),
                        "clips_per_gpu": B, "n_samples": N_SAMPLES, "mode": args.mode, "precision": args.precision,
                        "parity": PARITY_NOTE[args.precision],
                        "streams": 2 if (train and not args.serial) else 1,
-                       "realtime_factor": value * N_SAMPLES / 14000.0,
+                       "realtime_factor": value * (audio_seconds / B if args.mode == "infer-ragged" else N_SAMPLES / 14000.0),
                        "end_to_end_tflops": value * gflop / 1e3 / world},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,

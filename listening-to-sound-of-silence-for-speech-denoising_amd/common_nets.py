@@ -139,7 +139,7 @@ def run_encoder(plan, a, feat, feat_row, feat_third, feat_c_off, x3, w_gather=No
     lp = plan[-1]
     Wo = W if T_out is None else T_out
     if rag is not None and rag_out is not None:       # logical input columns = output columns = the clip's frame count
-        rk = dict(wl_tab=rag_out[0], wo_tab=rag_out[0], wg_stride=rag_out[1])
+        rk = dict(wl_tab=rag_out[0], wo_tab=rag_out[0], wg_stride=rag_out[1], valid_cols=sum(rag.n_vframes))
     E.conv(cur, 0, lp["cin_store"], lp["w"], 1, 1, lp["cout"], lp["scale"], lp["shift"], L.ACT_RELU,
            out=feat, out_dtype=L.DT_BF16X3 if x3 else L.DT_BF16, sb=Wo * feat_row, sh=1, sw=feat_row, sc=H,
            c_off=feat_c_off, third=feat_third, Ho=H, Wo=Wo, w_gather=w_gather, **rk)

@@ -110,7 +110,8 @@ def _run_up(lp, src, dst, c_off, rag=None, lsrc=0, ldst=0):
         rk = {}
         if rag is not None:     # per clip: its own source width, and the crop to ITS skip connection's width
             ws, wd = rag.widths(lsrc), rag.widths(ldst)
-            rk = dict(wl_tab=rag.tab(ws), wo_tab=rag.tab([min(a, (b - pw + 1) // 2) for a, b in zip(ws, wd)]))
+            wo = [min(a, (b - pw + 1) // 2) for a, b in zip(ws, wd)]
+            rk = dict(wl_tab=rag.tab(ws), wo_tab=rag.tab(wo), valid_cols=sum(wo))
         E.conv(src, 0, lp["cin_store"], w, 1 + ph, 1 + pw, lp["cout"], lp["scale"], lp["shift"], L.ACT_PRELU,
                out=dst.t, out_dtype=dst.dtype_code, sb=dst.H * dst.W * row, sh=2 * dst.W * row, sw=2 * row, sc=1,
                c_off=c_off, cout_store=lp["cout"], third=dst.cs, slope=lp["slope"], Ho=Ho, Wo=Wo,

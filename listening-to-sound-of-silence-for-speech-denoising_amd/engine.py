@@ -206,7 +206,7 @@ def fold_bn(bn, cout_pad):
 def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dtype, sb, sh, sw, sc,
          Ho, Wo, c_off=0, cout_store=None, third=0, stride=1, dil=(1, 1), pad=(0, 0), pad_mode=L.PAD_ZERO,
          slope=None, w_gather=None, out_elem_offset=0, in_dims=None, accumulate=False, stats_c=0, wl_tab=None,
-         wo_tab=None, wg_stride=0):
+         wo_tab=None, wg_stride=0, valid_cols=None):
     """Fill a sos_conv_desc and enqueue sos_conv2d_fwd.  `src` is an Act (or a (tensor,B,H,W,cs,nseg)
     view described by in_dims).  stats_c > 0: also return the fused BatchNorm partial sums of the first stats_c
     output channels as (partial [tiles][2][stats_c], tiles) for sos_bn_finalize."""
@@ -262,8 +262,10 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
                 L.check(L.lib().sos_conv2d_tune(C.byref(d), 8, 3, None, L.stream_ptr()), "sos_conv2d_tune")
     end = None
     if PROFILER is not None:
-        sig = ("conv", kh, kw, dil[0], dil[1], stride, d.in_nseg * cin, cout, B, Ho, Wo)
-        end = PROFILER.bracket(sig, 2.0 * B * Ho * Wo * cout * d.in_nseg * cin * kh * kw)
+        # ragged batches: only the clips' own columns are algorithmic work (valid_cols = their sum)
+        cols = B * Wo if valid_cols is None else valid_cols
+        sig = ("conv", kh, kw, dil[0], dil[1], stride, d.in_nseg * cin, cout, B, Ho, Wo) + (() if valid_cols is None else ("ragged", cols))
+        end = PROFILER.bracket(sig, 2.0 * Ho * cols * cout * d.in_nseg * cin * kh * kw)
     stats = None
     if stats_c:
         tiles = L.lib().sos_conv2d_tile_count(C.byref(d))
@@ -350,7 +352,8 @@ class Ragged:
 
     def kw(self, lin, lout=None):
         """conv keyword arguments for a layer reading level `lin` and writing level `lout`."""
-        return dict(wl_tab=self.level(lin), wo_tab=self.level(lin if lout is None else lout))
+        lout = lin if lout is None else lout
+        return dict(wl_tab=self.level(lin), wo_tab=self.level(lout), valid_cols=sum(self.widths(lout)))
 
 
 class PlanCache:

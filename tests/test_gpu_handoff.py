@@ -185,7 +185,9 @@ def test_known_clean_signal_path_reports_the_objective_measures(tmp_path):
     want = om.composite(c16, y16, 16000, eps=1e-20, pesq_raw=2.5)
     assert abs(info["ssnr_clip"] - want["segSNR"]) < 1e-3 * abs(want["segSNR"]) + 1e-3
     assert abs(info["overall_snr"] - want["overall_snr"]) < 1e-3 * abs(want["overall_snr"]) + 1e-3
-    assert abs(info["covl"] - want["covl"]) < 5e-3 and abs(info["cbak"] - want["cbak"]) < 5e-3
+    # composite scores on the 1..5 scale; the f32 LPC / spectral-slope kernels against the f64 oracle on an (untrained-
+    # network) output whose frames are partly ill-conditioned for the LPC fit: observed 2e-3 .. 6e-3 depending on the output
+    assert abs(info["covl"] - want["covl"]) < 1e-2 and abs(info["cbak"] - want["cbak"]) < 1e-2
     assert abs(info["ssnr_exsi"] - om.metrics_ssnr_exclude_silence(c16, y16, 16000, eps=1e-20)[1]) < 2e-2
     assert abs(info["l1"] - om.metrics_L1(y16, c16)) < 1e-5
     with open(os.path.join(out, "eval_results_snr10.json")) as fp:
