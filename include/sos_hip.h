@@ -39,28 +39,35 @@ const char* sos_last_error(void);
  * says "bf16" for an activation / packed-weight buffer it means "the library's 16-bit storage type". */
 const char* sos_storage_dtype(void);
 
-/* ---- a1  fast_stft: M1/transform.py:188-193 (librosa.stft(data,510,158,400),
- * hann-periodic window centred in n_fft, center=True, reflect pad) fused with
- * real_imag_expand (:10-17) and the caller's transpose to [2,F,T]
- * (M2/dataset.py:255).  wave f32 [B][wave_stride], out f32 [B][2][n_fft/2+1][T],
- * T = 1 + n_samples/hop.  window f32 [win_length], twiddle f32 [n_fft][2] (cos,sin). */
+/* ---- a1  fast_stft: M1/transform.py:188-193 (librosa.stft(data,510,158,400), hann-periodic window centred in
+ * n_fft, center=True, reflect pad) fused with real_imag_expand (:10-17) and the caller's transpose to [2,F,T]
+ * (M2/dataset.py:255).  The transform is a windowed-DFT GEMM on the matrix cores (csrc/stft_mfma.hip): the constant
+ * matrix is packed ONCE on the host into MFMA fragment order, as hi + lo half-precision parts (the product is taken as
+ * hi*hi + hi*lo + lo*hi with fp32 accumulation, ~22 significand bits), and uploaded by the caller:
+ *   sos_stft_matrix_bytes(): bytes of ONE part; sos_stft_pack_matrix(): fills two HOST buffers of that size.
+ * wave f32 [B][wave_stride], out f32 [B][2][n_fft/2+1][T], T = 1 + n_samples/hop.  Supported geometry: (n_fft+2) % 32
+ * == 0, win_length % 16 == 0, even hop, ceil(win/hop) <= 3 (the reference's 510/158/400); anything else is EINVAL. */
+int64_t sos_stft_matrix_bytes(int n_fft, int hop, int win_length);
+int sos_stft_pack_matrix(int n_fft, int hop, int win_length, void* hi /* host */, void* lo /* host */);
 int sos_stft_f32(const float* wave, int64_t batch, int64_t n_samples, int64_t wave_stride,
-                 const float* window, const float* twiddle, int n_fft, int hop, int win_length,
-                 float* out, int64_t n_frames,
+                 const void* mat_hi, const void* mat_lo /* device copies of the packed matrix */, int n_fft, int hop,
+                 int win_length, float* out, int64_t n_frames,
                  const int32_t* clip_samples /* optional device [B], ragged batch: clip b has clip_samples[b] <= n_samples
                     samples (reflected at ITS end) and 1 + clip_samples[b]/hop frames; rows keep the pitch n_frames */,
                  sos_stream_t stream);
 
-/* ---- a2  fast_istft: M1/transform.py:196-202 (librosa.istft(S,158,400)): irDFT,
- * window, overlap-add, divide by window-sum-square, trim n_fft/2 both ends.
- * spec f32 [B][2][F][T]; inv_wss f32 [n_fft + hop*(T-1)] = 1/wss where wss > tiny
- * else 1, or NULL: the kernel sums the window squares of the (<= 3) frames covering a sample itself;
- * out f32 [B][out_stride], hop*(T-1) samples written. */
-int sos_istft_f32(const float* spec, int64_t batch, int64_t n_frames, const float* window,
-                  const float* twiddle, const float* inv_wss, int n_fft, int hop, int win_length,
-                  float* out, int64_t out_stride,
+/* ---- a2  fast_istft: M1/transform.py:196-202 (librosa.istft(S,158,400)): inverse real DFT, synthesis window,
+ * overlap-add, division by the window-sum-square (where > tiny), trim n_fft/2 both ends -- the synthesis GEMM
+ * (window and irfft weights folded into the packed matrix, same hi/lo scheme), then a fixed-order overlap-add of the
+ * <= 3 frames covering a sample with the window-sum-square taken over those same frames.
+ * sos_istft_pack_matrix also fills win_sq f32 [win_length] (HOST), the squared window.
+ * spec f32 [B][2][F][T]; out f32 [B][out_stride], hop*(T-1) samples written. */
+int64_t sos_istft_matrix_bytes(int n_fft, int hop, int win_length);
+int sos_istft_pack_matrix(int n_fft, int hop, int win_length, void* hi /* host */, void* lo /* host */, float* win_sq /* host */);
+int sos_istft_f32(const float* spec, int64_t batch, int64_t n_frames, const void* mat_hi, const void* mat_lo,
+                  const float* win_sq /* device */, int n_fft, int hop, int win_length, float* out, int64_t out_stride,
                   const int32_t* clip_frames /* optional device [B], ragged batch: clip b has clip_frames[b] <= n_frames
-                     frames -> hop*(clip_frames[b]-1) samples; inv_wss must then be NULL */,
+                     frames -> hop*(clip_frames[b]-1) samples */,
                   sos_stream_t stream);
 
 /* ---- a4/a5  batch_fast_icRM_sigmoid: M1/transform.py:156-169 (and the numpy

@@ -57,7 +57,11 @@ _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 # name -> argtypes, exactly the prototypes of include/sos_hip.h
 SIGNATURES = {
     "sos_abi_version": [],
+    "sos_stft_matrix_bytes": [_I, _I, _I],
+    "sos_stft_pack_matrix": [_I, _I, _I, _P, _P],
     "sos_stft_f32": [_P, _L, _L, _L, _P, _P, _I, _I, _I, _P, _L, _P, _P],
+    "sos_istft_matrix_bytes": [_I, _I, _I],
+    "sos_istft_pack_matrix": [_I, _I, _I, _P, _P, _P],
     "sos_istft_f32": [_P, _L, _L, _P, _P, _P, _I, _I, _I, _P, _L, _P, _P],
     "sos_crm_apply_f32": [_P, _P, _P, _L, _L, _F, _F, _P],
     "sos_crm_apply_bwd_f32": [_P, _P, _P, _P, _L, _L, _F, _P],
@@ -122,7 +126,8 @@ def _load(path, want_dtype):
     for name, argtypes in SIGNATURES.items():
         fn = getattr(h, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = C.c_int64 if name in ("sos_wgrad_workspace_bytes", "sos_lstm_pack_bytes", "sos_conv2d_tile_count") else C.c_int
+        fn.restype = C.c_int64 if name in ("sos_wgrad_workspace_bytes", "sos_lstm_pack_bytes", "sos_conv2d_tile_count",
+                                             "sos_stft_matrix_bytes", "sos_istft_matrix_bytes") else C.c_int
     h.sos_last_error.restype = C.c_char_p
     h.sos_last_error.argtypes = []
     h.sos_storage_dtype.restype = C.c_char_p

@@ -1,4 +1,5 @@
-// frontend.hip -- STFT / ISTFT / complex-ratio-mask / bits->sample-mask kernels (gfx950).
+// frontend.hip -- complex-ratio-mask / add_signals / bits->sample-mask / layout kernels (gfx950); the STFT and ISTFT
+// live in stft_mfma.hip.
 //
 // Reference semantics (paths relative to /root/reference, M1 = model_1_silent_interval_detection/
 // audioonly_model, M2 = model_2_audio_denoising/audio_denoising_model):
@@ -6,203 +7,7 @@
 //   batch_fast_icRM_sigmoid M1/transform.py:156-169   fast_cRM_sigmoid :130-138
 //   convert_bitstreammask_to_audiomask M2/tools.py:340-362
 #include "sos_common.h"
-
-// ------------------------------------------------------------------------------------ STFT
-// One workgroup = 16 consecutive frames of one clip, one thread per frequency bin.
-// The 16 windowed frames are staged once in LDS as xw[n][16] so the inner loop reads them with
-// four broadcast ds_read_b128 per sample; the n_fft-entry (cos,sin) table is LDS resident and is
-// walked with an incremental (f*n mod n_fft) index.  Output is written planar [B][2][F][T], i.e.
-// real_imag_expand + the dataset's transpose are fused into the store.
-#define STFT_FT 16
-
-__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wave, int64_t n_samples,
-                                                   int64_t wave_stride, const float* __restrict__ window,
-                                                   const float* __restrict__ twiddle, int n_fft, int hop,
-                                                   int win, float* __restrict__ out, int64_t T,
-                                                   const int* __restrict__ n_tab) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xw = (float*)smem;                                  // [win][STFT_FT]
-    float2* tw = (float2*)(smem + (size_t)win * STFT_FT * 4);  // [n_fft]
-    const int tid = threadIdx.x;
-    const int64_t b = blockIdx.y;
-    const int64_t t0 = (int64_t)blockIdx.x * STFT_FT;
-    const int nbins = n_fft / 2 + 1;
-    const int lpad = (n_fft - win) / 2;
-    const float* wv = wave + b * wave_stride;
-    // ragged batch: clip b has n_tab[b] <= n_samples samples, i.e. Tc <= T frames, and is reflected at ITS end; the
-    // output keeps the row pitch T
-    int64_t Tc = T;
-    if (n_tab) {
-        n_samples = n_tab[b];
-        Tc = 1 + n_samples / hop;
-        if (t0 >= Tc) return;
-    }
-
-    for (int k = tid; k < n_fft; k += 256) tw[k] = make_float2(twiddle[2 * k], twiddle[2 * k + 1]);
-    for (int idx = tid; idx < win * STFT_FT; idx += 256) {
-        const int tt = idx / win, n = idx - tt * win;
-        const int64_t t = t0 + tt;
-        float v = 0.f;
-        if (t < Tc) {
-            int64_t i = t * hop + n + lpad - n_fft / 2;       // index into the un-padded clip
-            if (i < 0) i = -i;
-            if (i >= n_samples) i = 2 * (n_samples - 1) - i;
-            v = wv[i] * window[n];
-        }
-        xw[n * STFT_FT + tt] = v;
-    }
-    __syncthreads();
-
-    for (int f = tid; f < nbins; f += 256) {
-        float re[STFT_FT], im[STFT_FT];
-#pragma unroll
-        for (int i = 0; i < STFT_FT; ++i) { re[i] = 0.f; im[i] = 0.f; }
-        int k = (int)(((int64_t)f * lpad) % n_fft);
-        for (int n = 0; n < win; ++n) {
-            const float2 cs = tw[k];
-            const float4* xv = (const float4*)(xw + n * STFT_FT);
-#pragma unroll
-            for (int q = 0; q < STFT_FT / 4; ++q) {
-                const float4 v = xv[q];
-                re[4 * q + 0] = fmaf(v.x, cs.x, re[4 * q + 0]); im[4 * q + 0] = fmaf(-v.x, cs.y, im[4 * q + 0]);
-                re[4 * q + 1] = fmaf(v.y, cs.x, re[4 * q + 1]); im[4 * q + 1] = fmaf(-v.y, cs.y, im[4 * q + 1]);
-                re[4 * q + 2] = fmaf(v.z, cs.x, re[4 * q + 2]); im[4 * q + 2] = fmaf(-v.z, cs.y, im[4 * q + 2]);
-                re[4 * q + 3] = fmaf(v.w, cs.x, re[4 * q + 3]); im[4 * q + 3] = fmaf(-v.w, cs.y, im[4 * q + 3]);
-            }
-            k += f;
-            if (k >= n_fft) k -= n_fft;
-        }
-        float* ore = out + ((b * 2 + 0) * nbins + f) * T + t0;
-        float* oim = out + ((b * 2 + 1) * nbins + f) * T + t0;
-#pragma unroll
-        for (int i = 0; i < STFT_FT; ++i) {
-            if (t0 + i < Tc) { ore[i] = re[i]; oim[i] = im[i]; }
-        }
-    }
-}
-
-extern "C" int sos_stft_f32(const float* wave, int64_t batch, int64_t n_samples, int64_t wave_stride,
-                            const float* window, const float* twiddle, int n_fft, int hop, int win_length,
-                            float* out, int64_t n_frames, const int32_t* clip_samples, sos_stream_t stream) {
-    if (!wave || !window || !twiddle || !out) { sos_set_error("sos_stft_f32: null pointer"); return SOS_EINVAL; }
-    if (n_fft < 2 || (n_fft & 1) || win_length > n_fft || hop < 1 || n_samples <= n_fft / 2 ||
-        n_frames != 1 + n_samples / hop || batch < 1 || batch > 65535) {
-        sos_set_error("sos_stft_f32: bad geometry n_fft=%d hop=%d win=%d n=%lld T=%lld", n_fft, hop, win_length,
-                      (long long)n_samples, (long long)n_frames);
-        return SOS_EINVAL;
-    }
-    const size_t lds = (size_t)win_length * STFT_FT * 4 + (size_t)n_fft * 8;
-    if (lds > 64 * 1024) { sos_set_error("sos_stft_f32: window too long for LDS staging"); return SOS_ENOSPC; }
-    dim3 grid((unsigned)((n_frames + STFT_FT - 1) / STFT_FT), (unsigned)batch);
-    hipLaunchKernelGGL(stft_kernel, grid, dim3(256), lds, (hipStream_t)stream, wave, n_samples, wave_stride,
-                       window, twiddle, n_fft, hop, win_length, out, n_frames, clip_samples);
-    return sos_check_launch("sos_stft_f32");
-}
-
-// ----------------------------------------------------------------------------------- ISTFT
-// One workgroup = 256 consecutive output samples of one clip, one thread per sample.  The <= 6
-// frames that overlap the tile are staged in LDS; each thread evaluates the inverse real DFT of
-// its (up to 3) contributing frames at its own in-frame position, applies the synthesis window,
-// sums (overlap-add), and multiplies by the precomputed 1/window-sum-square.  The centre trim is
-// folded into the indexing.
-#define ISTFT_MAXFR 6
-
-__global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ spec, int64_t T,
-                                                    const float* __restrict__ window,
-                                                    const float* __restrict__ twiddle,
-                                                    const float* __restrict__ inv_wss, int n_fft, int hop, int win,
-                                                    float* __restrict__ out, int64_t out_stride, int64_t n_out,
-                                                    const int* __restrict__ t_tab) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nbins = n_fft / 2 + 1;
-    float2* tw = (float2*)smem;                               // [n_fft]
-    float* sre = (float*)(smem + (size_t)n_fft * 8);          // [ISTFT_MAXFR][nbins]
-    float* sim = sre + ISTFT_MAXFR * nbins;
-    const int tid = threadIdx.x;
-    const int64_t b = blockIdx.y;
-    const int64_t j0 = (int64_t)blockIdx.x * 256;
-    const int lpad = (n_fft - win) / 2;
-    const int half = n_fft / 2;
-    // ragged batch: clip b has t_tab[b] <= T frames (the spectrogram keeps the row pitch T) and hop*(Tc-1) output samples
-    const int64_t Tp = T;
-    if (t_tab) {
-        T = t_tab[b];
-        n_out = (int64_t)hop * (T - 1);
-        if (j0 >= n_out) return;
-    }
-    // frames overlapping [j0+half, j0+half+255]: n = p - t*hop in [lpad, lpad+win)
-    int64_t tlo = (j0 + half - lpad - win + 1 + hop - 1);
-    tlo = tlo <= 0 ? 0 : tlo / hop;
-    int64_t thi = (j0 + half + 255 - lpad) / hop;
-    if (thi > T - 1) thi = T - 1;
-    const int nfr = (int)(thi - tlo + 1);
-
-    for (int k = tid; k < n_fft; k += 256) tw[k] = make_float2(twiddle[2 * k], twiddle[2 * k + 1]);
-    for (int idx = tid; idx < ISTFT_MAXFR * nbins; idx += 256) {
-        const int fr = idx / nbins, f = idx - fr * nbins;
-        float r = 0.f, i = 0.f;
-        if (fr < nfr) {
-            r = spec[((b * 2 + 0) * nbins + f) * Tp + tlo + fr];
-            i = spec[((b * 2 + 1) * nbins + f) * Tp + tlo + fr];
-        }
-        sre[idx] = r;
-        sim[idx] = i;
-    }
-    __syncthreads();
-
-    const int64_t j = j0 + tid;
-    if (j >= n_out) return;
-    const int64_t p = j + half;
-    int64_t tmax = (p - lpad) / hop;
-    if (tmax > T - 1) tmax = T - 1;
-    float y = 0.f, wss = 0.f;
-    const float invn = 1.0f / (float)n_fft;
-    for (int s = 0; s < 3; ++s) {
-        const int64_t t = tmax - s;
-        if (t < 0 || t < tlo) break;
-        const int n = (int)(p - t * hop);
-        if (n >= lpad + win) break;           // earlier frames end even sooner
-        const int fr = (int)(t - tlo);
-        const float* fre = sre + fr * nbins;
-        const float* fim = sim + fr * nbins;
-        float acc = fre[0] + ((n & 1) ? -fre[nbins - 1] : fre[nbins - 1]);
-        float acc2 = 0.f;
-        int k = n;                            // (f*n) mod n_fft for f = 1
-        for (int f = 1; f < nbins - 1; ++f) {
-            const float2 cs = tw[k];
-            acc2 = fmaf(fre[f], cs.x, acc2);
-            acc2 = fmaf(-fim[f], cs.y, acc2);
-            k += n;
-            if (k >= n_fft) k -= n_fft;
-        }
-        const float wn = window[n - lpad];
-        y = fmaf(wn, (acc + 2.f * acc2) * invn, y);
-        wss = fmaf(wn, wn, wss);               // librosa.filters.window_sumsquare over the same (<= 3) frames
-    }
-    // divide by the window-sum-square where it exceeds tiny (librosa.istft); a caller-provided table takes precedence
-    const float inv = inv_wss ? inv_wss[p] : (wss > 1.17549435e-38f ? 1.0f / wss : 1.0f);
-    out[b * out_stride + j] = y * inv;
-}
-
-extern "C" int sos_istft_f32(const float* spec, int64_t batch, int64_t n_frames, const float* window,
-                             const float* twiddle, const float* inv_wss, int n_fft, int hop, int win_length,
-                             float* out, int64_t out_stride, const int32_t* clip_frames, sos_stream_t stream) {
-    if (!spec || !window || !twiddle || !out) { sos_set_error("sos_istft_f32: null pointer"); return SOS_EINVAL; }
-    if (clip_frames && inv_wss) { sos_set_error("sos_istft_f32: a ragged batch computes the window-sum-square in the kernel (inv_wss must be NULL)"); return SOS_EINVAL; }
-    const int64_t n_out = (int64_t)hop * (n_frames - 1);
-    if (n_fft < 2 || (n_fft & 1) || win_length > n_fft || hop < 1 || n_frames < 2 || batch < 1 || batch > 65535 ||
-        out_stride < n_out || (255 + win_length) / hop + 2 > ISTFT_MAXFR || (win_length + hop - 1) / hop > 3) {
-        sos_set_error("sos_istft_f32: bad geometry n_fft=%d hop=%d win=%d T=%lld", n_fft, hop, win_length,
-                      (long long)n_frames);
-        return SOS_EINVAL;
-    }
-    const int nbins = n_fft / 2 + 1;
-    const size_t lds = (size_t)n_fft * 8 + (size_t)ISTFT_MAXFR * nbins * 8;
-    dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)batch);
-    hipLaunchKernelGGL(istft_kernel, grid, dim3(256), lds, (hipStream_t)stream, spec, n_frames, window, twiddle,
-                       inv_wss, n_fft, hop, win_length, out, out_stride, n_out, clip_frames);
-    return sos_check_launch("sos_istft_f32");
-}
+#include <stdlib.h>
 
 // ------------------------------------------------------------------- complex ratio mask ops
 __device__ __forceinline__ float crm_recover(float c, float inv_a, float b) {

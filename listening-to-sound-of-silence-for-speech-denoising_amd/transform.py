@@ -19,16 +19,26 @@ WIN_LENGTH = 400
 _tables = {}
 
 
-def _front_tables(device, n_fft, win_length):
-    """hann (periodic, scipy get_window fftbins=True) and the (cos,sin) twiddle table."""
-    key = ("fe", str(device), n_fft, win_length)
+def _front_tables(device, n_fft, hop, win_length, inverse=False):
+    """The packed windowed-DFT matrix of the STFT (or the synthesis matrix + squared window of the ISTFT) in MFMA
+    fragment order, hi and lo half-precision parts: packed once on the host by the library (sos_*_pack_matrix) and
+    kept on the device."""
+    key = ("istft" if inverse else "stft", str(device), n_fft, hop, win_length)
     if key not in _tables:
-        n = np.arange(win_length, dtype=np.float64)
-        window = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)
-        k = np.arange(n_fft, dtype=np.float64)
-        tw = np.stack([np.cos(2.0 * np.pi * k / n_fft), np.sin(2.0 * np.pi * k / n_fft)], axis=1)
-        _tables[key] = (torch.from_numpy(window.astype(np.float32)).to(device),
-                        torch.from_numpy(tw.astype(np.float32)).to(device).contiguous())
+        h = L.lib()
+        nbytes = (h.sos_istft_matrix_bytes if inverse else h.sos_stft_matrix_bytes)(n_fft, hop, win_length)
+        if nbytes < 0:
+            raise ValueError((h.sos_last_error() or b"").decode())
+        hi, lo = np.empty(nbytes // 2, dtype=np.uint16), np.empty(nbytes // 2, dtype=np.uint16)
+        if inverse:
+            wsq = np.empty(win_length, dtype=np.float32)
+            L.check(h.sos_istft_pack_matrix(n_fft, hop, win_length, hi.ctypes.data, lo.ctypes.data, wsq.ctypes.data),
+                    "sos_istft_pack_matrix")
+            _tables[key] = (torch.from_numpy(hi.view(np.int16)).to(device), torch.from_numpy(lo.view(np.int16)).to(device),
+                            torch.from_numpy(wsq).to(device))
+        else:
+            L.check(h.sos_stft_pack_matrix(n_fft, hop, win_length, hi.ctypes.data, lo.ctypes.data), "sos_stft_pack_matrix")
+            _tables[key] = (torch.from_numpy(hi.view(np.int16)).to(device), torch.from_numpy(lo.view(np.int16)).to(device))
     return _tables[key]
 
 
@@ -42,9 +52,9 @@ def stft_batch(wave, n_fft=N_FFT, hop_length=HOP_LENGTH, win_length=WIN_LENGTH, 
     wave = wave.contiguous()
     B, N = wave.shape
     T = 1 + N // hop_length
-    window, tw = _front_tables(wave.device, n_fft, win_length)
+    mhi, mlo = _front_tables(wave.device, n_fft, hop_length, win_length)
     out = torch.empty((B, 2, n_fft // 2 + 1, T), dtype=torch.float32, device=wave.device)
-    L.check(L.lib().sos_stft_f32(L.ptr(wave), B, N, N, L.ptr(window), L.ptr(tw), n_fft, hop_length, win_length,
+    L.check(L.lib().sos_stft_f32(L.ptr(wave), B, N, N, L.ptr(mhi), L.ptr(mlo), n_fft, hop_length, win_length,
                                  L.ptr(out), T, L.ptr(clip_samples), L.stream_ptr()), "sos_stft_f32")
     return out
 
@@ -58,11 +68,11 @@ def istft_batch(spec, hop_length=HOP_LENGTH, win_length=WIN_LENGTH, clip_frames=
     spec = spec.contiguous()
     B, _, F, T = spec.shape
     n_fft = 2 * (F - 1)
-    window, tw = _front_tables(spec.device, n_fft, win_length)
+    mhi, mlo, wsq = _front_tables(spec.device, n_fft, hop_length, win_length, inverse=True)
     # the window-sum-square normalisation is computed inside the kernel (the <= 3 frames covering a sample)
     n_out = hop_length * (T - 1)
     out = torch.empty((B, n_out), dtype=torch.float32, device=spec.device)
-    L.check(L.lib().sos_istft_f32(L.ptr(spec), B, T, L.ptr(window), L.ptr(tw), None, n_fft, hop_length,
+    L.check(L.lib().sos_istft_f32(L.ptr(spec), B, T, L.ptr(mhi), L.ptr(mlo), L.ptr(wsq), n_fft, hop_length,
                                   win_length, L.ptr(out), n_out, L.ptr(clip_frames), L.stream_ptr()), "sos_istft_f32")
     return out
 

@@ -6,6 +6,7 @@ import sos_amd
 from sos_amd import transform, engine as E, _lib as L
 from sos_amd.dataset import synth_batch
 sos_amd.set_precision("fp16")
+NIT = 1500
 base = torch.from_numpy(synth_batch(500, 4)["mixed"]).cuda()
 x0 = base.contiguous()
 ref = transform.stft_batch(x0)
@@ -37,24 +38,39 @@ def fc_only():
     E.conv_to_act(h0, 0, f0["cin_store"], f0["w"], 1, 1, f0["cout"], f0["scale"], f0["shift"], L.ACT_RELU, m, cout_store=m.cs, Ho=1, Wo=n)
     out = torch.empty((B, n), dtype=torch.float32, device=dev)
     E.conv(m, 0, f2["cin_store"], f2["w"], 1, 1, 1, f2["scale"], f2["shift"], L.ACT_NONE, out=out, out_dtype=L.DT_F32, sb=n, sh=0, sw=1, sc=1, Ho=1, Wo=n)
-jobs = {
-    "pack_input": lambda: E.pack_input(S, False),
-    "encoder (pack+convs+feat)": enc_only,
-    "lstm (proj + recurrent)": lstm_only,
-    "fc head": fc_only,
-    "det full": lambda: det(s=S, v_num_frames=n),
-}
+a0 = E.pack_input(S, False)
+acts = [E.Act(B, F, T, 48, False, dev) for _ in range(2)]
+for a_ in acts: a_.t.normal_()
+def layer(i):
+    lp = plan["enc"][i]
+    src = a0 if i == 0 else acts[0]
+    def f():
+        E.conv_to_act(src, 0, lp["cin_store"], lp["w"], lp["kh"], lp["kw"], lp["cout"], lp["scale"], lp["shift"], L.ACT_RELU,
+                      acts[1], cout_store=48, dil=lp["dil"], pad=lp["pad"], Ho=F, Wo=T)
+    return f
+def featconv():
+    lp = plan["enc"][-1]
+    feat = torch.empty((B, n, 8 * F), dtype=E.act_dtype(), device=dev)
+    E.conv(acts[0], 0, lp["cin_store"], lp["w"], 1, 1, lp["cout"], lp["scale"], lp["shift"], L.ACT_RELU, out=feat, out_dtype=L.DT_BF16,
+           sb=n * 8 * F, sh=1, sw=8 * F, sc=F, c_off=0, third=8 * F, Ho=F, Wo=n, w_gather=CN.nearest_index(T, n, dev))
+import ctypes
+def layer0_dbg(bits):
+    def f():
+        os.environ["SOS_CONV_DBG"] = str(bits)
+        layer(0)()
+    return f
+jobs = {f"layer0 dbg={b}": layer0_dbg(b) for b in (0, 1, 8, 4, 2, 1 | 8, 1 | 8 | 4, 16)}
 for f in jobs.values():
     f()
 torch.cuda.synchronize()
 for name, fn in jobs.items():
-    bad = [0]
+    bad = [0, 0]
     bar = threading.Barrier(2)
     stop = [False]
     def t0():
         st = torch.cuda.Stream(); bar.wait()
         with torch.cuda.stream(st):
-            outs = [transform.stft_batch(x0) for _ in range(60)]
+            outs = [transform.stft_batch(x0) for _ in range(NIT)]
         st.synchronize(); stop[0] = True
         bad[0] = sum(0 if torch.equal(o, ref) else 1 for o in outs)
     def t1():
@@ -66,4 +82,4 @@ for name, fn in jobs.items():
                 st.synchronize()
     ths = [threading.Thread(target=t0), threading.Thread(target=t1)]
     [t.start() for t in ths]; [t.join() for t in ths]
-    print(f"{name:24s} corrupted STFT outputs: {bad[0]} / 60", flush=True)
+    print(f"{name:24s} corrupted STFT outputs: {bad[0]} / {NIT}", flush=True)
