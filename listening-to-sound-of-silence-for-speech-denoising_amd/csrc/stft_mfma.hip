@@ -39,6 +39,7 @@ typedef float fe_f32x16 __attribute__((ext_vector_type(16)));
 #define FE_IE 4096.0f           // ISTFT: synthesis-matrix scale
 #define FE_IADV 61              // ISTFT: frames a workgroup advances (FE_COLS minus the ceil(win/hop) = 3 halo frames)
 #define FE_IKC 64               // ISTFT: K (re|im, bin) values staged per chunk
+#define FE_RING 4               // matrix-fragment buffers in flight per wave (= k-steps of an ISTFT chunk)
 
 __device__ __forceinline__ fe_h8 fe_frag16(const uint4 v) { return __builtin_bit_cast(fe_h8, v); }
 
@@ -69,15 +70,27 @@ __global__ __launch_bounds__(256) void stft_mfma_kernel(StftParams p) {
     // the clip's own ends; frames of this tile past Tc are computed on clamped indices and never stored
     const long long i0 = t0 * p.hop + (p.n_fft - p.win) / 2 - p.n_fft / 2;
     const float* wv = p.wave + b * p.wave_stride;
-    for (int m = tid; m < p.span; m += 256) {
-        long long i = i0 + m;
-        if (i < 0) i = -i;
-        if (i >= ns) i = 2 * (ns - 1) - i;
-        i = i < 0 ? 0 : (i >= ns ? ns - 1 : i);
-        const float v = wv[i] * FE_SX;
-        const _Float16 h = (_Float16)v;
-        shi[m] = h;
-        slo[m] = (_Float16)(v - (float)h);
+    // 8 independent loads in flight per thread (a plain loop issues them one L2 round trip at a time: 40 us of 55)
+    for (int m0 = tid; m0 < p.span; m0 += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            long long i = i0 + m0 + u * 256;
+            if (i < 0) i = -i;
+            if (i >= ns) i = 2 * (ns - 1) - i;
+            i = i < 0 ? 0 : (i >= ns ? ns - 1 : i);
+            v[u] = wv[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = m0 + u * 256;
+            if (m < p.span) {
+                const float x = v[u] * FE_SX;
+                const _Float16 h = (_Float16)x;
+                shi[m] = h;
+                slo[m] = (_Float16)(x - (float)h);
+            }
+        }
     }
     __syncthreads();
 
@@ -97,8 +110,12 @@ __global__ __launch_bounds__(256) void stft_mfma_kernel(StftParams p) {
     bool rok[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) { rt[r] = wave + 4 * r; rok[r] = rt[r] < p.rtiles; if (!rok[r]) rt[r] = p.rtiles - 1; }
-    uint4 ahi[2][RT], alo[2][RT];
-    auto load_a = [&](const int buf, const int ks) {
+    // matrix fragments: a ring of FE_RING buffers, loaded FE_RING-1 k-steps ahead (an L2 round trip is ~3 k-steps of
+    // this wave's MFMAs; with one k-step of lead every k-step stalled on it: 56 us instead of ~15 for B = 64)
+    uint4 ahi[FE_RING][RT], alo[FE_RING][RT];
+    auto load_a = [&](auto buf_tag, const int ks) {
+        constexpr int buf = decltype(buf_tag)::value;
+        if (ks >= p.ksteps) return;
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
             const size_t idx = ((size_t)ks * p.rtiles + rt[r]) * 64 + lane;
@@ -115,28 +132,34 @@ __global__ __launch_bounds__(256) void stft_mfma_kernel(StftParams p) {
     // the two fragment buffers alternate with COMPILE-TIME indices (a run-time index would demote them to scratch)
     auto kstep = [&](auto cur_tag, const int ks) {
         constexpr int cur = decltype(cur_tag)::value;
-        if (ks + 1 < p.ksteps) load_a(cur ^ 1, ks + 1);         // next k-step's matrix fragments land while these MFMAs run
+        load_a(std::integral_constant<int, (cur + FE_RING - 1) % FE_RING>{}, ks + FE_RING - 1);
         fe_h8 bh[2], bl[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) { bh[c] = read_b(shi, c, ks); bl[c] = read_b(slo, c, ks); }
+        // the three partial products of a tile go to the SAME accumulator: issue them a full round of the 8 tiles apart
+        // (back-to-back dependent MFMAs wait for each other's write-back)
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const fe_h8 ah = fe_frag16(ahi[cur][r]), al = fe_frag16(alo[cur][r]);
+        for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[c], acc[r][c], 0, 0, 0);
-                acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[c], acc[r][c], 0, 0, 0);
-                acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[c], acc[r][c], 0, 0, 0);
-            }
-        }
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fe_frag16(pass == 2 ? alo[cur][r] : ahi[cur][r]),
+                                                                       pass == 1 ? bl[c] : bh[c], acc[r][c], 0, 0, 0);
     };
-    load_a(0, 0);
+    load_a(std::integral_constant<int, 0>{}, 0);
+    load_a(std::integral_constant<int, 1>{}, 1);
+    load_a(std::integral_constant<int, 2>{}, 2);
     int ks = 0;
-    for (; ks + 1 < p.ksteps; ks += 2) {
+    for (; ks + 3 < p.ksteps; ks += 4) {
         kstep(std::integral_constant<int, 0>{}, ks);
         kstep(std::integral_constant<int, 1>{}, ks + 1);
+        kstep(std::integral_constant<int, 2>{}, ks + 2);
+        kstep(std::integral_constant<int, 3>{}, ks + 3);
     }
     if (ks < p.ksteps) kstep(std::integral_constant<int, 0>{}, ks);
+    if (ks + 1 < p.ksteps) kstep(std::integral_constant<int, 1>{}, ks + 1);
+    if (ks + 2 < p.ksteps) kstep(std::integral_constant<int, 2>{}, ks + 2);
     // accumulator (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), column = lane&31): for a fixed register the 32 lanes of a
     // half wave hold 32 consecutive frames of one (re|im, bin) row -> 128-byte runs of the planar output
     const float scale = 1.0f / (FE_SX * FE_SD);
@@ -147,13 +170,10 @@ __global__ __launch_bounds__(256) void stft_mfma_kernel(StftParams p) {
         for (int c = 0; c < 2; ++c) {
             const long long t = t0 + c * 32 + l31;
             if (t >= Tc) continue;
+            // row j = (re|im plane cc, bin f) lives at plane-major offset (cc*nbins + f) = j: no division needed
+            float* o = p.out + (b * 2 * p.nbins + rt[r] * 32 + 4 * g) * p.T + t;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int j = rt[r] * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-                if (j >= 2 * p.nbins) continue;
-                const int cc = j / p.nbins, f = j - cc * p.nbins;
-                p.out[((b * 2 + cc) * p.nbins + f) * p.T + t] = acc[r][c][e] * scale;
-            }
+            for (int e = 0; e < 16; ++e) o[(size_t)((e & 3) + 8 * (e >> 2)) * p.T] = acc[r][c][e] * scale;
         }
     }
 }
@@ -233,35 +253,54 @@ __global__ __launch_bounds__(256) void istft_mfma_kernel(IstftParams p) {
         }
     };
     const int nchunks = 2 * p.nbins / FE_IKC;
+    static_assert(FE_IKC / 16 == FE_RING, "one chunk = FE_RING k-steps: the ring index is the k-step inside the chunk");
+    // synthesis-matrix fragments: ring of FE_RING buffers, FE_RING-1 k-steps ahead (see the STFT)
+    uint4 ehi[FE_RING][RT], elo[FE_RING][RT];
+    auto load_e = [&](auto buf_tag, const int ks) {
+        constexpr int buf = decltype(buf_tag)::value;
+        if (ks >= p.ksteps) return;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const size_t idx = ((size_t)ks * p.rtiles + rt[r]) * 64 + lane;
+            ehi[buf][r] = p.ehi[idx];
+            elo[buf][r] = p.elo[idx];
+        }
+    };
+    auto kstep = [&](auto kk_tag, const int ch) {
+        constexpr int kk = decltype(kk_tag)::value;
+        const int ks = ch * FE_RING + kk;
+        load_e(std::integral_constant<int, (kk + FE_RING - 1) % FE_RING>{}, ks + FE_RING - 1);
+        fe_h8 bh[2], bl[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int off = (c * 32 + l31) * BPITCH + kk * 32 + g * 16;
+            bh[c] = fe_frag16(*(const uint4*)(bhi + off));
+            bl[c] = fe_frag16(*(const uint4*)(blo + off));
+        }
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass)                   // same accumulator a full round of tiles apart (see the STFT)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                if (!rok[r]) continue;                         // wave-uniform
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fe_frag16(pass == 2 ? elo[kk][r] : ehi[kk][r]),
+                                                                       pass == 1 ? bl[c] : bh[c], acc[r][c], 0, 0, 0);
+            }
+    };
     load_chunk(0);
+    load_e(std::integral_constant<int, 0>{}, 0);
+    load_e(std::integral_constant<int, 1>{}, 1);
+    load_e(std::integral_constant<int, 2>{}, 2);
     for (int ch = 0; ch < nchunks; ++ch) {
         __syncthreads();                                       // the previous chunk's fragments have been read
         store_chunk();
         __syncthreads();
         if (ch + 1 < nchunks) load_chunk(ch + 1);              // in flight during this chunk's MFMAs
-#pragma unroll
-        for (int kk = 0; kk < FE_IKC / 16; ++kk) {
-            const int ks = ch * (FE_IKC / 16) + kk;
-            fe_h8 bh[2], bl[2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int off = (c * 32 + l31) * BPITCH + kk * 32 + g * 16;
-                bh[c] = fe_frag16(*(const uint4*)(bhi + off));
-                bl[c] = fe_frag16(*(const uint4*)(blo + off));
-            }
-#pragma unroll
-            for (int r = 0; r < RT; ++r) {
-                if (!rok[r]) continue;                         // wave-uniform
-                const size_t idx = ((size_t)ks * p.rtiles + rt[r]) * 64 + lane;
-                const fe_h8 ah = fe_frag16(p.ehi[idx]), al = fe_frag16(p.elo[idx]);
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[c], acc[r][c], 0, 0, 0);
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[c], acc[r][c], 0, 0, 0);
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[c], acc[r][c], 0, 0, 0);
-                }
-            }
-        }
+        kstep(std::integral_constant<int, 0>{}, ch);
+        kstep(std::integral_constant<int, 1>{}, ch);
+        kstep(std::integral_constant<int, 2>{}, ch);
+        kstep(std::integral_constant<int, 3>{}, ch);
     }
     __syncthreads();
     // frame signals to LDS: yf[frame][n], pitch odd (in dwords) so that the 32 frames of a store hit 32 banks
