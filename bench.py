@@ -222,7 +222,8 @@ def main():
         # separate runs, FETCH_SIZE doubled per the gfx950 correction); null when the signature has no PMC record
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv96.json")))
+            import glob
+            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv96.json")))[-1]))   # latest round
             if dom[0] == "conv" and tuple(dom[1:8]) == (5, 5, 1, 1, 1, 96, 96) and dom[8] == 64:
                 traffic = pmc["hbm_bytes_per_launch"]
         except Exception:

@@ -303,6 +303,14 @@ int sos_scale_f32(float* x, int64_t n, const float* s /* device scalar */, sos_s
 int sos_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int64_t step, float grad_scale, sos_stream_t stream);
 
+/* multi-tensor form: one launch for all parameter tensors of a model.  tensors: DEVICE array; chunks: DEVICE int32
+ * [n_chunks][2] = (tensor index, chunk index), SOS_ADAM_CHUNK elements per chunk, covering every tensor. */
+#define SOS_ADAM_CHUNK 16384
+typedef struct sos_adam_tensor { float* p; const float* g; float* m; float* v; int64_t n; } sos_adam_tensor;
+int sos_adam_multi_step(const sos_adam_tensor* tensors, int n_tensors, const int32_t* chunks, int64_t n_chunks, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                        sos_stream_t stream);
+
 /* backward of ReflectionPad2d(pad) (DownConvBlock, M2/networks.py:105): out (+)= fold of the padded-domain
  * gradient `padded` ([B][H+2pad][W+2pad]) onto the [B][H][W] interior. */
 int sos_reflect_fold(const sos_view* padded, int H, int W, int pad, const sos_view* out, int accumulate,

@@ -53,6 +53,7 @@ class WgradDesc(C.Structure):
 
 
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+ADAM_CHUNK = 16384          # SOS_ADAM_CHUNK of include/sos_hip.h
 
 # name -> argtypes, exactly the prototypes of include/sos_hip.h
 SIGNATURES = {
@@ -89,6 +90,7 @@ SIGNATURES = {
     "sos_mse_loss": [_P, _P, _L, _F, _P, _P, _P, _P],
     "sos_bce_logits_loss": [_P, _P, _L, _F, _P, _P, _P, _P],
     "sos_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P],
+    "sos_adam_multi_step": [_P, _I, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P],
     "sos_amax_f32": [_P, _L, _P, _P],
     "sos_loss_scale": [_P, _F, _P, _P],
     "sos_scale_f32": [_P, _L, _P, _P],

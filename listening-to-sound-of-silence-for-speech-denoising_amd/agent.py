@@ -104,32 +104,65 @@ def bce_with_logits_loss(x, y):
 
 # ------------------------------------------------------------------------------------- optimizer
 class FusedAdam(torch.optim.Optimizer):
-    """torch.optim.Adam (amsgrad=False) semantics and state_dict layout, one sos_adam_step launch per
-    parameter tensor; `grad_scale` folds the 1/world_size of the data-parallel average into it."""
+    """torch.optim.Adam (amsgrad=False) semantics and state_dict layout.  One step = the gradients gathered into one flat
+    buffer (a batched copy) + ONE sos_adam_multi_step launch per parameter group over a device table of (param, grad,
+    exp_avg, exp_avg_sq) pointers built once; `grad_scale` folds the 1/world_size of the data-parallel average in."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = 1.0
+        self._tables = {}
+
+    def _table(self, gi, ps):
+        key = tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in ps)
+        ent = self._tables.get(gi)
+        if ent is None or ent["key"] != key:
+            dev = ps[0].device
+            sizes = [p.numel() for p in ps]
+            flat_g = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            rows, chunks, off = [], [], 0
+            for ti, p in enumerate(ps):
+                st = self.state[p]
+                rows.append([p.data_ptr(), flat_g.data_ptr() + 4 * off, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), sizes[ti]])
+                chunks += [[ti, c] for c in range((sizes[ti] + L.ADAM_CHUNK - 1) // L.ADAM_CHUNK)]
+                off += sizes[ti]
+            ent = self._tables[gi] = dict(key=key, flat_g=flat_g, n=len(ps), nchunks=len(chunks),
+                                          views=list(torch.split(flat_g, sizes)),
+                                          tab=torch.tensor(rows, dtype=torch.int64, device=dev),
+                                          chunks=torch.tensor(chunks, dtype=torch.int32, device=dev))
+        return ent
 
     @torch.no_grad()
     def step(self, closure=None):
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            L.require_cuda(*ps)
+            for p in ps:
                 st = self.state[p]
                 if not st:
                     st["step"] = torch.zeros((), dtype=torch.float32)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
-                g = p.grad.contiguous()
-                L.require_cuda(p, g)
-                L.check(L.lib().sos_adam_step(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
-                                              float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                              float(group["weight_decay"]), int(st["step"]), float(self.grad_scale),
-                                              L.stream_ptr()), "sos_adam_step")
+            steps = {int(self.state[p]["step"]) for p in ps}
+            ent = self._table(gi, ps)
+            torch._foreach_copy_(ent["views"], [p.grad.reshape(-1) for p in ps])        # batched gather of the gradients
+            if len(steps) == 1:
+                L.check(L.lib().sos_adam_multi_step(L.ptr(ent["tab"]), ent["n"], L.ptr(ent["chunks"]), ent["nchunks"],
+                                                    float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                    float(group["weight_decay"]), steps.pop(), float(self.grad_scale),
+                                                    L.stream_ptr()), "sos_adam_multi_step")
+            else:       # parameters that joined the group at different times: per-tensor launches
+                for p, g in zip(ps, ent["views"]):
+                    st = self.state[p]
+                    L.check(L.lib().sos_adam_step(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
+                                                  float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                  float(group["weight_decay"]), int(st["step"]), float(self.grad_scale),
+                                                  L.stream_ptr()), "sos_adam_step")
+            for p in ps:
                 bump_version(p)     # raw-pointer write: invalidate the packed-weight caches keyed on _version
         return None
 

@@ -993,6 +993,36 @@ static bool tuned_lookup(const ShapeKey& k, ConvCfg* out) {
     *out = it->second;
     return true;
 }
+static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d);
+// A shape the table does not hold (another batch size, another clip length, a ragged batch's maxima) borrows the tiling
+// of the SAME LAYER measured at another geometry: every key field equal except B, H, W, Wl, Ho, Wo; among those the
+// entry with the same H / Ho and the most pixels wins (the BASELINE batch), provided the tiling is legal for the new
+// shape.  Depends only on the (static) table: deterministic across processes.  The result is stored under the new key.
+static bool tuned_borrow(const sos_conv_desc* d, const ShapeKey& k, ConvCfg* out) {
+    static const int same[] = {4, 5, 6, 7, 8, 9, 10, 11, 14, 15, 16, 17, 18};
+    ConvCfg best;
+    long long best_score = -1;
+    {
+        std::lock_guard<std::mutex> g(tuned_mutex());
+        for (const auto& kv : tuned_cache()) {
+            bool ok = true;
+            for (int i : same) ok = ok && kv.first.v[i] == k.v[i];
+            if (!ok) continue;
+            const long long score = ((kv.first.v[1] == k.v[1] && kv.first.v[12] == k.v[12]) ? (1LL << 50) : 0) +
+                                    (long long)kv.first.v[0] * kv.first.v[12] * kv.first.v[13];
+            if (score > best_score) { best_score = score; best = kv.second; }
+        }
+    }
+    if (best_score < 0) return false;
+    for (const ConvCfg& e : enumerate_cfgs(d))
+        if (e.NC == best.NC && e.lth == best.lth && e.ltw == best.ltw && e.ks == best.ks) {
+            *out = best;
+            std::lock_guard<std::mutex> g(tuned_mutex());
+            tuned_cache().emplace(k, best);
+            return true;
+        }
+    return false;
+}
 static void tuned_store(const ShapeKey& k, const ConvCfg& c, bool overwrite) {
     std::lock_guard<std::mutex> g(tuned_mutex());
     if (overwrite) tuned_cache()[k] = c;
@@ -1114,7 +1144,8 @@ extern "C" int64_t sos_conv2d_tile_count(const sos_conv_desc* d) {
     static const char* force = getenv("SOS_CONV_FORCE_CFG");
     if (!force) {
         ConvCfg c;
-        if (tuned_lookup(shape_key(d), &c)) return tiles_of(d, c);
+        const ShapeKey k = shape_key(d);
+        if (tuned_lookup(k, &c) || tuned_borrow(d, k, &c)) return tiles_of(d, c);
     }
     std::vector<ConvCfg> cfgs = enumerate_cfgs(d);
     if (cfgs.empty()) { sos_set_error("sos_conv2d_tile_count: no tile fits LDS"); return -1; }
@@ -1128,7 +1159,8 @@ extern "C" int sos_conv2d_fwd(const sos_conv_desc* d, sos_stream_t stream) {
     static const char* force = getenv("SOS_CONV_FORCE_CFG");
     if (!force) {
         ConvCfg c;
-        if (tuned_lookup(shape_key(d), &c)) return launch_cfg(d, c, (hipStream_t)stream);
+        const ShapeKey k = shape_key(d);
+        if (tuned_lookup(k, &c) || tuned_borrow(d, k, &c)) return launch_cfg(d, c, (hipStream_t)stream);
     }
     std::vector<ConvCfg> cfgs = enumerate_cfgs(d);
     if (cfgs.empty()) {

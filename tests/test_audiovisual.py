@@ -162,3 +162,45 @@ def test_agent_trains_the_variant_and_reduces_the_loss():
     losses = [float(ag.train_func(batch)[1]["bce"]) for _ in range(4)]
     print("audio-visual agent losses", losses)
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
+def test_full_size_variant_properties_60x224x224():
+    """BASELINE configs[4] at its stated frame geometry (60 frames of 224x224 + the 2x256x178 spectrogram per clip), where
+    the oracle (1.5 TFLOP per clip on the CPU) is too slow for a test: size-independent properties of the same kernels,
+    tilings and split factors instead.  Inference: eval-mode clips are independent, so permuting the batch permutes the
+    logits bit for bit, and a repeated call is bit-identical.  Training (fp16, the timed mode): one step of a batch made
+    of the same 2 clips twice has the loss of the 2-clip batch (BatchNorm3d moments over (B,T,H,W) are those of the
+    half batch up to f32 summation order), finite gradients for every parameter, and is deterministic."""
+    import sos_amd
+    from sos_amd import agent
+    from sos_amd.detector import networks as dnet
+    torch.manual_seed(0)
+    net = dnet.get_network(video=True).cuda().eval()
+    B = 4
+    s = spec_input(900, B, 178).cuda()
+    v = video_input(901, B, 60, 224, 224).cuda()
+    sos_amd.set_precision("fp16")
+    try:
+        with torch.no_grad():
+            a = net(s, v=v)
+            b = net(s, v=v)
+            perm = torch.tensor([2, 0, 3, 1], device="cuda")
+            c = net(s[perm].contiguous(), v=v[perm].contiguous())
+        assert a.shape == (B, 60) and bool(torch.isfinite(a).all())
+        assert torch.equal(a, b) and torch.equal(a[perm], c)
+        losses = []
+        for reps in (1, 2):
+            torch.manual_seed(1)
+            ag = agent.DetectorAgent(dnet.get_network(video=True), lr=1e-3)
+            batch = {"audio": s[:2].repeat(reps, 1, 1, 1), "frames": v[:2].repeat(reps, 1, 1, 1, 1),
+                     "label": (spec_input(902, 2, 60, 1)[:, 0, 0] > 0).float().cuda().repeat(reps, 1)}
+            _, l1 = ag.train_func(batch)
+            grads = [p.grad for p in ag.net.parameters()]
+            assert all(g is not None and bool(torch.isfinite(g).all()) for g in grads)
+            losses.append(float(l1["bce"]))
+            del ag
+        print("audio-visual full-size train loss, 2 clips vs the same 2 clips twice:", losses)
+        assert abs(losses[0] - losses[1]) < 2e-3 * abs(losses[0])
+    finally:
+        sos_amd.set_precision("bf16")

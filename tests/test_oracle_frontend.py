@@ -76,3 +76,32 @@ def test_si_sdr_properties():
     e = s + 0.1 * rng.standard_normal(4000)
     assert abs(ofe.si_sdr(e, s) - ofe.si_sdr(2 * e, s)) < 1e-9
     assert 18 < ofe.si_sdr(e, s) < 22
+
+
+def test_stft_istft_against_scipy_signal():
+    """Second, independent pin of the STFT / ISTFT restatement (librosa 0.7.1 itself is not installable here): scipy.signal
+    implements the same transform with different conventions -- segments of nperseg = 400 zero-padded at the END to nfft =
+    510 (librosa centres the window in n_fft: offset 55), 'even' boundary extension by nperseg/2 (librosa reflects by
+    n_fft/2, the extra 55 samples per side meet a zero window), spectrum scaling 1/sum(w).  After undoing the scale and
+    the 55-sample phase ramp both must agree on every frame; scipy's istft (NOLA normalisation by the window-sum-square,
+    boundary trim) must invert to the same waveform and length."""
+    import scipy.signal
+    rng = np.random.default_rng(7)
+    for n in (14000, 28000, 28123):
+        x = (rng.standard_normal(n) * np.hanning(n) * 0.3).astype(np.float32)
+        S = ofe.stft_complex(x.astype(np.float64))                              # (256, T)
+        w = scipy.signal.get_window("hann", 400)                                # periodic (fftbins=True)
+        f, t, Z = scipy.signal.stft(x.astype(np.float64), window=w, nperseg=400, noverlap=400 - 158, nfft=510,
+                                    boundary="even", padded=False, return_onesided=True, scaling="spectrum")
+        assert Z.shape == S.shape == (256, 1 + n // 158)
+        ramp = np.exp(-2j * np.pi * np.arange(256) * 55 / 510.0)[:, None]       # window centred in n_fft
+        Zl = Z * w.sum() * ramp
+        assert np.max(np.abs(Zl - S)) < 2e-7 * max(1.0, np.max(np.abs(S)))       # the restatement returns complex64 like librosa
+        # inverse: scipy on its own convention vs the restatement on librosa's
+        y = ofe.fast_istft(ofe.real_imag_expand(S))
+        _, ys = scipy.signal.istft(Z, window=w, nperseg=400, noverlap=400 - 158, nfft=510, input_onesided=True, boundary=True,
+                                   scaling="spectrum")
+        assert len(y) == 158 * (n // 158)
+        m = min(len(y), len(ys))
+        assert m >= len(y) - 400 and np.max(np.abs(ys[:m] - y[:m])) < 5e-6      # fast_istft returns float32
+        assert np.max(np.abs(y - x[:len(y)])) < 5e-6                            # and both are the signal

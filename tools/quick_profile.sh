@@ -6,5 +6,6 @@ rocprofv3 --kernel-trace --stats -d $O/prof_train -o t -- python bench.py --step
 rocprofv3 --kernel-trace --stats -d $O/prof_infer -o t -- python bench.py --mode infer --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_infer.log 2>&1
 python profiles/summarize_rocpd.py $(find $O/prof_train -name "*.db" | head -1) $O/train_kernels.md > /dev/null 2>&1
 python profiles/summarize_rocpd.py $(find $O/prof_infer -name "*.db" | head -1) $O/infer_kernels.md > /dev/null 2>&1
+find $O -name "*.db" -delete
 head -30 $O/train_kernels.md | cut -c1-200
 grep -E "stft|istft" $O/infer_kernels.md | cut -c1-200

@@ -1,23 +1,21 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): regenerates the measured artefacts that profiles/ keeps (copy them from gpurun_out/).
-#   bench JSON lines (train = BASELINE configs[1], infer), rocprofv3 --kernel-trace --stats summaries of both,
-#   and the HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs) of the dominant conv kernel.
+# Run on the GPU box (gpurun -- tools/refresh_profiles.sh [round tag]): regenerates the measured artefacts that profiles/
+# keeps (written to gpurun_out/refresh/, copy from there):
+#   bench JSON lines (train = BASELINE configs[1] in fp16 / bf16 / bf16x3, infer, infer-ragged = configs[3]),
+#   rocprofv3 --kernel-trace --stats summaries of the train / infer / ragged benches,
+#   the HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs) of the dominant conv kernel,
+#   the micro-benchmarks.  Every process loads the shipped tiling table: nothing is tuned here.
+R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/refresh; mkdir -p $O
-export SOS_CONV_TUNE_CACHE=/tmp/tune.txt
-# populate the tuned-tiling cache for every launch shape of both modes before anything is profiled
-python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-python bench.py --mode infer --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python tools/conv_bench.py > $O/conv_bench.txt 2>&1
 python tools/wgrad_bench.py > $O/wgrad_bench.txt 2>&1
 python tools/lstm_bench.py > $O/lstm_bench.txt 2>&1
 python tools/bn_bench.py > $O/bn_bench.txt 2>&1
-python tools/wave_io_bench.py > $O/wave_io_bench.txt 2>&1
-python tools/latency_bench.py > $O/latency_bench.txt 2>&1
-python tools/av_bench.py > $O/av_bench.txt 2>&1
-export SOS_CONV_TUNE_FROZEN=1
+python tools/frontend_bench.py > $O/frontend_bench.txt 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_train -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_train.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_infer -o t -- python bench.py --mode infer --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_infer.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_ragged -o t -- python bench.py --mode infer-ragged --steps 2 --warmup 1 --no-cpu-baseline > $O/prof_ragged.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | tr ' ' '_')
   rocprofv3 --pmc $c --kernel-include-regex conv_mfma -d $O/pmc_$n -o p --output-format csv -- python tools/conv_bench.py --only "ctx96 d1x1" --iters 3 --warm 0.05 > $O/pmc_$n.log 2>&1
@@ -39,10 +37,12 @@ out = {"kernel": "conv_mfma_kernel 96->96 5x5 B=64 (tools/conv_bench.py --only '
 json.dump(out, open("gpurun_out/refresh/pmc_conv96.json", "w"), indent=1)
 print(json.dumps(out))
 PY
-cp $O/pmc_conv96.json profiles/r01_pmc_conv96.json     # bench.py reports this record as roofline.traffic
-unset SOS_CONV_TUNE_FROZEN
-python bench.py --steps 10 --warmup 3 > $O/bench_train.json 2> $O/bench_train.err
-python bench.py --mode infer --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_infer.json 2> $O/bench_infer.err
-python profiles/summarize_rocpd.py $O/prof_train/t_results.db > $O/train_kernels.md 2>&1
-python profiles/summarize_rocpd.py $O/prof_infer/t_results.db > $O/infer_kernels.md 2>&1
-cat $O/bench_train.json | cut -c1-600; cat $O/bench_infer.json | cut -c1-300
+cp $O/pmc_conv96.json profiles/${R}_pmc_conv96.json     # bench.py reports this record as roofline.traffic
+python bench.py --steps 10 --warmup 3 > $O/bench_train_fp16.json 2> $O/bench_train_fp16.err
+python bench.py --precision bf16 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_train_bf16.json 2> $O/bench_train_bf16.err
+python bench.py --precision bf16x3 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_train_bf16x3.json 2> $O/bench_train_bf16x3.err
+python bench.py --mode infer --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_infer_fp16.json 2> $O/bench_infer_fp16.err
+python bench.py --mode infer-ragged --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_ragged_fp16.json 2> $O/bench_ragged_fp16.err
+for m in train infer ragged; do python profiles/summarize_rocpd.py $(find $O/prof_$m -name "*.db" | head -1) $O/${m}_kernels.md > /dev/null 2>&1; done
+find $O -name "*.db" -delete            # the summaries stay; gpurun copies at most 64 MiB back
+for f in $O/bench_*.json; do echo $f; cut -c1-420 $f; done
