@@ -70,6 +70,10 @@ int sos_istft_f32(const float* spec, int64_t batch, int64_t n_frames, const void
                      frames -> hop*(clip_frames[b]-1) samples */,
                   sos_stream_t stream);
 
+/* power_law: M1/transform.py:178-185, out = sign(x) |x|^power -- the optional companding of fast_stft / fast_istft
+ * (`power=True`: 0.3 before the STFT, 1/0.3 after the ISTFT). */
+int sos_power_law_f32(const float* x, int64_t n, float power, float* out, sos_stream_t stream);
+
 /* ---- a4/a5  batch_fast_icRM_sigmoid: M1/transform.py:156-169 (and the numpy
  * twin fast_icRM_sigmoid :141-153): M = (1/a)(log(c/(1-c+1e-8)+1e-10)+b), rec = M*Y
  * (complex).  Y, crm, rec: f32 [B][2][plane]. */

@@ -64,6 +64,7 @@ SIGNATURES = {
     "sos_istft_matrix_bytes": [_I, _I, _I],
     "sos_istft_pack_matrix": [_I, _I, _I, _P, _P, _P],
     "sos_istft_f32": [_P, _L, _L, _P, _P, _P, _I, _I, _I, _P, _L, _P, _P],
+    "sos_power_law_f32": [_P, _L, _F, _P, _P],
     "sos_crm_apply_f32": [_P, _P, _P, _L, _L, _F, _F, _P],
     "sos_crm_apply_bwd_f32": [_P, _P, _P, _P, _L, _L, _F, _P],
     "sos_crm_target_f32": [_P, _P, _P, _L, _L, _F, _F, _P],

@@ -188,6 +188,24 @@ def nearest_index(in_size, out_size, device):
     return _nearest_tables[key]
 
 
+_gather_range_tables = {}
+
+
+def nearest_ranges(in_size, out_size, device):
+    """Backward companion of nearest_index: for every source column w the half-open range [lo[w], hi[w]) of output
+    columns that read it (the gather is monotonic).  Computed on the host from the same formula and uploaded once per
+    (in, out, device): the backward pass neither synchronises nor copies in steady state."""
+    key = (int(in_size), int(out_size), str(device))
+    if key not in _gather_range_tables:
+        scale = np.float32(in_size) / np.float32(out_size)
+        idx = np.minimum(np.floor(np.arange(out_size, dtype=np.float32) * scale).astype(np.int64), in_size - 1)
+        cols = np.arange(in_size)
+        lo = np.searchsorted(idx, cols, side="left").astype(np.int32)
+        hi = np.searchsorted(idx, cols, side="right").astype(np.int32)
+        _gather_range_tables[key] = (torch.from_numpy(lo).to(device), torch.from_numpy(hi).to(device))
+    return _gather_range_tables[key]
+
+
 def nearest_index_ragged(rag, n_max, device):
     """(B, n_max) int32: row b = nearest_index(rag.T[b], rag.n_vframes[b]) padded with zeros (never read: the conv's
     per-clip logical width stops at n_vframes[b]); cached on the Ragged object."""

@@ -169,6 +169,22 @@ extern "C" int sos_add_signals_f32(const float* signal, const float* noises, con
     return sos_check_launch("sos_add_signals_f32");
 }
 
+// ------------------------------------------------------------ power-law companding of a waveform
+// power_law, M1/transform.py:178-185: sign(x) * |x|^p (p = 0.3 before the STFT, 1/0.3 after the ISTFT when the
+// reference's `power=True` switch is on; its callers leave it off).
+__global__ void power_law_kernel(const float* __restrict__ x, long long n, float p, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const float m = powf(fabsf(v), p);
+        out[i] = v >= 0.f ? m : -m;
+    }
+}
+extern "C" int sos_power_law_f32(const float* x, int64_t n, float power, float* out, sos_stream_t stream) {
+    if (!x || !out || n < 1 || !(power > 0.f)) { sos_set_error("sos_power_law_f32: bad args"); return SOS_EINVAL; }
+    hipLaunchKernelGGL(power_law_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, power, out);
+    return sos_check_launch("sos_power_law_f32");
+}
+
 // --------------------------------------------------------------------- bits -> sample mask
 // Pre-flip mask value of sample j: 1 if j lies in [int(i*r), int((i+1)*r - 1)) of a silent
 // frame i (bit 0), else 0.  All index arithmetic in IEEE double with explicit (un-fused)

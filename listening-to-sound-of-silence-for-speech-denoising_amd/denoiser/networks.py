@@ -372,6 +372,8 @@ class _JointTrainFn(torch.autograd.Function):
     def backward(ctx, g_npred, g_out):
         grads = ctx.net._backward(ctx.tape, g_npred, g_out)
         ctx.tape = None
+        if getattr(ctx.net, "grad_sink_factory", None) is not None:     # see detector/networks.py: the bucketer owns p.grad
+            return (None, None, None) + (None,) * len(list(ctx.net.parameters()))
         return (None, None, None) + tuple(grads[name].reshape(p.shape) for name, p in ctx.net.named_parameters())
 
 

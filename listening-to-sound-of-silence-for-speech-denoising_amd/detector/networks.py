@@ -30,6 +30,11 @@ class _TrainFn(torch.autograd.Function):
     def backward(ctx, g):
         grads = ctx.net._backward(ctx.tape, g)
         ctx.tape = None
+        if getattr(ctx.net, "grad_sink_factory", None) is not None:
+            # data-parallel: the gradients sit in the all-reduce buckets, whose collectives are still running; the
+            # bucketer assigns p.grad itself once they are done (GradBucketer.finalize) -- autograd gets nothing to
+            # accumulate (no clone racing with the in-place collective)
+            return (None, None, None, None) + (None,) * len(list(ctx.net.parameters()))
         return (None, None, None, None) + tuple(grads[name].reshape(p.shape) for name, p in ctx.net.named_parameters())
 
 
@@ -113,11 +118,11 @@ class AudioVisualNet(nn.Module):
         TO.act_bwd_from_y(d_m, tape["m"], L.ACT_RELU, dz0, plan["fc0"]["cout"])
         dh = TO.linear_backward(plan["fc0"], tape["h"], dz0, grads, "fc1.0", x3, dev)
         dfeat = TO.lstm_backward(plan["lstm"], tape["lstm"], dh, grads, "lstm", B, n, x3, dev)
-        lo, hi = TO.gather_ranges(tape["gather"].cpu().numpy(), T)
+        lo, hi = CN.nearest_ranges(T, n, dev)           # cached device tables: no host sync in the backward pass
         nseg = 3 if x3 else 1
         nfeat = 8 * F + self.video_feat
         dy = TO.feat_grad_to_nhwc(dfeat, nseg * nfeat, nfeat, 0, 8, B, F, T, n, x3,
-                                  torch.from_numpy(lo).to(dev), torch.from_numpy(hi).to(dev))
+                                  lo, hi)
         TO.encoder_backward(plan["enc"], tape["enc"], dy, grads, "encoder_audio", x3)
         if self.video_feat:
             TO.video_backward(plan["vid"], tape["vid"], dfeat, nseg * nfeat, nfeat, 8 * F, grads, "encoder_video", B, n, x3)

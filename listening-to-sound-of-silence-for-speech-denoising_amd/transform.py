@@ -102,21 +102,37 @@ def real_imag_shrink(F, dim='new'):
         return F[:, ::2] + F[:, 1::2] * 1j
 
 
+def power_law_batch(x, power=0.3):
+    """power_law, M1/transform.py:178-185, on a GPU tensor: sign(x) |x|^power."""
+    L.require_cuda(x)
+    x = x.contiguous().float()
+    out = torch.empty_like(x)
+    L.check(L.lib().sos_power_law_f32(L.ptr(x), x.numel(), float(power), L.ptr(out), L.stream_ptr()), "sos_power_law_f32")
+    return out
+
+
+def power_law(data, power=0.3):
+    """M1/transform.py:178-185: numpy in, float64 out like the reference (its mask array is float64)."""
+    x = torch.as_tensor(np.asarray(data, dtype=np.float32), device=_device())
+    return power_law_batch(x, power).cpu().numpy().astype(np.float64)
+
+
 def fast_stft(data, power=False, n_fft=N_FFT, hop_length=HOP_LENGTH, win_length=WIN_LENGTH):
-    """M1/transform.py:188-193: 1-D waveform -> ndarray [F, T, 2]."""
-    if power:
-        raise NotImplementedError("power-law front-end (transform.py:178-185) is unused by the reference callers")
+    """M1/transform.py:188-193: 1-D waveform -> ndarray [F, T, 2].  power=True: A**0.3 companding first (:191-192)."""
     w = torch.as_tensor(np.asarray(data, dtype=np.float32), device=_device()).reshape(1, -1)
+    if power:
+        w = power_law_batch(w, 0.3)
     S = stft_batch(w, n_fft, hop_length, win_length)[0]          # (2, F, T)
     return S.permute(1, 2, 0).cpu().numpy().astype(np.float64)
 
 
 def fast_istft(F, power=False, hop_length=HOP_LENGTH, win_length=WIN_LENGTH):
-    """M1/transform.py:196-202: [F, T, 2] -> 1-D float32 of length hop*(T-1)."""
-    if power:
-        raise NotImplementedError("power-law front-end (transform.py:178-185) is unused by the reference callers")
+    """M1/transform.py:196-202: [F, T, 2] -> 1-D float32 of length hop*(T-1) (float64 with power=True, like the reference)."""
     S = torch.as_tensor(np.asarray(F, dtype=np.float32), device=_device()).permute(2, 0, 1).unsqueeze(0)
-    return istft_batch(S, hop_length, win_length)[0].cpu().numpy()
+    y = istft_batch(S, hop_length, win_length)
+    if power:                                                   # :200-201, the inverse companding
+        return power_law_batch(y, 1.0 / 0.3)[0].cpu().numpy().astype(np.float64)
+    return y[0].cpu().numpy()
 
 
 class _CrmApply(torch.autograd.Function):

@@ -51,6 +51,15 @@ def real_imag_shrink(f):
     return f[:, :, 0] + f[:, :, 1] * 1j
 
 
+def power_law(data, power=0.3):
+    """M1/transform.py:178-185."""
+    data = np.asarray(data)
+    mask = np.zeros(data.shape)
+    mask[data >= 0] = 1
+    mask[data < 0] = -1
+    return np.power(np.abs(data), power) * mask
+
+
 def fast_stft(data, n_fft=N_FFT, hop_length=HOP_LENGTH, win_length=WIN_LENGTH):
     """M1/transform.py:188-193 (power=False)."""
     return real_imag_expand(stft_complex(data, n_fft, hop_length, win_length))

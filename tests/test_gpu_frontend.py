@@ -163,3 +163,19 @@ def test_add_signals_golden_and_edge_cases(golden):
     m, c, n = tools.add_signals(g["sig"], [g["noi"], np.zeros_like(g["noi"])], 5, None)
     m2, c2, n2 = ofe.add_signals(g["sig"], g["noi"], 5, None)
     assert np.allclose(m, m2, atol=3e-6) and np.array_equal(c, g["sig"]) and not n[1].any()
+
+
+def test_power_law_front_end():
+    """`power=True` of fast_stft / fast_istft (M1/transform.py:178-202, unused by the reference's callers): sign(x)|x|^0.3
+    before the STFT, ^(1/0.3) after the ISTFT; product functions vs the oracle restatement."""
+    from sos_amd import transform
+    x = (hashed(77, (14000,)) * 0.4).astype(np.float32)
+    x[::97] = 0.0
+    assert rel_err(transform.power_law(x), ofe.power_law(x)) < 2e-6
+    assert transform.power_law(x).dtype == np.float64 and not transform.power_law(x)[::97].any()
+    S = transform.fast_stft(x, power=True)
+    assert rel_err(S, ofe.fast_stft(ofe.power_law(x).astype(np.float32))) < 1e-5
+    y = transform.fast_istft(S, power=True)
+    want = ofe.power_law(ofe.fast_istft(ofe.fast_stft(ofe.power_law(x).astype(np.float32))), 1.0 / 0.3)
+    assert y.shape == want.shape and rel_err(y, want) < 1e-4
+    assert rel_err(y, x[:len(y)]) < 1e-3                       # companding then expanding is the identity
