@@ -17,7 +17,7 @@ scale = torch.ones(C, device=dev); shift = torch.zeros(C, device=dev); mean = to
 gamma = torch.ones(C, device=dev); dgamma = torch.empty(C, device=dev); dbeta = torch.empty(C, device=dev)
 vx, vdy, vdx, vy = E.view(x, 0, C), E.view(dy, 0, C), E.view(dx, 0, C), E.view(y, 0, C)
 def bwd(): L.check(L.lib().sos_bn_bwd(ctypes.byref(vdy), ctypes.byref(vx), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
-                                      L.ACT_RELU, None, L.ptr(partial), L.ptr(coef), L.ptr(dgamma), L.ptr(dbeta), None, ctypes.byref(vdx), L.stream_ptr()), "bwd")
+                                      L.ACT_RELU, None, L.ptr(partial), L.ptr(coef), L.ptr(dgamma), L.ptr(dbeta), None, ctypes.byref(vdx), None, L.stream_ptr()), "bwd")
 def stats(): L.check(L.lib().sos_bn_stats(ctypes.byref(vx), L.ptr(partial), L.stream_ptr()), "stats")
 def apply(): L.check(L.lib().sos_bn_act_apply(ctypes.byref(vx), L.ptr(scale), L.ptr(shift), L.ACT_RELU, None, ctypes.byref(vy), 0, 0, 0, None, L.stream_ptr()), "apply")
 byt = npix * C * 2
