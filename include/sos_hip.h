@@ -315,6 +315,14 @@ int sos_adam_multi_step(const sos_adam_tensor* tensors, int n_tensors, const int
                         float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                         sos_stream_t stream);
 
+/* Re-pack every 16-bit weight tensor of a model from its fp32 parameters in ONE launch (after an optimizer step).
+ * entries: DEVICE array; entry e fills out[0..n) (16-bit storage type) from idx[0..n) (device int64): idx > 0 = absolute
+ * address of the fp32 source element, idx < 0 = the low part of the value at -idx (hi|lo|hi thirds of the three-pass
+ * mode), 0 = zero padding.  chunks as for sos_adam_multi_step (SOS_ADAM_CHUNK elements each). */
+typedef struct sos_pack_entry { const int64_t* idx; void* out; int64_t n; } sos_pack_entry;
+int sos_gather_pack_multi(const sos_pack_entry* entries, int n_entries, const int32_t* chunks, int64_t n_chunks,
+                          sos_stream_t stream);
+
 /* backward of ReflectionPad2d(pad) (DownConvBlock, M2/networks.py:105): out (+)= fold of the padded-domain
  * gradient `padded` ([B][H+2pad][W+2pad]) onto the [B][H][W] interior. */
 int sos_reflect_fold(const sos_view* padded, int H, int W, int pad, const sos_view* out, int accumulate,

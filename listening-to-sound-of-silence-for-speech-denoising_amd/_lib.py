@@ -92,6 +92,7 @@ SIGNATURES = {
     "sos_bce_logits_loss": [_P, _P, _L, _F, _P, _P, _P, _P],
     "sos_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P],
     "sos_adam_multi_step": [_P, _I, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P],
+    "sos_gather_pack_multi": [_P, _I, _P, _L, _P],
     "sos_amax_f32": [_P, _L, _P, _P],
     "sos_loss_scale": [_P, _F, _P, _P],
     "sos_scale_f32": [_P, _L, _P, _P],

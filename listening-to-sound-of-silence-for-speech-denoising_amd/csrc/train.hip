@@ -195,3 +195,35 @@ extern "C" int sos_adam_multi_step(const sos_adam_tensor* tensors, int n_tensors
                        grad_scale);
     return sos_check_launch("sos_adam_multi_step");
 }
+
+
+// ---- packed 16-bit weights refreshed after an optimizer step: ONE launch per model instead of ~10 torch kernels per
+// packed tensor.  Every packed element is a pure relocation of one fp32 parameter element (tap-major order, channel
+// padding, flipped / transposed / phase-sliced data-gradient layouts, the hi|lo|hi thirds of the three-pass mode), so the
+// Python side records the relocation ONCE as a table of absolute source addresses (engine.PackRecorder) and this kernel
+// replays it: idx > 0: the value at that address; idx < 0: its low part (v - float(half(v))) ; idx == 0: zero padding.
+struct PackEntry { const long long* idx; bf16_t* out; long long n; };
+__global__ __launch_bounds__(256) void gather_pack_kernel(const PackEntry* __restrict__ tab, const int2* __restrict__ chunks) {
+    const int2 c = chunks[blockIdx.x];
+    const PackEntry e = tab[c.x];
+    const long long lo = (long long)c.y * SOS_ADAM_CHUNK;
+    const long long hi = lo + SOS_ADAM_CHUNK < e.n ? lo + SOS_ADAM_CHUNK : e.n;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const long long a = e.idx[i];
+        bf16_t r = 0;
+        if (a > 0) r = f2bf(*(const float*)a);
+        else if (a < 0) { const float v = *(const float*)(-a); r = f2bf(v - bf2f(f2bf(v))); }
+        e.out[i] = r;
+    }
+}
+extern "C" int sos_gather_pack_multi(const sos_pack_entry* entries, int n_entries, const int32_t* chunks, int64_t n_chunks,
+                                     sos_stream_t stream) {
+    static_assert(sizeof(sos_pack_entry) == sizeof(PackEntry), "sos_pack_entry layout");
+    if (!entries || !chunks || n_entries < 1 || n_chunks < 1 || n_chunks > 0x7fffffff) {
+        sos_set_error("sos_gather_pack_multi: bad args");
+        return SOS_EINVAL;
+    }
+    hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream,
+                       (const PackEntry*)entries, (const int2*)chunks);
+    return sos_check_launch("sos_gather_pack_multi");
+}

@@ -198,7 +198,7 @@ class InpaintNet(nn.Module):
                     mid=[P(self.mid[i], x3) for i in range(8)], mid8=TO.up_train_plan(self.mid[8], x3),
                     up1_0=P(self.up1[0], x3, perm_up1), up1_1=TO.up_train_plan(self.up1[1], x3),
                     up2_0=P(self.up2[0], x3), up2_1=_down_plan(self.up2[1], x3),
-                    up2_1_wd=E.pack_weight(self.up2[1].block[1].weight.detach().float().flip(2, 3).transpose(0, 1).contiguous(),
+                    up2_1_wd=E.pack_weight(lambda: self.up2[1].block[1].weight.detach().float().flip(2, 3).transpose(0, 1).contiguous(),
                                            16, x3))
 
     def forward_train(self, plan, x, y, x3):
@@ -385,7 +385,7 @@ class JointModel(nn.Module):
         self.stage1 = InpaintNet()
         self.stage2 = ContextAggNet(config.kernel_sizes, config.dilations)
         self._cache = E.PlanCache()
-        self._tcache = E.PlanCache()
+        self._tcache = E.PlanCache(record=True)
 
     def _build_plan(self):
         x3 = E.is_x3()

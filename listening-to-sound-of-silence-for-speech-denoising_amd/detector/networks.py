@@ -53,7 +53,7 @@ class AudioVisualNet(nn.Module):
             self.encoder_video = CN.make_video_branch(CN.VIDEO_KERNEL_SIZES, CN.VIDEO_STRIDES, nf=128, outf=256)
         self.freq_bins = freq_bins
         self._cache = E.PlanCache()
-        self._tcache = E.PlanCache()
+        self._tcache = E.PlanCache(record=True)
 
     def _build_plan(self):
         x3 = E.is_x3()

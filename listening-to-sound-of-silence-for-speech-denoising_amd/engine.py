@@ -171,10 +171,18 @@ def pack_input(x, x3=None, mul=None):
 
 
 def pack_weight(w, cin_store, x3, in_perm=None):
-    """Conv weight (O, I, kh, kw) f32 -> bf16 [kh*kw][O_pad][nseg*cin_store].  In bf16x3 mode the
+    """Conv weight (O, I, kh, kw) f32 -> 16-bit [kh*kw][O_pad][nseg*cin_store].  In bf16x3 mode the
     K axis is [w_hi | w_lo | w_hi], matching activations stored [x_hi | x_hi | x_lo], so one MFMA
     pass computes x_hi*w_hi + x_hi*w_lo + x_lo*w_hi.  `in_perm` reorders input channels (concat
-    buffers whose parts are stored in a different order than torch.cat's)."""
+    buffers whose parts are stored in a different order than torch.cat's).
+    `w` may be a zero-argument callable returning the (layout-derived) weight: under a PackRecorder in replay mode
+    (the per-step refresh of a training plan) it is not even evaluated -- the packed tensor was refreshed by
+    sos_gather_pack_multi."""
+    rec = getattr(_TLS, "pack_rec", None)
+    if rec is not None and rec.mode == "replay":
+        return rec.next_out()
+    if callable(w):
+        w = w()
     O, I, kh, kw = w.shape
     w = w.detach().float()
     if in_perm is not None:
@@ -183,11 +191,108 @@ def pack_weight(w, cin_store, x3, in_perm=None):
     Op = pad_to(O, 32)
     full = torch.zeros((kh * kw, Op, cin_store), dtype=torch.float32, device=w.device)
     full[:, :O, :I] = wp
+    if rec is not None and rec.mode == "index":
+        # parameters hold their own (1-based) element ids: `full` is the relocation map; low parts carry a minus sign
+        rec.idx.append(torch.cat([full, -full, full], dim=2).contiguous() if x3 else full.contiguous())
+        return full
     hi = full.to(act_dtype())
     if not x3:
-        return hi.contiguous()
-    lo = (full - hi.float()).to(act_dtype())
-    return torch.cat([hi, lo, hi], dim=2).contiguous()
+        out = hi.contiguous()
+    else:
+        lo = (full - hi.float()).to(act_dtype())
+        out = torch.cat([hi, lo, hi], dim=2).contiguous()
+    if rec is not None and rec.mode == "value":
+        rec.outs.append(out)
+    return out
+
+
+class PackRecorder:
+    """Turns the per-step re-packing of a plan's weights (~10 torch kernels per packed tensor, ~1000 per training step)
+    into one sos_gather_pack_multi launch.  Built once per (module, precision, parameter storage): the plan builder runs
+    a second time with every parameter temporarily holding its own element ids, so each pack_weight call yields the
+    relocation map of its output; the maps become tables of absolute source addresses.  Every map is VERIFIED against
+    the value-built tensor before it is trusted (a packed tensor that is not a pure relocation of parameter elements
+    disables the recorder, and the plan is simply rebuilt by torch as before)."""
+
+    ENABLED = _os.environ.get("SOS_PACK_GATHER", "1") != "0"
+
+    def __init__(self, module, build):
+        self.mode, self.outs, self.idx, self.k, self.ok = "value", [], [], 0, False
+        params = [p for p in module.parameters()]
+        prev = getattr(_TLS, "pack_rec", None)
+        _TLS.pack_rec = self
+        try:
+            self.plan = build()
+            if not self.ENABLED or not self.outs or sum(p.numel() for p in params) >= (1 << 24):
+                return                                  # ids must be exact in float32
+            saved, start = [], 0
+            starts = []
+            for p in params:
+                saved.append(p.data)
+                starts.append(start)
+                p.data = torch.arange(start + 1, start + 1 + p.numel(), dtype=torch.float32, device=p.device).reshape(p.shape)
+                start += p.numel()
+            self.mode = "index"
+            try:
+                build()
+            finally:
+                for p, d in zip(params, saved):
+                    p.data = d
+        finally:
+            _TLS.pack_rec = prev
+            self.mode = "idle"
+        if len(self.idx) != len(self.outs) or any(i.shape != o.shape for i, o in zip(self.idx, self.outs)):
+            return
+        dev = self.outs[0].device
+        ptrs = torch.tensor([p.data_ptr() for p in params], dtype=torch.int64, device=dev)
+        st = torch.tensor(starts, dtype=torch.int64, device=dev)
+        tabs, rows, chunks = [], [], []
+        for ei, (ids, out) in enumerate(zip(self.idx, self.outs)):
+            a = ids.reshape(-1).abs().round().to(torch.int64)
+            pi = torch.bucketize(a, st, right=False) - 1                    # ids of parameter k lie in (start_k, start_k + n_k]
+            pi = pi.clamp_(min=0)
+            addr = ptrs[pi] + 4 * (a - 1 - st[pi])
+            addr = torch.where(a == 0, torch.zeros_like(addr), torch.where(ids.reshape(-1) < 0, -addr, addr)).contiguous()
+            tabs.append(addr)
+            rows.append([addr.data_ptr(), out.data_ptr(), out.numel()])
+            chunks += [[ei, c] for c in range((out.numel() + L.ADAM_CHUNK - 1) // L.ADAM_CHUNK)]
+        self.idx = None
+        self.tabs = tabs
+        self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self.chunks = torch.tensor(chunks, dtype=torch.int32, device=dev)
+        self.n, self.nchunks = len(rows), len(chunks)
+        # trust, but verify: replay into scratch copies and compare with what torch built
+        keep = [o.clone() for o in self.outs]
+        for o in self.outs:
+            o.zero_()
+        self.refresh()
+        self.ok = all(torch.equal(a, b) for a, b in zip(self.outs, keep))
+        if not self.ok:
+            for o, kcopy in zip(self.outs, keep):
+                o.copy_(kcopy)
+
+    def refresh(self):
+        L.check(L.lib().sos_gather_pack_multi(L.ptr(self.table), self.n, L.ptr(self.chunks), self.nchunks, L.stream_ptr()),
+                "sos_gather_pack_multi")
+
+    def next_out(self):
+        o = self.outs[self.k]
+        self.k += 1
+        return o
+
+    def replay(self, build):
+        """Refresh every packed weight (one launch) and rebuild the plan around them (the builder's other, small pieces
+        -- bias vectors, the LSTM's fragment pack -- are recomputed as usual)."""
+        self.refresh()
+        prev = getattr(_TLS, "pack_rec", None)
+        _TLS.pack_rec, self.mode, self.k = self, "replay", 0
+        try:
+            plan = build()
+        finally:
+            _TLS.pack_rec, self.mode = prev, "idle"
+        if self.k != len(self.outs):
+            raise RuntimeError("PackRecorder: the plan builder changed its pack_weight sequence")
+        return plan
 
 
 def pad_vec(v, n, fill=0.0):
@@ -358,18 +463,33 @@ class Ragged:
 
 class PlanCache:
     """Packed weights keyed by the parameters' in-place version counters (optimizer steps and
-    load_state_dict bump them), the device and the precision mode."""
+    load_state_dict bump them), the device, the precision mode and the parameters' storage.  When only the VALUES changed
+    (an optimizer step) the packed weights are refreshed in place by one gather launch (PackRecorder) instead of being
+    rebuilt by torch."""
 
-    def __init__(self):
+    def __init__(self, record=False):
+        # record=True (training plans: refreshed every optimizer step): PackRecorder.  Its recording pass briefly swaps
+        # the parameters' storage, so inference plans -- which DataParallel-style callers may build from several host
+        # threads at once, and which are rebuilt only when new weights are loaded -- do not use it.
         self.key = None
         self.plan = None
+        self.rec = None
+        self.record = record
 
     def get(self, module, build):
         ts = list(module.parameters()) + list(module.buffers())
-        key = (get_precision(), str(ts[0].device), tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts))
+        base = (get_precision(), str(ts[0].device), tuple(t.data_ptr() for t in ts), tuple(tuple(t.shape) for t in ts))
+        key = (base, tuple(t._version for t in ts))
         if key != self.key:
             with torch.no_grad():
-                self.plan = build()
+                if self.rec is not None and self.rec.ok and self.rec_base == base:
+                    self.plan = self.rec.replay(build)
+                elif self.record:
+                    self.rec, self.rec_base = PackRecorder(module, build), base
+                    self.plan = self.rec.plan
+                    self.rec.plan = None
+                else:
+                    self.plan = build()
             self.key = key
         return self.plan
 

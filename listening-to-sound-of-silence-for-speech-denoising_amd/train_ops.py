@@ -75,8 +75,8 @@ def act_bwd_from_y(dy, y, act, dz, C):
 def dgrad_weight(w, x3):
     """Conv2d weight (O,I,kh,kw) -> packed weight of the data-gradient conv: taps flipped, channel
     roles swapped, contraction over the (padded) O channels."""
-    wd = w.detach().float().flip(2, 3).transpose(0, 1).contiguous()        # (I, O, kh, kw)
-    return E.pack_weight(wd, E.pad_to(w.shape[0], 16), x3)
+    # (I, O, kh, kw); a callable: not evaluated when the packed tensor is refreshed by the gather kernel (engine.PackRecorder)
+    return E.pack_weight(lambda: w.detach().float().flip(2, 3).transpose(0, 1).contiguous(), E.pad_to(w.shape[0], 16), x3)
 
 
 # ------------------------------------------------------------------ zero-padded Conv2d+BN+ReLU stack
@@ -309,10 +309,10 @@ def feat_grad_to_nhwc(dfeat, row, third, c_off, C, B, H, W, Wo, x3, lo=None, hi=
 def lstm_train_plan(lstm, cin_store, x3):
     H = lstm.hidden_size
     perm, inv = E.lstm_gate_perm(H, lstm.weight_ih_l0.device)     # gate-interleaved projection rows (sos_hip.h)
-    w_ih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse], dim=0).detach()[perm]    # (8H, I)
+    w_ih = lambda: torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse], dim=0).detach()[perm]    # noqa: E731  (8H, I)
     bias = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse]).detach()[perm]
-    w = E.pack_weight(w_ih[:, :, None, None], cin_store, x3)
-    wd = E.pack_weight(w_ih.t().contiguous()[:, :, None, None], E.pad_to(8 * H, 16), x3)      # (I, 8H)
+    w = E.pack_weight(lambda: w_ih()[:, :, None, None], cin_store, x3)
+    wd = E.pack_weight(lambda: w_ih().t().contiguous()[:, :, None, None], E.pad_to(8 * H, 16), x3)      # (I, 8H)
     dev = w.device
     return dict(w=w, wd=wd, wpk=E.lstm_pack(lstm, x3), H=H, I=lstm.input_size, cin_store=cin_store, inv=inv,
                 scale=E.pad_vec(torch.ones(8 * H, device=dev), w.shape[1], 1.0), shift=E.pad_vec(bias, w.shape[1]))
@@ -375,8 +375,8 @@ def lstm_backward(lp, tape, dh, grads, prefix, B, T, x3, dev):
 
 # ---------------------------------------------------------------------------------------- Linear
 def linear_train_plan(lin, cin_store, x3):
-    w = E.pack_weight(lin.weight[:, :, None, None], cin_store, x3)
-    wd = E.pack_weight(lin.weight.detach().t().contiguous()[:, :, None, None], E.pad_to(lin.out_features, 16), x3)
+    w = E.pack_weight(lambda: lin.weight[:, :, None, None], cin_store, x3)
+    wd = E.pack_weight(lambda: lin.weight.detach().t().contiguous()[:, :, None, None], E.pad_to(lin.out_features, 16), x3)
     return dict(w=w, wd=wd, lin=lin, cout=lin.out_features, cin=lin.in_features, cin_store=cin_store,
                 scale=E.pad_vec(torch.ones(lin.out_features, device=w.device), w.shape[1], 1.0),
                 shift=E.pad_vec(lin.bias, w.shape[1]))
@@ -417,13 +417,13 @@ def down_train_plan(blk, x3, in_perm=None):
     k, s, d = conv.kernel_size[0], conv.stride[0], conv.dilation[0]
     cin_store = E.pad_to(conv.in_channels, 16)
     cout_cs = E.pad_to(conv.out_channels, 16)
-    w = conv.weight.detach().float()
-    wperm = w if in_perm is None else w[:, in_perm]
-    plan = dict(w=E.pack_weight(w, cin_store, x3, in_perm), conv=conv, bn=blk.block[2] if has_bn else None, prelu=prelu,
+    wf = lambda: conv.weight.detach().float()                                    # noqa: E731
+    wperm = lambda: wf() if in_perm is None else wf()[:, in_perm]                 # noqa: E731
+    plan = dict(w=E.pack_weight(wf, cin_store, x3, in_perm), conv=conv, bn=blk.block[2] if has_bn else None, prelu=prelu,
                 k=k, stride=s, dil=d, pad=(k - 1) // 2 * d, cout=conv.out_channels, cin=conv.in_channels,
                 cin_store=cin_store, in_perm=in_perm)
     if s == 1:
-        plan["wd"] = E.pack_weight(wperm.flip(2, 3).transpose(0, 1).contiguous(), cout_cs, x3)
+        plan["wd"] = E.pack_weight(lambda: wperm().flip(2, 3).transpose(0, 1).contiguous(), cout_cs, x3)
     else:
         assert s == 2 and d == 1
         phases = {}
@@ -432,7 +432,7 @@ def down_train_plan(blk, x3, in_perm=None):
                 Mh, Mw = (k + 1 - ph) // 2, (k + 1 - pw) // 2
                 a = [ph + 2 * (Mh - 1 - t) for t in range(Mh)]
                 b = [pw + 2 * (Mw - 1 - t) for t in range(Mw)]
-                sub = wperm[:, :, a][:, :, :, b].transpose(0, 1).contiguous()        # (I, O, Mh, Mw)
+                sub = lambda a=a, b=b: wperm()[:, :, a][:, :, :, b].transpose(0, 1).contiguous()     # noqa: E731  (I, O, Mh, Mw)
                 phases[(ph, pw)] = (E.pack_weight(sub, cout_cs, x3), Mh, Mw)
         plan["wd_phases"] = phases
     return plan
@@ -442,12 +442,12 @@ def up_train_plan(blk, x3):
     """UpConvBlock: block.0 ConvTranspose2d(k3,s2,p1,op1), block.1 BN, block.2 PReLU."""
     ct, bn, prelu = blk.block[0], blk.block[1], blk.block[2]
     cin_store = E.pad_to(ct.in_channels, 16)
-    w = ct.weight.detach().float()                                                    # (Cin, Cout, 3, 3)
+    w = lambda: ct.weight.detach().float()                                            # noqa: E731  (Cin, Cout, 3, 3)
     taps = {0: [1], 1: [2, 0]}
     phases = {}
     for ph in (0, 1):
         for pw in (0, 1):
-            sub = w[:, :, taps[ph]][:, :, :, taps[pw]].permute(1, 0, 2, 3).contiguous()
+            sub = lambda ph=ph, pw=pw: w()[:, :, taps[ph]][:, :, :, taps[pw]].permute(1, 0, 2, 3).contiguous()   # noqa: E731
             phases[(ph, pw)] = E.pack_weight(sub, cin_store, x3)
     # data gradient: d_in[hi] = sum_a d_raw[2hi - 1 + a] W[ci][co][a] -> stride-2 conv, weight (O=Cin, I=Cout)
     wd = E.pack_weight(w, E.pad_to(ct.out_channels, 16), x3)
