@@ -121,6 +121,9 @@ def main():
                          "three-pass hi/lo split (3x the MACs, ~fp32 accuracy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="train mode: run the two models back to back on one stream")
+    ap.add_argument("--force-buckets", action="store_true",
+                    help="world of one: run the data-parallel gradient path anyway (bucket copies + RCCL all-reduce of every "
+                         "bucket on a 1-rank group) to measure its overhead on a single GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,9 +133,15 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_buckets:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ["SOS_FORCE_BUCKETS"] = "1"
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import sos_amd
     from sos_amd import agent, engine, pipeline, tools, transform
@@ -246,7 +255,7 @@ def main():
                                    + (", detector BCE + denoiser 2xMSE, Adam lr 1e-3, per-rank BatchNorm" if train else ""),
                        "clips_per_gpu": B, "n_samples": N_SAMPLES, "mode": args.mode, "precision": args.precision,
                        "parity": PARITY_NOTE[args.precision],
-                       "streams": 2 if (train and not args.serial) else 1,
+                       "streams": 2 if (train and not args.serial) else 1, "forced_gradient_buckets": bool(args.force_buckets),
                        "realtime_factor": value * (audio_seconds / B if args.mode == "infer-ragged" else N_SAMPLES / 14000.0),
                        "end_to_end_tflops": value * gflop / 1e3 / world},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
