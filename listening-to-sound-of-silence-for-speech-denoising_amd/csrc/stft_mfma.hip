@@ -270,6 +270,9 @@ __global__ __launch_bounds__(256) void istft_mfma_kernel(IstftParams p) {
         constexpr int kk = decltype(kk_tag)::value;
         const int ks = ch * FE_RING + kk;
         load_e(std::integral_constant<int, (kk + FE_RING - 1) % FE_RING>{}, ks + FE_RING - 1);
+        // the next chunk's spectrogram values go out AFTER this k-step's fragment prefetch: vector-memory waits complete in
+        // order, so issued the other way round the fragments needed three k-steps from now would wait for all 16 of them
+        if (kk == 0 && ch + 1 < nchunks) load_chunk(ch + 1);
         fe_h8 bh[2], bl[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -296,8 +299,7 @@ __global__ __launch_bounds__(256) void istft_mfma_kernel(IstftParams p) {
         __syncthreads();                                       // the previous chunk's fragments have been read
         store_chunk();
         __syncthreads();
-        if (ch + 1 < nchunks) load_chunk(ch + 1);              // in flight during this chunk's MFMAs
-        kstep(std::integral_constant<int, 0>{}, ch);
+        kstep(std::integral_constant<int, 0>{}, ch);           // (also issues the next chunk's loads: in flight during the MFMAs)
         kstep(std::integral_constant<int, 1>{}, ch);
         kstep(std::integral_constant<int, 2>{}, ch);
         kstep(std::integral_constant<int, 3>{}, ch);
@@ -319,20 +321,41 @@ __global__ __launch_bounds__(256) void istft_mfma_kernel(IstftParams p) {
             }
     }
     __syncthreads();
-    // overlap-add in a fixed order (newest frame first, like the round-1 kernel) + window-sum-square normalisation
+    // overlap-add in a fixed order (newest frame first, like the round-1 kernel) + window-sum-square normalisation.
+    // A sample is covered by at most 3 frames (host check): the three terms are independent, predicated loads from LDS
+    // (the squared window sits behind the frame signals), and 4 samples are in flight per thread -- the first version's
+    // data-dependent loop with a global window read per term serialised ~100 round trips per thread (15 of 75 us).
+    float* w2 = yf + FE_COLS * ypitch;
+    for (int n = tid; n < p.win; n += 256) w2[n] = p.win2[n];
+    __syncthreads();
     const long long jend = j0 + (long long)FE_IADV * p.hop < n_out ? j0 + (long long)FE_IADV * p.hop : n_out;
-    for (long long j = j0 + tid; j < jend; j += 256) {
-        const long long pp = j + half;
-        long long tmax = (pp - lpad) / p.hop;
-        if (tmax > Tc - 1) tmax = Tc - 1;
-        float y = 0.f, wss = 0.f;
-        for (long long t = tmax; t >= tlo; --t) {
-            const int n = (int)(pp - t * p.hop) - lpad;
-            if (n >= p.win) break;
-            y += yf[(int)(t - tlo) * ypitch + n];
-            wss += p.win2[n];
+    const int ihop = p.hop;
+    for (long long jb = j0 + tid; jb < jend; jb += 4 * 256) {
+        float y[4], wss[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long j = jb + u * 256;
+            const long long pp = j + half;
+            long long tmax = (pp - lpad) / ihop;
+            if (tmax > Tc - 1) tmax = Tc - 1;
+            const int n0 = (int)(pp - tmax * ihop) - lpad;               // sample index inside the newest covering frame
+            const int f0 = (int)(tmax - tlo);
+            y[u] = 0.f; wss[u] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int n = n0 + q * ihop, f = f0 - q;
+                const bool ok = j < jend && f >= 0 && n < p.win;
+                const int nn = ok ? n : 0, ff = ok ? f : 0;
+                const float v = yf[ff * ypitch + nn], w = w2[nn];
+                y[u] += ok ? v : 0.f;
+                wss[u] += ok ? w : 0.f;
+            }
         }
-        p.out[b * p.out_stride + j] = wss > 1.17549435e-38f ? y / wss : y;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long j = jb + u * 256;
+            if (j < jend) p.out[b * p.out_stride + j] = wss[u] > 1.17549435e-38f ? y[u] / wss[u] : y[u];
+        }
     }
 }
 
@@ -464,7 +487,7 @@ extern "C" int sos_istft_f32(const float* spec, int64_t batch, int64_t n_frames,
     p.out = out; p.out_stride = out_stride; p.t_tab = clip_frames;
     if (p.rtiles > 16 || (2 * p.nbins) % FE_IKC) { sos_set_error("sos_istft_f32: window / n_fft not supported by the tile"); return SOS_ENOSPC; }
     size_t lds = (size_t)2 * FE_COLS * (FE_IKC * 2 + 16);
-    const size_t ylds = (size_t)FE_COLS * (p.rtiles * 32 + 1) * 4;
+    const size_t ylds = (size_t)FE_COLS * (p.rtiles * 32 + 1) * 4 + (size_t)win_length * 4;      // frame signals + squared window
     if (ylds > lds) lds = ylds;
     if (lds > 160 * 1024) { sos_set_error("sos_istft_f32: window too long for LDS staging"); return SOS_ENOSPC; }
     static sos_device_once once;
