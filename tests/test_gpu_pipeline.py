@@ -291,8 +291,12 @@ def test_si_sdr_parity_with_briefly_trained_weights():
         s_in = ofe.si_sdr(raw["mixed"][i][:len(y)], raw["clean"][i])
         for precision, tol in (("bf16x3", 0.05), ("fp16", 0.05), ("bf16", 0.05)):
             r = res[precision]
-            if not np.array_equal(r["bits"][i].cpu().numpy(), bits):
-                continue                                    # a frame decision within rounding of the threshold flipped
+            flips = int(np.sum(r["bits"][i].cpu().numpy() != bits))
+            # bit-flip gate: frame decisions (sigmoid >= 0.5) may only differ from the fp32 path where a logit sits within
+            # rounding of the threshold -- at most one of the 60 frames in the 16-bit modes, none in the parity mode
+            assert flips <= (0 if precision == "bf16x3" else 1), (precision, i, flips)
+            if flips:
+                continue
             s_hip = ofe.si_sdr(r["out"][i].cpu().numpy(), raw["clean"][i])
             print(precision, "clip", i, "SI-SDR in", round(s_in, 2), "oracle", round(s_or, 3), "HIP", round(s_hip, 3))
             assert abs(s_hip - s_or) <= tol, (precision, s_hip, s_or)
