@@ -186,14 +186,20 @@ class GradBucketer:
 
     def reset(self):
         self.buckets, self.cur, self.cur_fill, self.handles, self.views = [], None, 0, [], {}
+        self.pending = ([], [])
 
     def _launch(self, flat, fill):
+        # the bucket's gradients are gathered with ONE batched copy (a copy per tensor was 322 launches per step), then
+        # its all-reduce starts while the backward pass goes on
+        if self.pending[0]:
+            torch._foreach_copy_(self.pending[0], self.pending[1])
+            self.pending = ([], [])
         if self.collective:
             self.handles.append(dist.all_reduce(flat[:fill], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def ready(self, name, g):
         """Called by the backward pass when a parameter gradient is final; returns the bucket view that
-        now holds it."""
+        will hold it (filled when the bucket is flushed)."""
         n = g.numel()
         cap = max(self.bucket_bytes // 4, n)
         if self.cur is None or self.cur_fill + n > self.cur.numel():
@@ -203,7 +209,8 @@ class GradBucketer:
             self.cur_fill = 0
             self.buckets.append(self.cur)
         v = self.cur[self.cur_fill:self.cur_fill + n]
-        v.copy_(g.reshape(-1))
+        self.pending[0].append(v)
+        self.pending[1].append(g.reshape(-1))
         self.cur_fill += n
         self.views[name] = v.view(self.shapes[name])
         return self.views[name]
@@ -213,6 +220,9 @@ class GradBucketer:
         1/world average is applied by the optimizer's grad_scale)."""
         if self.cur is not None and self.cur_fill:
             self._launch(self.cur, self.cur_fill)
+        elif self.pending[0]:
+            torch._foreach_copy_(self.pending[0], self.pending[1])
+            self.pending = ([], [])
         for h in self.handles:
             h.wait()
         for name, v in self.views.items():
@@ -221,6 +231,7 @@ class GradBucketer:
 
     def reset_keep_views(self):
         self.cur, self.cur_fill, self.handles, self.buckets, self.views = None, 0, [], [], {}
+        self.pending = ([], [])
 
 
 class GradSink(dict):
