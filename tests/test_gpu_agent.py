@@ -183,7 +183,8 @@ def test_bucketed_all_reduce_path_on_rccl_world_of_one():
     assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, r.stdout[-3000:]
 
 
-def test_detector_learns_the_synthetic_task():
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_detector_learns_the_synthetic_task(precision):
     """End-to-end sanity beyond one-step parity: 40 Adam steps on fresh synthetic batches (speech bursts gated by the
     frame labels + coloured noise) lower the BCE loss of the silent-interval detector and lift its frame accuracy
     above the majority-class rate."""
@@ -191,7 +192,7 @@ def test_detector_learns_the_synthetic_task():
     from sos_amd import agent
     from sos_amd.dataset import make_batch
     from sos_amd.detector import networks as dnet
-    sos_amd.set_precision("bf16")
+    sos_amd.set_precision(precision)
     torch.manual_seed(0)
     ag = agent.DetectorAgent(dnet.get_network(), lr=1e-3)
     losses = []
@@ -203,10 +204,12 @@ def test_detector_learns_the_synthetic_task():
     acc = float(((out >= 0) == (test["label"] > 0.5)).float().mean())
     base = float(max(test["label"].mean(), 1 - test["label"].mean()))
     print("detector losses", [round(x, 3) for x in losses[::5]], "val accuracy", acc, "majority", base)
+    sos_amd.set_precision("bf16")
     assert np.mean(losses[-5:]) < 0.8 * np.mean(losses[:5]) and acc > base + 0.02
 
 
-def test_denoiser_learns_the_synthetic_task():
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_denoiser_learns_the_synthetic_task(precision):
     """60 Adam steps on fresh synthetic batches lower both MSE terms of the two-stage denoiser, and the masked output of
     a held-out batch ends up closer to the clean spectrogram than the noisy input is."""
     import sos_amd
@@ -214,7 +217,7 @@ def test_denoiser_learns_the_synthetic_task():
     from sos_amd.common import MyConfig
     from sos_amd.dataset import make_batch
     from sos_amd.denoiser import networks as jnet
-    sos_amd.set_precision("bf16")
+    sos_amd.set_precision(precision)
     torch.manual_seed(0)
     ag = agent.DenoiserAgent(jnet.get_network(MyConfig()), lr=1e-3)
     l1, l2 = [], []
@@ -227,5 +230,34 @@ def test_denoiser_learns_the_synthetic_task():
     err_out = float(((rec - test["clean"]) ** 2).mean())
     err_in = float(((test["mixed"] - test["clean"]) ** 2).mean())
     print("denoiser stage1", [round(x, 4) for x in l1[::10]], "stage2", [round(x, 4) for x in l2[::10]], "val MSE out/in", err_out, err_in)
+    sos_amd.set_precision("bf16")
     assert np.mean(l1[-5:]) < 0.8 * np.mean(l1[:5]) and np.mean(l2[-5:]) < 0.8 * np.mean(l2[:5])
     assert err_out < err_in
+
+
+def test_fp16_training_tracks_the_parity_mode():
+    """The timed mode's training (half storage, loss-scaled backward) against the bf16x3 parity mode (~fp32 accuracy) from
+    the same initial weights on the same batches: the loss curves of the first 25 denoiser steps agree step by step (the
+    trajectories are those of the same optimisation, not merely both decreasing)."""
+    import sos_amd
+    from sos_amd import agent
+    from sos_amd.common import MyConfig
+    from sos_amd.dataset import make_batch
+    from sos_amd.denoiser import networks as jnet
+    curves = {}
+    try:
+        for precision in ("bf16x3", "fp16"):
+            sos_amd.set_precision(precision)
+            torch.manual_seed(0)
+            ag = agent.DenoiserAgent(jnet.get_network(MyConfig()), lr=1e-3)
+            c = []
+            for it in range(25):
+                _, ls = ag.train_func(make_batch("denoiser", 7000 + 8 * it, 8))
+                c.append(float(ls["stage1"].detach()) + float(ls["stage2"].detach()))
+            curves[precision] = np.array(c)
+            del ag
+    finally:
+        sos_amd.set_precision("bf16")
+    rel = np.abs(curves["fp16"] - curves["bf16x3"]) / curves["bf16x3"]
+    print("loss curves bf16x3", np.round(curves["bf16x3"][::4], 4), "fp16", np.round(curves["fp16"][::4], 4), "max rel diff", rel.max())
+    assert rel[:5].max() < 2e-2 and rel.max() < 0.15 and curves["fp16"][-5:].mean() < 0.7 * curves["fp16"][:3].mean()
