@@ -261,3 +261,36 @@ def test_fp16_training_tracks_the_parity_mode():
     rel = np.abs(curves["fp16"] - curves["bf16x3"]) / curves["bf16x3"]
     print("loss curves bf16x3", np.round(curves["bf16x3"][::4], 4), "fp16", np.round(curves["fp16"][::4], 4), "max rel diff", rel.max())
     assert rel[:5].max() < 2e-2 and rel.max() < 0.15 and curves["fp16"][-5:].mean() < 0.7 * curves["fp16"][:3].mean()
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16x3"])
+def test_gather_refresh_of_packed_weights_equals_torch_repacking(precision):
+    """After an optimizer step the packed 16-bit weights of a training plan are refreshed by ONE sos_gather_pack_multi
+    launch that replays relocation maps recorded once (engine.PackRecorder) instead of ~1000 torch kernels.  The maps
+    are verified when they are recorded; here the end-to-end guarantee: four training steps of both networks give
+    bit-identical losses with the refresh on and off, and the recorder did take the gather path."""
+    import sos_amd
+    from sos_amd import agent, engine
+    from sos_amd.common import MyConfig
+    from sos_amd.dataset import make_batch
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+    sos_amd.set_precision(precision)
+    res = {}
+    try:
+        for gather in (True, False):
+            engine.PackRecorder.ENABLED = gather
+            torch.manual_seed(0)
+            aj = agent.DenoiserAgent(jnet.get_network(MyConfig()), lr=1e-3)
+            ad = agent.DetectorAgent(dnet.get_network(), lr=1e-3)
+            ls = []
+            for it in range(4):
+                _, l = aj.train_func(make_batch("denoiser", 100 + 4 * it, 4))
+                _, l2 = ad.train_func(make_batch("detector", 100 + 4 * it, 4))
+                ls.append((float(l["stage1"].detach()), float(l["stage2"].detach()), float(l2["bce"].detach())))
+            res[gather] = ls
+            assert bool(aj.net._tcache.rec.ok) == gather and bool(ad.net._tcache.rec.ok) == gather
+    finally:
+        engine.PackRecorder.ENABLED = True
+        sos_amd.set_precision("bf16")
+    assert res[True] == res[False], res
