@@ -39,32 +39,62 @@ def denoise(detector, denoiser, mixed, sr=SR, fps=FPS, bits=None, return_all=Fal
     return out
 
 
+def _group_geometry(ns, device, sr, fps):
+    """Per-clip frame / video-frame counts of a ragged group and their device tables (engine.Ragged)."""
+    from . import engine as E
+    T = [1 + n // transform.HOP_LENGTH for n in ns]
+    nv = [n_video_frames(n, sr, fps) for n in ns]
+    rag = E.Ragged(T, device, n_vframes=nv, n_samples=ns)
+    rag.tab(ns), rag.tab(nv), rag.level(0)          # uploaded here, not inside a later stream capture
+    return rag
+
+
+def _denoise_group_padded(detector, denoiser, wave, rag, sr, fps):
+    """The launch sequence of one ragged group on its padded waveform buffer (B, max samples); no host <-> device traffic
+    (capturable in a hipGraph).  Returns the padded output (B, hop * (max T - 1)) and the detector's logits / bits."""
+    ns, nv = rag.n_samples, rag.n_vframes
+    t_ns, t_nv = rag.tab(ns), rag.tab(nv)
+    S_mixed = transform.stft_batch(wave, clip_samples=t_ns)
+    logits = detector(s=S_mixed, v_num_frames=max(nv), rag=rag)
+    bits, _ = tools.threshold_bits(logits, SIGMOID_THRESHOLD)
+    mask, noise_sig = tools.bits_to_mask_batch(bits, float(sr) / fps, wave.shape[1], wave, clip_frames=t_nv, clip_samples=t_ns)
+    S_noise = transform.stft_batch(noise_sig, clip_samples=t_ns)
+    n_pred, crm = denoiser(S_mixed, S_noise, rag=rag)
+    S_out = transform.batch_fast_icRM_sigmoid(S_mixed, crm)
+    return transform.istft_batch(S_out, clip_frames=rag.level(0)), logits, bits
+
+
+def _pad_group(clips):
+    ns = [int(c.numel()) for c in clips]
+    wave = torch.zeros((len(clips), max(ns)), dtype=torch.float32, device=clips[0].device)
+    for b, c in enumerate(clips):
+        wave[b, :ns[b]] = c
+    return wave, ns
+
+
 def _denoise_group(detector, denoiser, clips, sr, fps):
     """One launch sequence for clips of DIFFERENT lengths: buffers sized for the longest clip, every kernel takes the
     clips' own sample / frame / video-frame counts from device tables (engine.Ragged), so each clip is computed exactly
     as if it were run alone: reflect padding of the STFT at its own end, zero / reflect conv borders at its own last
     frame, its own stride-2 sizes and transposed-conv crops, BiLSTM reverse pass from its own last frame, overlap-add
     normalisation of its own frame count."""
-    from . import engine as E
-    dev = clips[0].device
-    ns = [int(c.numel()) for c in clips]
-    B, Nmax = len(clips), max(ns)
-    wave = torch.zeros((B, Nmax), dtype=torch.float32, device=dev)
-    for b, c in enumerate(clips):
-        wave[b, :ns[b]] = c
-    T = [1 + n // transform.HOP_LENGTH for n in ns]
-    nv = [n_video_frames(n, sr, fps) for n in ns]
-    rag = E.Ragged(T, dev, n_vframes=nv, n_samples=ns)
-    t_ns, t_nv = rag.tab(ns), rag.tab(nv)
-    S_mixed = transform.stft_batch(wave, clip_samples=t_ns)
-    logits = detector(s=S_mixed, v_num_frames=max(nv), rag=rag)
-    bits, _ = tools.threshold_bits(logits, SIGMOID_THRESHOLD)
-    mask, noise_sig = tools.bits_to_mask_batch(bits, float(sr) / fps, Nmax, wave, clip_frames=t_nv, clip_samples=t_ns)
-    S_noise = transform.stft_batch(noise_sig, clip_samples=t_ns)
-    n_pred, crm = denoiser(S_mixed, S_noise, rag=rag)
-    S_out = transform.batch_fast_icRM_sigmoid(S_mixed, crm)
-    out = transform.istft_batch(S_out, clip_frames=rag.level(0))
-    return [out[b, :transform.HOP_LENGTH * (T[b] - 1)] for b in range(B)], dict(logits=logits, bits=bits, rag=rag)
+    wave, ns = _pad_group(clips)
+    rag = _group_geometry(ns, wave.device, sr, fps)
+    out, logits, bits = _denoise_group_padded(detector, denoiser, wave, rag, sr, fps)
+    return [out[b, :transform.HOP_LENGTH * (rag.T[b] - 1)] for b in range(len(clips))], dict(logits=logits, bits=bits, rag=rag)
+
+
+def _ragged_groups(clips, max_batch, max_columns):
+    """Clips sorted by length (longest first) and cut into groups of <= max_batch clips and <= max_columns
+    (clips x frames of the group's longest) spectrogram columns: lists of indices into `clips`."""
+    order = sorted(range(len(clips)), key=lambda i: -int(clips[i].numel()))
+    groups, j = [], 0
+    while j < len(order):
+        t_long = 1 + int(clips[order[j]].numel()) // transform.HOP_LENGTH
+        nb = max(1, min(max_batch, max_columns // t_long, len(order) - j))
+        groups.append(order[j:j + nb])
+        j += nb
+    return groups
 
 
 @torch.no_grad()
@@ -79,19 +109,13 @@ def denoise_ragged(detector, denoiser, clips, sr=SR, fps=FPS, max_batch=256, max
     for c in clips:
         if c.dim() != 1:
             raise ValueError("denoise_ragged expects 1-D waveforms")
-    order = sorted(range(len(clips)), key=lambda i: -int(clips[i].numel()))
     outs, extra = [None] * len(clips), [None] * len(clips)
-    j = 0
-    while j < len(order):
-        t_long = 1 + int(clips[order[j]].numel()) // transform.HOP_LENGTH        # the group's longest clip comes first
-        nb = max(1, min(max_batch, max_columns // t_long, len(order) - j))
-        part = order[j:j + nb]
+    for part in _ragged_groups(clips, max_batch, max_columns):
         ys, info = _denoise_group(detector, denoiser, [clips[i].contiguous().float() for i in part], sr, fps)
         for k, i in enumerate(part):
             outs[i] = ys[k]
             if return_all:
                 extra[i] = dict(logits=info["logits"][k, :info["rag"].n_vframes[k]], bits=info["bits"][k, :info["rag"].n_vframes[k]])
-        j += nb
     return (outs, extra) if return_all else outs
 
 
@@ -143,6 +167,49 @@ class GraphedDenoiser:
         entry[1].copy_(mixed)
         entry[0].replay()
         return entry[2].clone() if clone else entry[2]
+
+    def _capture_mixed(self, wave, rag):
+        static_in = wave.clone()
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                _denoise_group_padded(self.detector, self.denoiser, static_in, rag, self.sr, self.fps)
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = _denoise_group_padded(self.detector, self.denoiser, static_in, rag, self.sr, self.fps)[0]
+        return [graph, static_in, static_out, 0, rag]
+
+    @torch.no_grad()
+    def denoise_mixed(self, clips, max_batch=256, max_columns=65536):
+        """BASELINE configs[3] as stated -- variable-length clips, hipGraph-captured forward: the ragged launch sequence of
+        every group (pipeline.denoise_ragged's grouping, per-clip geometry in the kernels) is captured once per LENGTH MIX
+        and replayed for new audio of the same lengths (a serving loop with fixed chunk sizes, a benchmark's repeated
+        batch).  The per-clip tables are uploaded before the capture and kept alive with the graph."""
+        from . import get_precision
+        for c in clips:
+            if c.dim() != 1 or not c.is_cuda or c.dtype != torch.float32:
+                raise ValueError("denoise_mixed expects 1-D float32 GPU waveforms")
+        wv = tuple(t._version for m in (self.detector, self.denoiser) for t in list(m.parameters()) + list(m.buffers()))
+        outs = [None] * len(clips)
+        for part in _ragged_groups(clips, max_batch, max_columns):
+            wave, ns = _pad_group([clips[i] for i in part])
+            key = ("mixed", tuple(ns), wave.device.index, get_precision(), hash(wv))
+            entry = self._graphs.get(key)
+            if entry is None:
+                if len(self._graphs) >= self.max_graphs:
+                    del self._graphs[min(self._graphs, key=lambda k: self._graphs[k][3])]
+                entry = self._graphs[key] = self._capture_mixed(wave, _group_geometry(ns, wave.device, self.sr, self.fps))
+            self._tick = getattr(self, "_tick", 0) + 1
+            entry[3] = self._tick
+            entry[1].copy_(wave)
+            entry[0].replay()
+            T = entry[4].T
+            for k, i in enumerate(part):
+                outs[i] = entry[2][k, :transform.HOP_LENGTH * (T[k] - 1)].clone()
+        return outs
 
     def denoise_ragged(self, clips, max_batch=64):
         """Equal-length buckets of `clips`, each replayed from its graph (streams of fixed-size chunks: the shapes repeat,

@@ -218,6 +218,25 @@ def test_ragged_batch_256_clips_1_to_10_s():
         sos_amd.set_precision("bf16")
 
 
+def test_graph_replay_of_a_mixed_length_group_equals_eager():
+    """BASELINE configs[3] as stated (variable lengths + hipGraph-captured forward): GraphedDenoiser.denoise_mixed captures
+    the ragged launch sequence of a length mix once and replays it for new audio of the same lengths -- bit-identical to
+    the eager ragged path, also after the first replay and for a second length mix."""
+    from sos_amd import pipeline
+    _, _, det, jm = _nets_closed_form()
+    g = pipeline.GraphedDenoiser(det, jm, max_graphs=4)
+    lens = [30011, 14000, 51800, 14157, 28000]
+    for seed in (410, 420, 430):
+        clips = [torch.from_numpy(_long_wave(seed + i, n)).cuda() for i, n in enumerate(lens)]
+        want = pipeline.denoise_ragged(det, jm, clips)
+        got = g.denoise_mixed(clips)
+        assert all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(got, want))
+    assert len(g._graphs) == 1
+    clips2 = [torch.from_numpy(_long_wave(500 + i, n)).cuda() for i, n in enumerate(lens[:3][::-1])]
+    assert all(torch.equal(a, b) for a, b in zip(g.denoise_mixed(clips2), pipeline.denoise_ragged(det, jm, clips2)))
+    assert len(g._graphs) == 2
+
+
 def test_graph_replay_equals_eager_launches():
     """BASELINE configs[3]: the hipGraph-captured chain replays the same kernels with the same tilings, so its
     output is bit-identical to the eager launches -- for new inputs, for several shapes, and across evictions."""
