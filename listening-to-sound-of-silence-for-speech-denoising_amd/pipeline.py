@@ -12,6 +12,7 @@ from . import transform
 SR = 14000
 FPS = 30.0
 SIGMOID_THRESHOLD = 0.5     # M1/predict.py:30
+MIN_FRAMES = 65             # ((T + 1) // 2 + 1) // 2 > 16, the reflect padding of InpaintNet's dilation-16 block
 
 
 def n_video_frames(n_samples, sr=SR, fps=FPS):
@@ -44,6 +45,10 @@ def _group_geometry(ns, device, sr, fps):
     from . import engine as E
     T = [1 + n // transform.HOP_LENGTH for n in ns]
     nv = [n_video_frames(n, sr, fps) for n in ns]
+    if min(T) < MIN_FRAMES:
+        # the U-Net's dilation-16 block reflects 16 columns at a quarter of the resolution: nn.ReflectionPad2d raises for a
+        # shorter input (M2/networks.py:105,181), and so does the single-clip path (sos_conv2d_fwd's descriptor check)
+        raise ValueError(f"clips need at least {MIN_FRAMES} STFT frames ({MIN_FRAMES * transform.HOP_LENGTH} samples); got {min(ns)} samples")
     rag = E.Ragged(T, device, n_vframes=nv, n_samples=ns)
     rag.tab(ns), rag.tab(nv), rag.level(0)          # uploaded here, not inside a later stream capture
     return rag

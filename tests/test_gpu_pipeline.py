@@ -218,6 +218,20 @@ def test_ragged_batch_256_clips_1_to_10_s():
         sos_amd.set_precision("bf16")
 
 
+def test_ragged_rejects_clips_shorter_than_the_reflect_padding():
+    """nn.ReflectionPad2d(16) at a quarter of the resolution needs more than 64 frames: the reference raises for shorter
+    files; the ragged path (whose kernels clamp reflected indices) must refuse them too instead of computing something."""
+    from sos_amd import pipeline
+    _, _, det, jm = _nets_closed_form()
+    ok = torch.from_numpy(_long_wave(600, 14000)).cuda()
+    short = torch.from_numpy(_long_wave(601, 64 * 158 - 1)).cuda()          # 64 frames
+    with pytest.raises(ValueError):
+        pipeline.denoise_ragged(det, jm, [ok, short])
+    with pytest.raises((ValueError, RuntimeError)):
+        pipeline.denoise(det, jm, short[None])
+    assert pipeline.denoise_ragged(det, jm, [ok, torch.from_numpy(_long_wave(602, 65 * 158)).cuda()])[1].shape == (158 * 65,)
+
+
 def test_graph_replay_of_a_mixed_length_group_equals_eager():
     """BASELINE configs[3] as stated (variable lengths + hipGraph-captured forward): GraphedDenoiser.denoise_mixed captures
     the ragged launch sequence of a length mix once and replays it for new audio of the same lengths -- bit-identical to
