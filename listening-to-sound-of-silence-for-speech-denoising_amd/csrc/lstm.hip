@@ -20,6 +20,7 @@
 // the next product's B operand).  With lo arrays given (bf16x3 mode) every product is the three
 // passes hi*hi + hi*lo + lo*hi.
 #include "sos_common.h"
+#include <stdlib.h>
 
 typedef sos_half_t bf16x8 __attribute__((ext_vector_type(8)));   // 8 storage-type (bf16, or fp16 in the SOS_F16 build) MFMA operands
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -102,7 +103,12 @@ extern "C" int sos_lstm_pack_whh(const float* whh, int H, void* fwd_hi, void* fw
 // depend on h) are in flight while the current tile is computed.  X3 = true (three-pass precision mode): hi and
 // lo fragments of the current tile only (register budget).  In both, a tile's xproj values for the NEXT step
 // are re-loaded right after this step consumed them.
-template <bool X3>
+// RES > 0 (plain 16-bit mode only): W_hh does not change over the T steps, so it is made RESIDENT instead of streamed from
+// L2 every step: the first RES tiles of every wave live in registers (RES * KFT fragments of 4 VGPRs), the remaining
+// tiles of the workgroup in LDS (one workgroup per CU: the whole 160 KB is its own) -- a step is then MFMAs, the h
+// exchange through LDS and one barrier, no global weight traffic (H = 200: 320 KB per step before; 6.9 -> ~2 us / step).
+// KFT = compile-time k-fragment count (register arrays need constant bounds).
+template <bool X3, int RES = 0, int KFT = 8>
 __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __restrict__ xproj, const uint4* __restrict__ wh,
                                                                const uint4* __restrict__ wl, int B, int T, int H,
                                                                bf16_t* __restrict__ out, int out_cs, int out_x3,
@@ -136,6 +142,31 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
     const uint4* whd = wh + (size_t)dir * NT * KF * 64 + lane;
     const uint4* wld = X3 ? wl + (size_t)dir * NT * KF * 64 + lane : nullptr;
     const int cnt = NT > wave ? (NT - wave + LM_WAVES - 1) / LM_WAVES : 0;      // this wave's tiles (wave-uniform)
+    // resident W_hh: register tiles, and the LDS image of the other tiles behind the two h buffers
+    // (vector VALUES, one per register tile, not arrays: hipcc leaves a RES x KFT array of uint4 -- or four small ones
+    // selected by the unrolled tile index -- in scratch memory, 17 us per step instead of 7)
+    static_assert(RES <= 4, "register tiles are spelled out below");
+    typedef unsigned wvec_t __attribute__((ext_vector_type(4 * KFT)));
+    wvec_t wr0 = {}, wr1 = {}, wr2 = {}, wr3 = {};
+    auto wput = [](wvec_t& w, const int kk, const uint4 v) { w[4 * kk] = v.x; w[4 * kk + 1] = v.y; w[4 * kk + 2] = v.z; w[4 * kk + 3] = v.w; };
+    auto wget = [](const wvec_t& w, const int kk) { return make_uint4(w[4 * kk], w[4 * kk + 1], w[4 * kk + 2], w[4 * kk + 3]); };
+    char* wlds = smem + (size_t)2 * P * LM_NB * HP;
+    if constexpr (RES > 0) {
+#pragma unroll
+        for (int ti = 0; ti < LM_FT; ++ti) {
+            if (ti >= cnt) continue;      // (not `break`: the loop must unroll completely for the register arrays)
+            const int tile = wave + LM_WAVES * ti;
+#pragma unroll
+            for (int kk = 0; kk < KFT; ++kk) {
+                const uint4 v = whd[((size_t)tile * KF + kk) * 64];
+                if (ti == 0 && RES > 0) wput(wr0, kk, v);
+                else if (ti == 1 && RES > 1) wput(wr1, kk, v);
+                else if (ti == 2 && RES > 2) wput(wr2, kk, v);
+                else if (ti == 3 && RES > 3) wput(wr3, kk, v);
+                else *(uint4*)(wlds + ((size_t)(tile - RES * LM_WAVES) * KFT + kk) * 1024 + lane * 16) = v;
+            }
+        }
+    }
     uint4 w0[8], w1[8];                                  // bf16: ping-pong of hi fragments; x3: hi and lo of the current tile
     f32x4 xc[LM_FT];
     auto load_frags = [&](uint4 (&w)[8], const uint4* base, const int tile) {
@@ -156,7 +187,7 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
         xc[ti] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ti < cnt) load_x(ti, 0);
     }
-    if (!X3 && cnt > 0) load_frags(w0, whd, wave);
+    if (!X3 && RES == 0 && cnt > 0) load_frags(w0, whd, wave);
     __syncthreads();
 
     for (int step = 0; step < Tg; ++step) {
@@ -195,12 +226,12 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
 #pragma unroll
         for (int ti = 0; ti < LM_FT; ++ti) {
             const int tile = wave + LM_WAVES * ti;       // wave-uniform
-            if (ti >= cnt) break;
+            if (ti >= cnt) continue;      // (not `break`: the loop must unroll completely for the register arrays)
             constexpr int dummy = 0; (void)dummy;
             if (X3) {
                 load_frags(w0, whd, tile);
                 load_frags(w1, wld, tile);
-            } else {
+            } else if constexpr (RES == 0) {
                 const int nxt = ti + 1 < cnt ? tile + LM_WAVES : wave;
                 if (ti & 1) load_frags(w0, whd, nxt); else load_frags(w1, whd, nxt);
                 __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of this tile's MFMAs
@@ -215,6 +246,19 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
                         acc = SOS_MFMA_16x16x32(frag(w0[kk]), frag(hf[kk]), acc, 0, 0, 0);
                         acc = SOS_MFMA_16x16x32(frag(w0[kk]), frag(hl[kk]), acc, 0, 0, 0);
                         acc = SOS_MFMA_16x16x32(frag(w1[kk]), frag(hf[kk]), acc, 0, 0, 0);
+                    } else if constexpr (RES > 0) {
+                        if (kk < KFT) {
+                            constexpr int kq = 0;
+                            (void)kq;
+                            const int kc = kk < KFT ? kk : 0;
+                            uint4 wv;
+                            if (ti == 0 && RES > 0) wv = wget(wr0, kc);
+                            else if (ti == 1 && RES > 1) wv = wget(wr1, kc);
+                            else if (ti == 2 && RES > 2) wv = wget(wr2, kc);
+                            else if (ti == 3 && RES > 3) wv = wget(wr3, kc);
+                            else wv = *(const uint4*)(wlds + ((size_t)(tile - RES * LM_WAVES) * KFT + kk) * 1024 + lane * 16);
+                            acc = SOS_MFMA_16x16x32(frag(wv), frag(hf[kk]), acc, 0, 0, 0);
+                        }
                     } else {
                         acc = SOS_MFMA_16x16x32(frag((ti & 1) ? w1[kk] : w0[kk]), frag(hf[kk]), acc, 0, 0, 0);
                     }
@@ -241,7 +285,7 @@ __global__ __launch_bounds__(LM_THREADS) void lstm_fwd_kernel(const float* __res
                 }
             }
         }
-        if (!X3 && (cnt & 1)) {                          // the wrap-around prefetch landed in w1: the next step starts in w0
+        if (!X3 && RES == 0 && (cnt & 1)) {              // the wrap-around prefetch landed in w1: the next step starts in w0
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) w0[kk] = w1[kk];
         }
@@ -283,6 +327,30 @@ extern "C" int sos_lstm_bidir_fwd(const float* xproj, const void* wpk_hi, const 
     { const char* e = getenv("SOS_LSTM_DBG"); dbg = e ? atoi(e) : 0; }
 #endif
     const size_t lds = (size_t)2 * (wpk_lo ? 2 : 1) * LM_NB * (lm_kf(H) * 64 + 16);
+    // resident W_hh (plain 16-bit mode, the two hidden sizes of the reference: 100 and 200): 4 register tiles per wave, the
+    // rest of the H/4 tiles in LDS
+    constexpr int RES = 4;
+    const int NT = H / 4, KF = lm_kf(H);
+    const size_t wl_tiles = NT > RES * LM_WAVES ? (size_t)(NT - RES * LM_WAVES) : 0;
+    const size_t lds_res = lds + wl_tiles * KF * 1024;
+    static const char* no_res = getenv("SOS_LSTM_STREAM_W");          // A/B switch: stream W_hh from L2 as in round 1
+    if (!wpk_lo && !no_res && lds_res <= 160 * 1024 && (KF == 7 || KF == 4)) {
+        static sos_device_once once;
+        (void)sos_per_device_once(once, [] {
+            (void)hipFuncSetAttribute((const void*)lstm_fwd_kernel<false, RES, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)lstm_fwd_kernel<false, RES, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            return (int)SOS_OK;
+        });
+        if (KF == 7)
+            hipLaunchKernelGGL((lstm_fwd_kernel<false, RES, 7>), grid, dim3(LM_THREADS), lds_res, (hipStream_t)stream, xproj,
+                               (const uint4*)wpk_hi, (const uint4*)wpk_lo, (int)B, (int)T, H, (bf16_t*)out_bf16, out_cs, 0,
+                               (long long)out_third, save_gates, save_c, dbg, lengths);
+        else
+            hipLaunchKernelGGL((lstm_fwd_kernel<false, RES, 4>), grid, dim3(LM_THREADS), lds_res, (hipStream_t)stream, xproj,
+                               (const uint4*)wpk_hi, (const uint4*)wpk_lo, (int)B, (int)T, H, (bf16_t*)out_bf16, out_cs, 0,
+                               (long long)out_third, save_gates, save_c, dbg, lengths);
+        return sos_check_launch("sos_lstm_bidir_fwd");
+    }
     if (wpk_lo)
         hipLaunchKernelGGL(lstm_fwd_kernel<true>, grid, dim3(LM_THREADS), lds, (hipStream_t)stream, xproj, (const uint4*)wpk_hi,
                            (const uint4*)wpk_lo, (int)B, (int)T, H, (bf16_t*)out_bf16, out_cs,
