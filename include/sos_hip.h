@@ -222,6 +222,11 @@ typedef struct sos_view {
  * nblk = sos_bn_stats_blocks(npix). */
 int sos_bn_stats_blocks(int64_t npix);
 int sos_bn_stats(const sos_view* x, float* partial, sos_stream_t stream);
+/* Optional pre-pass for long partial lists (the conv's fused statistics: one row per output tile): adds the nblk rows
+ * of partial [nblk][ncol] in sos_bn_fold_rows() slices, folded: f32 [sos_bn_fold_rows()][ncol]; then call
+ * sos_bn_finalize(folded, sos_bn_fold_rows(), ...) with ncol = 2*C.  Empty slices (nblk < rows) are written as 0. */
+int sos_bn_fold_rows(void);
+int sos_bn_fold_partials(const float* partial, int nblk, int ncol, float* folded, sos_stream_t stream);
 /* Stage 2: mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale (for the apply
  * pass), save_mean / save_invstd (for backward); running stats updated with momentum and the
  * UNBIASED variance, num_batches_tracked += 1 (torch semantics).  gamma/beta may be NULL (=1/0). */

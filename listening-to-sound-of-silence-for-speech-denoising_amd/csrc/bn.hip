@@ -117,6 +117,7 @@ __device__ __forceinline__ void store8(const View& v, long long pix, int c8, con
 }
 
 #define BN_MAX_BLOCKS 2048
+#define SOS_BN_FOLD_ROWS 64
 
 extern "C" int sos_bn_stats_blocks(int64_t npix) {
     int64_t b = (npix + 255) / 256;
@@ -206,6 +207,41 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     if (save_invstd) save_invstd[c] = invstd;
     if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
     if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * count / (count > 1.0 ? count - 1.0 : 1.0));
+}
+
+// The conv epilogue's fused statistics arrive as one row per output tile (12 288 rows for a 96-channel layer at B = 64):
+// bn_finalize_kernel's one-workgroup-per-channel walk reads them 4 bytes per 768-byte row (32 us).  This pre-pass adds
+// the rows in SOS_BN_FOLD_ROWS slices with row-contiguous (coalesced) reads; fixed order -> deterministic.
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ partial, int nblk, int ncol, int rows_per,
+                                                      float* __restrict__ folded) {
+    __shared__ double red[4][64];
+    const int tid = threadIdx.x, cl = tid & 63, lane = tid >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rows_per, r1 = min(nblk, r0 + rows_per);
+    double acc = 0.0;
+    if (col < ncol) {
+        int r = r0 + lane;
+        for (; r + 12 < r1; r += 16) {
+            const float a0 = partial[(size_t)r * ncol + col], a1 = partial[(size_t)(r + 4) * ncol + col];
+            const float a2 = partial[(size_t)(r + 8) * ncol + col], a3 = partial[(size_t)(r + 12) * ncol + col];
+            acc += (double)a0; acc += (double)a1; acc += (double)a2; acc += (double)a3;
+        }
+        for (; r < r1; r += 4) acc += (double)partial[(size_t)r * ncol + col];
+    }
+    red[lane][cl] = acc;
+    __syncthreads();
+    if (lane == 0 && col < ncol)
+        folded[(size_t)blockIdx.y * ncol + col] = (float)(((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl]);
+}
+
+extern "C" int sos_bn_fold_rows(void) { return SOS_BN_FOLD_ROWS; }
+
+extern "C" int sos_bn_fold_partials(const float* partial, int nblk, int ncol, float* folded, sos_stream_t stream) {
+    if (!partial || !folded || nblk < 1 || ncol < 1) { sos_set_error("sos_bn_fold_partials: bad args"); return SOS_EINVAL; }
+    const int rows_per = (nblk + SOS_BN_FOLD_ROWS - 1) / SOS_BN_FOLD_ROWS;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((ncol + 63) / 64, SOS_BN_FOLD_ROWS), dim3(256), 0, (hipStream_t)stream, partial,
+                       nblk, ncol, rows_per, folded);
+    return sos_check_launch("sos_bn_fold_partials");
 }
 
 extern "C" int sos_bn_finalize(const float* partial, int nblk, int C, int64_t count, const float* gamma,

@@ -510,6 +510,9 @@ def view(act, c_off=0, C=None, third_index=None):
     return v
 
 
+BN_FOLD_ROWS = 64       # sos_bn_fold_rows()
+
+
 def bn_train(raw, c_off, Cn, bn, act, slope, dst, dst_c_off=0, feat=None, stats=None):
     """Training-mode BatchNorm (+activation) of the raw conv output `raw[:, c_off:c_off+C]`:
     stats -> finalize (updates bn.running_* in place like torch) -> apply into `dst`.
@@ -523,6 +526,11 @@ def bn_train(raw, c_off, Cn, bn, act, slope, dst, dst_c_off=0, feat=None, stats=
         nblk = L.lib().sos_bn_stats_blocks(xv.npix)
         partial = torch.empty((nblk, 2, Cn), dtype=torch.float32, device=dev)
         L.check(L.lib().sos_bn_stats(C.byref(xv), L.ptr(partial), L.stream_ptr()), "sos_bn_stats")
+    if nblk > 4 * BN_FOLD_ROWS:      # one row per conv tile: add the rows up with coalesced reads first
+        folded = torch.empty((BN_FOLD_ROWS, 2, Cn), dtype=torch.float32, device=dev)
+        L.check(L.lib().sos_bn_fold_partials(L.ptr(partial), nblk, 2 * Cn, L.ptr(folded), L.stream_ptr()),
+                "sos_bn_fold_partials")
+        partial, nblk = folded, BN_FOLD_ROWS
     scale = torch.empty(Cn, dtype=torch.float32, device=dev)
     shift = torch.empty_like(scale)
     mean = torch.empty_like(scale)
