@@ -613,6 +613,140 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// ---- 1x1 gradients with many channels on both sides (Linear layers, the LSTM input projections: dW_ih [1600][3072] over
+// 11 392 pixels): a plain "TN" GEMM  dW[m][n] = sum_k G[k][m] X[k][n].  The pixel-tile kernel above gives such a shape
+// 96 x 128 tiles with half of its waves idle (one tap: 4 (tap, n-tile) pairs for 8 waves) and re-reads X once per 96
+// rows (0.059 of peak).  Here: 128 x 128 tiles, 4 waves of 64 x 64 (2 x 2 MFMA tiles), 64-pixel stages double buffered
+// by LDS-DMA, the same [sub-image of 32 channels][pixel][64 B] LDS images and ds_read_b64_tr_b16 operand reads as
+// wgrad_kernel, split-K partial sums into the same [ksplit][1][Mp][Np] buffer for wgrad_reduce_kernel.
+// Channels past M / N read the neighbouring channels (or zeros past the buffer end): they only reach rows / columns that
+// are not stored.  Pixels past the split's end lie beyond the buffer resource's range: zeros.
+struct WgGemmParams {
+    const bf16_t* g; const bf16_t* x; float* partial;
+    int K, g_cs, x_cs, Mp, Np, tiles_n, ntiles, ksplit, kper;
+};
+#define WGG_KT 64
+#define WGG_BUF 32768          // one stage: 16 KB of G + 16 KB of X
+
+__global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgGemmParams p) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned sbase = (unsigned)(uintptr_t)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware id mapping: an XCD's L2 serves a contiguous run of (split, tile) pairs (n fastest: they share the G tile)
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, q = nblk / 8, r = nblk % 8;
+        const int xcd = bid % 8, loc = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int split = bid / p.ntiles, tile = bid - split * p.ntiles;
+    const int m0 = (tile / p.tiles_n) * 128, n0 = (tile % p.tiles_n) * 128;
+    const int kbeg = split * p.kper, kend = min(p.K, kbeg + p.kper);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, (unsigned)((long long)kend * p.g_cs * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)((long long)kend * p.x_cs * 2), 0x00020000);
+    // DMA: instruction i of a stage fills 1 KB = 16 pixels x 64 B of sub-image (i & 15) >> 2 of G (i < 16) or X
+    const unsigned lane_g = (unsigned)(((lane >> 2) * p.g_cs + (lane & 3) * 8) * 2);
+    const unsigned lane_x = (unsigned)(((lane >> 2) * p.x_cs + (lane & 3) * 8) * 2);
+    auto issue_stage = [&](const int k0, const int buf) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = wave + 4 * u;                 // wave-uniform
+            const int j = i & 15, sub = j >> 2, pb = j & 3;
+            const unsigned dst = (unsigned)(buf * WGG_BUF + i * 1024);
+            if (i < 16) {
+                const unsigned so = (unsigned)(((long long)(k0 + pb * 16) * p.g_cs + m0 + sub * 32) * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr_t)(smem + dst), 16, lane_g + so, 0, 0, 0);
+            } else {
+                const unsigned so = (unsigned)(((long long)(k0 + pb * 16) * p.x_cs + n0 + sub * 32) * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + dst), 16, lane_x + so, 0, 0, 0);
+            }
+        }
+    };
+    const int g4 = lane >> 4, s16 = lane & 15;
+    const int chan_off = (16 * (g4 & 1) + 4 * (s16 & 3)) * 2;    // byte offset of this lane's 4-channel run
+    const int krow = 8 * (g4 >> 1) + (s16 >> 2);                 // pixel inside a 16-pixel k-step; +4 for the 2nd read
+    const unsigned glane = (unsigned)(krow * 64 + chan_off);
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned aoff = (unsigned)(wm * 2 * 4096) + glane, boff = (unsigned)(16384 + wn * 2 * 4096) + glane;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    int cur = 0;
+    if (kbeg < kend) issue_stage(kbeg, 0);
+    for (int k0 = kbeg; k0 < kend; k0 += WGG_KT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                           // stage k0 has landed in buffer `cur`; buffer cur^1 is free
+        if (k0 + WGG_KT < kend) issue_stage(k0 + WGG_KT, cur ^ 1);
+        const unsigned ab = sbase + (unsigned)(cur * WGG_BUF) + aoff, bb = sbase + (unsigned)(cur * WGG_BUF) + boff;
+        u32x4 av[2][2], bv[2][2];
+        auto rd = [&](const unsigned addr) {
+            const uint2 lo = lds_tr(addr), hi = lds_tr_off<256>(addr);
+            return u32x4{lo.x, lo.y, hi.x, hi.y};
+        };
+        auto read_step = [&](const int ks, const int set) {
+            av[set][0] = rd(ab + ks * 1024); av[set][1] = rd(ab + 4096 + ks * 1024);
+            bv[set][0] = rd(bb + ks * 1024); bv[set][1] = rd(bb + 4096 + ks * 1024);
+        };
+        read_step(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < WGG_KT / 16; ++ks) {
+            const int set = ks & 1;
+            if (ks + 1 < WGG_KT / 16) {
+                read_step(ks + 1, set ^ 1);
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(av[set][0]), "+v"(av[set][1]), "+v"(bv[set][0]), "+v"(bv[set][1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[set][0]), "+v"(av[set][1]), "+v"(bv[set][0]), "+v"(bv[set][1]));
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = SOS_MFMA_32x32x16(__builtin_bit_cast(bf16x8, av[set][a]), __builtin_bit_cast(bf16x8, bv[set][b]),
+                                                  acc[a][b], 0, 0, 0);
+        }
+        cur ^= 1;
+    }
+    // D[row = m][col = n], row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
+    float* out = p.partial + (size_t)split * p.Mp * p.Np;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + (wn * 2 + b) * 32 + (lane & 31);
+        if (n >= p.Np) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.Mp) out[(size_t)m * p.Np + n] = acc[a][b][r];
+            }
+        }
+    }
+#endif
+}
+
+// split-K of the GEMM path: the fewest "rounds x stages" over 512 workgroup slots (2 per CU) plus the cost of writing
+// and folding ksplit partial planes; never more planes than the workspace holds
+static int wg_gemm_split(int ntiles, int K, int64_t plane_bytes, int cap) {
+    int best = 1;
+    double bt = 1e300;
+    for (int ks = 1; ks <= cap && ks <= 32; ++ks) {
+        const int kper = ((K + ks - 1) / ks + WGG_KT - 1) / WGG_KT * WGG_KT;
+        if ((int64_t)(ks - 1) * kper >= K) continue;             // an empty split
+        const double rounds = (double)(((int64_t)ntiles * ks + 511) / 512);
+        const double t = rounds * (kper / WGG_KT) * 0.45 + (double)ks * plane_bytes * 2 / 4.0e6;
+        if (t < bt) { bt = t; best = ks; }
+    }
+    return best;
+}
+
 // ksplit <= 0 in the descriptor = automatic: one workgroup per CU (MI355X: 256) over (pixel split, m-group, n-group),
 // bounded by 256 MB of partial sums.
 static const int WG_NCU = 256;
@@ -646,7 +780,35 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
             flat.B = 1; flat.Hg = flat.Hx = 1; flat.Wg = flat.Wx = (int)npx;
         }
     }
+    const bool is_flat = flat.B == 1 && flat.Hg == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_top == 0 &&
+                         d->pad_left == 0 && d->Hg == d->Hx && d->Wg == d->Wx;
     d = &flat;
+    if (is_flat && d->M >= 128 && d->N >= 128 && !getenv("SOS_WGRAD_NO_GEMM")) {
+        WgGemmParams q;
+        q.g = (const bf16_t*)d->g + d->g_off; q.x = (const bf16_t*)d->x + d->x_off; q.partial = d->partial;
+        q.K = d->Wg; q.g_cs = d->g_cs; q.x_cs = d->x_cs;
+        q.Mp = (d->M + 31) / 32 * 32; q.Np = (d->N + 31) / 32 * 32;
+        q.tiles_n = (q.Np + 127) / 128;
+        q.ntiles = ((q.Mp + 127) / 128) * q.tiles_n;
+        const int cap = d->ksplit > 0 ? d->ksplit : wg_max_split(d);
+        q.ksplit = wg_gemm_split(q.ntiles, q.K, (int64_t)q.Mp * q.Np * 4, cap);
+        q.kper = ((q.K + q.ksplit - 1) / q.ksplit + WGG_KT - 1) / WGG_KT * WGG_KT;
+        hipStream_t s = (hipStream_t)stream;
+        static sos_device_once gemm_once;
+        (void)sos_per_device_once(gemm_once, [] {
+            (void)hipFuncSetAttribute((const void*)wgrad_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WGG_BUF);
+            return (int)SOS_OK;
+        });
+        hipLaunchKernelGGL(wgrad_gemm_kernel, dim3((unsigned)(q.ntiles * q.ksplit)), dim3(256), 2 * WGG_BUF, s, q);
+        int rc = sos_check_launch("sos_conv2d_wgrad(gemm)");
+        if (rc) return rc;
+        const long long total = (long long)d->M * d->N;
+        long long gb = (total + 63) / 64;
+        if (gb > 8192) gb = 8192;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, d->partial, q.ksplit, 1, d->M, d->N,
+                           q.Mp, q.Np, d->dw, d->accumulate, d->scale, d->scale_dev);
+        return sos_check_launch("sos_conv2d_wgrad(reduce)");
+    }
     WgParams p;
     p.g = (const bf16_t*)d->g; p.x = (const bf16_t*)d->x; p.partial = d->partial;
     p.B = d->B; p.Hg = d->Hg; p.Wg = d->Wg; p.g_cs = d->g_cs; p.g_off = d->g_off;

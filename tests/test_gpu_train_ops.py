@@ -94,6 +94,10 @@ CASES = [
     ("5x5 s2 reflect", 128, 64, (5, 5), 2, (1, 1), (2, 2), "reflect", 18, 41),
     ("1x1 linear", 100, 200, (1, 1), 1, (1, 1), (0, 0), "zeros", 1, 77),
     ("3x3 narrow", 2, 64, (3, 3), 1, (1, 1), (1, 1), "reflect", 12, 19),
+    # GEMM path of the 1x1 gradients (M, N >= 128): ragged M / N tiles, pixel counts that are not multiples of the
+    # 64-pixel stage, several splits
+    ("1x1 gemm 160x256", 160, 256, (1, 1), 1, (1, 1), (0, 0), "zeros", 1, 77),
+    ("1x1 gemm 288x416 long", 288, 416, (1, 1), 1, (1, 1), (0, 0), "zeros", 7, 331),
     # 16x16x32 kernel (M, N in (32, 48], 25 or 9 taps): dense, dilated with residue classes, reflect border
     ("16: 5x5 48x48", 48, 48, (5, 5), 1, (1, 1), (2, 2), "zeros", 37, 50),
     ("16: 5x5 dil(4,4) 48x40", 48, 40, (5, 5), 1, (4, 4), (8, 8), "zeros", 30, 41),
