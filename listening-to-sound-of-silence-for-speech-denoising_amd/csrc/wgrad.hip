@@ -792,6 +792,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
         q.ntiles = ((q.Mp + 127) / 128) * q.tiles_n;
         const int cap = d->ksplit > 0 ? d->ksplit : wg_max_split(d);
         q.ksplit = wg_gemm_split(q.ntiles, q.K, (int64_t)q.Mp * q.Np * 4, cap);
+        { const char* e = getenv("SOS_WGG_SPLIT"); if (e && atoi(e) >= 1 && atoi(e) <= cap) q.ksplit = atoi(e); }
         q.kper = ((q.K + q.ksplit - 1) / q.ksplit + WGG_KT - 1) / WGG_KT * WGG_KT;
         hipStream_t s = (hipStream_t)stream;
         static sos_device_once gemm_once;
