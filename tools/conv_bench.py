@@ -45,13 +45,14 @@ def main():
         if a.only and a.only not in name:
             continue
         src = E.Act(B, H, W, cin, False, dev)
-        if os.environ.get('SOS_BENCH_ZERO'):
+        zmode = os.environ.get('SOS_BENCH_ZERO', '')      # '1': all-zero operands, 'a': zero activations, 'w': zero weights (power experiments)
+        if zmode in ('1', 'a'):
             src.t.zero_()
         else:
             src.t.normal_()
         Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
         dst = E.Act(B, Ho, Wo, E.pad_to(cout, 16), False, dev)
-        w = E.pack_weight(torch.randn(cout, cin, k[0], k[1], device=dev) * (0.0 if os.environ.get('SOS_BENCH_ZERO') else 0.05), cin, False)
+        w = E.pack_weight(torch.randn(cout, cin, k[0], k[1], device=dev) * (0.0 if zmode in ('1', 'w') else 0.05), cin, False)
         scale = torch.ones(w.shape[1], device=dev)
         shift = torch.zeros(w.shape[1], device=dev)
         pad = ((k[0] - 1) // 2 * dil[0], (k[1] - 1) // 2 * dil[1])
