@@ -40,6 +40,8 @@ typedef float fe_f32x16 __attribute__((ext_vector_type(16)));
 #define FE_IADV 61              // ISTFT: frames a workgroup advances (FE_COLS minus the ceil(win/hop) = 3 halo frames)
 #define FE_IKC 64               // ISTFT: K (re|im, bin) values staged per chunk
 #define FE_RING 4               // matrix-fragment buffers in flight per wave (= k-steps of an ISTFT chunk)
+#define FE_SWAVES 8              // STFT: waves per workgroup
+#define FE_IWAVES 16            // ISTFT: waves per workgroup (two per SIMD: the kernel is latency bound, one workgroup per CU)
 
 __device__ __forceinline__ fe_h8 fe_frag16(const uint4 v) { return __builtin_bit_cast(fe_h8, v); }
 
@@ -56,7 +58,7 @@ struct StftParams {
 
 // One workgroup = FE_COLS consecutive frames of one clip x all 2*nbins output rows; wave w owns the row tiles
 // {w, w+4, ...} (4 of the 16 for n_fft = 510) and both 32-frame column tiles.
-__global__ __launch_bounds__(256) void stft_mfma_kernel(StftParams p) {
+__global__ __launch_bounds__(FE_SWAVES * 64) void stft_mfma_kernel(StftParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* shi = (_Float16*)smem;
     _Float16* slo = shi + p.span;
@@ -71,11 +73,12 @@ __global__ __launch_bounds__(256) void stft_mfma_kernel(StftParams p) {
     const long long i0 = t0 * p.hop + (p.n_fft - p.win) / 2 - p.n_fft / 2;
     const float* wv = p.wave + b * p.wave_stride;
     // 8 independent loads in flight per thread (a plain loop issues them one L2 round trip at a time: 40 us of 55)
-    for (int m0 = tid; m0 < p.span; m0 += 8 * 256) {
+    constexpr int NTHR = FE_SWAVES * 64;
+    for (int m0 = tid; m0 < p.span; m0 += 8 * NTHR) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            long long i = i0 + m0 + u * 256;
+            long long i = i0 + m0 + u * NTHR;
             if (i < 0) i = -i;
             if (i >= ns) i = 2 * (ns - 1) - i;
             i = i < 0 ? 0 : (i >= ns ? ns - 1 : i);
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void stft_mfma_kernel(StftParams p) {
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int m = m0 + u * 256;
+            const int m = m0 + u * NTHR;
             if (m < p.span) {
                 const float x = v[u] * FE_SX;
                 const _Float16 h = (_Float16)x;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void stft_mfma_kernel(StftParams p) {
     }
     __syncthreads();
 
-    constexpr int RT = 4;                        // row tiles per wave
+    constexpr int RT = 16 / FE_SWAVES;           // row tiles per wave
     fe_f32x16 acc[RT][2];
 #pragma unroll
     for (int r = 0; r < RT; ++r)
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256) void stft_mfma_kernel(StftParams p) {
     int rt[RT];
     bool rok[RT];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) { rt[r] = wave + 4 * r; rok[r] = rt[r] < p.rtiles; if (!rok[r]) rt[r] = p.rtiles - 1; }
+    for (int r = 0; r < RT; ++r) { rt[r] = wave + FE_SWAVES * r; rok[r] = rt[r] < p.rtiles; if (!rok[r]) rt[r] = p.rtiles - 1; }
     // matrix fragments: a ring of FE_RING buffers, loaded FE_RING-1 k-steps ahead (an L2 round trip is ~3 k-steps of
     // this wave's MFMAs; with one k-step of lead every k-step stalled on it: 56 us instead of ~15 for B = 64)
     uint4 ahi[FE_RING][RT], alo[FE_RING][RT];
@@ -193,9 +196,11 @@ struct IstftParams {
 
 // One workgroup = FE_IADV*hop consecutive output samples of one clip: the (<= FE_COLS) frames that overlap them are
 // synthesised by the GEMM (rows = sample inside the frame, columns = frames), written to LDS and overlap-added.
-__global__ __launch_bounds__(256) void istft_mfma_kernel(IstftParams p) {
+__global__ __launch_bounds__(FE_IWAVES * 64) void istft_mfma_kernel(IstftParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int RT = 4;
+    constexpr int RT = 16 / FE_IWAVES, NTHR = FE_IWAVES * 64;          // row tiles per wave
+    constexpr int SW = FE_IWAVES < 8 ? FE_IWAVES : 8, SH = 8 / SW;     // waves that stage the chunk; K groups per staging thread
+    static_assert(FE_IWAVES == 4 || FE_IWAVES == 8 || FE_IWAVES == 16, "16 row-tile slots and 8 K groups per chunk are split over the waves");
     constexpr int BPITCH = FE_IKC * 2 + 16;                    // bytes per frame row of a staged K chunk (padded: banks)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -226,28 +231,29 @@ __global__ __launch_bounds__(256) void istft_mfma_kernel(IstftParams p) {
     int rt[RT];
     bool rok[RT];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) { rt[r] = wave + 4 * r; rok[r] = rt[r] < p.rtiles; if (!rok[r]) rt[r] = p.rtiles - 1; }
+    for (int r = 0; r < RT; ++r) { rt[r] = wave + FE_IWAVES * r; rok[r] = rt[r] < p.rtiles; if (!rok[r]) rt[r] = p.rtiles - 1; }
 
-    // staging: thread = (frame column tid & 63, 8-value K group tid >> 6 and + 4): coalesced reads along t
+    // staging: thread = (frame column tid & 63, 8-value K group tid >> 6 (and + 4 with 4 waves)): coalesced reads along t
     const int scol = tid & 63, sgrp = tid >> 6;
-    const bool col_ok = scol < nfr;
+    const bool col_ok = scol < nfr && sgrp < SW;
     const float* sp = p.spec + (size_t)b * 2 * p.nbins * p.T + tlo + scol;
-    float stage[2][8];
+    float stage[SH][8];
     auto load_chunk = [&](const int ch) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k0 = ch * FE_IKC + (sgrp + 4 * h) * 8;                       // row (re|im, bin) of the spectrogram
+        for (int h = 0; h < SH; ++h) {
+            const int k0 = ch * FE_IKC + ((sgrp & (SW - 1)) + SW * h) * 8;                       // row (re|im, bin) of the spectrogram
 #pragma unroll
             for (int e = 0; e < 8; ++e) stage[h][e] = col_ok ? sp[(size_t)(k0 + e) * p.T] * FE_IS : 0.f;
         }
     };
     auto store_chunk = [&]() {
+        if (sgrp >= SW) return;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < SH; ++h) {
             fe_h8 hv, lv;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { hv[e] = (_Float16)stage[h][e]; lv[e] = (_Float16)(stage[h][e] - (float)hv[e]); }
-            const int off = scol * BPITCH + (sgrp + 4 * h) * 16;
+            const int off = scol * BPITCH + (sgrp + SW * h) * 16;
             *(uint4*)(bhi + off) = __builtin_bit_cast(uint4, hv);
             *(uint4*)(blo + off) = __builtin_bit_cast(uint4, lv);
         }
@@ -326,15 +332,15 @@ __global__ __launch_bounds__(256) void istft_mfma_kernel(IstftParams p) {
     // (the squared window sits behind the frame signals), and 4 samples are in flight per thread -- the first version's
     // data-dependent loop with a global window read per term serialised ~100 round trips per thread (15 of 75 us).
     float* w2 = yf + FE_COLS * ypitch;
-    for (int n = tid; n < p.win; n += 256) w2[n] = p.win2[n];
+    for (int n = tid; n < p.win; n += NTHR) w2[n] = p.win2[n];
     __syncthreads();
     const long long jend = j0 + (long long)FE_IADV * p.hop < n_out ? j0 + (long long)FE_IADV * p.hop : n_out;
     const int ihop = p.hop;
-    for (long long jb = j0 + tid; jb < jend; jb += 4 * 256) {
+    for (long long jb = j0 + tid; jb < jend; jb += 4 * NTHR) {
         float y[4], wss[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long long j = jb + u * 256;
+            const long long j = jb + u * NTHR;
             const long long pp = j + half;
             long long tmax = (pp - lpad) / ihop;
             if (tmax > Tc - 1) tmax = Tc - 1;
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(256) void istft_mfma_kernel(IstftParams p) {
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long long j = jb + u * 256;
+            const long long j = jb + u * NTHR;
             if (j < jend) p.out[b * p.out_stride + j] = wss[u] > 1.17549435e-38f ? y[u] / wss[u] : y[u];
         }
     }
@@ -465,7 +471,7 @@ extern "C" int sos_stft_f32(const float* wave, int64_t batch, int64_t n_samples,
         return (int)SOS_OK;
     });
     dim3 grid((unsigned)((n_frames + FE_COLS - 1) / FE_COLS), (unsigned)batch);
-    hipLaunchKernelGGL(stft_mfma_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(stft_mfma_kernel, grid, dim3(FE_SWAVES * 64), lds, (hipStream_t)stream, p);
     return sos_check_launch("sos_stft_f32");
 }
 
@@ -496,6 +502,6 @@ extern "C" int sos_istft_f32(const float* spec, int64_t batch, int64_t n_frames,
         return (int)SOS_OK;
     });
     dim3 grid((unsigned)((n_out + (int64_t)FE_IADV * hop - 1) / ((int64_t)FE_IADV * hop)), (unsigned)batch);
-    hipLaunchKernelGGL(istft_mfma_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(istft_mfma_kernel, grid, dim3(FE_IWAVES * 64), lds, (hipStream_t)stream, p);
     return sos_check_launch("sos_istft_f32");
 }
