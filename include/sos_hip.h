@@ -164,6 +164,12 @@ typedef struct sos_conv_desc {
     const int32_t* wl_tab;
     const int32_t* wo_tab;
     int32_t w_gather_stride;
+    /* optional TEMPORAL taps (Conv3d with temporal stride 1 and padding (kt-1)/2, M1/networks.py:54-77: the audio-visual
+     * variant's video branch): the B images are clips of t_frames consecutive frames and the contraction also runs over
+     * t_taps neighbouring frames, image b reading frames b + dt - t_pad (dt < t_taps) of ITS clip, zeros outside the
+     * clip.  The contraction index is (range s < in_nseg, dt, channel): weights [kh*kw][cout_pad][in_nseg*t_taps*cin].
+     * t_taps <= 1: plain 2-D convolution.  Replaces a materialised time-stacked input (sos_time_stack). */
+    int32_t t_frames, t_taps, t_pad;
 } sos_conv_desc;
 
 int sos_conv2d_fwd(const sos_conv_desc* desc /* host pointer */, sos_stream_t stream);
@@ -262,6 +268,10 @@ typedef struct sos_wgrad_desc {
     int32_t accumulate;     /* 0: dw = result, 1: dw += result */
     float scale;
     const float* scale_dev; /* optional device scalar multiplied into `scale` (1 / loss scale of the fp16 mode) */
+    /* optional TEMPORAL taps (see sos_conv_desc): N = t_taps * t_cin columns, column n = dt * t_cin + c pairs image b of
+     * G with channel c of frame b + dt - t_pad of X (same clip of t_frames frames, zeros outside); t_cin % 128 == 0.
+     * t_taps <= 1: off. */
+    int32_t t_frames, t_taps, t_pad, t_cin;
 } sos_wgrad_desc;
 int64_t sos_wgrad_workspace_bytes(const sos_wgrad_desc* desc);
 int sos_conv2d_wgrad(const sos_wgrad_desc* desc, sos_stream_t stream);

@@ -33,6 +33,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32), ("act_param", C.c_void_p), ("accumulate", C.c_int32),
         ("stats", C.c_void_p), ("stats_c", C.c_int32),
         ("wl_tab", C.c_void_p), ("wo_tab", C.c_void_p), ("w_gather_stride", C.c_int32),
+        ("t_frames", C.c_int32), ("t_taps", C.c_int32), ("t_pad", C.c_int32),
     ]
 
 
@@ -49,7 +50,8 @@ class WgradDesc(C.Structure):
                 ("x_off", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
                 ("stride", C.c_int32), ("dil_h", C.c_int32), ("dil_w", C.c_int32), ("pad_top", C.c_int32),
                 ("pad_left", C.c_int32), ("pad_mode", C.c_int32), ("ksplit", C.c_int32), ("partial", C.c_void_p),
-                ("dw", C.c_void_p), ("accumulate", C.c_int32), ("scale", C.c_float), ("scale_dev", C.c_void_p)]
+                ("dw", C.c_void_p), ("accumulate", C.c_int32), ("scale", C.c_float), ("scale_dev", C.c_void_p),
+                ("t_frames", C.c_int32), ("t_taps", C.c_int32), ("t_pad", C.c_int32), ("t_cin", C.c_int32)]
 
 
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double

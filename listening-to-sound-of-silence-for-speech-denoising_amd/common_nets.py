@@ -59,6 +59,11 @@ def make_video_branch(kernel_sizes, strides, nf=256, outf=256):
     return nn.Sequential(*blocks)
 
 
+# SOS_VIDEO_STACK=1: materialise the time-stacked input of every Conv3dBlock (sos_time_stack) instead of the conv kernel's
+# temporal taps (A/B timing, and the path the round-1 goldens were first checked on)
+NO_TEMPORAL_TAPS = __import__("os").environ.get("SOS_VIDEO_STACK") == "1"
+
+
 def video_plan(enc, x3):
     """Per Conv3dBlock: the (O, I, kt, kh, kw) weight as a 2-D conv weight over the time-stacked input
     (contraction index dt*I + i, csrc/video.hip), packed like every other conv weight; eval BatchNorm3d folded."""
@@ -79,13 +84,25 @@ def video_plan(enc, x3):
 
 
 def run_video_branch(plan, frames, B, T, feat, feat_row, feat_third, feat_c_off, x3):
-    """frames: Act [B*T, H, W, 16] (3 real channels).  Every block = time stack (kt > 1) + one 2-D conv with the
-    folded BN + ReLU epilogue; the last block's output is averaged over (H, W) into the feature matrix
-    feat[b][t][feat_c_off + c] (torch.mean(f_v, dim=(-2,-1)) + the channel concat, M1/networks.py:136,141)."""
+    """frames: Act [B*T, H, W, 16] (3 real channels).  Every block = one conv with the folded BN + ReLU epilogue whose
+    contraction runs over the kt neighbouring frames inside the kernel (temporal taps of sos_conv_desc); only the first
+    block (3 channels per frame: 5 frames packed into 16 channels) reads a materialised time stack.  The last block's
+    output is averaged over (H, W) into the feature matrix feat[b][t][feat_c_off + c] (torch.mean(f_v, dim=(-2,-1)) +
+    the channel concat, M1/networks.py:136,141)."""
     dev = frames.t.device
     cur, C = frames, 3
     for lp in plan:
         H, W = cur.H, cur.W
+        native = lp["kt"] > 1 and C % 16 == 0 and cur.cs == C and lp["cin_store"] == lp["kt"] * C and not NO_TEMPORAL_TAPS
+        if native:
+            s = lp["stride"]
+            Ho = (H + 2 * lp["pad"][0] - lp["kh"]) // s + 1
+            Wo = (W + 2 * lp["pad"][1] - lp["kw"]) // s + 1
+            dst = E.Act(B * T, Ho, Wo, E.pad_to(lp["cout"], 16), x3, dev)
+            E.conv_to_act(cur, 0, C, lp["w"], lp["kh"], lp["kw"], lp["cout"], lp["scale"], lp["shift"], L.ACT_RELU, dst,
+                          cout_store=dst.cs, stride=s, pad=lp["pad"], Ho=Ho, Wo=Wo, temporal=(T, lp["kt"]))
+            cur, C = dst, lp["cout"]
+            continue
         if lp["kt"] > 1 or cur.cs != lp["cin_store"]:
             st = E.Act(B * T, H, W, lp["cin_store"], x3, dev)
             L.check(L.lib().sos_time_stack(L.ptr(cur.t), B, T, H * W, C, cur.cs, cur.nseg, lp["kt"], L.ptr(st.t),

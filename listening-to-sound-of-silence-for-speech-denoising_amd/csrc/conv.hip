@@ -47,6 +47,7 @@ struct ConvParams {
     const float* slope;
     const int* wgather;
     int B, H, W, Wl, in_cs, cin_off, cin, ktot, cps, seg_stride;
+    int tT, tk, tpad;       // temporal taps: frames per clip, taps, temporal padding (1, 1, 0: plain 2-D conv)
     int kh, kw, cout, cout_pad, cout_store;
     int stride, dh, dw, pad_t, pad_l, pad_mode;
     int Ho, Wo;
@@ -388,16 +389,22 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
     // lane t: patch byte offset of tap t (<= 64 taps; validated on the host) -- one v_readlane per tap instead of
     // scalar row/column bookkeeping
     const int tapoff = ((min(lane, ntaps - 1) / p.kw) * p.PW + (min(lane, ntaps - 1) % p.kw)) * PSTRIDE;
-    const long long in_b = (long long)b * p.H * p.W;
+    // temporal taps: the buffer resource spans the image's whole CLIP (tT frames), a chunk of temporal tap dt reads frame
+    // tfr + dt - tpad; frames before / behind the clip fall outside the resource's range and are read as zeros
+    const int tfr = b % p.tT;
+    const long long frame_elems = (long long)p.H * p.W * p.in_cs;
+    const long long in_b = (long long)(b - tfr) * p.H * p.W;
     const __amdgpu_buffer_rsrc_t in_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + in_b * p.in_cs), 0, (unsigned)(p.H * p.W * p.in_cs) * 2u, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + in_b * p.in_cs), 0, (unsigned)(p.tT * frame_elems) * 2u, 0x00020000);
     build_pixel_table(p, pixtab, tid, hin0, win0, rw0, Wl, wgather);
 
     for (int cc = 0; cc < p.nchunks; ++cc) {
         __syncthreads();   // everyone is done reading the previous chunk's patch / weight buffers
         // ---- stage the input patch of this channel chunk (the first barrier above also publishes the pixel table)
         if (!CDBG(1)) {
-            const long long cbase = (long long)p.cin_off + (long long)(cc / p.cps) * p.seg_stride + (long long)(cc % p.cps) * KC;
+            const int seg = cc / p.cps;            // (channel range, temporal tap)
+            const long long cbase = (long long)p.cin_off + (long long)(seg / p.tk) * p.seg_stride + (long long)(cc % p.cps) * KC +
+                                    (long long)(tfr + seg % p.tk - p.tpad) * frame_elems;
             stage_patch_dma<CPR>(p, patch, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc,
                                  (unsigned)(cbase * 2));
         }
@@ -894,8 +901,11 @@ static size_t lds_bytes(int npix, int nt, int ks) {           // ks >= 100: sing
 
 // the 16-row kernel (conv16_kernel) handles: one bf16 channel segment of 16 or 48 channels, bf16 NHWC output,
 // cout <= 16 or 33..48 (i.e. shapes where tiles of 32 output channels waste MFMA rows)
+// contracted channel ranges: hi|hi|lo thirds x temporal taps
+static inline int nseg_eff(const sos_conv_desc* d) { return d->in_nseg * (d->t_taps > 1 ? d->t_taps : 1); }
+
 static int nt16_for(const sos_conv_desc* d) {
-    if (d->in_nseg != 1 || d->out_dtype != SOS_DT_BF16 || d->out_sc != 1 || (d->cin != 16 && d->cin != 48)) return 0;
+    if (d->in_nseg != 1 || d->t_taps > 1 || d->out_dtype != SOS_DT_BF16 || d->out_sc != 1 || (d->cin != 16 && d->cin != 48)) return 0;
     if (d->cout <= 16) return 1;
     if (d->cout > 32 && d->cout <= 48) return 3;
     return 0;
@@ -954,7 +964,7 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
                 if (k16 % ks) continue;
                 const size_t lds = lds_bytes(npix, nt, ks);
                 if (lds > LDS_LIMIT) continue;
-                const int nchunks = d->in_nseg * k16 / ks;
+                const int nchunks = nseg_eff(d) * k16 / ks;
                 double per_block = 256.0 * taps * nchunks * ks + 3.0 * npix * nchunks * ks + 40.0 * nchunks * (6 + taps);
                 if (lds > LDS_LIMIT / 2) per_block *= 1.3;     // a lone workgroup per CU hides nothing
                 out.push_back({NC, lth, ltw, ks, blocks * per_block});
@@ -983,7 +993,7 @@ struct ShapeKey {
 
 static ShapeKey shape_key(const sos_conv_desc* d) {
     ShapeKey k;
-    const int vals[19] = {d->B, d->H, d->W, d->Wl, d->cin, d->in_nseg, d->cout_pad, d->kh, d->kw, d->stride, d->dil_h,
+    const int vals[19] = {d->B, d->H, d->W, d->Wl, d->cin, nseg_eff(d), d->cout_pad, d->kh, d->kw, d->stride, d->dil_h,
                           d->dil_w, d->Ho, d->Wo, d->out_dtype, d->out_sc == 1 ? 1 : 0, d->pad_mode, d->w_gather ? 1 : 0,
                           d->cout};
     memcpy(k.v, vals, sizeof(vals));
@@ -1057,6 +1067,15 @@ static int validate(const sos_conv_desc* d) {
                       d->cin, d->in_cs, d->cin_off, d->cout, d->cout_pad, d->kh, d->kw, d->stride, d->dil_h, d->dil_w);
         return SOS_EINVAL;
     }
+    if (d->t_taps > 1) {
+        const long long frame_bytes = (long long)d->H * d->W * d->in_cs * 2;
+        if (d->t_frames < 1 || d->B % d->t_frames || d->t_pad < 0 || d->t_pad >= d->t_taps || d->w_gather || d->wl_tab ||
+            (d->t_frames + d->t_taps) * frame_bytes >= 0xffffff00ll) {
+            sos_set_error("sos_conv2d_fwd: bad temporal taps (B=%d frames=%d taps=%d pad=%d; a clip plus the temporal halo "
+                          "must stay below 4 GB)", d->B, d->t_frames, d->t_taps, d->t_pad);
+            return SOS_EINVAL;
+        }
+    }
     if (d->stats && (d->out_dtype == SOS_DT_F32 || d->out_sc != 1 || d->stats_c < 1 || d->stats_c > d->cout_pad || d->accumulate)) {
         sos_set_error("sos_conv2d_fwd: fused statistics need a dense bf16 NHWC output without accumulation");
         return SOS_EINVAL;
@@ -1124,8 +1143,9 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     p.PH = (TH - 1) * d->stride + d->kh; p.PW = (TW - 1) * d->stride + d->kw;
     p.npix = p.NC * p.PH * p.PW;
     p.cps = c.ks > 0 ? d->cin / (16 * (ks_enc % 100)) : 1;
-    p.nchunks = p.cps * d->in_nseg;
-    p.ktot = d->cin * d->in_nseg;
+    p.nchunks = p.cps * nseg_eff(d);
+    p.ktot = d->cin * nseg_eff(d);
+    p.tk = d->t_taps > 1 ? d->t_taps : 1; p.tT = d->t_taps > 1 ? d->t_frames : 1; p.tpad = d->t_taps > 1 ? d->t_pad : 0;
     p.seg_stride = d->in_seg_stride;
     p.tiles_h = (Hc + TH - 1) / TH; p.tiles_w = (Wc + TW - 1) / TW; p.ngw = (d->dil_w + p.NC - 1) / p.NC;
     const long long nblk = (long long)d->B * d->dil_h * p.tiles_h * p.ngw * p.tiles_w;

@@ -20,6 +20,6 @@ int sos_check_launch(const char* what) {
     return SOS_OK;
 }
 
-extern "C" int sos_abi_version(void) { return 2; }
+extern "C" int sos_abi_version(void) { return 3; }
 extern "C" const char* sos_storage_dtype(void) { return SOS_STORAGE_NAME; }
 extern "C" const char* sos_last_error(void) { return g_err; }

@@ -49,6 +49,7 @@ struct WgParams {
     int dbuf;                 // two operand buffers: the next tile is fetched while this one is multiplied
     int dbg;                  // SOS_WGRAD_DBG ablation mask (0 in production)
     int ny, nz, xcdmap;       // m-groups / n-groups of the 1-D grid (wgrad_kernel), XCD-aware id mapping on/off
+    int tT, tcin, tpad;       // temporal taps (tT = 0: off): frames per clip, channels per frame, temporal padding
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -99,6 +100,7 @@ struct WgStage {
     int TH, TW, xspan_h, xspan_w;
     unsigned gimg_bytes, ximg_bytes;
     bool reflect;
+    int dtoff;                                    // temporal taps: frame offset of this workgroup's X columns
 
     __device__ __forceinline__ WgStage(const WgParams& p_, char* smem_, int tid, int gsub, int xsub, int m0, int n0)
         : p(p_), smem(smem_) {
@@ -112,9 +114,13 @@ struct WgStage {
         ninstr = (npieces + 63) >> 6;
         tab = (unsigned)(uintptr_t)smem + (unsigned)p.bufbytes * (p.dbuf ? 2 : 1);
         glim = min(p.M - m0, p.g_cs - p.g_off - m0 - 7);
-        xlim = min(p.N - n0, p.x_cs - p.x_off - n0 - 7);
+        // temporal taps: column n = dt * tcin + c is channel c of the frame dt - tpad away (an n-group never straddles two
+        // frames: tcin is a multiple of the widest n-group)
+        const int nc = p.tT ? n0 % p.tcin : n0;
+        dtoff = p.tT ? n0 / p.tcin - p.tpad : 0;
+        xlim = p.tT ? min(p.tcin - nc, p.x_cs - p.x_off - nc - 7) : min(p.N - n0, p.x_cs - p.x_off - n0 - 7);
         gq = (unsigned)(p.g_off + m0 + q8) * 2;
-        xq = (unsigned)(p.x_off + n0 + q8) * 2;
+        xq = (unsigned)(p.x_off + nc + q8) * 2;
         TH = 1 << p.logTH; TW = 1 << p.logTW;
         xspan_h = (p.PH - 1) * p.dh; xspan_w = (p.NC - 1) * p.stride + (p.PW - 1) * p.dw;
         gimg_bytes = (unsigned)p.Hg * p.Wg * p.g_cs * 2; ximg_bytes = (unsigned)p.Hx * p.Wx * p.x_cs * 2;
@@ -154,7 +160,13 @@ struct WgStage {
         o.xslow = reflect && !o.xfast;
         o.gfast = o.gh0 + (TH - 1) * p.dh < p.Hg && o.gw0 + (p.NC - 1) + (TW - 1) * p.dw < p.Wg;
         o.rg = __builtin_amdgcn_make_buffer_rsrc((void*)(p.g + (size_t)t * p.Hg * p.Wg * p.g_cs), 0, gimg_bytes, 0x00020000);
-        o.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)t * p.Hx * p.Wx * p.x_cs), 0, ximg_bytes, 0x00020000);
+        int xi = t;
+        unsigned xbytes = ximg_bytes;
+        if (p.tT) {                      // the frame dtoff away, inside the same clip; outside: an empty resource (all zeros)
+            const int fr = t % p.tT + dtoff;
+            if (fr < 0 || fr >= p.tT) xbytes = 0u; else xi = t + dtoff;
+        }
+        o.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)xi * p.Hx * p.Wx * p.x_cs), 0, xbytes, 0x00020000);
         return o;
     }
     // sub-image index of X piece l (wave-uniform)
@@ -771,16 +783,23 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
         sos_set_error("sos_conv2d_wgrad: bad descriptor");
         return SOS_EINVAL;
     }
+    const bool temporal = d->t_taps > 1;
+    if (temporal && (d->t_frames < 1 || d->B % d->t_frames || d->t_cin < 128 || d->t_cin % 128 || d->N != d->t_taps * d->t_cin ||
+                     d->t_pad < 0 || d->t_pad >= d->t_taps || d->x_off + d->t_cin > d->x_cs)) {
+        sos_set_error("sos_conv2d_wgrad: bad temporal taps (B=%d frames=%d taps=%d cin=%d N=%d)", d->B, d->t_frames, d->t_taps,
+                      d->t_cin, d->N);
+        return SOS_EINVAL;
+    }
     // 1x1 kernels (Linear layers, LSTM projections): the pixel arrays of G and X are congruent, so the batch
     // is one long row -- full 256-pixel tiles instead of one ragged tile per (short) image.
     sos_wgrad_desc flat = *d;
-    if (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_top == 0 && d->pad_left == 0 && d->Hg == d->Hx && d->Wg == d->Wx) {
+    if (!temporal && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_top == 0 && d->pad_left == 0 && d->Hg == d->Hx && d->Wg == d->Wx) {
         const uint64_t npx = (uint64_t)d->B * d->Hg * d->Wg;
         if (npx * (uint64_t)d->g_cs * 2 < 0xfff00000ull && npx * (uint64_t)d->x_cs * 2 < 0xfff00000ull) {
             flat.B = 1; flat.Hg = flat.Hx = 1; flat.Wg = flat.Wx = (int)npx;
         }
     }
-    const bool is_flat = flat.B == 1 && flat.Hg == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_top == 0 &&
+    const bool is_flat = !temporal && flat.B == 1 && flat.Hg == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_top == 0 &&
                          d->pad_left == 0 && d->Hg == d->Hx && d->Wg == d->Wx;
     d = &flat;
     if (is_flat && d->M >= 128 && d->N >= 128 && !getenv("SOS_WGRAD_NO_GEMM")) {
@@ -817,6 +836,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     p.M = d->M; p.N = d->N; p.Mp = (d->M + 31) / 32 * 32; p.Np = (d->N + 31) / 32 * 32;
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.dh = d->dil_h; p.dw = d->dil_w;
     p.pad_t = d->pad_top; p.pad_l = d->pad_left; p.pad_mode = d->pad_mode;
+    p.tT = temporal ? d->t_frames : 0; p.tcin = temporal ? d->t_cin : 0; p.tpad = temporal ? d->t_pad : 0;
     const int taps = d->kh * d->kw;
     if (taps > WG_WAVES * WG_PAIRS) { sos_set_error("sos_conv2d_wgrad: kernel with %d taps not supported", taps); return SOS_ENOSPC; }
     int ntb = WG_WAVES * WG_PAIRS / taps;         // (tap, n-tile) pairs per workgroup <= 32
@@ -832,7 +852,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     }
     // small channel counts: the 16x16x32 kernel owns all of dW in one workgroup (no padding to 32)
     const int m16 = (d->M + 15) / 16, n16 = (d->N + 15) / 16;
-    const bool use16 = m16 == 3 && n16 == 3 && (taps == 25 || taps == 9) && !getenv("SOS_WGRAD_NO16");
+    const bool use16 = !temporal && m16 == 3 && n16 == 3 && (taps == 25 || taps == 9) && !getenv("SOS_WGRAD_NO16");
     // pixel tile (NC x TH x TW = 256): fewest k-steps among the shapes whose operands fit LDS (double
     // buffered, <= 16 DMA slots, if possible); shrink the channel tile if none fits
     const size_t lds_max = 160 * 1024;

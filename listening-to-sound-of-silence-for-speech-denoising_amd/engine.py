@@ -311,10 +311,12 @@ def fold_bn(bn, cout_pad):
 def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dtype, sb, sh, sw, sc,
          Ho, Wo, c_off=0, cout_store=None, third=0, stride=1, dil=(1, 1), pad=(0, 0), pad_mode=L.PAD_ZERO,
          slope=None, w_gather=None, out_elem_offset=0, in_dims=None, accumulate=False, stats_c=0, wl_tab=None,
-         wo_tab=None, wg_stride=0, valid_cols=None):
+         wo_tab=None, wg_stride=0, valid_cols=None, temporal=None):
     """Fill a sos_conv_desc and enqueue sos_conv2d_fwd.  `src` is an Act (or a (tensor,B,H,W,cs,nseg)
     view described by in_dims).  stats_c > 0: also return the fused BatchNorm partial sums of the first stats_c
-    output channels as (partial [tiles][2][stats_c], tiles) for sos_bn_finalize."""
+    output channels as (partial [tiles][2][stats_c], tiles) for sos_bn_finalize.  temporal = (frames per clip, kt): the
+    B images are clips of consecutive frames and the contraction also runs over kt neighbouring frames (Conv3d with
+    temporal stride 1, padding (kt - 1) // 2); `cin` stays the channels of ONE frame."""
     d = L.ConvDesc()
     if in_dims is None:
         t, B, H, W, cs, nseg = src.t, src.B, src.H, src.W, src.cs, src.nseg
@@ -346,12 +348,14 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
     d.act = act
     d.act_param = slope.data_ptr() if slope is not None else None
     d.accumulate = 1 if accumulate else 0
+    if temporal is not None and temporal[1] > 1:
+        d.t_frames, d.t_taps, d.t_pad = temporal[0], temporal[1], (temporal[1] - 1) // 2
     if wl_tab is not None:                # ragged batch: per-image logical input width / valid output width (sos_hip.h)
         d.wl_tab, d.wo_tab, d.w_gather_stride = wl_tab.data_ptr(), wo_tab.data_ptr(), wg_stride
     _load_tune_cache()
     if AUTOTUNE:
         key = (B, H, W, d.Wl, cin, d.in_nseg, d.cout_pad, cout, kh, kw, stride, dil, Ho, Wo, out_dtype, sc == 1, pad_mode,
-               w_gather is not None)
+               w_gather is not None, d.t_taps)
         if key not in _tuned and not torch.cuda.is_current_stream_capturing():
             _tuned.add(key)
             if accumulate:
@@ -369,8 +373,9 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
     if PROFILER is not None:
         # ragged batches: only the clips' own columns are algorithmic work (valid_cols = their sum)
         cols = B * Wo if valid_cols is None else valid_cols
-        sig = ("conv", kh, kw, dil[0], dil[1], stride, d.in_nseg * cin, cout, B, Ho, Wo) + (() if valid_cols is None else ("ragged", cols))
-        end = PROFILER.bracket(sig, 2.0 * Ho * cols * cout * d.in_nseg * cin * kh * kw)
+        kin = d.in_nseg * max(1, d.t_taps) * cin
+        sig = ("conv", kh, kw, dil[0], dil[1], stride, kin, cout, B, Ho, Wo) + (() if valid_cols is None else ("ragged", cols))
+        end = PROFILER.bracket(sig, 2.0 * Ho * cols * cout * kin * kh * kw)
     stats = None
     if stats_c:
         tiles = L.lib().sos_conv2d_tile_count(C.byref(d))
@@ -575,10 +580,11 @@ _wg_ws = {}
 
 
 def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0, 0), pad_mode=L.PAD_ZERO,
-          accumulate=False, scale=1.0, gs=None):
+          accumulate=False, scale=1.0, gs=None, temporal=None):
     """dw[m][n][a][b] (+)= scale * sum_p G[p][m] X[p*stride + (a,b)*dil - pad][n] (sos_conv2d_wgrad).
     g, x: Act.  In bf16x3 mode the product (g_hi+g_lo)(x_hi+x_lo) is taken as hi*hi + hi*lo + lo*hi
-    with three accumulating passes over the thirds."""
+    with three accumulating passes over the thirds.  temporal = (frames per clip, kt, channels per frame): column
+    n = dt * channels + c pairs image b of G with channel c of frame b + dt - (kt - 1) // 2 of X (sos_wgrad_desc)."""
     import ctypes
     dev = g.t.device
     gs = cur_gs() if gs is None else gs
@@ -590,6 +596,8 @@ def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0,
         d.x, d.Hx, d.Wx, d.x_cs, d.x_off = x.t.data_ptr(), x.H, x.W, x.nseg * x.cs, x_off + xt * x.cs
         d.M, d.N, d.kh, d.kw, d.stride, d.dil_h, d.dil_w = M, N, kh, kw, stride, dil[0], dil[1]
         d.pad_top, d.pad_left, d.pad_mode = pad[0], pad[1], pad_mode
+        if temporal is not None and temporal[1] > 1:
+            d.t_frames, d.t_taps, d.t_pad, d.t_cin = temporal[0], temporal[1], (temporal[1] - 1) // 2, temporal[2]
         npix = g.B * g.H * g.W
         d.ksplit = 0                               # automatic pixel-range split (one workgroup per CU)
         need = L.lib().sos_wgrad_workspace_bytes(ctypes.byref(d))

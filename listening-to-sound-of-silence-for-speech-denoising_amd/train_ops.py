@@ -172,6 +172,7 @@ def _phase_dgrad_weights(w2, s, pad, cout_cs, x3):
 
 
 def video_train_plan(enc, x3):
+    from .common_nets import NO_TEMPORAL_TAPS
     plan = []
     for blk in enc:
         conv, bn = blk.block[0], blk.block[1]
@@ -183,7 +184,18 @@ def video_train_plan(enc, x3):
         lp = dict(w=E.pack_weight(w2, cin_store, x3), conv=conv, bn=bn, kt=kt, kh=kh, kw=kw, stride=s, pad=pad, cin=I,
                   cout=O, cin_store=cin_store)
         cout_cs = E.pad_to(O, 16)
-        if s == 1:
+        # temporal taps inside the kernels (no materialised time stack) for the blocks whose frames hold whole 128-channel
+        # groups and whose weight gradient is one wgrad call (stride <= 2)
+        lp["native"] = kt > 1 and I % 128 == 0 and O % 16 == 0 and s <= 2 and not NO_TEMPORAL_TAPS
+        if lp["native"]:
+            # data gradient: dx[t] = sum_dt corr(dy[t + tpad - dt], w[:, :, dt]) -- a conv over dy with temporal taps
+            # s' = kt - 1 - dt, written as the "forward" weight (kt*O, I, kh, kw) whose data-gradient transform is taken
+            w2n = conv.weight.detach().flip(2).permute(2, 0, 1, 3, 4).reshape(kt * O, I, kh, kw)
+            if s == 1:
+                lp["wd"] = dgrad_weight(w2n, x3)
+            else:
+                lp["wd_phases"] = _phase_dgrad_weights(w2n, s, pad, kt * cout_cs, x3)
+        elif s == 1:
             lp["wd"] = dgrad_weight(w2, x3)
         else:
             lp["wd_phases"] = _phase_dgrad_weights(w2, s, pad, cout_cs, x3)
@@ -200,7 +212,9 @@ def video_forward_train(plan, frames, B, T, feat, feat_row, feat_third, feat_c_o
     for lp in plan:
         H, W = cur.H, cur.W
         st = cur
-        if lp["kt"] > 1 or cur.cs != lp["cin_store"]:
+        if lp["native"]:
+            st = None
+        elif lp["kt"] > 1 or cur.cs != lp["cin_store"]:
             st = E.Act(B * T, H, W, lp["cin_store"], x3, dev)
             L.check(L.lib().sos_time_stack(L.ptr(cur.t), B, T, H * W, C, cur.cs, cur.nseg, lp["kt"], L.ptr(st.t), st.cs,
                                            L.stream_ptr()), "sos_time_stack")
@@ -210,8 +224,12 @@ def video_forward_train(plan, frames, B, T, feat, feat_row, feat_third, feat_c_o
         cs = E.pad_to(lp["cout"], 16)
         one, zero = ones_zeros(lp["w"].shape[1], dev)
         raw = E.Act(B * T, Ho, Wo, cs, x3, dev)
-        E.conv_to_act(st, 0, lp["cin_store"], lp["w"], lp["kh"], lp["kw"], lp["cout"], one, zero, L.ACT_NONE, raw,
-                      cout_store=cs, stride=s, pad=lp["pad"], Ho=Ho, Wo=Wo)
+        if lp["native"]:
+            E.conv_to_act(cur, 0, C, lp["w"], lp["kh"], lp["kw"], lp["cout"], one, zero, L.ACT_NONE, raw,
+                          cout_store=cs, stride=s, pad=lp["pad"], Ho=Ho, Wo=Wo, temporal=(T, lp["kt"]))
+        else:
+            E.conv_to_act(st, 0, lp["cin_store"], lp["w"], lp["kh"], lp["kw"], lp["cout"], one, zero, L.ACT_NONE, raw,
+                          cout_store=cs, stride=s, pad=lp["pad"], Ho=Ho, Wo=Wo)
         y = E.Act(B * T, Ho, Wo, cs, x3, dev, zero=cs > E.pad_to(lp["cout"], 8))
         saved = E.bn_train(raw, 0, lp["cout"], lp["bn"], L.ACT_RELU, None, y, 0)
         tape.append(dict(src=cur, src_C=C, stacked=st, raw=raw, saved=saved))
@@ -239,7 +257,11 @@ def video_backward(plan, tape, dfeat, f_row, f_third, f_c_off, grads, prefix, B,
         grads[f"{prefix}.{i}.block.1.weight"], grads[f"{prefix}.{i}.block.1.bias"] = dgamma, dbeta
         kt, I, O = lp["kt"], lp["cin"], lp["cout"]
         dw2 = torch.empty((O, kt * I, lp["kh"], lp["kw"]), dtype=torch.float32, device=dev)
-        if lp["stride"] >= 3:
+        if lp["native"]:
+            src = tp["src"]
+            E.wgrad(d_raw, 0, O, src, 0, kt * I, lp["kh"], lp["kw"], dw2, stride=lp["stride"], pad=lp["pad"],
+                    temporal=(T, kt, I))
+        elif lp["stride"] >= 3:
             # stride 3 (the two smallest feature maps): the wgrad kernel's pixel tile would need a 9x patch; gather the
             # pixels each tap touches (a strided view of the zero-padded input, layout plumbing) and run 1x1 wgrads
             sd_, (ph_, pw_) = lp["stride"], lp["pad"]
@@ -261,6 +283,28 @@ def video_backward(plan, tape, dfeat, f_row, f_third, f_c_off, grads, prefix, B,
         grads[f"{prefix}.{i}.block.0.weight"] = dw2.reshape(O, kt, I, lp["kh"], lp["kw"]).permute(0, 2, 1, 3, 4).contiguous()
         if i == 0:
             break
+        if lp["native"]:
+            # data gradient straight onto the frames: conv over d_raw with (flipped) temporal taps
+            src = tp["src"]
+            dx = E.Act(src.B, src.H, src.W, src.cs, x3, dev, zero=lp["stride"] > 1)
+            if lp["stride"] == 1:
+                one, zero = ones_zeros(lp["wd"].shape[1], dev)
+                E.conv_to_act(d_raw, 0, d_raw.cs, lp["wd"], lp["kh"], lp["kw"], I, one, zero, L.ACT_NONE, dx,
+                              cout_store=dx.cs, pad=(lp["kh"] - 1 - lp["pad"][0], lp["kw"] - 1 - lp["pad"][1]), Ho=src.H, Wo=src.W,
+                              temporal=(T, kt))
+            else:
+                s = lp["stride"]
+                row = dx.nseg * dx.cs
+                for (rh, rw), (w, Mh, Mw, ph, pw) in lp["wd_phases"].items():
+                    Hp, Wp = (src.H - rh + s - 1) // s, (src.W - rw + s - 1) // s
+                    if Hp < 1 or Wp < 1:
+                        continue
+                    one, zero = ones_zeros(w.shape[1], dev)
+                    E.conv(d_raw, 0, d_raw.cs, w, Mh, Mw, I, one, zero, L.ACT_NONE, out=dx.t, out_dtype=dx.dtype_code,
+                           sb=dx.H * dx.W * row, sh=s * dx.W * row, sw=s * row, sc=1, cout_store=dx.cs, third=dx.cs,
+                           pad=(ph, pw), Ho=Hp, Wo=Wp, out_elem_offset=(rh * dx.W + rw) * row, temporal=(T, kt))
+            dy = dx
+            continue
         d_st = E.Act(st.B, st.H, st.W, st.cs, x3, dev, zero=lp["stride"] > 1 or st.cs > E.pad_to(kt * I, 8))
         if lp["stride"] == 1:
             one, zero = ones_zeros(lp["wd"].shape[1], dev)

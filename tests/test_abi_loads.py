@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(precision, storage):
     for name in declared:
         assert hasattr(h, name), f"{name} declared in sos_hip.h but not exported"
     assert set(_lib.SIGNATURES) | {"sos_last_error"} == declared
-    assert h.sos_abi_version() == 2
+    assert h.sos_abi_version() == 3
     assert h.sos_storage_dtype() == storage
 
 
@@ -43,7 +43,7 @@ def test_tune_table_load_rejects_foreign_and_illegal_entries(tmp_path):
     assert h.sos_conv2d_tune_load(str(bad).encode()) < 0
     shape = "64 256 178 178 96 1 96 5 5 1 1 1 256 178 0 1 0 0 96"
     mixed = tmp_path / "mixed.txt"
-    mixed.write_text("sos_conv_tune 2 abi 2 nkey 19\n"
+    mixed.write_text("sos_conv_tune 2 abi 3 nkey 19\n"
                      f"{shape} 1 4 4 6\n"            # legal: 16x16 pixels, 6 k-steps per chunk
                      f"{shape} 1 4 4 7\n"            # 7 does not divide cin/16
                      f"{shape} 4 2 4 6\n"            # 4 residue classes need dil_w >= 4
