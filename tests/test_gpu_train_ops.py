@@ -141,3 +141,59 @@ def test_conv_transpose_weight_grad():
     dw = torch.empty(Cin, Cout, 3, 3, dtype=torch.float32, device="cuda")
     E.wgrad(xa, 0, Cin, ga, 0, Cout, 3, 3, dw, stride=2, pad=(1, 1))
     assert rel_err(dw.cpu(), w.grad) < 1e-3
+
+
+# ---------------------------------------------------------------------------- temporal taps (Conv3d) inside the kernels
+def _frames_act(x5, x3):
+    """f32 (B, C, T, H, W) -> Act of B*T frames [B*T, H, W, C] (+ the values it holds, same shape as x5)."""
+    B, Cc, T, H, W = x5.shape
+    a, held = _act_from_nchw(x5.permute(0, 2, 1, 3, 4).reshape(B * T, Cc, H, W), x3, cs=Cc)
+    return a, held.reshape(B, T, Cc, H, W).permute(0, 2, 1, 3, 4).contiguous()
+
+
+@pytest.mark.parametrize("x3", [False, True])
+@pytest.mark.parametrize("kt,stride", [(5, 1), (3, 2)])
+def test_temporal_taps_conv_and_gradients_match_conv3d(kt, stride, x3):
+    """sos_conv_desc / sos_wgrad_desc temporal taps = nn.Conv3d(I, O, (kt,3,3), stride (1,s,s), padding ((kt-1)/2,1,1))
+    (M1/networks.py:54-77) on clips of T frames: forward, weight gradient and data gradient against torch autograd, with
+    clips short enough (T = 4) that most frames touch the temporal padding."""
+    from sos_amd import engine as E, _lib as L, train_ops as TO
+    B, T, I, O, H, W = 2, 4, 128, 32, 9, 11
+    x = torch.from_numpy(hashed(71, (B, I, T, H, W)).astype(np.float32))
+    xa, xheld = _frames_act(x, x3)
+    w = torch.from_numpy((0.05 * hashed(72, (O, I, kt, 3, 3))).astype(np.float32))
+    xr = xheld.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y = F.conv3d(xr, wr, None, (1, stride, stride), ((kt - 1) // 2, 1, 1))
+    Ho, Wo = y.shape[-2:]
+    # ---- forward
+    w2 = w.permute(0, 2, 1, 3, 4).reshape(O, kt * I, 3, 3).cuda()
+    wp = E.pack_weight(w2, kt * I, x3)
+    one, zero = TO.ones_zeros(wp.shape[1], torch.device("cuda"))
+    dst = E.Act(B * T, Ho, Wo, 32, x3, torch.device("cuda"), zero=True)
+    E.conv_to_act(xa, 0, I, wp, 3, 3, O, one, zero, L.ACT_NONE, dst, cout_store=32, stride=stride, pad=(1, 1), Ho=Ho, Wo=Wo,
+                  temporal=(T, kt))
+    got = _act_to_nchw(dst, O).reshape(B, T, O, Ho, Wo).permute(0, 2, 1, 3, 4)
+    e = rel_err(got, y.detach())
+    print("temporal conv", kt, stride, "x3" if x3 else "16-bit", e)
+    assert e < (3e-5 if x3 else 1e-2)
+    # ---- gradients
+    g = torch.from_numpy(hashed(73, tuple(y.shape)).astype(np.float32))
+    ga, gheld = _frames_act(g, x3)
+    y.backward(gheld)
+    dw2 = torch.empty(O, kt * I, 3, 3, dtype=torch.float32, device="cuda")
+    E.wgrad(ga, 0, O, xa, 0, kt * I, 3, 3, dw2, stride=stride, pad=(1, 1), temporal=(T, kt, I))
+    dw = dw2.reshape(O, kt, I, 3, 3).permute(0, 2, 1, 3, 4).cpu()
+    e = rel_err(dw, wr.grad)
+    print("temporal wgrad", e)
+    assert e < (2e-4 if x3 else 2e-3)
+    if stride == 1:         # data gradient: the same conv over dy with the temporal taps flipped (train_ops.video_train_plan)
+        w2n = w.flip(2).permute(2, 0, 1, 3, 4).reshape(kt * O, I, 3, 3).cuda()
+        wd = TO.dgrad_weight(w2n, x3)
+        one, zero = TO.ones_zeros(wd.shape[1], torch.device("cuda"))
+        dx = E.Act(B * T, H, W, I, x3, torch.device("cuda"), zero=True)
+        E.conv_to_act(ga, 0, ga.cs, wd, 3, 3, I, one, zero, L.ACT_NONE, dx, cout_store=I, pad=(1, 1), Ho=H, Wo=W, temporal=(T, kt))
+        gotx = _act_to_nchw(dx, I).reshape(B, T, I, H, W).permute(0, 2, 1, 3, 4)
+        e = rel_err(gotx, xr.grad)
+        print("temporal dgrad", e)
+        assert e < (3e-5 if x3 else 1e-2)
