@@ -40,7 +40,9 @@ typedef float fe_f32x16 __attribute__((ext_vector_type(16)));
 #define FE_IADV 61              // ISTFT: frames a workgroup advances (FE_COLS minus the ceil(win/hop) = 3 halo frames)
 #define FE_IKC 64               // ISTFT: K (re|im, bin) values staged per chunk
 #define FE_RING 4               // matrix-fragment buffers in flight per wave (= k-steps of an ISTFT chunk)
-#define FE_SWAVES 8              // STFT: waves per workgroup
+#define FE_SWAVES 4              // STFT: waves per workgroup
+#define FE_SRS 4                 // STFT: workgroups that share a frame tile, each computing 16 / FE_SRS of the row tiles
+#define FE_SLD 24               // STFT: sample loads in flight per thread while staging
 #define FE_IWAVES 16            // ISTFT: waves per workgroup (two per SIMD: the kernel is latency bound, one workgroup per CU)
 
 __device__ __forceinline__ fe_h8 fe_frag16(const uint4 v) { return __builtin_bit_cast(fe_h8, v); }
@@ -72,12 +74,14 @@ __global__ __launch_bounds__(FE_SWAVES * 64) void stft_mfma_kernel(StftParams p)
     // the clip's own ends; frames of this tile past Tc are computed on clamped indices and never stored
     const long long i0 = t0 * p.hop + (p.n_fft - p.win) / 2 - p.n_fft / 2;
     const float* wv = p.wave + b * p.wave_stride;
-    // 8 independent loads in flight per thread (a plain loop issues them one L2 round trip at a time: 40 us of 55)
+    // FE_SLD independent loads in flight per thread: the whole span of the reference geometry (10 360 samples, 21 per
+    // thread) is one round trip to HBM (a plain loop issues them one round trip at a time: 40 us of 55; batches of 8
+    // were three round trips, ~5 us of 28)
     constexpr int NTHR = FE_SWAVES * 64;
-    for (int m0 = tid; m0 < p.span; m0 += 8 * NTHR) {
-        float v[8];
+    for (int m0 = tid; m0 < p.span; m0 += FE_SLD * NTHR) {
+        float v[FE_SLD];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < FE_SLD; ++u) {
             long long i = i0 + m0 + u * NTHR;
             if (i < 0) i = -i;
             if (i >= ns) i = 2 * (ns - 1) - i;
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(FE_SWAVES * 64) void stft_mfma_kernel(StftParams p)
             v[u] = wv[i];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < FE_SLD; ++u) {
             const int m = m0 + u * NTHR;
             if (m < p.span) {
                 const float x = v[u] * FE_SX;
@@ -97,7 +101,8 @@ __global__ __launch_bounds__(FE_SWAVES * 64) void stft_mfma_kernel(StftParams p)
     }
     __syncthreads();
 
-    constexpr int RT = 16 / FE_SWAVES;           // row tiles per wave
+    constexpr int RT = 16 / (FE_SWAVES * FE_SRS);    // row tiles per wave
+    static_assert(RT >= 1, "16 row-tile slots over FE_SRS workgroups of FE_SWAVES waves");
     fe_f32x16 acc[RT][2];
 #pragma unroll
     for (int r = 0; r < RT; ++r)
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(FE_SWAVES * 64) void stft_mfma_kernel(StftParams p)
     int rt[RT];
     bool rok[RT];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) { rt[r] = wave + FE_SWAVES * r; rok[r] = rt[r] < p.rtiles; if (!rok[r]) rt[r] = p.rtiles - 1; }
+    for (int r = 0; r < RT; ++r) { rt[r] = (int)blockIdx.z * (FE_SWAVES * RT) + wave + FE_SWAVES * r; rok[r] = rt[r] < p.rtiles; if (!rok[r]) rt[r] = p.rtiles - 1; }
     // matrix fragments: a ring of FE_RING buffers, loaded FE_RING-1 k-steps ahead (an L2 round trip is ~3 k-steps of
     // this wave's MFMAs; with one k-step of lead every k-step stalled on it: 56 us instead of ~15 for B = 64)
     uint4 ahi[FE_RING][RT], alo[FE_RING][RT];
@@ -470,7 +475,9 @@ extern "C" int sos_stft_f32(const float* wave, int64_t batch, int64_t n_samples,
         (void)hipFuncSetAttribute((const void*)stft_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return (int)SOS_OK;
     });
-    dim3 grid((unsigned)((n_frames + FE_COLS - 1) / FE_COLS), (unsigned)batch);
+    // 64 frames x all rows per workgroup would be 192 workgroups for 64 two-second clips (a quarter of the CUs idle, no
+    // co-resident workgroup to cover staging / stores): the rows are split over FE_SRS workgroups that stage the same span
+    dim3 grid((unsigned)((n_frames + FE_COLS - 1) / FE_COLS), (unsigned)batch, FE_SRS);
     hipLaunchKernelGGL(stft_mfma_kernel, grid, dim3(FE_SWAVES * 64), lds, (hipStream_t)stream, p);
     return sos_check_launch("sos_stft_f32");
 }
