@@ -279,7 +279,7 @@ int sos_conv2d_wgrad(const sos_wgrad_desc* desc, sos_stream_t stream);
 /* ---- backward of the BatchNorm(+activation) / bias(+activation) tail of a conv block (autograd of
  * nn.BatchNorm2d + ReLU/PReLU in train mode).  dy: grad of the block output; x: raw conv output;
  * scale/shift/mean/invstd: from sos_bn_finalize (mean == invstd == NULL: no BatchNorm);
- * partial: f32 [sos_bn_stats_blocks(npix)][3][C]; coef: f32 [4][C] scratch.  Writes dgamma, dbeta
+ * partial: f32 scratch of 3 * C * sos_bn_stats_blocks(npix) floats; coef: f32 [4][C] scratch.  Writes dgamma, dbeta
  * (or the bias gradient), dslope[0] (PReLU) and dx = grad of the raw conv output. */
 int sos_bn_bwd(const sos_view* dy, const sos_view* x, const float* scale, const float* shift, const float* mean,
                const float* invstd, const float* gamma, int act, const float* slope, float* partial, float* coef,

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(View dy, View x, con
         const int g = c >> 3, e = c & 7;
         float acc = 0.f;
         for (int l = 0; l < PL; ++l) acc += red[(l * CG + g) * 24 + which * 8 + e];
-        partial[((size_t)blockIdx.x * 3 + which) * x.C + c] = acc;
+        partial[((size_t)which * x.C + c) * gridDim.x + blockIdx.x] = acc;      // [3][C][blocks]: the finalize reads a channel's row contiguously
     }
 }
 
@@ -433,9 +433,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     const int c = blockIdx.x, tid = threadIdx.x;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
     for (int b = tid; b < nblk; b += 256) {
-        s1 += (double)partial[((size_t)b * 3 + 0) * C + c];
-        s2 += (double)partial[((size_t)b * 3 + 1) * C + c];
-        s3 += (double)partial[((size_t)b * 3 + 2) * C + c];
+        s1 += (double)partial[((size_t)0 * C + c) * nblk + b];
+        s2 += (double)partial[((size_t)1 * C + c) * nblk + b];
+        s3 += (double)partial[((size_t)2 * C + c) * nblk + b];
     }
     r1[tid] = s1; r2[tid] = s2; r3[tid] = s3;
     __syncthreads();

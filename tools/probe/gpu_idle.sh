@@ -27,6 +27,15 @@ for s, e, n in iv:
 busy += cur_e - cur_s
 tot = t1 - t0
 ksum = sum(min(e, t1) - max(s, t0) for s, e, n in iv if e > t0)
+import collections
+small = collections.defaultdict(lambda: [0, 0])
+for s_, e_, n_ in iv:
+    if e_ > t0 and e_ - s_ < 20000:
+        small[n_[:80]][0] += 1; small[n_[:80]][1] += e_ - s_
+ns = sum(v[0] for v in small.values()); ts = sum(v[1] for v in small.values())
+print(f"kernels shorter than 20 us in the window: {ns/6:.0f} per step, {ts/6e6:.2f} ms per step")
+for k, v in sorted(small.items(), key=lambda kv: -kv[1][1])[:25]:
+    print(f"  {v[1]/6e6:7.3f} ms/step {v[0]/6:7.1f} calls/step  {k}")
 print(f"window {tot/1e6:.1f} ms, GPU busy (union of kernels) {busy/1e6:.1f} ms = {100*busy/tot:.1f} %, idle {100*(tot-busy)/tot:.1f} %, sum of kernel times {ksum/1e6:.1f} ms")
 PY
 rm -rf $O/t
