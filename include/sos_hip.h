@@ -151,8 +151,9 @@ typedef struct sos_conv_desc {
     int32_t accumulate;     /* 1: add to the existing bf16 output (dense NHWC outputs only): gradient
                                fan-in of skip connections in the backward pass            */
     /* optional fused BatchNorm statistics of the (bf16-rounded) output, dense bf16 NHWC outputs only:
-     * stats[tile][0][c] = sum, stats[tile][1][c] = sum of squares over the tile's valid pixels, c < stats_c;
-     * tile < sos_conv2d_tile_count(desc); feed to sos_bn_finalize(partial = stats, nblk = tile count). */
+     * stats[0][c][tile] = sum, stats[1][c][tile] = sum of squares over the tile's valid pixels, c < stats_c,
+     * tile < sos_conv2d_tile_count(desc) (2 * stats_c * tiles floats; a channel's tile sums are contiguous for the
+     * finalize); feed to sos_bn_finalize(partial = stats, nblk = tile count). */
     float* stats;
     int32_t stats_c;
     /* optional RAGGED batch (BASELINE configs[3]: clips of different lengths in one launch; the reference runs each
@@ -224,15 +225,10 @@ typedef struct sos_view {
 
 /* ---- BatchNorm2d(train) of Conv2dBlock/ConvBlock/DownConvBlock/UpConvBlock (M1/networks.py:38-39,
  * M2/networks.py:38-39,107-108,137-138): batch statistics over all pixels of the raw conv output.
- * Stage 1 writes deterministic per-workgroup partial sums (no atomics): partial f32 [nblk][2][C],
+ * Stage 1 writes deterministic per-workgroup partial sums (no atomics): partial f32 [2][C][nblk] (a channel's sums contiguous),
  * nblk = sos_bn_stats_blocks(npix). */
 int sos_bn_stats_blocks(int64_t npix);
 int sos_bn_stats(const sos_view* x, float* partial, sos_stream_t stream);
-/* Optional pre-pass for long partial lists (the conv's fused statistics: one row per output tile): adds the nblk rows
- * of partial [nblk][ncol] in sos_bn_fold_rows() slices, folded: f32 [sos_bn_fold_rows()][ncol]; then call
- * sos_bn_finalize(folded, sos_bn_fold_rows(), ...) with ncol = 2*C.  Empty slices (nblk < rows) are written as 0. */
-int sos_bn_fold_rows(void);
-int sos_bn_fold_partials(const float* partial, int nblk, int ncol, float* folded, sos_stream_t stream);
 /* Stage 2: mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale (for the apply
  * pass), save_mean / save_invstd (for backward); running stats updated with momentum and the
  * UNBIASED variance, num_batches_tracked += 1 (torch semantics).  gamma/beta may be NULL (=1/0). */

@@ -100,8 +100,6 @@ SIGNATURES = {
     "sos_scale_f32": [_P, _L, _P, _P],
     "sos_bn_stats_blocks": [_L],
     "sos_bn_stats": [C.POINTER(View), _P, _P],
-    "sos_bn_fold_rows": [],
-    "sos_bn_fold_partials": [_P, _I, _I, _P, _P],
     "sos_bn_finalize": [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "sos_bn_act_apply": [C.POINTER(View), _P, _P, _I, _P, C.POINTER(View), _I, _I, _I, _P, _P],
     "sos_wgrad_workspace_bytes": [C.POINTER(WgradDesc)],

@@ -117,7 +117,6 @@ __device__ __forceinline__ void store8(const View& v, long long pix, int c8, con
 }
 
 #define BN_MAX_BLOCKS 2048
-#define SOS_BN_FOLD_ROWS 64
 
 extern "C" int sos_bn_stats_blocks(int64_t npix) {
     int64_t b = (npix + 255) / 256;
@@ -159,7 +158,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(View x, float* __restrict
         const int g = c >> 3, e = c & 7;
         float acc = 0.f;
         for (int l = 0; l < PL; ++l) acc += red[(l * CG + g) * 16 + which * 8 + e];
-        partial[((size_t)blockIdx.x * 2 + which) * x.C + c] = acc;
+        partial[((size_t)which * x.C + c) * gridDim.x + blockIdx.x] = acc;       // [2][C][blocks]
     }
 }
 
@@ -172,8 +171,9 @@ extern "C" int sos_bn_stats(const sos_view* x, float* partial, sos_stream_t stre
     return sos_check_launch("sos_bn_stats");
 }
 
-// one workgroup per channel: 256 threads stride over the per-workgroup partial sums (fixed order ->
-// deterministic), double accumulation, LDS tree.
+// one workgroup per channel: 256 threads stride over the channel's row of per-workgroup partial sums ([2][C][blocks]:
+// contiguous, so the 12 288 tile sums of a conv epilogue are read coalesced; fixed order -> deterministic), double
+// accumulation, LDS tree.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
@@ -182,10 +182,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     __shared__ double rs[256], rq[256];
     const int c = blockIdx.x, tid = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = tid; b < nblk; b += 256) {
-        s += (double)partial[((size_t)b * 2 + 0) * C + c];
-        q += (double)partial[((size_t)b * 2 + 1) * C + c];
+    const float* ps = partial + ((size_t)0 * C + c) * nblk;
+    const float* pq = partial + ((size_t)1 * C + c) * nblk;
+    int b = tid;
+    for (; b + 768 < nblk; b += 1024) {          // 8 loads in flight per thread (12 288 conv tiles: 48 per thread); fixed order
+        const float a0 = ps[b], a1 = ps[b + 256], a2 = ps[b + 512], a3 = ps[b + 768];
+        const float c0 = pq[b], c1 = pq[b + 256], c2 = pq[b + 512], c3 = pq[b + 768];
+        s += (double)a0; s += (double)a1; s += (double)a2; s += (double)a3;
+        q += (double)c0; q += (double)c1; q += (double)c2; q += (double)c3;
     }
+    for (; b < nblk; b += 256) { s += (double)ps[b]; q += (double)pq[b]; }
     rs[tid] = s; rq[tid] = q;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
@@ -207,41 +213,6 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     if (save_invstd) save_invstd[c] = invstd;
     if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
     if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * count / (count > 1.0 ? count - 1.0 : 1.0));
-}
-
-// The conv epilogue's fused statistics arrive as one row per output tile (12 288 rows for a 96-channel layer at B = 64):
-// bn_finalize_kernel's one-workgroup-per-channel walk reads them 4 bytes per 768-byte row (32 us).  This pre-pass adds
-// the rows in SOS_BN_FOLD_ROWS slices with row-contiguous (coalesced) reads; fixed order -> deterministic.
-__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ partial, int nblk, int ncol, int rows_per,
-                                                      float* __restrict__ folded) {
-    __shared__ double red[4][64];
-    const int tid = threadIdx.x, cl = tid & 63, lane = tid >> 6;
-    const int col = blockIdx.x * 64 + cl;
-    const int r0 = blockIdx.y * rows_per, r1 = min(nblk, r0 + rows_per);
-    double acc = 0.0;
-    if (col < ncol) {
-        int r = r0 + lane;
-        for (; r + 12 < r1; r += 16) {
-            const float a0 = partial[(size_t)r * ncol + col], a1 = partial[(size_t)(r + 4) * ncol + col];
-            const float a2 = partial[(size_t)(r + 8) * ncol + col], a3 = partial[(size_t)(r + 12) * ncol + col];
-            acc += (double)a0; acc += (double)a1; acc += (double)a2; acc += (double)a3;
-        }
-        for (; r < r1; r += 4) acc += (double)partial[(size_t)r * ncol + col];
-    }
-    red[lane][cl] = acc;
-    __syncthreads();
-    if (lane == 0 && col < ncol)
-        folded[(size_t)blockIdx.y * ncol + col] = (float)(((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl]);
-}
-
-extern "C" int sos_bn_fold_rows(void) { return SOS_BN_FOLD_ROWS; }
-
-extern "C" int sos_bn_fold_partials(const float* partial, int nblk, int ncol, float* folded, sos_stream_t stream) {
-    if (!partial || !folded || nblk < 1 || ncol < 1) { sos_set_error("sos_bn_fold_partials: bad args"); return SOS_EINVAL; }
-    const int rows_per = (nblk + SOS_BN_FOLD_ROWS - 1) / SOS_BN_FOLD_ROWS;
-    hipLaunchKernelGGL(bn_fold_kernel, dim3((ncol + 63) / 64, SOS_BN_FOLD_ROWS), dim3(256), 0, (hipStream_t)stream, partial,
-                       nblk, ncol, rows_per, folded);
-    return sos_check_launch("sos_bn_fold_partials");
 }
 
 extern "C" int sos_bn_finalize(const float* partial, int nblk, int C, int64_t count, const float* gamma,
@@ -432,11 +403,15 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     __shared__ double r1[256], r2[256], r3[256];
     const int c = blockIdx.x, tid = threadIdx.x;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int b = tid; b < nblk; b += 256) {
-        s1 += (double)partial[((size_t)0 * C + c) * nblk + b];
-        s2 += (double)partial[((size_t)1 * C + c) * nblk + b];
-        s3 += (double)partial[((size_t)2 * C + c) * nblk + b];
+    const float* p1 = partial + ((size_t)0 * C + c) * nblk;
+    const float* p2 = partial + ((size_t)1 * C + c) * nblk;
+    const float* p3 = partial + ((size_t)2 * C + c) * nblk;
+    int b = tid;
+    for (; b + 256 < nblk; b += 512) {           // 6 loads in flight per thread; fixed order
+        const float a0 = p1[b], a1 = p1[b + 256], c0 = p2[b], c1 = p2[b + 256], e0 = p3[b], e1 = p3[b + 256];
+        s1 += (double)a0; s1 += (double)a1; s2 += (double)c0; s2 += (double)c1; s3 += (double)e0; s3 += (double)e1;
     }
+    for (; b < nblk; b += 256) { s1 += (double)p1[b]; s2 += (double)p2[b]; s3 += (double)p3[b]; }
     r1[tid] = s1; r2[tid] = s2; r3[tid] = s3;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {

@@ -177,7 +177,7 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
             const int g8 = cc >> 3, e = cc & 7;
             float acc = 0.f;
             for (int l = 0; l < PL; ++l) acc += red[(l * PPX + g8) * 16 + which * 8 + e];
-            if (n0 + cc < p.stats_c) p.stats[((size_t)blockIdx.x * 2 + which) * p.stats_c + n0 + cc] = acc;
+            if (n0 + cc < p.stats_c) p.stats[((size_t)which * p.stats_c + n0 + cc) * p.nblk + blockIdx.x] = acc;   // [2][C][tiles]
         }
     }
     // ---- cooperative store: consecutive lanes write consecutive 16-byte pieces of a pixel's

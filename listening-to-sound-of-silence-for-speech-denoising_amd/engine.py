@@ -314,7 +314,7 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
          wo_tab=None, wg_stride=0, valid_cols=None, temporal=None):
     """Fill a sos_conv_desc and enqueue sos_conv2d_fwd.  `src` is an Act (or a (tensor,B,H,W,cs,nseg)
     view described by in_dims).  stats_c > 0: also return the fused BatchNorm partial sums of the first stats_c
-    output channels as (partial [tiles][2][stats_c], tiles) for sos_bn_finalize.  temporal = (frames per clip, kt): the
+    output channels as (partial [2][stats_c][tiles], tiles) for sos_bn_finalize.  temporal = (frames per clip, kt): the
     B images are clips of consecutive frames and the contraction also runs over kt neighbouring frames (Conv3d with
     temporal stride 1, padding (kt - 1) // 2); `cin` stays the channels of ONE frame."""
     d = L.ConvDesc()
@@ -381,7 +381,7 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
         tiles = L.lib().sos_conv2d_tile_count(C.byref(d))
         if tiles < 1:
             raise RuntimeError("sos_conv2d_tile_count: " + (L.lib().sos_last_error() or b"").decode())
-        stats = (torch.empty((tiles, 2, stats_c), dtype=torch.float32, device=out.device), int(tiles))
+        stats = (torch.empty((2, stats_c, tiles), dtype=torch.float32, device=out.device), int(tiles))
         d.stats, d.stats_c = stats[0].data_ptr(), stats_c
     L.check(L.lib().sos_conv2d_fwd(C.byref(d), L.stream_ptr()), "sos_conv2d_fwd")
     if end is not None:
@@ -515,9 +515,6 @@ def view(act, c_off=0, C=None, third_index=None):
     return v
 
 
-BN_FOLD_ROWS = 64       # sos_bn_fold_rows()
-
-
 def bn_train(raw, c_off, Cn, bn, act, slope, dst, dst_c_off=0, feat=None, stats=None):
     """Training-mode BatchNorm (+activation) of the raw conv output `raw[:, c_off:c_off+C]`:
     stats -> finalize (updates bn.running_* in place like torch) -> apply into `dst`.
@@ -529,13 +526,8 @@ def bn_train(raw, c_off, Cn, bn, act, slope, dst, dst_c_off=0, feat=None, stats=
         partial, nblk = stats
     else:
         nblk = L.lib().sos_bn_stats_blocks(xv.npix)
-        partial = torch.empty((nblk, 2, Cn), dtype=torch.float32, device=dev)
+        partial = torch.empty((2, Cn, nblk), dtype=torch.float32, device=dev)
         L.check(L.lib().sos_bn_stats(C.byref(xv), L.ptr(partial), L.stream_ptr()), "sos_bn_stats")
-    if nblk > 4 * BN_FOLD_ROWS:      # one row per conv tile: add the rows up with coalesced reads first
-        folded = torch.empty((BN_FOLD_ROWS, 2, Cn), dtype=torch.float32, device=dev)
-        L.check(L.lib().sos_bn_fold_partials(L.ptr(partial), nblk, 2 * Cn, L.ptr(folded), L.stream_ptr()),
-                "sos_bn_fold_partials")
-        partial, nblk = folded, BN_FOLD_ROWS
     scale = torch.empty(Cn, dtype=torch.float32, device=dev)
     shift = torch.empty_like(scale)
     mean = torch.empty_like(scale)

@@ -29,7 +29,7 @@ def colsum(act, c_off, C):
     dev = act.t.device
     v = E.view(act, c_off, C)
     nblk = L.lib().sos_bn_stats_blocks(v.npix)
-    partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=dev)
+    partial = torch.empty((2, C, nblk), dtype=torch.float32, device=dev)
     L.check(L.lib().sos_bn_stats(ctypes.byref(v), L.ptr(partial), L.stream_ptr()), "sos_bn_stats")
     out = torch.empty(C, dtype=torch.float32, device=dev)
     scratch = torch.empty((2, C), dtype=torch.float32, device=dev)
@@ -54,7 +54,7 @@ def bn_bwd(dy, dy_off, raw, raw_off, C, saved, gamma, act, slope, dx, dx_off=0):
     dev = raw.t.device
     dyv, xv, dxv = E.view(dy, dy_off, C), E.view(raw, raw_off, C), E.view(dx, dx_off, C)
     nblk = L.lib().sos_bn_stats_blocks(xv.npix)
-    partial = torch.empty((nblk, 3, C), dtype=torch.float32, device=dev)
+    partial = torch.empty((3, C, nblk), dtype=torch.float32, device=dev)
     coef = torch.empty((4, C), dtype=torch.float32, device=dev)
     dgamma = torch.empty(C, dtype=torch.float32, device=dev)
     dbeta = torch.empty(C, dtype=torch.float32, device=dev)

@@ -64,27 +64,6 @@ def test_bn_train_stats_and_apply(x3):
     assert rel_err(saved["invstd"].cpu(), torch.rsqrt(held.var(dim=(0, 2, 3), unbiased=False) + 1e-5)) < 1e-5
 
 
-@pytest.mark.parametrize("nblk,C", [(12288, 96), (300, 48), (70, 5)])
-def test_bn_fold_partials_matches_row_sum(nblk, C):
-    """The pre-pass that adds the conv epilogue's per-tile statistics rows (coalesced, fixed order) = the plain row sum,
-    and bn_train through it = bn_train on the unfolded list."""
-    from sos_amd import engine as E, _lib as L
-    g = torch.Generator().manual_seed(5)
-    part = (torch.randn(nblk, 2, C, generator=g) * 3 + 1).float().cuda()
-    rows = L.lib().sos_bn_fold_rows()
-    assert rows == E.BN_FOLD_ROWS
-    folded = torch.full((rows, 2, C), float("nan"), device="cuda")
-    L.check(L.lib().sos_bn_fold_partials(L.ptr(part), nblk, 2 * C, L.ptr(folded), L.stream_ptr()), "fold")
-    got = folded.double().sum(0).cpu()
-    want = part.double().sum(0).cpu()
-    assert torch.isfinite(folded).all()
-    assert rel_err(got, want) < 1e-6
-    # second run: bit-identical (fixed order)
-    f2 = torch.empty_like(folded)
-    L.check(L.lib().sos_bn_fold_partials(L.ptr(part), nblk, 2 * C, L.ptr(f2), L.stream_ptr()), "fold")
-    assert torch.equal(folded, f2)
-
-
 CASES = [
     # name, Cout(M), Cin(N), k, stride, dil, pad, pad_mode, H, W
     ("5x5 dil(2,1) zero", 48, 96, (5, 5), 1, (2, 1), (4, 2), "zeros", 20, 40),
