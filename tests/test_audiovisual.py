@@ -57,10 +57,14 @@ def test_state_dict_layout_of_the_variant():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("stacked", [False, True], ids=["temporal-taps", "time-stack"])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
-def test_hip_audiovisual_forward_matches_goldens(golden, precision):
+def test_hip_audiovisual_forward_matches_goldens(golden, precision, stacked, monkeypatch):
+    """stacked: the materialised time stacks of round 1 (SOS_VIDEO_STACK=1) instead of the kernels' temporal taps."""
     import sos_amd
+    from sos_amd import common_nets as CN
     from sos_amd.detector import networks as dnet
+    monkeypatch.setattr(CN, "NO_TEMPORAL_TAPS", stacked)
     g = golden("audiovisual")
     s, v = _inputs(g)
     net = dnet.get_network(video=True)
@@ -111,13 +115,16 @@ def test_hip_video_features_match_oracle_blockwise(golden):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("stacked", [False, True], ids=["temporal-taps", "time-stack"])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
-def test_hip_audiovisual_train_step_matches_reference_autograd(golden, precision):
+def test_hip_audiovisual_train_step_matches_reference_autograd(golden, precision, stacked, monkeypatch):
     """Train-mode forward (BatchNorm3d batch statistics), BCE loss and every parameter gradient of the variant against
-    the reference modules' autograd (goldens).  Tolerances as for the audio networks (tests/test_gpu_train_nets.py)."""
+    the reference modules' autograd (goldens).  Tolerances as for the audio networks (tests/test_gpu_train_nets.py).
+    stacked: the materialised time stacks (SOS_VIDEO_STACK=1) instead of the kernels' temporal taps."""
     import sos_amd
-    from sos_amd import agent
+    from sos_amd import agent, common_nets as CN
     from sos_amd.detector import networks as dnet
+    monkeypatch.setattr(CN, "NO_TEMPORAL_TAPS", stacked)
     from test_gpu_train_nets import _check_grads
     g = golden("audiovisual")
     i_s, i_v, i_l, B, T, Tv, HW = [int(x) for x in g["train_idx"]]
