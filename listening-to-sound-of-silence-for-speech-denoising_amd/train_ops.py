@@ -565,6 +565,9 @@ def _reflect_dgrad(lp, d_raw, src, cin_off, gb, x3):
     reflect_fold(dpad, H, W, p, gb.of(src), cin_off, lp["cin"], accumulate=True)
 
 
+_INV_PERM = {}           # (concat permutation, device) -> its inverse as a device index tensor
+
+
 def down_backward(t, gb, grads, name, x3, need_src_grad=True):
     lp, raw = t["lp"], t["raw"]
     dev = raw.t.device
@@ -576,9 +579,16 @@ def down_backward(t, gb, grads, name, x3, need_src_grad=True):
     E.wgrad(d_raw, 0, lp["cout"], t["src"], t["cin_off"], lp["cin"], lp["k"], lp["k"], dw, stride=lp["stride"],
             dil=(lp["dil"], lp["dil"]), pad=(lp["pad"], lp["pad"]), pad_mode=L.PAD_REFLECT)
     if lp["in_perm"] is not None:           # dw is in the stored channel order; undo the concat permutation
-        inv = torch.empty(len(lp["in_perm"]), dtype=torch.long)
-        inv[torch.tensor(lp["in_perm"])] = torch.arange(len(lp["in_perm"]))
-        dw = dw[:, inv.to(dw.device)].contiguous()
+        key = (tuple(lp["in_perm"]), str(dw.device))
+        inv = _INV_PERM.get(key)
+        if inv is None:
+            # built ONCE (the plan dicts are rebuilt every optimizer step): a pageable host -> device copy here blocks the
+            # host until the stream has drained, i.e. until the whole stage-2 backward has run (107 ms of "enqueue" time
+            # per step instead of ~25)
+            inv = torch.empty(len(lp["in_perm"]), dtype=torch.long)
+            inv[torch.tensor(lp["in_perm"])] = torch.arange(len(lp["in_perm"]))
+            inv = _INV_PERM[key] = inv.to(dw.device)
+        dw = dw[:, inv].contiguous()
     grads[f"{name}.block.1.weight"] = dw
     if need_src_grad:
         _reflect_dgrad(lp, d_raw, t["src"], t["cin_off"], gb, x3)

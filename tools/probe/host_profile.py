@@ -1,0 +1,34 @@
+"""cProfile of the host side of one training step (enqueue only)."""
+import cProfile, os, pstats, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+import sos_amd
+from sos_amd import agent, tools, transform
+from sos_amd.common import MyConfig
+from sos_amd.dataset import synth_batch
+from sos_amd.denoiser import networks as jnet
+from sos_amd.detector import networks as dnet
+sos_amd.set_precision("fp16")
+torch.manual_seed(0)
+B, N = 64, 28000
+det, jm = dnet.get_network().cuda().train(), jnet.get_network(MyConfig()).cuda().train()
+raw = synth_batch(0, 8)
+tile = lambda a: torch.from_numpy(np.tile(a, (8, 1))[:B]).cuda().contiguous()
+mixed, clean, full_noise, bits = tile(raw["mixed"]), tile(raw["clean"]), tile(raw["full_noise"]), tile(raw["bits"])
+mask, noise_sig = tools.bits_to_mask_batch(bits, 14000 / 30.0, N, mixed)
+S = transform.stft_batch(torch.cat([mixed, clean * (1 - mask), noise_sig, full_noise]))
+bj = {"mixed": S[:B].contiguous(), "clean": S[B:2 * B].contiguous(), "noise": S[2 * B:3 * B].contiguous(), "full_noise": S[3 * B:].contiguous()}
+bd = {"audio": bj["mixed"], "label": bits.float()}
+ad, aj = agent.DetectorAgent(det, lr=1e-3), agent.DenoiserAgent(jm, lr=1e-3)
+for _ in range(3):
+    agent.train_concurrent([(aj, bj), (ad, bd)])
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(3):
+    agent.train_concurrent([(aj, bj), (ad, bd)])
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("cumulative").print_stats(45)
+st.sort_stats("tottime").print_stats(25)
