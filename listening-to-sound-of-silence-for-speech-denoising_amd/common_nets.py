@@ -233,5 +233,5 @@ def nearest_index_ragged(rag, n_max, device):
         for b, (Tc, nc) in enumerate(zip(rag.T, rag.n_vframes)):
             scale = np.float32(Tc) / np.float32(nc)
             rows[b, :nc] = np.minimum(np.floor(np.arange(nc, dtype=np.float32) * scale).astype(np.int64), Tc - 1)
-        t = rag._tabs[key] = torch.from_numpy(rows).to(device)
+        t = rag._tabs[key] = E.upload(rows, torch.int32, device)
     return t

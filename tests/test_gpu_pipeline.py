@@ -299,9 +299,9 @@ def test_si_sdr_parity_with_briefly_trained_weights():
         aj = agent.DenoiserAgent(jnet.get_network(MyConfig()), lr=1e-3)
         for it in range(40):
             ad.train_func(make_batch("detector", 5000 + 16 * it, 16))
-        for it in range(100):
+        for it in range(300):                  # (100 steps leave the gain check below at the mercy of the trajectory: 0.4 .. 1.7 dB)
             _, losses = aj.train_func(make_batch("denoiser", 7000 + 8 * it, 8))
-            if it % 20 == 0 or it == 99:
+            if it % 50 == 0 or it == 299:
                 print("fp16 denoiser step", it, {k: round(float(v), 4) for k, v in losses.items()})
     finally:
         sos_amd.set_precision("bf16")
