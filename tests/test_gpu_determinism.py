@@ -112,3 +112,40 @@ def test_fresh_threads_first_use_races():
         t.join(timeout=300)
     assert not errors, errors
     assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
+
+
+def test_steady_state_steps_do_not_synchronise_with_the_host():
+    """A training step and the inference pipelines enqueue their launches without waiting for the device: under
+    torch.cuda.set_sync_debug_mode('error') every synchronising torch call (a pageable host->device copy, .item(), ...)
+    raises.  (One such copy per step used to hold the host until the stage-2 backward had drained; per-call tables held
+    the ragged pipeline 24 times per batch.)  Warm-up runs first: plans, tables and workspaces are built there."""
+    from sos_amd import agent, pipeline
+    from sos_amd.common import MyConfig
+    from sos_amd.dataset import make_batch, synth_batch
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+    sos_amd.set_precision("fp16")
+    try:
+        torch.manual_seed(0)
+        ad = agent.DetectorAgent(dnet.get_network(), lr=1e-3)
+        aj = agent.DenoiserAgent(jnet.get_network(MyConfig()), lr=1e-3)
+        bd, bj = make_batch("detector", 100, 4), make_batch("denoiser", 200, 4)
+        det, jm = dnet.get_network().cuda().eval(), jnet.get_network(MyConfig()).cuda().eval()
+        base = torch.from_numpy(synth_batch(300, 4)["mixed"]).cuda()
+        clips = [base[0, :14000].contiguous(), base[1], base[2, :20000].contiguous(), base[3]]
+        for _ in range(2):
+            ad.train_func(bd); aj.train_func(bj)
+            pipeline.denoise(det, jm, base)
+            pipeline.denoise_ragged(det, jm, clips)
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            ad.train_func(bd); aj.train_func(bj)
+            agent.train_concurrent([(aj, bj), (ad, bd)])
+            pipeline.denoise(det, jm, base)
+            pipeline.denoise_ragged(det, jm, clips)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
+    finally:
+        sos_amd.set_precision("bf16")
