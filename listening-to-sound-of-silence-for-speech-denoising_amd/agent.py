@@ -324,16 +324,32 @@ class BaseAgent(object):
 
 def train_concurrent(jobs):
     """One training step of several independent agents (the reference trains its two models in two separate
-    processes), each on its own HIP stream: [(agent, batch), ...] -> [(outputs, losses), ...].  The MFMA-bound
-    kernels of one model overlap the HBM-bound BatchNorm passes and the latency-bound LSTM steps of the other."""
+    processes), each on its own HIP stream: [(agent, batch), ...] -> [(outputs, losses), ...].
+    Put the big model first.  If its network announces the end of its heavy backward phase (`after_stage2_backward` of
+    denoiser.networks.JointModel), the other agents' streams wait for that point: their steps then run under the big
+    model's U-Net backward and optimizer -- many medium-sized, partly HBM-bound kernels that leave room -- instead of
+    time-sharing the chip with its chip-filling 96-channel convolutions (which made every such kernel ~8 % longer and
+    gave nothing back: 485 vs 477 utt/s fully overlapped vs back to back).  SOS_STREAM_OVERLAP=full
+    restores the unconstrained overlap."""
     cur = torch.cuda.current_stream()
     outs = []
-    for ag, data in jobs:
+    gate = None
+    for k, (ag, data) in enumerate(jobs):
         if getattr(ag, "stream", None) is None:
             ag.stream = torch.cuda.Stream(device=ag.device)
         ag.stream.wait_stream(cur)
-        with torch.cuda.stream(ag.stream):
-            outs.append(ag.train_func(data))
+        net = getattr(ag, "net", None)
+        if k == 0 and len(jobs) > 1 and hasattr(net, "_backward_scaled") and os.environ.get("SOS_STREAM_OVERLAP") != "full":
+            gate = torch.cuda.Event()
+            net.after_stage2_backward = gate.record          # runs inside backward: records on this agent's stream
+        elif gate is not None:
+            ag.stream.wait_event(gate)
+        try:
+            with torch.cuda.stream(ag.stream):
+                outs.append(ag.train_func(data))
+        finally:
+            if k == 0 and gate is not None:
+                net.after_stage2_backward = None
     for ag, _ in jobs:
         cur.wait_stream(ag.stream)
     return outs

@@ -417,6 +417,9 @@ class JointModel(nn.Module):
         if g_out is None:
             g_out = torch.zeros((B, 2, F, T), dtype=torch.float32, device=dev)
         d_np = self.stage2.backward(plan["s2"], tape["t2"], g_out, grads, x3)          # Act [B,F,T,16]
+        hook = getattr(self, "after_stage2_backward", None)
+        if hook is not None:           # agent.train_concurrent: another model's step may start here (see there)
+            hook()
         if g_npred is not None:
             direct = E.pack_input(g_npred, x3, mul=E.cur_gs().mul)                     # loss gradient on n_pred
             TO.reflect_fold(direct, F, T, 0, d_np, 0, 2, accumulate=True)              # pad 0: plain add
