@@ -50,6 +50,8 @@ struct WgParams {
     int dbg;                  // SOS_WGRAD_DBG ablation mask (0 in production)
     int ny, nz, xcdmap;       // m-groups / n-groups of the 1-D grid (wgrad_kernel), XCD-aware id mapping on/off
     int tT, tcin, tpad;       // temporal taps (tT = 0: off): frames per clip, channels per frame, temporal padding
+    int ntg, taps_all;        // kernels with more taps than one workgroup holds (7x7): ntg workgroups own kh tap ROWS each
+                              // (kh / kw above are then the group's), taps_all = taps of the whole kernel
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -101,9 +103,11 @@ struct WgStage {
     unsigned gimg_bytes, ximg_bytes;
     bool reflect;
     int dtoff;                                    // temporal taps: frame offset of this workgroup's X columns
+    int xrow;                                     // tap-row group: input-row offset of this workgroup's first tap row
 
-    __device__ __forceinline__ WgStage(const WgParams& p_, char* smem_, int tid, int gsub, int xsub, int m0, int n0)
+    __device__ __forceinline__ WgStage(const WgParams& p_, char* smem_, int tid, int gsub, int xsub, int m0, int n0, int tg = 0)
         : p(p_), smem(smem_) {
+        xrow = tg * p_.kh * p_.dh;
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         lanepix = lane >> LP;
@@ -153,7 +157,7 @@ struct WgStage {
         const int rh = t % p.dh; t /= p.dh;
         WgTile o;
         o.gh0 = rh + ti * TH * p.dh; o.gw0 = gw * p.NC + tj * TW * p.dw;
-        o.xh0 = o.gh0 * p.stride - p.pad_t; o.xw0 = o.gw0 * p.stride - p.pad_l;
+        o.xh0 = o.gh0 * p.stride - p.pad_t + xrow; o.xw0 = o.gw0 * p.stride - p.pad_l;
         o.gorg = (unsigned)((o.gh0 * p.Wg + o.gw0) * p.g_cs * 2);
         o.xorg = (unsigned)((o.xh0 * p.Wx + o.xw0) * p.x_cs * 2);      // may be "negative": wraps, valid lanes land in range
         o.xfast = o.xh0 >= 0 && o.xw0 >= 0 && o.xh0 + xspan_h < p.Hx && o.xw0 + xspan_w < p.Wx;
@@ -257,8 +261,9 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
         split = lin % p.ksplit;
         yz = lin / p.ksplit;
     }
-    const int m0 = (yz / p.nz) * (MT * 32), n0 = (yz % p.nz) * (NTB * 32);
-    const int taps = p.kh * p.kw;
+    const int zz = yz % p.nz, tg = zz % p.ntg;                     // p.nz = n-groups x tap-row groups
+    const int m0 = (yz / p.nz) * (MT * 32), n0 = (zz / p.ntg) * (NTB * 32);
+    const int taps = p.kh * p.kw;                                  // of this workgroup's tap-row group
     const int npairs = taps * NTB;
     constexpr int NP = BAL ? 3 : WG_PAIRS;                      // full (tap, n-tile) pairs per wave
     const bool hasx = BAL && wave < MT;                          // this wave also owns m-tile `wave` of the last tap
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     const int krow = 8 * (g4 >> 1) + (s16 >> 2);                 // pixel (k) inside a 16-pixel k-step; +4 for 2nd read
     const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTH) - 1, lsh = p.logTW + p.logTH;
 
-    const WgStage<2, NTB> st(p, smem, tid, MT, NTB, m0, n0);
+    const WgStage<2, NTB> st(p, smem, tid, MT, NTB, m0, n0, tg);
     const int ninstr = st.ninstr;
 
     f32x16 acc[MT][NP], accx;
@@ -394,14 +399,14 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
         }
     }
     // ---- write this split's partial tiles: D[row = m][col = n], row = (reg&3)+8*(reg>>2)+4*(lane>>5), col = lane&31
-    float* out = p.partial + (size_t)split * taps * p.Mp * p.Np;
+    float* out = p.partial + ((size_t)split * p.taps_all + (size_t)tg * taps) * p.Mp * p.Np;
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
         const int pr = wave + WG_WAVES * u;
         if (pr >= npairs) continue;
         const int tap = pr / NTB, nt = pr - tap * NTB;
         const int n = n0 + nt * 32 + (lane & 31);
-        if (n >= p.Np) continue;
+        if (n >= p.Np || tg * taps + tap >= p.taps_all) continue;      // (phantom tap of the last tap-row group)
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
 #pragma unroll
@@ -837,8 +842,15 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.dh = d->dil_h; p.dw = d->dil_w;
     p.pad_t = d->pad_top; p.pad_l = d->pad_left; p.pad_mode = d->pad_mode;
     p.tT = temporal ? d->t_frames : 0; p.tcin = temporal ? d->t_cin : 0; p.tpad = temporal ? d->t_pad : 0;
-    const int taps = d->kh * d->kw;
-    if (taps > WG_WAVES * WG_PAIRS) { sos_set_error("sos_conv2d_wgrad: kernel with %d taps not supported", taps); return SOS_ENOSPC; }
+    // more taps than one workgroup's 32 (tap, n-tile) pairs (7x7): the tap ROWS are divided over ntg workgroups that read the
+    // same G tile at the same time on the same XCD (one launch, G fetched from HBM once instead of once per row)
+    // (the last group may own fewer real rows: its phantom taps are computed on the rows below and never stored)
+    int khg = d->kh;
+    if (khg * d->kw > WG_WAVES * WG_PAIRS) khg = WG_WAVES * WG_PAIRS / d->kw < 1 ? 1 : WG_WAVES * WG_PAIRS / d->kw;
+    const int taps_all = d->kh * d->kw;
+    const int taps = khg * d->kw;
+    p.kh = khg; p.ntg = (d->kh + khg - 1) / khg; p.taps_all = taps_all;
+    if (taps > WG_WAVES * WG_PAIRS) { sos_set_error("sos_conv2d_wgrad: kernel with %d taps per row not supported", taps); return SOS_ENOSPC; }
     int ntb = WG_WAVES * WG_PAIRS / taps;         // (tap, n-tile) pairs per workgroup <= 32
     ntb = ntb >= 4 ? 4 : (ntb >= 2 ? 2 : 1);
     const int ntiles_n = p.Np / 32, ntiles_m = p.Mp / 32;
@@ -852,7 +864,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     }
     // small channel counts: the 16x16x32 kernel owns all of dW in one workgroup (no padding to 32)
     const int m16 = (d->M + 15) / 16, n16 = (d->N + 15) / 16;
-    const bool use16 = !temporal && m16 == 3 && n16 == 3 && (taps == 25 || taps == 9) && !getenv("SOS_WGRAD_NO16");
+    const bool use16 = !temporal && p.ntg == 1 && m16 == 3 && n16 == 3 && (taps == 25 || taps == 9) && !getenv("SOS_WGRAD_NO16");
     // pixel tile (NC x TH x TW = 256): fewest k-steps among the shapes whose operands fit LDS (double
     // buffered, <= 16 DMA slots, if possible); shrink the channel tile if none fits
     const size_t lds_max = 160 * 1024;
@@ -866,7 +878,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
                 const int ltw = 8 - lnc - lth;
                 if (ltw < 2) continue;
                 const int TH = 1 << lth, TW = 1 << ltw;
-                const int PH = (TH - 1) * d->stride + d->kh, PW = (TW - 1) * d->stride + d->kw;
+                const int PH = (TH - 1) * d->stride + khg, PW = (TW - 1) * d->stride + d->kw;
                 if ((TH - 1 + d->kh) * d->dil_h >= 0x7fff || (d->stride * NC + (PW - 1) * d->dil_w) >= 0x7fff) continue;
                 const int npixp = use16 ? (NC * PH * PW + 31) / 32 * 32 : (NC * PH * PW + 15) / 16 * 16;
                 const size_t one = use16 ? ((size_t)256 * 32 * m16 + (size_t)npixp * 32 * n16 + 1023) / 1024 * 1024
@@ -886,7 +898,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     {
         const int TH = 1 << p.logTH, TW = 1 << p.logTW;
         p.tiles_h = (Hc + TH - 1) / TH; p.tiles_w = (Wc + TW - 1) / TW; p.ngw = (d->dil_w + p.NC - 1) / p.NC;
-        p.PH = (TH - 1) * d->stride + d->kh; p.PW = (TW - 1) * d->stride + d->kw;
+        p.PH = (TH - 1) * d->stride + khg; p.PW = (TW - 1) * d->stride + d->kw;
         p.npix = p.NC * p.PH * p.PW;
     }
     const size_t lds = (size_t)p.bufbytes * (p.dbuf ? 2 : 1) + (size_t)(256 + p.npixp) * 8;
@@ -894,7 +906,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     p.nsteps = d->B * d->dil_h * p.ngw * p.tiles_h * p.tiles_w;
     int ksplit = d->ksplit;
     if (ksplit <= 0) {
-        const int groups = use16 ? 1 : mgroups * ((ntiles_n + ntb - 1) / ntb);
+        const int groups = use16 ? 1 : mgroups * ((ntiles_n + ntb - 1) / ntb) * p.ntg;
         ksplit = WG_NCU / groups;
         if (ksplit < 1) ksplit = 1;
         const int cap = wg_max_split(d);
@@ -903,7 +915,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     if (ksplit > p.nsteps) ksplit = p.nsteps;                            // never an empty split
     p.ksplit = ksplit;
     p.steps_per_split = (p.nsteps + ksplit - 1) / ksplit;
-    p.ny = mgroups; p.nz = (ntiles_n + ntb - 1) / ntb;
+    p.ny = mgroups; p.nz = (ntiles_n + ntb - 1) / ntb * p.ntg;
     p.xcdmap = 0;
     if (!use16 && d->ksplit <= 0 && p.ny * p.nz > 1 && p.ny * p.nz <= 16 && !getenv("SOS_WGRAD_NOXCD")) {
         // one workgroup per CU: an XCD (32 CUs) takes floor(32 / groups) splits, all groups of a split on one XCD
@@ -952,10 +964,10 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
 #undef SOS_WG_ATTR
     int rc = sos_check_launch("sos_conv2d_wgrad");
     if (rc) return rc;
-    const long long total = (long long)d->M * d->N * taps;
+    const long long total = (long long)d->M * d->N * taps_all;
     long long gb = (total + 63) / 64;
     if (gb > 8192) gb = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, d->partial, ksplit, taps, d->M, d->N,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, d->partial, ksplit, taps_all, d->M, d->N,
                        p.Mp, p.Np, d->dw, d->accumulate, d->scale, d->scale_dev);
     return sos_check_launch("sos_conv2d_wgrad(reduce)");
 }

@@ -273,13 +273,8 @@ def video_backward(plan, tape, dfeat, f_row, f_third, f_c_off, grads, prefix, B,
                     dwa = torch.empty((O, kt * I, 1, 1), dtype=torch.float32, device=dev)
                     E.wgrad(d_raw, 0, O, sub, 0, kt * I, 1, 1, dwa)
                     dw2[:, :, a:a + 1, b_:b_ + 1] = dwa
-        elif lp["kh"] * lp["kw"] <= 32:
+        else:       # (7x7: the wgrad kernel divides the tap rows over workgroups of one launch)
             E.wgrad(d_raw, 0, O, st, 0, kt * I, lp["kh"], lp["kw"], dw2, stride=lp["stride"], pad=lp["pad"])
-        else:       # 7x7: more taps than one wgrad workgroup holds -> one kernel row (1 x kw taps) per call
-            for a in range(lp["kh"]):
-                dwa = torch.empty((O, kt * I, 1, lp["kw"]), dtype=torch.float32, device=dev)
-                E.wgrad(d_raw, 0, O, st, 0, kt * I, 1, lp["kw"], dwa, stride=lp["stride"], pad=(lp["pad"][0] - a, lp["pad"][1]))
-                dw2[:, :, a:a + 1] = dwa
         grads[f"{prefix}.{i}.block.0.weight"] = dw2.reshape(O, kt, I, lp["kh"], lp["kw"]).permute(0, 2, 1, 3, 4).contiguous()
         if i == 0:
             break

@@ -73,6 +73,9 @@ CASES = [
     ("5x5 s2 reflect", 128, 64, (5, 5), 2, (1, 1), (2, 2), "reflect", 18, 41),
     ("1x1 linear", 100, 200, (1, 1), 1, (1, 1), (0, 0), "zeros", 1, 77),
     ("3x3 narrow", 2, 64, (3, 3), 1, (1, 1), (1, 1), "reflect", 12, 19),
+    # 49 taps: more than one workgroup's 32 (tap, n-tile) pairs -> tap rows divided over the workgroups of one launch
+    ("7x7 s2 16ch", 128, 16, (7, 7), 2, (1, 1), (3, 3), "zeros", 30, 44),
+    ("7x7 s1 48x32", 48, 32, (7, 7), 1, (1, 1), (3, 3), "zeros", 17, 23),
     # GEMM path of the 1x1 gradients (M, N >= 128): ragged M / N tiles, pixel counts that are not multiples of the
     # 64-pixel stage, several splits
     ("1x1 gemm 160x256", 160, 256, (1, 1), 1, (1, 1), (0, 0), "zeros", 1, 77),
