@@ -4,6 +4,7 @@ once with timing-based autotuning on, so that every launch shape they contain ge
 the table to gpurun_out/tune_table_gfx950.txt (copy it into the package and commit it).
 
     gpurun -- python tools/make_tune_table.py
+    gpurun -- python tools/make_tune_table.py --extend-av      (adds the audio-visual variant's shapes to the committed table)
 
 Every later process loads the committed table and never times anything: all processes (and all ranks of a
 data-parallel job) then run identical tilings, i.e. identical summation orders (engine.py, conv.hip)."""
@@ -16,8 +17,12 @@ OUT = os.path.join(ROOT, "gpurun_out", "tune_table_gfx950.txt")
 os.makedirs(os.path.dirname(OUT), exist_ok=True)
 os.environ["SOS_CONV_TUNE"] = "1"
 os.environ["SOS_CONV_TUNE_CACHE"] = OUT
+EXTEND_AV = "--extend-av" in sys.argv        # keep the committed table, add the audio-visual variant's shapes
 if os.path.exists(OUT):
     os.remove(OUT)
+if EXTEND_AV:
+    import shutil
+    shutil.copy(os.path.join(ROOT, "listening-to-sound-of-silence-for-speech-denoising_amd", "tune_table_gfx950.txt"), OUT)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -49,7 +54,29 @@ def workloads(B):
     torch.cuda.synchronize()
 
 
+def av_workloads():
+    """Audio-visual variant (BASELINE configs[4] geometry): inference at 1 / 4 / 16 clips, a training step at 8 / 32."""
+    torch.manual_seed(0)
+    net = dnet.get_network(video=True).cuda().eval()
+    for B in (1, 4, 16):
+        with torch.no_grad():
+            net(torch.randn(B, 2, 256, 178, device="cuda"), v=torch.rand(B, 3, 60, 224, 224, device="cuda"))
+    for B in (8, 32):
+        ag = agent.DetectorAgent(dnet.get_network(video=True), lr=1e-3)
+        ag.train_func({"audio": torch.randn(B, 2, 256, 178, device="cuda"), "frames": torch.rand(B, 3, 60, 224, 224, device="cuda"),
+                       "label": (torch.rand(B, 60, device="cuda") > 0.3).float()})
+        del ag
+    torch.cuda.synchronize()
+
+
 def main():
+    if EXTEND_AV:
+        sos_amd.set_precision("fp16")
+        av_workloads()
+        from sos_amd import _lib
+        _lib.lib().sos_conv2d_tune_save(OUT.encode())
+        print("wrote", OUT, sum(1 for _ in open(OUT)) - 1, "entries")
+        return
     # the table is shared by both builds (same kernels, same shapes): tune on the bf16 one; bf16x3 has its own
     # (three-segment) shapes
     for prec, batches in (("bf16", (64, 32, 16, 8, 4, 2, 1)), ("bf16x3", (64, 2, 1))):
