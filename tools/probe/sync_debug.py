@@ -9,6 +9,10 @@ from sos_amd.common import MyConfig
 from sos_amd.dataset import synth_batch
 from sos_amd.denoiser import networks as jnet
 from sos_amd.detector import networks as dnet
+if os.environ.get("SOS_FORCE_BUCKETS") == "1":          # the data-parallel gradient path in a world of one
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 sos_amd.set_precision("fp16")
 torch.manual_seed(0)
 B, N = 64, 28000
