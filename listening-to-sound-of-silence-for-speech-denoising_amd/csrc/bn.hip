@@ -24,6 +24,16 @@ static inline View to_view(const sos_view* v) {
     return o;
 }
 
+// pixel lanes of a 256-thread workgroup for CG 8-channel groups: the largest count whose pixels span whole 128-byte lines
+// (96 channels: 20 pixels x 192 B = 30 lines instead of 21 x 192 B = 31.5 -- neighbouring workgroups then never share a
+// line), never fewer than 3/4 of the lanes the threads allow
+__host__ __device__ static inline int bn_pl(int CG, int row_elems) {
+    const int PL = 256 / CG;
+    for (int q = PL; q >= 1 && 4 * q >= 3 * PL; --q)
+        if ((q * row_elems * 2) % 128 == 0) return q;
+    return PL;
+}
+
 static int check_view(const sos_view* v, const char* what) {
     if (!v || !v->ptr || v->npix < 1 || v->C < 1 || v->C > 2048 || v->row % 8 || v->c_off % 8 || (v->x3 && v->third % 8)) {
         sos_set_error("%s: bad view", what);
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(View x, float* __restrict
     constexpr int BN_U = 4;
     __shared__ float red[256 * 16];
     const int CG = (x.C + 7) / 8;           // <= 256 (C <= 2048)
-    const int PL = 256 / CG;
+    const int PL = bn_pl(CG, x.row);
     const int tid = threadIdx.x;
     const int cg = tid % CG, pl = tid / CG;
     float s[8], q[8];
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(View x, const float* __re
                                                        const float* __restrict__ slope_p, View y) {
     constexpr int BN_U = 4;
     const int CG = (x.C + 7) / 8;
-    const int PL = 256 / CG;
+    const int PL = bn_pl(CG, x.row);
     const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
     if (pl >= PL) return;
     const float slope = slope_p ? slope_p[0] : 0.f;
@@ -323,7 +333,7 @@ extern "C" int sos_bn_act_apply(const sos_view* x, const float* scale, const flo
     rc = check_view(y, "sos_bn_act_apply");
     if (rc) return rc;
     if (y->npix != x->npix || y->C < x->C) { sos_set_error("sos_bn_act_apply: view mismatch"); return SOS_EINVAL; }
-    const int PLh = 256 / ((x->C + 7) / 8);
+    const int PLh = bn_pl((x->C + 7) / 8, x->row);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for((x->npix + PLh - 1) / PLh * 256)), dim3(256), 0, (hipStream_t)stream,
                        to_view(x), scale, shift, act, slope, to_view(y));
     return sos_check_launch("sos_bn_act_apply");
