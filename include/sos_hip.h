@@ -33,6 +33,9 @@ enum { SOS_PAD_ZERO = 0, SOS_PAD_REFLECT = 1 };
 enum { SOS_DT_BF16 = 0, SOS_DT_BF16X3 = 1, SOS_DT_F32 = 2 };
 
 int sos_abi_version(void);
+/* size in bytes of the descriptor structs as compiled into the library; which = 0: sos_view, 1: sos_conv_desc,
+ * 2: sos_wgrad_desc; anything else: -1 */
+int sos_struct_size(int which);
 const char* sos_last_error(void);
 /* The package builds this ABI twice from the same sources: libsos_hip.so computes on bfloat16 storage ("bf16"),
  * libsos_hip_f16.so on IEEE half ("fp16", same MFMA rate, 11 instead of 8 significand bits).  Wherever this header

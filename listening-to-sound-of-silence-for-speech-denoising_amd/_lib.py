@@ -60,6 +60,7 @@ ADAM_CHUNK = 16384          # SOS_ADAM_CHUNK of include/sos_hip.h
 # name -> argtypes, exactly the prototypes of include/sos_hip.h
 SIGNATURES = {
     "sos_abi_version": [],
+    "sos_struct_size": [_I],
     "sos_stft_matrix_bytes": [_I, _I, _I],
     "sos_stft_pack_matrix": [_I, _I, _I, _P, _P],
     "sos_stft_f32": [_P, _L, _L, _L, _P, _P, _I, _I, _I, _P, _L, _P, _P],
@@ -140,6 +141,10 @@ def _load(path, want_dtype):
     got = h.sos_storage_dtype().decode()
     if got != want_dtype:
         raise ImportError(f"{path} computes on {got} storage, expected {want_dtype}")
+    for which, mirror in ((0, View), (1, ConvDesc), (2, WgradDesc)):
+        if h.sos_struct_size(which) != C.sizeof(mirror):
+            raise ImportError(f"{path}: {mirror.__name__} is {C.sizeof(mirror)} bytes here but {h.sos_struct_size(which)} in the "
+                              "library (include/sos_hip.h and _lib.py have drifted apart, or the library is stale: rebuild it)")
     return h
 
 

@@ -21,5 +21,15 @@ int sos_check_launch(const char* what) {
 }
 
 extern "C" int sos_abi_version(void) { return 3; }
+// sizeof() of the descriptor structs the caller fills (0: sos_view, 1: sos_conv_desc, 2: sos_wgrad_desc): a binding whose mirror
+// of a struct has drifted from the header finds out when it loads the library, not through a corrupted launch
+extern "C" int sos_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(sos_view);
+        case 1: return (int)sizeof(sos_conv_desc);
+        case 2: return (int)sizeof(sos_wgrad_desc);
+    }
+    return -1;
+}
 extern "C" const char* sos_storage_dtype(void) { return SOS_STORAGE_NAME; }
 extern "C" const char* sos_last_error(void) { return g_err; }
