@@ -42,7 +42,7 @@ typedef float fe_f32x16 __attribute__((ext_vector_type(16)));
 #define FE_RING 4               // matrix-fragment buffers in flight per wave (= k-steps of an ISTFT chunk)
 #define FE_SWAVES 4              // STFT: waves per workgroup
 #define FE_SRS 4                 // STFT: workgroups that share a frame tile, each computing 16 / FE_SRS of the row tiles
-#define FE_SLD 24               // STFT: sample loads in flight per thread while staging
+#define FE_SLD 42               // STFT: sample loads in flight per thread while staging
 #define FE_IWAVES 16            // ISTFT: waves per workgroup (two per SIMD: the kernel is latency bound, one workgroup per CU)
 
 __device__ __forceinline__ fe_h8 fe_frag16(const uint4 v) { return __builtin_bit_cast(fe_h8, v); }
@@ -74,8 +74,8 @@ __global__ __launch_bounds__(FE_SWAVES * 64) void stft_mfma_kernel(StftParams p)
     // the clip's own ends; frames of this tile past Tc are computed on clamped indices and never stored
     const long long i0 = t0 * p.hop + (p.n_fft - p.win) / 2 - p.n_fft / 2;
     const float* wv = p.wave + b * p.wave_stride;
-    // FE_SLD independent loads in flight per thread: the whole span of the reference geometry (10 360 samples, 21 per
-    // thread) is one round trip to HBM (a plain loop issues them one round trip at a time: 40 us of 55; batches of 8
+    // FE_SLD independent loads in flight per thread: the whole span of the reference geometry (10 360 samples, 41 per
+    // thread of a 4-wave workgroup) is one round trip to HBM (a plain loop issues them one round trip at a time: 40 us of 55; batches of 8
     // were three round trips, ~5 us of 28)
     constexpr int NTHR = FE_SWAVES * 64;
     for (int m0 = tid; m0 < p.span; m0 += FE_SLD * NTHR) {
