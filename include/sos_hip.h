@@ -316,10 +316,25 @@ int sos_bce_logits_loss(const float* x, const float* y, int64_t n, float upstrea
  * where f32 gradients become 16-bit (sos_pack_grad_f32 / sos_pack_nchw_to_nhwc `mul`) and 1/S where parameter
  * gradients leave (sos_wgrad_desc.scale_dev, sos_bn_bwd out_scale, sos_scale_f32): exact, the pass is linear. */
 int sos_amax_f32(const float* x, int64_t n, float* amax, sos_stream_t stream);
-int sos_loss_scale(const float* amax, float target, float* scale2, sos_stream_t stream);
+int sos_loss_scale(const float* amax, float target, float* scale2, const float* guard /* optional: SOS_GUARD state, the
+                   target is multiplied by its back-off factor */, sos_stream_t stream);
 int sos_scale_f32(float* x, int64_t n, const float* s /* device scalar */, sos_stream_t stream);
+/* ---- overflow guard of a training step (no counterpart in the reference, which trains in fp32: M2/agent.py:101-106;
+ * the analogue of torch.cuda.amp.GradScaler's found_inf / skipped step, decided ON THE DEVICE: no host sync).
+ * guard: device f32 [SOS_GUARD_FLOATS], zero-initialised by the caller once per model:
+ *   [0] found  : 1 if the gradients checked last were not all finite, else 0 -- the optimizer kernels skip their whole
+ *                update (parameters, exp_avg, exp_avg_sq untouched) while it is 1
+ *   [1] backoff: factor in (0, 1] applied to sos_loss_scale's target (0 reads as 1): halved by every overflow (floor 2^-20),
+ *                doubled again after SOS_GUARD_GROWTH consecutive finite steps
+ *   [2] finite steps since the last change of [1];  [3] steps skipped so far;  [4] scratch (raw flag bits)
+ * sos_grad_guard scans g[0..n) (a flat gradient buffer of the model, after the all-reduce) into the scratch flag and, when
+ * `finalize` is non-zero, updates the state from it (several buffers: finalize with the last one). */
+#define SOS_GUARD_FLOATS 5
+#define SOS_GUARD_GROWTH 200
+int sos_grad_guard(const float* g, int64_t n, float* guard, int finalize, sos_stream_t stream);
+/* skip: optional device scalar (the guard's [0]): a non-zero value turns the launch into a no-op */
 int sos_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int64_t step, float grad_scale, sos_stream_t stream);
+                  float eps, float weight_decay, int64_t step, float grad_scale, const float* skip, sos_stream_t stream);
 
 /* multi-tensor form: one launch for all parameter tensors of a model.  tensors: DEVICE array; chunks: DEVICE int32
  * [n_chunks][2] = (tensor index, chunk index), SOS_ADAM_CHUNK elements per chunk, covering every tensor. */
@@ -327,7 +342,7 @@ int sos_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
 typedef struct sos_adam_tensor { float* p; const float* g; float* m; float* v; int64_t n; } sos_adam_tensor;
 int sos_adam_multi_step(const sos_adam_tensor* tensors, int n_tensors, const int32_t* chunks, int64_t n_chunks, float lr,
                         float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
-                        sos_stream_t stream);
+                        const float* skip /* optional, see sos_adam_step */, sos_stream_t stream);
 
 /* Re-pack every 16-bit weight tensor of a model from its fp32 parameters in ONE launch (after an optimizer step).
  * entries: DEVICE array; entry e fills out[0..n) (16-bit storage type) from idx[0..n) (device int64): idx > 0 = absolute

@@ -14,7 +14,11 @@ tensors are not on a GPU.
 """
 __version__ = "0.1.0"
 
+import threading as _threading
+
 _PRECISION = "bf16"
+_TLS = _threading.local()
+MODES = ("bf16", "bf16x3", "fp16", "mixed")
 
 
 def set_precision(mode):
@@ -27,12 +31,53 @@ def set_precision(mode):
               -DSOS_F16 build of the same sources): 11 significand bits instead of 8, i.e. ~8x less rounding
               noise than 'bf16' at equal cost; training keeps the activation gradients in half's exponent
               range with a power-of-two loss scale chosen on the device (engine.GradScale).
-    A forward pass and its backward pass must run in the same mode."""
+    'mixed' : the DETECTOR -- the only producer of thresholded values (M1/predict.py:117-119: the per-frame
+              silent / non-silent decisions) -- runs in 'bf16x3', everything else in 'fp16'.  The frame decisions
+              then agree with the f32 reference unless a logit lies within ~1e-5 of the threshold, at 3x the cost of
+              the detector only (11 % of the algorithmic FLOPs).
+    A forward pass and its backward pass must run in the same mode (the networks record the mode on their tape)."""
     global _PRECISION
-    if mode not in ("bf16", "bf16x3", "fp16"):
-        raise ValueError("precision must be 'bf16', 'bf16x3' or 'fp16'")
+    if mode not in MODES:
+        raise ValueError("precision must be one of " + ", ".join(repr(m) for m in MODES))
     _PRECISION = mode
 
 
-def get_precision():
+def get_mode():
+    """The mode set_precision() chose (may be 'mixed')."""
     return _PRECISION
+
+
+def get_precision():
+    """The EFFECTIVE mode of the code that asks: the innermost precision_scope of this host thread, else the global
+    mode ('mixed' reads as 'fp16' outside the detector)."""
+    ov = getattr(_TLS, "override", None)
+    if ov is not None:
+        return ov
+    return "fp16" if _PRECISION == "mixed" else _PRECISION
+
+
+def detector_precision():
+    """Mode the silent-interval detector runs in: 'bf16x3' under 'mixed', else the effective mode."""
+    if getattr(_TLS, "override", None) is None and _PRECISION == "mixed":
+        return "bf16x3"
+    return get_precision()
+
+
+class precision_scope:
+    """`with precision_scope('bf16x3'):` -- everything this host thread enqueues inside runs in that mode (thread
+    local, nests); None = no change."""
+
+    def __init__(self, mode):
+        if mode is not None and mode not in ("bf16", "bf16x3", "fp16"):
+            raise ValueError("precision_scope takes 'bf16', 'bf16x3', 'fp16' or None")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, "override", None)
+        if self.mode is not None:
+            _TLS.override = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.override = self.prev
+        return False

@@ -56,6 +56,8 @@ class WgradDesc(C.Structure):
 
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 ADAM_CHUNK = 16384          # SOS_ADAM_CHUNK of include/sos_hip.h
+GUARD_FLOATS = 5            # SOS_GUARD_FLOATS
+EXPECTED_ABI = 4            # sos_abi_version() of the library these argument lists were written for
 
 # name -> argtypes, exactly the prototypes of include/sos_hip.h
 SIGNATURES = {
@@ -93,11 +95,12 @@ SIGNATURES = {
     "sos_lstm_bidir_bwd": [_P, _I, _I, _L, _P, _P, _P, _P, _L, _L, _I, _P, _P],
     "sos_mse_loss": [_P, _P, _L, _F, _P, _P, _P, _P],
     "sos_bce_logits_loss": [_P, _P, _L, _F, _P, _P, _P, _P],
-    "sos_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P],
-    "sos_adam_multi_step": [_P, _I, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P],
+    "sos_grad_guard": [_P, _L, _P, _I, _P],
+    "sos_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P, _P],
+    "sos_adam_multi_step": [_P, _I, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P, _P],
     "sos_gather_pack_multi": [_P, _I, _P, _L, _P],
     "sos_amax_f32": [_P, _L, _P, _P],
-    "sos_loss_scale": [_P, _F, _P, _P],
+    "sos_loss_scale": [_P, _F, _P, _P, _P],
     "sos_scale_f32": [_P, _L, _P, _P],
     "sos_bn_stats_blocks": [_L],
     "sos_bn_stats": [C.POINTER(View), _P, _P],
@@ -135,6 +138,9 @@ def _load(path, want_dtype):
         fn.argtypes = argtypes
         fn.restype = C.c_int64 if name in ("sos_wgrad_workspace_bytes", "sos_lstm_pack_bytes", "sos_conv2d_tile_count",
                                              "sos_stft_matrix_bytes", "sos_istft_matrix_bytes") else C.c_int
+    if h.sos_abi_version() != EXPECTED_ABI:
+        raise ImportError(f"{path} exports ABI version {h.sos_abi_version()}, this binding was written for {EXPECTED_ABI} "
+                          "(the argument lists differ: rebuild the library, or drop the SOS_HIP_LIB / SOS_HIP_LIB_F16 override)")
     h.sos_last_error.restype = C.c_char_p
     h.sos_last_error.argtypes = []
     h.sos_storage_dtype.restype = C.c_char_p

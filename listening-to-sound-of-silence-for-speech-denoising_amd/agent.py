@@ -111,6 +111,7 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = 1.0
+        self.guard = None          # engine.guard_state(net): device-side overflow guard, the step is skipped when a gradient is Inf / NaN
         self._tables = {}
 
     def _table(self, gi, ps):
@@ -134,8 +135,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        work = []
         for gi, group in enumerate(self.param_groups):
-            b1, b2 = group["betas"]
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
@@ -147,21 +148,34 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
-            steps = {int(self.state[p]["step"]) for p in ps}
             ent = self._table(gi, ps)
             torch._foreach_copy_(ent["views"], [p.grad.reshape(-1) for p in ps])        # batched gather of the gradients
+            work.append((group, ps, ent))
+        skip = None
+        if self.guard is not None and work:
+            # one pass over the flat gradients (65 MB for the denoiser: ~15 us): any Inf / NaN -> found = 1, the Adam
+            # kernels return at once, exp_avg / exp_avg_sq / the weights stay as they are, and the loss-scale target backs
+            # off.  Decided on the device: no host synchronisation.  (The host-side step counters still advance: the bias
+            # correction of later steps sees one step more than was applied.)
+            for k, (_, _, ent) in enumerate(work):
+                L.check(L.lib().sos_grad_guard(L.ptr(ent["flat_g"]), ent["flat_g"].numel(), L.ptr(self.guard),
+                                               1 if k == len(work) - 1 else 0, L.stream_ptr()), "sos_grad_guard")
+            skip = self.guard
+        for group, ps, ent in work:
+            b1, b2 = group["betas"]
+            steps = {int(self.state[p]["step"]) for p in ps}
             if len(steps) == 1:
                 L.check(L.lib().sos_adam_multi_step(L.ptr(ent["tab"]), ent["n"], L.ptr(ent["chunks"]), ent["nchunks"],
                                                     float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                     float(group["weight_decay"]), steps.pop(), float(self.grad_scale),
-                                                    L.stream_ptr()), "sos_adam_multi_step")
+                                                    L.ptr(skip), L.stream_ptr()), "sos_adam_multi_step")
             else:       # parameters that joined the group at different times: per-tensor launches
                 for p, g in zip(ps, ent["views"]):
                     st = self.state[p]
                     L.check(L.lib().sos_adam_step(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
                                                   float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                   float(group["weight_decay"]), int(st["step"]), float(self.grad_scale),
-                                                  L.stream_ptr()), "sos_adam_step")
+                                                  L.ptr(skip), L.stream_ptr()), "sos_adam_step")
             for p in ps:
                 bump_version(p)     # raw-pointer write: invalidate the packed-weight caches keyed on _version
         return None
@@ -268,6 +282,8 @@ class BaseAgent(object):
         broadcast_module_state(self.net)
         self.optimizer = FusedAdam(self.net.parameters(), lr)
         self.optimizer.grad_scale = 1.0 / self.world
+        from .engine import guard_state
+        self.optimizer.guard = guard_state(self.net)
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, lr_step_size)
         force = dist.is_initialized() and os.environ.get("SOS_FORCE_BUCKETS") == "1"
         self.bucketer = GradBucketer(list(self.net.named_parameters())) if (self.world > 1 or force) else None
@@ -339,7 +355,7 @@ def train_concurrent(jobs):
             ag.stream = torch.cuda.Stream(device=ag.device)
         ag.stream.wait_stream(cur)
         net = getattr(ag, "net", None)
-        if k == 0 and len(jobs) > 1 and hasattr(net, "_backward_scaled") and os.environ.get("SOS_STREAM_OVERLAP") != "full":
+        if k == 0 and len(jobs) > 1 and getattr(net, "ANNOUNCES_STAGE2_BACKWARD", False) and os.environ.get("SOS_STREAM_OVERLAP") != "full":
             gate = torch.cuda.Event()
             net.after_stage2_backward = gate.record          # runs inside backward: records on this agent's stream
         elif gate is not None:

@@ -1281,12 +1281,14 @@ extern "C" int sos_conv2d_tune(const sos_conv_desc* d, int max_candidates, int i
     return SOS_OK;
 }
 
-// Persist / restore the tiling table.  Text file: a header line `sos_conv_tune <format> abi <sos_abi_version> nkey 19`,
+// Persist / restore the tiling table.  Text file: a header line `sos_conv_tune <format> abi <SOS_TUNE_KEY_GEN> nkey 19`
+// (the generation of the shape-key / tiling-tuple MEANING: it changes when sos_conv_desc fields a key is built from change
+// meaning, not with every sos_abi_version bump -- entries are re-validated against enumerate_cfgs() on load anyway),
 // then 19 shape ints + 4 tiling ints per line (ks == 0 / -1: 16-row kernel).  The package ships a table for the
 // BASELINE shapes (tune_table_gfx950.txt) so that every process -- and every rank of a data-parallel job -- runs the
 // SAME tilings, hence the same summation order; timing-based autotuning is opt-in.
 #define SOS_TUNE_FORMAT 2
-extern "C" int sos_abi_version(void);
+#define SOS_TUNE_KEY_GEN 3
 
 // the sos_conv_desc fields enumerate_cfgs() / nt16_for() read, rebuilt from a shape key
 static sos_conv_desc desc_of_key(const ShapeKey& k) {
@@ -1305,7 +1307,7 @@ extern "C" int sos_conv2d_tune_save(const char* path) {
     snprintf(tmp, sizeof(tmp), "%s.tmp.%ld", path, (long)getpid());
     FILE* f = fopen(tmp, "w");
     if (!f) { sos_set_error("sos_conv2d_tune_save: cannot open %s", tmp); return SOS_EINVAL; }
-    fprintf(f, "sos_conv_tune %d abi %d nkey 19\n", SOS_TUNE_FORMAT, sos_abi_version());
+    fprintf(f, "sos_conv_tune %d abi %d nkey 19\n", SOS_TUNE_FORMAT, SOS_TUNE_KEY_GEN);
     {
         std::lock_guard<std::mutex> g(tuned_mutex());
         for (const auto& kv : tuned_cache()) {
@@ -1330,7 +1332,7 @@ extern "C" int sos_conv2d_tune_load(const char* path) {
     if (!f) return 0;                    // nothing cached yet
     int fmt = -1, abi = -1, nkey = -1;
     if (fscanf(f, " sos_conv_tune %d abi %d nkey %d", &fmt, &abi, &nkey) != 3 || fmt != SOS_TUNE_FORMAT ||
-        abi != sos_abi_version() || nkey != 19) {
+        abi != SOS_TUNE_KEY_GEN || nkey != 19) {
         fclose(f);
         sos_set_error("sos_conv2d_tune_load: %s was written by another build (format %d abi %d)", path, fmt, abi);
         return SOS_EINVAL;

@@ -92,8 +92,10 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     }
     if (threadIdx.x == 0) atomicMax((unsigned*)amax, __float_as_uint(red[0]));
 }
-__global__ void loss_scale_kernel(const float* __restrict__ amax, float target, float* __restrict__ scale2) {
+__global__ void loss_scale_kernel(const float* __restrict__ amax, float target, float* __restrict__ scale2,
+                                  const float* __restrict__ guard) {
     const float a = amax[0];
+    if (guard && guard[1] > 0.f) target *= guard[1];          // back-off after overflows (sos_grad_guard)
     float S = 1.f;
     if (a > 0.f && a < 3.0e38f) {
         int e = (int)floorf(log2f(target / a));
@@ -113,9 +115,9 @@ extern "C" int sos_amax_f32(const float* x, int64_t n, float* amax, sos_stream_t
     hipLaunchKernelGGL(amax_kernel, dim3(loss_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, amax);
     return sos_check_launch("sos_amax_f32");
 }
-extern "C" int sos_loss_scale(const float* amax, float target, float* scale2, sos_stream_t stream) {
+extern "C" int sos_loss_scale(const float* amax, float target, float* scale2, const float* guard, sos_stream_t stream) {
     if (!amax || !scale2 || !(target > 0.f)) { sos_set_error("sos_loss_scale: bad args"); return SOS_EINVAL; }
-    hipLaunchKernelGGL(loss_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, amax, target, scale2);
+    hipLaunchKernelGGL(loss_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, amax, target, scale2, guard);
     return sos_check_launch("sos_loss_scale");
 }
 extern "C" int sos_scale_f32(float* x, int64_t n, const float* s, sos_stream_t stream) {
@@ -126,9 +128,42 @@ extern "C" int sos_scale_f32(float* x, int64_t n, const float* s, sos_stream_t s
     return sos_check_launch("sos_scale_f32");
 }
 
+// ---- overflow guard (sos_hip.h): any Inf / NaN among a model's parameter gradients -> the step is skipped on the device
+__global__ __launch_bounds__(256) void grad_guard_kernel(const float* __restrict__ g, long long n, unsigned* __restrict__ raw) {
+    int bad = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        bad |= (__float_as_uint(g[i]) & 0x7f800000u) == 0x7f800000u;
+    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(raw, 1u);
+}
+__global__ void grad_guard_finalize_kernel(float* __restrict__ st) {
+    unsigned* raw = (unsigned*)(st + 4);
+    const unsigned bad = *raw;
+    *raw = 0u;
+    float b = st[1] > 0.f ? st[1] : 1.f;
+    if (bad) {
+        st[0] = 1.f;
+        st[3] += 1.f;
+        st[2] = 0.f;
+        b = fmaxf(0.5f * b, 9.5367431640625e-07f);          // 2^-20
+    } else {
+        st[0] = 0.f;
+        st[2] += 1.f;
+        if (st[2] >= (float)SOS_GUARD_GROWTH && b < 1.f) { b = fminf(1.f, 2.f * b); st[2] = 0.f; }
+    }
+    st[1] = b;
+}
+extern "C" int sos_grad_guard(const float* g, int64_t n, float* guard, int finalize, sos_stream_t stream) {
+    if (!g || !guard || n < 1) { sos_set_error("sos_grad_guard: bad args"); return SOS_EINVAL; }
+    hipLaunchKernelGGL(grad_guard_kernel, dim3(loss_blocks(n)), dim3(256), 0, (hipStream_t)stream, g, (long long)n,
+                       (unsigned*)(guard + 4));
+    if (finalize) hipLaunchKernelGGL(grad_guard_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, guard);
+    return sos_check_launch("sos_grad_guard");
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
-                            float bc1, float bc2_sqrt, float gscale) {
+                            float bc1, float bc2_sqrt, float gscale, const float* __restrict__ skip) {
+    if (skip && skip[0] != 0.f) return;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float gi = g[i] * gscale;
         const float pi = p[i];
@@ -144,14 +179,15 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 /* torch.optim.Adam (amsgrad=False) single-tensor update; step = 1-based step count after increment. */
 extern "C" int sos_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, int64_t step, float grad_scale, sos_stream_t stream) {
+                             float eps, float weight_decay, int64_t step, float grad_scale, const float* skip,
+                             sos_stream_t stream) {
     if (!p || !g || !m || !v || n < 1 || step < 1) { sos_set_error("sos_adam_step: bad args"); return SOS_EINVAL; }
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2 = 1.0f - powf(beta2, (float)step);
     long long gb = (n + 255) / 256;
     if (gb > 2048) gb = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr,
-                       beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+                       beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale, skip);
     return sos_check_launch("sos_adam_step");
 }
 
@@ -162,7 +198,8 @@ extern "C" int sos_adam_step(float* p, const float* g, float* m, float* v, int64
 struct AdamTensor { float* p; const float* g; float* m; float* v; long long n; };
 __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTensor* __restrict__ tab, const int2* __restrict__ chunks,
                                                          float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                         float bc2_sqrt, float gscale) {
+                                                         float bc2_sqrt, float gscale, const float* __restrict__ skip) {
+    if (skip && skip[0] != 0.f) return;         // overflow guard: the whole step is dropped (uniform over the grid)
     const int2 c = chunks[blockIdx.x];
     const AdamTensor t = tab[c.x];
     const long long lo = (long long)c.y * SOS_ADAM_CHUNK;
@@ -182,7 +219,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTensor* __res
 
 extern "C" int sos_adam_multi_step(const sos_adam_tensor* tensors, int n_tensors, const int32_t* chunks, int64_t n_chunks,
                                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                                   float grad_scale, sos_stream_t stream) {
+                                   float grad_scale, const float* skip, sos_stream_t stream) {
     static_assert(sizeof(sos_adam_tensor) == sizeof(AdamTensor), "sos_adam_tensor layout");
     if (!tensors || !chunks || n_tensors < 1 || n_chunks < 1 || n_chunks > 0x7fffffff || step < 1) {
         sos_set_error("sos_adam_multi_step: bad args");
@@ -192,7 +229,7 @@ extern "C" int sos_adam_multi_step(const sos_adam_tensor* tensors, int n_tensors
     const float bc2 = 1.0f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream,
                        (const AdamTensor*)tensors, (const int2*)chunks, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
-                       grad_scale);
+                       grad_scale, skip);
     return sos_check_launch("sos_adam_multi_step");
 }
 

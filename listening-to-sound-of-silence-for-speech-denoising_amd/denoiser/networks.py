@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
+from .. import get_precision, precision_scope
 from .. import common_nets as CN
 from .. import engine as E
 from .. import train_ops as TO
@@ -380,6 +381,8 @@ class _JointTrainFn(torch.autograd.Function):
 class JointModel(nn.Module):
     """M2/networks.py:208-217: n_pred = stage1(n, x); out = stage2(x, n_pred); returns both."""
 
+    ANNOUNCES_STAGE2_BACKWARD = True     # _backward_scaled calls self.after_stage2_backward() (agent.train_concurrent's gate)
+
     def __init__(self, config):
         super().__init__()
         self.stage1 = InpaintNet()
@@ -400,12 +403,14 @@ class JointModel(nn.Module):
         x3 = plan["x3"]
         n_pred, t1 = self.stage1.forward_train(plan["s1"], n, x, x3)
         out, t2 = self.stage2.forward_train(plan["s2"], x, n_pred, x3)
-        return (n_pred, out), dict(plan=plan, t1=t1, t2=t2, x3=x3)
+        return (n_pred, out), dict(plan=plan, t1=t1, t2=t2, x3=x3, mode=get_precision())
 
     def _backward(self, tape, g_npred, g_out):
         g_npred = g_npred.contiguous().float() if g_npred is not None else None
         g_out = g_out.contiguous().float() if g_out is not None else None
-        with E.backward_scale(g_npred, g_out):      # fp16 mode: one loss scale for both entering gradients
+        E.check_tape_weights(self, tape)
+        # the pass runs in the mode its forward ran in; fp16 mode: one loss scale for both entering gradients
+        with precision_scope(tape.get("mode")), E.backward_scale(g_npred, g_out, guard=E.guard_state(self)):
             return self._backward_scaled(tape, g_npred, g_out)
 
     def _backward_scaled(self, tape, g_npred, g_out):

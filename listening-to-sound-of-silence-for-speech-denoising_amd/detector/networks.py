@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
+from .. import detector_precision, precision_scope
 from .. import common_nets as CN
 from .. import engine as E
 from .. import train_ops as TO
@@ -22,7 +23,10 @@ class _TrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, s, n, v, *params):
-        out, tape = net._forward_train(s, n, v)
+        mode = detector_precision()             # 'bf16x3' under set_precision('mixed'); the backward re-enters it
+        with precision_scope(mode):
+            out, tape = net._forward_train(s, n, v)
+        tape["mode"] = mode
         ctx.net, ctx.tape = net, tape
         return out
 
@@ -102,7 +106,8 @@ class AudioVisualNet(nn.Module):
 
     def _backward(self, tape, g):
         g = g.contiguous().float()
-        with E.backward_scale(g):           # fp16 mode: loss scale for this pass (a no-op in the bf16 modes)
+        E.check_tape_weights(self, tape)
+        with precision_scope(tape.get("mode")), E.backward_scale(g, guard=E.guard_state(self)):   # fp16 mode: loss scale for this pass (a no-op in the bf16 modes)
             return self._backward_scaled(tape, g)
 
     def _backward_scaled(self, tape, g):
@@ -148,11 +153,14 @@ class AudioVisualNet(nn.Module):
         if self.training:
             return _TrainFn.apply(self, s.contiguous().float(), int(v_num_frames),
                                   v.contiguous().float() if v is not None else None, *self.parameters())
+        with precision_scope(detector_precision()):
+            return self._forward_eval(s, int(v_num_frames), v, rag)
+
+    def _forward_eval(self, s, n, v, rag):
         plan = self._cache.get(self, self._build_plan)
         x3 = plan["x3"]
         dev = s.device
         B, _, F, T = s.shape
-        n = int(v_num_frames)
         a = E.pack_input(s, x3)
         nseg = 3 if x3 else 1
         nfeat = 8 * F + self.video_feat

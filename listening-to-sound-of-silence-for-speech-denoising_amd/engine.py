@@ -62,15 +62,21 @@ def _load_tune_cache():
     with _tune_lock:
         if which in _cache_loaded:
             return
-        path = _TUNE_CACHE or SHIPPED_TUNE_TABLE
+        # the shipped table first, then the user's cache file of THIS library (X for the bf16 build, X.f16 for the fp16
+        # build) laid over it if it exists; a user file this build cannot read is reported and ignored
+        user = None if not _TUNE_CACHE else _TUNE_CACHE + ("" if which == "bf16" else ".f16")
         if _os.environ.get("SOS_CONV_TUNE_TABLE", "1") != "0":      # =0: cost-model picks only (A/B of the table itself)
-            n = L.lib().sos_conv2d_tune_load(path.encode())
+            n = L.lib().sos_conv2d_tune_load(SHIPPED_TUNE_TABLE.encode())
             if n < 0:
                 raise RuntimeError("sos_conv2d_tune_load: " + (L.lib().sos_last_error() or b"").decode())
-        if AUTOTUNE and _TUNE_CACHE and int(_os.environ.get("RANK", "0")) == 0:
+            if user and _os.path.exists(user):
+                if L.lib().sos_conv2d_tune_load(user.encode()) < 0:
+                    import warnings
+                    warnings.warn("SOS_CONV_TUNE_CACHE %s ignored: %s" % (user, (L.lib().sos_last_error() or b"").decode()))
+        if AUTOTUNE and user and int(_os.environ.get("RANK", "0")) == 0:
             import atexit
             h = L.lib()
-            atexit.register(lambda: h.sos_conv2d_tune_save((_TUNE_CACHE + ("" if which == "bf16" else ".f16")).encode()))
+            atexit.register(lambda: h.sos_conv2d_tune_save(user.encode()))
         _cache_loaded.add(which)
 
 
@@ -110,7 +116,7 @@ class GradScale:
 
     TARGET = 256.0          # the entering gradients are scaled to max|g| in [256, 512): 2^7 of headroom, 2^-32 of floor
 
-    def __init__(self, *grads):
+    def __init__(self, *grads, guard=None):
         self.mul = self.inv = None
         if get_precision() != "fp16":
             return
@@ -121,7 +127,8 @@ class GradScale:
         buf = torch.zeros(3, dtype=torch.float32, device=dev)
         for g in gs:
             L.check(L.lib().sos_amax_f32(L.ptr(g), g.numel(), L.ptr(buf), L.stream_ptr()), "sos_amax_f32")
-        L.check(L.lib().sos_loss_scale(L.ptr(buf), self.TARGET, L.ptr(buf[1:]), L.stream_ptr()), "sos_loss_scale")
+        # guard: the model's overflow-guard state (guard_state); its back-off factor lowers the target after overflows
+        L.check(L.lib().sos_loss_scale(L.ptr(buf), self.TARGET, L.ptr(buf[1:]), L.ptr(guard), L.stream_ptr()), "sos_loss_scale")
         self.buf, self.mul, self.inv = buf, buf[1:2], buf[2:3]
 
     def unscale(self, t):
@@ -141,8 +148,8 @@ class backward_scale:
     colsum / pack_grad pick the pass's GradScale up through cur_gs() (thread local: DataParallel-style callers run one
     backward per host thread)."""
 
-    def __init__(self, *grads):
-        self.gs = GradScale(*grads)
+    def __init__(self, *grads, guard=None):
+        self.gs = GradScale(*grads, guard=guard)
 
     def __enter__(self):
         self.prev = getattr(_TLS, "gs", NO_SCALE)
@@ -156,6 +163,17 @@ class backward_scale:
 
 def cur_gs():
     return getattr(_TLS, "gs", NO_SCALE)
+
+
+def guard_state(net):
+    """The overflow-guard state of a model (include/sos_hip.h, sos_grad_guard): device f32 [SOS_GUARD_FLOATS] =
+    {found, back-off, finite steps, skipped steps, scratch}, created on first use on the parameters' device.  The
+    backward pass reads its back-off factor (loss scale), the optimizer writes it (FusedAdam.guard)."""
+    dev = next(net.parameters()).device
+    g = net.__dict__.get("_sos_guard")
+    if g is None or g.device != dev:
+        g = net.__dict__["_sos_guard"] = torch.zeros(L.GUARD_FLOATS, dtype=torch.float32, device=dev)
+    return g
 
 
 def pack_input(x, x3=None, mul=None):
@@ -493,6 +511,7 @@ class PlanCache:
         self.plan = None
         self.rec = None
         self.record = record
+        self.rec_failed = set()     # bases whose recording did not verify: plain rebuilds from then on
 
     def get(self, module, build):
         ts = list(module.parameters()) + list(module.buffers())
@@ -502,14 +521,29 @@ class PlanCache:
             with torch.no_grad():
                 if self.rec is not None and self.rec.ok and self.rec_base == base:
                     self.plan = self.rec.replay(build)
-                elif self.record:
+                elif self.record and base not in self.rec_failed:
                     self.rec, self.rec_base = PackRecorder(module, build), base
                     self.plan = self.rec.plan
                     self.rec.plan = None
+                    if not self.rec.ok:
+                        self.rec_failed.add(base)
                 else:
                     self.plan = build()
             self.key = key
+            if isinstance(self.plan, dict):
+                # a training tape is only valid for the weights its forward pass ran with (the packed tensors are
+                # refreshed IN PLACE after an optimizer step): check_tape_weights() compares these in backward
+                self.plan["_wver"] = tuple(p._version for p in module.parameters())
         return self.plan
+
+
+def check_tape_weights(module, tape):
+    """Backward of a tape whose forward ran with older weights would silently use the new ones (the packed weights of a
+    training plan are refreshed in place by PackRecorder.replay): refuse."""
+    want = tape["plan"].get("_wver")
+    if want is not None and want != tuple(p._version for p in module.parameters()):
+        raise RuntimeError("sos_amd: the parameters changed (optimizer step / load_state_dict) between this forward pass and "
+                           "its backward pass; run backward before stepping the optimizer")
 
 
 # --------------------------------------------------------------------------- training helpers

@@ -159,7 +159,7 @@ class GraphedDenoiser:
         if mixed.dim() != 2 or not mixed.is_cuda or mixed.dtype != torch.float32:
             raise ValueError("GraphedDenoiser expects a float32 (B, N) GPU tensor")
         # precision mode and weight versions are part of the key: a graph replays the buffers packed at capture time
-        from . import get_precision
+        from . import get_mode as get_precision
         wv = tuple(t._version for m in (self.detector, self.denoiser) for t in list(m.parameters()) + list(m.buffers()))
         key = (tuple(mixed.shape), mixed.device.index, get_precision(), hash(wv))
         entry = self._graphs.get(key)
@@ -193,7 +193,7 @@ class GraphedDenoiser:
         every group (pipeline.denoise_ragged's grouping, per-clip geometry in the kernels) is captured once per LENGTH MIX
         and replayed for new audio of the same lengths (a serving loop with fixed chunk sizes, a benchmark's repeated
         batch).  The per-clip tables are uploaded before the capture and kept alive with the graph."""
-        from . import get_precision
+        from . import get_mode as get_precision
         for c in clips:
             if c.dim() != 1 or not c.is_cuda or c.dtype != torch.float32:
                 raise ValueError("denoise_mixed expects 1-D float32 GPU waveforms")

@@ -56,9 +56,13 @@ def test_state_dict_layout_of_the_variant():
     assert not hasattr(audio_only, "encoder_video") and audio_only.lstm.input_size == 2048
 
 
+# eval logits of the variant in IEEE-half storage vs the reference classes (8 video + 12 audio blocks, BiLSTM, FC head)
+AV_FP16_LOGITS = 1e-2
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("stacked", [False, True], ids=["temporal-taps", "time-stack"])
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
 def test_hip_audiovisual_forward_matches_goldens(golden, precision, stacked, monkeypatch):
     """stacked: the materialised time stacks of round 1 (SOS_VIDEO_STACK=1) instead of the kernels' temporal taps."""
     import sos_amd
@@ -79,9 +83,10 @@ def test_hip_audiovisual_forward_matches_goldens(golden, precision, stacked, mon
         sos_amd.set_precision("bf16")
     e = rel_err(out.cpu(), g["logits"])
     print(precision, "audio-visual logits rel err", e)
-    assert out.shape == (1, 12) and e < (1e-3 if precision == "bf16x3" else 5e-2)
+    # fp16 = the storage type tools/av_bench.py times the variant in
+    assert out.shape == (1, 12) and e < {"bf16x3": 1e-3, "fp16": AV_FP16_LOGITS, "bf16": 5e-2}[precision]
     # clips of a batch are independent: the first clip of a batch of two equals the single-clip run
-    assert out_b2.shape == (2, 12) and rel_err(out_b2[0].cpu(), out[0].cpu()) < (2e-4 if precision == "bf16x3" else 2e-2)
+    assert out_b2.shape == (2, 12) and rel_err(out_b2[0].cpu(), out[0].cpu()) < {"bf16x3": 2e-4, "fp16": 5e-3, "bf16": 2e-2}[precision]
     with pytest.raises(ValueError):
         net(s.cuda())                                    # the variant needs frames
     with pytest.raises(ValueError):
@@ -116,7 +121,7 @@ def test_hip_video_features_match_oracle_blockwise(golden):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("stacked", [False, True], ids=["temporal-taps", "time-stack"])
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
 def test_hip_audiovisual_train_step_matches_reference_autograd(golden, precision, stacked, monkeypatch):
     """Train-mode forward (BatchNorm3d batch statistics), BCE loss and every parameter gradient of the variant against
     the reference modules' autograd (goldens).  Tolerances as for the audio networks (tests/test_gpu_train_nets.py).
@@ -142,13 +147,15 @@ def test_hip_audiovisual_train_step_matches_reference_autograd(golden, precision
         x3 = precision == "bf16x3"
         e = rel_err(out.detach().cpu(), g["train_logits"])
         print(precision, "train logits rel err", e, "loss", float(loss), "ref", float(g["train_loss"]))
-        assert e < (1e-3 if x3 else 0.1)
-        assert abs(float(loss) / float(g["train_loss"]) - 1) < (1e-3 if x3 else 5e-2)
-        worst = _check_grads(list(net.named_parameters()), g["train_gradnorm"], g["train_gradhead"], 3e-2 if x3 else 0.4, precision)
+        f16 = precision == "fp16"
+        assert e < (1e-3 if x3 else 2e-2 if f16 else 0.1)
+        assert abs(float(loss) / float(g["train_loss"]) - 1) < (1e-3 if x3 else 1e-2 if f16 else 5e-2)
+        worst = _check_grads(list(net.named_parameters()), g["train_gradnorm"], g["train_gradhead"],
+                             3e-2 if x3 else 0.15 if f16 else 0.4, precision)
         print(precision, "worst grad err", worst)
         sd = net.state_dict()
-        assert rel_err(sd["encoder_video.7.block.1.running_mean"].cpu(), g["train_rm7"]) < (1e-3 if x3 else 5e-2)
-        assert rel_err(sd["encoder_video.0.block.1.running_var"].cpu(), g["train_rv0"]) < (1e-3 if x3 else 5e-2)
+        assert rel_err(sd["encoder_video.7.block.1.running_mean"].cpu(), g["train_rm7"]) < (1e-3 if x3 else 1e-2 if f16 else 5e-2)
+        assert rel_err(sd["encoder_video.0.block.1.running_var"].cpu(), g["train_rv0"]) < (1e-3 if x3 else 1e-2 if f16 else 5e-2)
         assert int(sd["encoder_video.3.block.1.num_batches_tracked"]) == 1
     finally:
         sos_amd.set_precision("bf16")

@@ -9,9 +9,12 @@ from util import rel_err, silent_gate, spec_input
 
 pytestmark = pytest.mark.gpu
 
-# tolerance on ||a-b||_inf / ||b||_inf per tensor: bf16x3 carries ~16 mantissa bits end to end
-# (north_star bar 1e-3); plain bf16 carries 8 and is checked against its own, looser bound.
-TOL = {"bf16x3": 1e-3, "bf16": 6e-2, "fp16": 5e-3}
+# tolerance on ||a-b||_inf / ||b||_inf PER TENSOR (logits, n_pred, mask): bf16x3 carries ~16 mantissa bits end to end
+# (north_star bar 1e-3; observed 1-4e-5); fp16, the timed storage type, meets the bar on the spectrogram / mask (observed
+# 6-7e-4) and has its own explicit logit bound (observed 1.5-1.8e-3: the detector's head contracts 2048 features of 12
+# stacked blocks into ONE number per frame); 'mixed' runs the detector in bf16x3, so its logits meet the bar as well;
+# plain bf16 carries 8 bits and is checked against its own, looser bounds.
+TOL = {"bf16x3": (1e-3, 1e-3, 1e-3), "mixed": (2e-4, 1e-3, 1e-3), "fp16": (3e-3, 1e-3, 1e-3), "bf16": (6e-2, 6e-2, 6e-2)}
 
 
 def _nets():
@@ -25,7 +28,7 @@ def _nets():
     return det.cuda().eval(), jm.cuda().eval()
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16", "mixed"])
 def test_eval_forward_matches_reference_goldens(golden, precision):
     g = golden("networks")
     sos_amd.set_precision(precision)
@@ -41,7 +44,7 @@ def test_eval_forward_matches_reference_goldens(golden, precision):
             errs = (rel_err(lo.cpu(), g[f"det_logits_{tag}"]), rel_err(n_pred.cpu(), g[f"n_pred_{tag}"]),
                     rel_err(out.cpu(), g[f"mask_{tag}"]))
             print(precision, tag, "rel err logits/n_pred/mask:", errs)
-            assert max(errs) < TOL[precision], errs
+            assert all(e < t for e, t in zip(errs, TOL[precision])), (errs, TOL[precision])
     finally:
         sos_amd.set_precision("bf16")
 

@@ -11,12 +11,22 @@ from oracle import nets as onet
 
 pytestmark = pytest.mark.gpu
 
+# waveform bound (||a-b||_inf / ||b||_inf) of a denoiser that STORES activations and weights in IEEE half: the storage
+# format's rounding (2^-12 per element) through 15-30 stacked conv blocks, the BiLSTM and the mask's 10 * logit() gives
+# 1-3e-3 on these clips -- tools/probe/precision_study.py reproduces the same figure on the f32 oracle with nothing but
+# .half() round trips inserted, i.e. the kernels add nothing beyond the format (observed on the GPU: 1.1e-3 .. 4.8e-3)
+WAVE_TOL_FP16 = 6e-3
 
-def _oracle_chain(sd1, sd2, wave, n_frames):
+
+def _oracle_chain(sd1, sd2, wave, n_frames, bits=None):
+    """The reference chain on one clip.  bits: frame decisions to use INSTEAD of the oracle detector's (a 1x-cost 16-bit
+    mode may flip a frame whose logit lies within its rounding of the threshold; everything downstream of the decisions is
+    then still compared, on the decisions the GPU took)."""
     S = torch.from_numpy(ofe.fast_stft(wave).transpose(2, 0, 1)[None].astype(np.float32))
     with torch.no_grad():
         lo = onet.detector_forward(sd1, S, n_frames)
-    bits = (torch.sigmoid(lo) >= 0.5).numpy().astype(np.uint8)[0]
+    if bits is None:
+        bits = (torch.sigmoid(lo) >= 0.5).numpy().astype(np.uint8)[0]
     mask = ofe.convert_bitstreammask_to_audiomask(wave, 14000 / 30.0, list(bits))
     Sn = torch.from_numpy(ofe.fast_stft(wave * mask).transpose(2, 0, 1)[None].astype(np.float32))
     with torch.no_grad():
@@ -29,10 +39,14 @@ def _oracle_chain(sd1, sd2, wave, n_frames):
 # (||a-b||_inf / ||b||_inf), fidelity floor (SI-SDR of the HIP waveform w.r.t. the oracle's, dB), SI-SDR-vs-clean
 # bound where the score is > -25 dB / below.  fp16 is the timed mode: it has to hold the north_star's 0.05 dB where
 # the metric is conditioned at all.
-_PIPE_BOUNDS = {"bf16x3": (2e-4, 1e-3, 70.0, 0.05, 0.05), "fp16": (3e-3, 1e-2, 40.0, 0.05, 0.1), "bf16": (2e-2, 1e-1, 20.0, 0.1, 0.5)}
+# 'mixed' (detector in bf16x3, denoiser in fp16) is the mode the pipeline is meant to be run in at 1x denoiser cost: its
+# frame decisions are REQUIRED to equal the reference's (STRICT_BITS), like the parity mode's.
+_PIPE_BOUNDS = {"bf16x3": (0.0, 1e-3, 70.0, 0.05, 0.05), "mixed": (0.0, WAVE_TOL_FP16, 40.0, 0.05, 0.1),
+                "fp16": (3e-3, WAVE_TOL_FP16, 40.0, 0.05, 0.1), "bf16": (2e-2, 1e-1, 20.0, 0.1, 0.5)}
+STRICT_BITS = ("bf16x3", "mixed")
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "mixed", "fp16", "bf16"])
 def test_pipeline_matches_oracle_and_si_sdr(precision):
     from sos_amd import pipeline
     from sos_amd.common import MyConfig
@@ -61,31 +75,36 @@ def test_pipeline_matches_oracle_and_si_sdr(precision):
     for i in range(len(raw["mixed"])):
         lo, bits, mask, y = _oracle_chain(sd1, sd2, raw["mixed"][i], n_frames)
         bits_gpu = r["bits"][i].cpu().numpy()
-        # frames whose logit is within the forward tolerance of the threshold may legitimately flip
-        unsure = np.abs(lo) < band * max(1.0, np.abs(lo).max())
-        assert np.array_equal(bits_gpu[~unsure], bits[~unsure])
         assert 0 < bits.sum() < len(bits)
-        if np.array_equal(bits_gpu, bits):
-            # identical bit-stream -> identical sample mask (bit exact) and comparable waveforms
-            assert np.array_equal(r["mask"][i].cpu().numpy(), mask)
-            out = r["out"][i].cpu().numpy()
-            assert out.shape == y.shape == (158 * 177,)
-            err = np.max(np.abs(out - y)) / np.max(np.abs(y))
-            d_sdr = abs(ofe.si_sdr(out, raw["clean"][i]) - ofe.si_sdr(y, raw["clean"][i]))
-            print(precision, "clip", i, "waveform rel err", err, "SI-SDR", ofe.si_sdr(y, raw["clean"][i]), "delta dB", d_sdr)
-            # bf16x3 is the parity mode (north_star 1e-3); plain bf16 carries 0.5-2e-2 per-layer rounding noise whose sum
-            # depends on the summation order of the conv tilings the autotuner picks (observed 1.6e-2 .. 5.9e-2 here)
-            assert err < err_tol
-            # fidelity of the HIP waveform w.r.t. the oracle's waveform, as an SI-SDR (dB)
-            fid = ofe.si_sdr(out, y)
-            assert fid > fid_min, fid
-            # north_star: SI-SDR (vs clean) within 0.05 dB of the reference path.  The weights here are
-            # untrained, so the output is nearly uncorrelated with `clean` (SI-SDR -20 .. -40 dB) and the
-            # metric is ill-conditioned below ~-25 dB (a 3 % waveform change moves a -39 dB score by 0.2 dB):
-            # the 0.05 dB bar is enforced for bf16x3 (observed 2e-5 .. 5e-4 dB); plain bf16 gets 0.1 dB where the score is
-            # > -25 dB (observed 0.045 dB with one tiling choice: too close to 0.05 for a bound that has to hold for
-            # whatever tilings the autotuner picks) and 0.5 dB below.
-            assert d_sdr < (sdr_hi if ofe.si_sdr(y, raw["clean"][i]) > -25.0 else sdr_lo)
+        if precision in STRICT_BITS:
+            # north_star "frame indices bit-exact": no tolerance band, no flipped frame
+            assert np.array_equal(bits_gpu, bits), (precision, i, np.flatnonzero(bits_gpu != bits), lo[bits_gpu != bits])
+        else:
+            # a 1x-cost 16-bit detector: frames whose logit is within its forward tolerance of the threshold may flip;
+            # everything downstream is then compared on the decisions the GPU took (never skipped)
+            unsure = np.abs(lo) < band * max(1.0, np.abs(lo).max())
+            assert np.array_equal(bits_gpu[~unsure], bits[~unsure])
+            if not np.array_equal(bits_gpu, bits):
+                lo, bits, mask, y = _oracle_chain(sd1, sd2, raw["mixed"][i], n_frames, bits=bits_gpu)
+        # identical bit-stream -> identical sample mask (bit exact) and comparable waveforms
+        assert np.array_equal(r["mask"][i].cpu().numpy(), mask)
+        out = r["out"][i].cpu().numpy()
+        assert out.shape == y.shape == (158 * 177,)
+        err = np.max(np.abs(out - y)) / np.max(np.abs(y))
+        d_sdr = abs(ofe.si_sdr(out, raw["clean"][i]) - ofe.si_sdr(y, raw["clean"][i]))
+        print(precision, "clip", i, "waveform rel err", err, "SI-SDR", ofe.si_sdr(y, raw["clean"][i]), "delta dB", d_sdr)
+        # bf16x3 is the parity mode (north_star 1e-3); plain bf16 carries 0.5-2e-2 per-layer rounding noise whose sum
+        # depends on the summation order of the conv tilings (observed 1.6e-2 .. 5.9e-2 here)
+        assert err < err_tol
+        # fidelity of the HIP waveform w.r.t. the oracle's waveform, as an SI-SDR (dB)
+        fid = ofe.si_sdr(out, y)
+        assert fid > fid_min, fid
+        # north_star: SI-SDR (vs clean) within 0.05 dB of the reference path.  The weights here are
+        # untrained, so the output is nearly uncorrelated with `clean` (SI-SDR -20 .. -40 dB) and the
+        # metric is ill-conditioned below ~-25 dB (a 3 % waveform change moves a -39 dB score by 0.2 dB):
+        # the 0.05 dB bar is enforced for bf16x3 (observed 2e-5 .. 5e-4 dB); plain bf16 gets 0.1 dB where the score is
+        # > -25 dB and 0.5 dB below.
+        assert d_sdr < (sdr_hi if ofe.si_sdr(y, raw["clean"][i]) > -25.0 else sdr_lo)
 
 
 def test_ragged_batch_matches_per_clip_and_oracle():
@@ -154,14 +173,14 @@ def _long_wave(seed, n):
 def test_ragged_one_launch_1s_and_10s_vs_oracle():
     """A 1 s clip (T = 89) and a 10 s clip (T = 887) -- the two ends of BASELINE configs[3] -- plus odd lengths in the SAME
     launch sequence: every clip equals its stand-alone run, every intermediate decision (frame bits) is the clip's own,
-    and the 1 s / 10 s outputs match the oracle chain (1e-3 in the bf16x3 parity mode; fp16, the timed mode, within
-    its own bound)."""
+    and the 1 s / 10 s outputs match the oracle chain (1e-3 in the bf16x3 parity mode; 'mixed' -- parity-precision
+    detector, fp16 denoiser -- within the half-storage bound, with the SAME frame decisions as the oracle)."""
     from sos_amd import pipeline
     sd1, sd2, det, jm = _nets_closed_form()
     lens = [140000, 14000, 28123, 97531, 14000 + 157, 51800]
     waves = [_long_wave(300 + 10 * i, n) for i, n in enumerate(lens)]
     clips = [torch.from_numpy(w).cuda() for w in waves]
-    for precision, tol_single, tol_oracle in (("bf16x3", 2e-4, 1e-3), ("fp16", 1e-2, 1e-2)):
+    for precision, tol_single, tol_oracle in (("bf16x3", 2e-4, 1e-3), ("mixed", 1e-2, 1e-2)):
         sos_amd.set_precision(precision)
         try:
             outs, extra = pipeline.denoise_ragged(det, jm, clips, return_all=True)
@@ -169,20 +188,16 @@ def test_ragged_one_launch_1s_and_10s_vs_oracle():
             for i, (w, o, s1) in enumerate(zip(waves, outs, singles)):
                 T = 1 + len(w) // 158
                 assert o.shape == (158 * (T - 1),) and bool(torch.isfinite(o).all())
-                assert extra[i]["bits"].shape == s1["bits"][0].shape
-                if torch.equal(extra[i]["bits"], s1["bits"][0]):         # same frame decisions -> comparable waveforms
-                    e = float((o - s1["out"][0]).abs().max() / s1["out"][0].abs().max())
-                    print(precision, "ragged vs alone, clip", i, "len", len(w), "rel err", e)
-                    assert e < tol_single
-                else:                                                     # a logit within rounding of the threshold
-                    lo = s1["logits"][0]
-                    flipped = extra[i]["bits"] != s1["bits"][0]
-                    assert float(lo[flipped].abs().max()) < 2e-2 * max(1.0, float(lo.abs().max()))
+                # both modes run the detector at parity precision: the ragged launch takes the SAME frame decisions as
+                # the clip's stand-alone run (the tilings, hence the summation orders, differ between the two)
+                assert torch.equal(extra[i]["bits"], s1["bits"][0]), (precision, i)
+                e = float((o - s1["out"][0]).abs().max() / s1["out"][0].abs().max())
+                print(precision, "ragged vs alone, clip", i, "len", len(w), "rel err", e)
+                assert e < tol_single
             for i in (0, 1):                                              # the 10 s and the 1 s clip against the oracle
                 nf = pipeline.n_video_frames(lens[i])
                 lo, bits, mask, y = _oracle_chain(sd1, sd2, waves[i], nf)
-                if not np.array_equal(extra[i]["bits"].cpu().numpy(), bits):
-                    continue
+                assert np.array_equal(extra[i]["bits"].cpu().numpy(), bits), (precision, i)      # frame indices bit-exact
                 yg = outs[i].cpu().numpy()
                 err = np.abs(yg - y).max() / max(np.abs(y).max(), 1e-9)
                 print(precision, "ragged vs oracle, clip", i, "len", lens[i], "rel err", err)
@@ -311,7 +326,7 @@ def test_si_sdr_parity_with_briefly_trained_weights():
     raw = synth_batch(123456, 3)
     n_frames = pipeline.n_video_frames(raw["mixed"].shape[1])
     res = {}
-    for precision in ("bf16x3", "fp16", "bf16"):
+    for precision in ("bf16x3", "mixed", "fp16", "bf16"):
         sos_amd.set_precision(precision)
         try:
             res[precision] = pipeline.denoise(det, jm, torch.from_numpy(raw["mixed"]).cuda(), return_all=True)
@@ -322,16 +337,17 @@ def test_si_sdr_parity_with_briefly_trained_weights():
         lo, bits, mask, y = _oracle_chain(sd1, sd2, raw["mixed"][i], n_frames)
         s_or = ofe.si_sdr(y, raw["clean"][i])
         s_in = ofe.si_sdr(raw["mixed"][i][:len(y)], raw["clean"][i])
-        for precision, tol in (("bf16x3", 0.05), ("fp16", 0.05), ("bf16", 0.05)):
+        for precision, tol in (("bf16x3", 0.05), ("mixed", 0.05), ("fp16", 0.05), ("bf16", 0.05)):
             r = res[precision]
-            flips = int(np.sum(r["bits"][i].cpu().numpy() != bits))
-            # bit-flip gate: frame decisions (sigmoid >= 0.5) may only differ from the fp32 path where a logit sits within
-            # rounding of the threshold -- at most one of the 60 frames in the 16-bit modes, none in the parity mode
-            assert flips <= (0 if precision == "bf16x3" else 1), (precision, i, flips)
-            if flips:
-                continue
+            bits_gpu = r["bits"][i].cpu().numpy()
+            flips = int(np.sum(bits_gpu != bits))
+            # frame decisions (sigmoid >= 0.5): none may differ from the fp32 path in the parity mode and in 'mixed' (its
+            # detector runs at parity precision); the 1x-cost 16-bit detectors may flip at most one of the 60 frames (a
+            # logit within rounding of the threshold) -- the rest of the chain is then compared on THEIR decisions
+            assert flips <= (0 if precision in STRICT_BITS else 1), (precision, i, flips)
+            s_ref = s_or if not flips else ofe.si_sdr(_oracle_chain(sd1, sd2, raw["mixed"][i], n_frames, bits=bits_gpu)[3], raw["clean"][i])
             s_hip = ofe.si_sdr(r["out"][i].cpu().numpy(), raw["clean"][i])
-            print(precision, "clip", i, "SI-SDR in", round(s_in, 2), "oracle", round(s_or, 3), "HIP", round(s_hip, 3))
-            assert abs(s_hip - s_or) <= tol, (precision, s_hip, s_or)
+            print(precision, "clip", i, "SI-SDR in", round(s_in, 2), "oracle", round(s_ref, 3), "HIP", round(s_hip, 3), "flips", flips)
+            assert abs(s_hip - s_ref) <= tol, (precision, s_hip, s_ref)
         gains.append(s_or - s_in)
     assert np.mean(gains) > 1.0, gains                      # the briefly trained chain really denoises
