@@ -1,22 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the Listening-to-Sound-of-Silence hot path on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched with
-torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver launches it with
+torch.distributed.run, one rank per GPU (RCCL); started WITHOUT a launcher (`WORLD_SIZE` unset) and N > 1 it launches the
+N ranks itself (re-exec under `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1`) and fails
+loudly when fewer than N devices are visible.  `n_gpus` in the line is the size of the communicator, verified with an
+all-reduce of ones.  Rank 0 prints ONE JSON line.
 
 A "step" is one pass of the hot path over one batch of synthetic 2 s clips resident in HBM:
   --mode train (default, BASELINE.json configs[1]): detector forward/backward/Adam (BCE) AND denoiser
-               forward/backward/Adam (MSE + MSE through the mask apply) on the same B clips, bf16, the two
-               (independent) models on one HIP stream each;
+               forward/backward/Adam (MSE + MSE through the mask apply) on the same B clips, 16-bit storage + f32
+               accumulation, the two (independent) models on one HIP stream each;
                for N > 1 the gradients are averaged with bucketed RCCL all-reduces overlapped with backward
   --mode infer: STFT -> detector -> bits->mask -> STFT(noise) -> JointModel -> mask apply -> ISTFT
   --mode infer-ragged (BASELINE.json configs[3]): the same chain over --batch (default 256) clips of DIFFERENT lengths,
                U(1 s, 10 s) with seed 99, per-clip geometry inside the kernels (pipeline.denoise_ragged)
 Each rank processes its own batch (independent utterances): weak scaling.
+
+The default run (N = 1, train) also times, AFTER the headline loop and outside its timed region, the other lines of the
+round on the same box and attaches them as `secondary` (inference, ragged inference, training in bf16 -- the literal
+BASELINE configs[1] dtype -- and in 'mixed'); `value` / `config` / `dtype` describe the headline loop only.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -30,10 +38,13 @@ import torch         # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 N_SAMPLES = 28000             # 2 s @ 14 kHz: the reference-true geometry
 GFLOP_PER_UTT_INFER = 446.5
-DEFAULT_PRECISION = "fp16"
+DEFAULT_PRECISION = {"train": "fp16", "infer": "mixed", "infer-ragged": "mixed"}
 # measured against the reference goldens (tests/test_gpu_nets.py, tests/test_gpu_train_nets.py); north_star bar: 1e-3
 PARITY_NOTE = {
-    "fp16": "eval n_pred/mask <= 7e-4, logits <= 1.8e-3 rel vs reference goldens (tests assert 5e-3); SI-SDR delta <= 0.05 dB",
+    "fp16": "eval n_pred/mask <= 7e-4 (asserted 1e-3), logits <= 1.8e-3 (asserted 3e-3) rel vs reference goldens; SI-SDR delta <= 0.05 dB; "
+            "frame decisions of a 1x-cost 16-bit detector may flip within 3e-3 of the threshold (use 'mixed' for inference)",
+    "mixed": "detector in bf16x3 (logits <= 4e-5 rel, frame decisions equal the f32 reference's), everything else fp16: eval "
+             "n_pred/mask <= 7e-4 (asserted 1e-3); SI-SDR delta <= 0.05 dB",
     "bf16": "eval outputs 0.5-1.9e-2 rel vs reference goldens (tests assert 6e-2): does NOT meet the 1e-3 bar",
     "bf16x3": "eval outputs 1-4e-5 rel vs reference goldens (tests assert 1e-3)",
 }
@@ -49,17 +60,17 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(runs=5):
+def cpu_baseline(runs=3):
     """The oracle (CPU restatement of the reference path, torch fp32 + numpy f64) timed on the host cores with the
     protocol SURVEY.md 8-d / BASELINE.md 3 fix: BASELINE configs[0] = ONE 2 s clip through the whole inference pipeline
-    (STFT -> detector -> bits->mask -> STFT -> JointModel -> mask apply -> ISTFT), 1 warm-up, median of `runs` runs;
-    plus the denoiser's training forward+backward at B=2 (1 warm-up, median of 3)."""
+    (STFT -> detector -> bits->mask -> STFT -> JointModel -> mask apply -> ISTFT), 1 warm-up, median of `runs` runs --
+    at 8, 32 and 128 torch threads (as far as the host has them), the BEST of which is reported with its thread count;
+    plus the denoiser's training forward+backward at B=2 at that thread count (1 warm-up, best of 2)."""
     import statistics
     from oracle import frontend as ofe
     from oracle import nets as onet
     from sos_amd.dataset import synth_batch
-    cores = max(1, min(os.cpu_count() or 1, 128))
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     sd1 = onet.closed_form_state(onet.detector_spec(), seed=1)
     sd2 = onet.closed_form_state(onet.joint_spec(), seed=2)
     raw = synth_batch(0, 2)
@@ -75,16 +86,22 @@ def cpu_baseline(runs=5):
         rec = onet.mask_apply(S, crm)
         return [ofe.fast_istft(r.permute(1, 2, 0).numpy()) for r in rec]
 
-    def timed(fn, n):
+    def timed(fn, n, reduce=statistics.median):
         fn()                                   # warm-up
         ts = []
         for _ in range(n):
             t0 = time.perf_counter()
             fn()
             ts.append(time.perf_counter() - t0)
-        return statistics.median(ts)
+        return reduce(ts)
 
-    t_inf = timed(lambda: infer(raw["mixed"][:1]), runs)
+    per_threads = {}
+    for nt in sorted({min(t, ncpu) for t in (8, 32, 128)}):
+        torch.set_num_threads(nt)
+        per_threads[nt] = timed(lambda: infer(raw["mixed"][:1]), runs)
+    cores = min(per_threads, key=per_threads.get)
+    t_inf = per_threads[cores]
+    torch.set_num_threads(cores)
 
     # denoiser training step (forward + backward, train-mode BatchNorm) at B=2
     S = lambda a: torch.from_numpy(np.stack([ofe.fast_stft(w).transpose(2, 0, 1) for w in a]).astype(np.float32))  # noqa: E731
@@ -100,13 +117,145 @@ def cpu_baseline(runs=5):
         _, losses = onet.denoiser_losses(sdt, batch, training=True)
         (losses["stage1"] + losses["stage2"]).backward()
 
-    t_trn = timed(train, 3)
+    t_trn = timed(train, 2, min)
     return {"value": 1.0 / t_inf, "unit": "utterances/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
-            "threads": torch.get_num_threads(),
+            "host_cpus": ncpu, "threads": cores,
+            "infer_s_per_clip_by_threads": {str(k): round(v, 3) for k, v in per_threads.items()},
             "sample": f"BASELINE configs[0]: one 2 s clip (28000 samples) through the full inference pipeline, torch-CPU fp32 + numpy, "
-                      f"1 warm-up + median of {runs} runs = {t_inf:.2f} s/clip; denoiser fwd+bwd at B=2: median of 3 = {t_trn:.2f} s/step",
+                      f"1 warm-up + median of {runs} runs at {sorted(per_threads)} threads, best = {cores} threads: {t_inf:.2f} s/clip; "
+                      f"denoiser fwd+bwd at B=2 at {cores} threads: best of 2 = {t_trn:.2f} s/step",
             "infer_s_per_clip_b1": t_inf, "denoiser_train_s_per_step_b2": t_trn,
             "denoiser_train_utt_per_s_b2": 2.0 / t_trn}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and become the launcher."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node (no CPU fallback, no oversubscription)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execve(sys.executable, cmd, env)
+
+
+class Workload:
+    """One (mode, precision) line: builds the resident inputs and models, exposes step()."""
+
+    def __init__(self, mode, precision, B, rank, serial=False, graph=False):
+        import sos_amd
+        from sos_amd import agent, pipeline, tools, transform
+        from sos_amd.common import MyConfig
+        from sos_amd.dataset import synth_batch
+        from sos_amd.denoiser import networks as jnet
+        from sos_amd.detector import networks as dnet
+        self.mode, self.precision, self.B, self.graph = mode, precision, B, graph
+        self.pipeline = pipeline
+        sos_amd.set_precision(precision)
+        torch.manual_seed(0)
+        det = dnet.get_network().cuda().eval()
+        jm = jnet.get_network(MyConfig()).cuda().eval()
+        self.det, self.jm = det, jm
+        base = synth_batch(1000 * rank, min(B, 8))["mixed"]
+        mixed = torch.from_numpy(np.tile(base, ((B + len(base) - 1) // len(base), 1))[:B]).cuda().contiguous()
+        self.mixed = mixed
+        self.audio_seconds = B * N_SAMPLES / 14000.0
+        self.lens = None
+        if mode == "train":
+            # batch dicts of the reference schema (M1/dataset.py:348-352, M2/dataset.py:311-320), resident in HBM
+            raw = synth_batch(1000 * rank, min(B, 8))
+            rep = (B + len(raw["mixed"]) - 1) // len(raw["mixed"])
+            tile = lambda a: torch.from_numpy(np.tile(a, (rep, 1))[:B]).cuda().contiguous()   # noqa: E731
+            clean, full_noise, bits = tile(raw["clean"]), tile(raw["full_noise"]), tile(raw["bits"])
+            mask, noise_sig = tools.bits_to_mask_batch(bits, 14000 / 30.0, N_SAMPLES, mixed)
+            S = transform.stft_batch(torch.cat([mixed, clean * (1 - mask), noise_sig, full_noise]))
+            batch_jm = {"mixed": S[:B].contiguous(), "clean": S[B:2 * B].contiguous(), "noise": S[2 * B:3 * B].contiguous(),
+                        "full_noise": S[3 * B:].contiguous()}
+            batch_det = {"audio": batch_jm["mixed"], "label": bits.float()}
+            ag_det = agent.DetectorAgent(det.train(), lr=1e-3)
+            ag_jm = agent.DenoiserAgent(jm.train(), lr=1e-3)
+            self.agents = (ag_det, ag_jm)
+
+            def step():
+                if serial:
+                    ag_det.train_func(batch_det)
+                    ag_jm.train_func(batch_jm)
+                else:           # the two models are independent: one HIP stream each
+                    agent.train_concurrent([(ag_jm, batch_jm), (ag_det, batch_det)])
+            self.eager = step
+        elif mode == "infer-ragged":
+            # BASELINE configs[3]: lengths drawn uniformly from 1-10 s with seed 99 (SURVEY.md 8-d), every rank its own draw
+            lens = [int(v) for v in np.random.default_rng(99 + rank).uniform(14000, 140000, B)]
+            pool = np.concatenate(list(synth_batch(2000 * rank, 20)["mixed"]))
+            pool_t = torch.from_numpy(np.ascontiguousarray(pool)).cuda()
+            clips = [pool_t[(4099 * i) % (len(pool) - 140000):][:n].contiguous() for i, n in enumerate(lens)]
+            self.lens, self.audio_seconds = lens, sum(lens) / 14000.0
+            graphed = pipeline.GraphedDenoiser(det, jm, max_graphs=16) if graph else None
+            self.eager = lambda: pipeline.denoise_ragged(det, jm, clips)
+            step = (lambda: graphed.denoise_mixed(clips)) if graph else self.eager
+        else:
+            graphed = pipeline.GraphedDenoiser(det, jm) if graph else None
+            self.eager = lambda: pipeline.denoise(det, jm, mixed)
+            step = (lambda: graphed(mixed, clone=False)) if graph else self.eager
+        self.step = step
+
+    def gflop_per_utt(self):
+        g = GFLOP_PER_UTT_INFER * (3.0 if self.mode == "train" else 1.0)   # algorithmic (reference) FLOPs: bf16x3's 3x MACs do not count
+        if self.lens is not None:                                         # FLOPs scale with the frames of a clip: 2 s = 178 frames
+            g *= sum(1 + n // 158 for n in self.lens) / (178.0 * self.B)
+        return g
+
+
+def run_timed(wl, steps, warmup, barrier, profile=True):
+    """W untimed warm-up steps, then exactly K steps between barrier + synchronize; returns (seconds, dominant launch
+    signature, its HIP-event summary).  profile=False: no event brackets (secondary lines)."""
+    import sos_amd
+    from sos_amd import engine
+    sos_amd.set_precision(wl.precision)
+    dom = prof = None
+    use_graph = wl.graph and wl.mode != "train"
+    if profile and use_graph:
+        # hipGraph replay: individual launches cannot be bracketed inside a replayed graph, so the dominant kernel is found
+        # and timed (HIP events on the launch stream) in an EAGER pass of the same step before the graphs are captured
+        engine.PROFILER = engine.LaunchProfiler()
+        wl.eager()
+        summ = engine.PROFILER.summary()
+        dom = max(summ, key=lambda k: summ[k]["total_ms"])
+        engine.PROFILER = engine.LaunchProfiler(only=dom)
+        for _ in range(2):
+            wl.eager()
+        prof = engine.PROFILER.summary()[dom]
+        engine.PROFILER = None
+        for _ in range(max(1, warmup)):
+            wl.step()                                   # captures the graphs
+    elif profile:
+        # warm-up; the first pass also finds the dominant kernel launch signature
+        engine.PROFILER = engine.LaunchProfiler()
+        for _ in range(max(1, warmup)):
+            wl.step()
+        summ = engine.PROFILER.summary()
+        dom = max(summ, key=lambda k: summ[k]["total_ms"])
+        engine.PROFILER = engine.LaunchProfiler(only=dom)
+    else:
+        for _ in range(max(1, warmup)):
+            wl.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if profile and not use_graph:
+        prof = engine.PROFILER.summary()[dom]
+    engine.PROFILER = None
+    return dt, dom, prof
 
 
 def main():
@@ -116,10 +265,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU per step (default 64; 256 for infer-ragged)")
     ap.add_argument("--mode", default="train", choices=["train", "infer", "infer-ragged"])
-    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["bf16", "fp16", "bf16x3"],
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "bf16x3", "mixed"],
                     help="16-bit storage type of activations/weights (MFMA rate is the same for bf16 and fp16); bf16x3 = "
-                         "three-pass hi/lo split (3x the MACs, ~fp32 accuracy)")
+                         "three-pass hi/lo split (3x the MACs, ~fp32 accuracy); mixed = detector in bf16x3 (frame decisions "
+                         "equal the f32 reference's), everything else fp16.  Default: fp16 for train, mixed for inference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (inference, ragged, bf16 / mixed training)")
     ap.add_argument("--serial", action="store_true", help="train mode: run the two models back to back on one stream")
     ap.add_argument("--graph", action="store_true",
                     help="infer / infer-ragged: replay hipGraph-captured launch sequences (pipeline.GraphedDenoiser) instead "
@@ -128,131 +279,65 @@ def main():
                     help="world of one: run the data-parallel gradient path anyway (bucket copies + RCCL all-reduce of every "
                          "bucket on a 1-rank group) to measure its overhead on a single GPU")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.precision is None:
+        args.precision = DEFAULT_PRECISION[args.mode]
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _self_launch(args.gpus)                       # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
     dist = None
+    n_gpus = 1
     if world > 1 or args.force_buckets:
         import torch.distributed as dist
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
             os.environ["SOS_FORCE_BUCKETS"] = "1"
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # the communicator that will carry the gradients: count its members
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)
+        n_gpus = int(round(float(ones.item())))
+        if n_gpus != world:
+            raise SystemExit(f"bench.py: the RCCL communicator has {n_gpus} members, expected {world}")
 
     import sos_amd
-    from sos_amd import agent, engine, pipeline, tools, transform
-    from sos_amd.common import MyConfig
-    from sos_amd.dataset import synth_batch
-    from sos_amd.denoiser import networks as jnet
-    from sos_amd.detector import networks as dnet
 
     if args.batch is None:
         args.batch = 256 if args.mode == "infer-ragged" else 64
-    sos_amd.set_precision(args.precision)
-    torch.manual_seed(0)
-    det = dnet.get_network().cuda().eval()
-    jm = jnet.get_network(MyConfig()).cuda().eval()
     B = args.batch
-    base = synth_batch(1000 * rank, min(B, 8))["mixed"]
-    mixed = torch.from_numpy(np.tile(base, ((B + len(base) - 1) // len(base), 1))[:B]).cuda().contiguous()
-
-    if args.mode == "train":
-        # batch dicts of the reference schema (M1/dataset.py:348-352, M2/dataset.py:311-320), resident in HBM
-        raw = synth_batch(1000 * rank, min(B, 8))
-        rep = (B + len(raw["mixed"]) - 1) // len(raw["mixed"])
-        tile = lambda a: torch.from_numpy(np.tile(a, (rep, 1))[:B]).cuda().contiguous()   # noqa: E731
-        clean, full_noise, bits = tile(raw["clean"]), tile(raw["full_noise"]), tile(raw["bits"])
-        mask, noise_sig = tools.bits_to_mask_batch(bits, 14000 / 30.0, N_SAMPLES, mixed)
-        S = transform.stft_batch(torch.cat([mixed, clean * (1 - mask), noise_sig, full_noise]))
-        batch_jm = {"mixed": S[:B].contiguous(), "clean": S[B:2 * B].contiguous(), "noise": S[2 * B:3 * B].contiguous(),
-                    "full_noise": S[3 * B:].contiguous()}
-        batch_det = {"audio": batch_jm["mixed"], "label": bits.float()}
-        ag_det = agent.DetectorAgent(det.train(), lr=1e-3)
-        ag_jm = agent.DenoiserAgent(jm.train(), lr=1e-3)
-
-        def step():
-            if args.serial:
-                ag_det.train_func(batch_det)
-                ag_jm.train_func(batch_jm)
-            else:           # the two models are independent: one HIP stream each
-                agent.train_concurrent([(ag_jm, batch_jm), (ag_det, batch_det)])
-    elif args.mode == "infer-ragged":
-        # BASELINE configs[3]: lengths drawn uniformly from 1-10 s with seed 99, every rank its own draw
-        lens = [int(v) for v in np.random.default_rng(99 + rank).uniform(14000, 140000, B)]
-        pool = np.concatenate(list(synth_batch(2000 * rank, 20)["mixed"]))
-        pool_t = torch.from_numpy(np.ascontiguousarray(pool)).cuda()
-        ragged_clips = [pool_t[(4099 * i) % (len(pool) - 140000):][:n].contiguous() for i, n in enumerate(lens)]
-        audio_seconds = sum(lens) / 14000.0
-
-        graphed = pipeline.GraphedDenoiser(det, jm, max_graphs=16) if args.graph else None
-
-        def step():   # noqa: E306
-            return graphed.denoise_mixed(ragged_clips) if graphed is not None else pipeline.denoise_ragged(det, jm, ragged_clips)
-    else:
-        graphed = pipeline.GraphedDenoiser(det, jm) if args.graph else None
-
-        def step():
-            return graphed(mixed, clone=False) if graphed is not None else pipeline.denoise(det, jm, mixed)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = args.graph and args.mode != "train"
-    if use_graph:
-        # hipGraph replay: individual launches cannot be bracketed inside a replayed graph, so the dominant kernel is found
-        # and timed (HIP events on the launch stream) in an EAGER pass of the same step before the graphs are captured;
-        # `value` is the replayed steps
-        eager = (lambda: pipeline.denoise_ragged(det, jm, ragged_clips)) if args.mode == "infer-ragged" else (lambda: pipeline.denoise(det, jm, mixed))
-        engine.PROFILER = engine.LaunchProfiler()
-        eager()
-        summ = engine.PROFILER.summary()
-        dom = max(summ, key=lambda k: summ[k]["total_ms"])
-        engine.PROFILER = engine.LaunchProfiler(only=dom)
-        for _ in range(2):
-            eager()
-        prof = engine.PROFILER.summary()[dom]
-        engine.PROFILER = None
-        for _ in range(max(1, args.warmup)):
-            step()                                   # captures the graphs
-    else:
-        # warm-up; the first pass also finds the dominant kernel launch signature
-        engine.PROFILER = engine.LaunchProfiler()
-        for _ in range(max(1, args.warmup)):
-            step()
-        summ = engine.PROFILER.summary()
-        dom = max(summ, key=lambda k: summ[k]["total_ms"])
-        engine.PROFILER = engine.LaunchProfiler(only=dom)
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if not use_graph:
-        prof = engine.PROFILER.summary()[dom]
-    engine.PROFILER = None
+    wl = Workload(args.mode, args.precision, B, rank, serial=args.serial, graph=args.graph)
+    dt, dom, prof = run_timed(wl, args.steps, args.warmup, barrier)
     if dist is not None:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     if rank == 0:
-        value = world * B * args.steps / dt
+        value = n_gpus * B * args.steps / dt
         ach = prof["flops"] / (prof["avg_ms"] * 1e-3) / 1e12
         train = args.mode == "train"
-        gflop = GFLOP_PER_UTT_INFER * (3.0 if train else 1.0)      # algorithmic (reference) FLOPs: bf16x3's 3x MACs do not count
-        if args.mode == "infer-ragged":                            # FLOPs scale with the frames of a clip: 2 s = 178 frames
-            gflop *= sum(1 + n // 158 for n in lens) / (178.0 * B)
+        gflop = wl.gflop_per_utt()
+        audio_seconds = wl.audio_seconds
         # HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs, FETCH_SIZE doubled per the gfx950 correction); null when the signature has no PMC record
         traffic = None
@@ -267,7 +352,7 @@ def main():
             "metric": ("utterances/sec (variable-length clips 1-10 s), " if args.mode == "infer-ragged" else "utterances/sec (2 s clips), ") +
                       ("training step: detector + denoiser forward/backward/Adam" if train
                        else "inference pipeline STFT->detector->mask->denoiser->ISTFT"),
-            "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "utterances/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": ("training (BASELINE configs[1])" if train else
@@ -283,14 +368,39 @@ def main():
                        "parity": PARITY_NOTE[args.precision],
                        "streams": 2 if (train and not args.serial) else 1, "forced_gradient_buckets": bool(args.force_buckets),
                        "hipgraph": bool(args.graph),
-                       "realtime_factor": value * (audio_seconds / B if args.mode == "infer-ragged" else N_SAMPLES / 14000.0),
-                       "end_to_end_tflops": value * gflop / 1e3 / world},
+                       "realtime_factor": value * audio_seconds / B,
+                       "end_to_end_tflops": value * gflop / 1e3 / n_gpus},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "kernel": ("wgrad_kernel " if dom[0] == "wgrad" else "conv_mfma_kernel ") + str(dom),
                          "launches": prof["launches"],
                          "avg_ms": prof["avg_ms"], "flops_per_launch": prof["flops"]},
         }
+        if world == 1 and train and not args.no_secondary and not args.force_buckets and not args.serial:
+            # the round's other lines on the same box, AFTER (and outside) the headline's timed region
+            del wl
+            torch.cuda.empty_cache()
+            sec = {}
+            for key, mode, prec, b, k, w in (("infer_mixed_utt_s", "infer", "mixed", 64, 10, 3),
+                                             ("infer_fp16_utt_s", "infer", "fp16", 64, 10, 3),
+                                             ("ragged_mixed_clips_s", "infer-ragged", "mixed", 256, 3, 1),
+                                             ("train_bf16_utt_s", "train", "bf16", 64, 10, 3),
+                                             ("train_mixed_utt_s", "train", "mixed", 64, 10, 3)):
+                try:
+                    w2 = Workload(mode, prec, b, rank)
+                    dt2, _, _ = run_timed(w2, k, w, barrier, profile=False)
+                    sec[key] = round(b * k / dt2, 1)
+                    if mode == "infer-ragged":
+                        sec["ragged_realtime_factor"] = round(b * k / dt2 * w2.audio_seconds / b, 0)
+                    del w2
+                    torch.cuda.empty_cache()
+                except Exception as e:        # a secondary line never takes the headline down
+                    sec[key] = None
+                    sec[key + "_error"] = repr(e)[:200]
+            sec["note"] = ("same box, after the headline loop: infer = B=64 2 s clips x 10 steps; ragged = BASELINE configs[3], B=256 "
+                           "U(1 s,10 s) x 3 steps; train_* = the headline workload in another precision x 10 steps")
+            line["secondary"] = sec
+            sos_amd.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

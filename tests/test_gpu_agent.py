@@ -294,3 +294,82 @@ def test_gather_refresh_of_packed_weights_equals_torch_repacking(precision):
         engine.PackRecorder.ENABLED = True
         sos_amd.set_precision("bf16")
     assert res[True] == res[False], res
+
+
+def test_overflow_guard_skips_the_step_on_the_device():
+    """fp16 training (bench.py's timed mode): a parameter gradient that is Inf / NaN must not reach Adam's moments or the
+    weights.  The guard (sos_grad_guard, decided on the device, no host sync) turns the optimizer launch of THAT step
+    into a no-op for every parameter group, halves the loss-scale target, and the next finite step trains again."""
+    import sos_amd
+    from sos_amd import _lib as L, agent, engine
+    from sos_amd.dataset import make_batch
+    from sos_amd.detector import networks as dnet
+    sos_amd.set_precision("fp16")
+    try:
+        torch.manual_seed(0)
+        ag = agent.DetectorAgent(dnet.get_network(), lr=1e-3)
+        batch = make_batch("detector", 8100, 2)
+        ag.train_func(batch)                                                 # a normal step: the moments exist
+        guard = ag.optimizer.guard
+        assert guard is engine.guard_state(ag.net) and guard.cpu().tolist()[:4] == [0.0, 1.0, 1.0, 0.0]
+        snap = {n: p.detach().clone() for n, p in ag.net.named_parameters()}
+        mom = {n: (ag.optimizer.state[p]["exp_avg"].clone(), ag.optimizer.state[p]["exp_avg_sq"].clone()) for n, p in ag.net.named_parameters()}
+        # an overflowing backward: the loss itself is finite, ONE weight-gradient element is Inf (what a 16-bit store
+        # beyond 65504 inside the pass produces)
+        ag.net.train()
+        _, losses = ag.forward(batch)
+        ag.optimizer.zero_grad(set_to_none=True)
+        sum(losses.values()).backward()
+        name, p_bad = list(ag.net.named_parameters())[7]
+        p_bad.grad.view(-1)[3] = float("inf")
+        ag.optimizer.step()
+        torch.cuda.synchronize()
+        st = guard.cpu().tolist()
+        assert st[0] == 1.0 and st[1] == 0.5 and st[3] == 1.0, st           # found, target backed off, one step skipped
+        for n, p in ag.net.named_parameters():
+            assert torch.equal(p.detach(), snap[n]), n
+            assert torch.equal(ag.optimizer.state[p]["exp_avg"], mom[n][0]) and torch.equal(ag.optimizer.state[p]["exp_avg_sq"], mom[n][1]), n
+        # NaN in the INPUT: the loss and every gradient are NaN -> skipped as well, the weights stay finite
+        bad = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        bad["audio"][0, 0, 3, 5] = float("nan")
+        ag.train_func(bad)
+        torch.cuda.synchronize()
+        st = guard.cpu().tolist()
+        assert st[0] == 1.0 and st[1] == 0.25 and st[3] == 2.0, st
+        assert all(torch.equal(p.detach(), snap[n]) for n, p in ag.net.named_parameters())
+        # the next finite step is applied (with the backed-off loss scale) and learns
+        _, l0 = ag.train_func(batch)
+        torch.cuda.synchronize()
+        st = guard.cpu().tolist()
+        assert st[0] == 0.0 and st[1] == 0.25 and st[3] == 2.0, st
+        assert any(not torch.equal(p.detach(), snap[n]) for n, p in ag.net.named_parameters())
+        assert all(bool(torch.isfinite(p).all()) for p in ag.net.parameters())
+        # the back-off recovers: SOS_GUARD_GROWTH finite steps double it again (driven through the C ABI on a small buffer)
+        g = torch.ones(1000, device="cuda")
+        for _ in range(200):
+            L.check(L.lib().sos_grad_guard(L.ptr(g), g.numel(), L.ptr(guard), 1, L.stream_ptr()), "sos_grad_guard")
+        assert guard.cpu().tolist()[1] == 0.5
+        # several buffers, one decision: the flag of the first buffer survives until the finalising call
+        g2 = g.clone()
+        g2[17] = float("nan")
+        L.check(L.lib().sos_grad_guard(L.ptr(g2), g2.numel(), L.ptr(guard), 0, L.stream_ptr()), "sos_grad_guard")
+        L.check(L.lib().sos_grad_guard(L.ptr(g), g.numel(), L.ptr(guard), 1, L.stream_ptr()), "sos_grad_guard")
+        assert guard.cpu().tolist()[0] == 1.0
+    finally:
+        sos_amd.set_precision("bf16")
+
+
+def test_backward_after_an_optimizer_step_is_refused():
+    """A training tape is valid for the weights its forward ran with (the packed weights are refreshed in place): forward,
+    optimizer step, backward of the OLD forward raises instead of silently mixing old activations with new weights."""
+    from sos_amd import agent
+    from sos_amd.dataset import make_batch
+    from sos_amd.detector import networks as dnet
+    torch.manual_seed(0)
+    ag = agent.DetectorAgent(dnet.get_network(), lr=1e-3)
+    batch = make_batch("detector", 8200, 2)
+    ag.net.train()
+    _, stale = ag.forward(batch)
+    ag.train_func(batch)                       # forward + backward + Adam: the weights move on
+    with pytest.raises(RuntimeError, match="parameters changed"):
+        sum(stale.values()).backward()
