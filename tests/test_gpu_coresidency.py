@@ -153,7 +153,11 @@ def _victims(dev):
 
 
 def _flat(o):
-    return tuple(t.detach().clone() for t in (o if isinstance(o, tuple) else (o,)))
+    """Outputs as raw bit patterns (NaN == NaN: the comparison is about bits, not values)."""
+    def bits(t):
+        t = t.detach().clone().contiguous()
+        return t.view({2: torch.int16, 4: torch.int32, 8: torch.int64}.get(t.element_size(), t.dtype)) if t.is_floating_point() else t
+    return tuple(bits(t) for t in (o if isinstance(o, tuple) else (o,)))
 
 
 @pytest.mark.parametrize("precision", ["fp16"])

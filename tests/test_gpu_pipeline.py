@@ -42,7 +42,7 @@ def _oracle_chain(sd1, sd2, wave, n_frames, bits=None):
 # 'mixed' (detector in bf16x3, denoiser in fp16) is the mode the pipeline is meant to be run in at 1x denoiser cost: its
 # frame decisions are REQUIRED to equal the reference's (STRICT_BITS), like the parity mode's.
 _PIPE_BOUNDS = {"bf16x3": (0.0, 1e-3, 70.0, 0.05, 0.05), "mixed": (0.0, WAVE_TOL_FP16, 40.0, 0.05, 0.1),
-                "fp16": (3e-3, WAVE_TOL_FP16, 40.0, 0.05, 0.1), "bf16": (2e-2, 1e-1, 20.0, 0.1, 0.5)}
+                "fp16": (3e-3, WAVE_TOL_FP16, 40.0, 0.05, 0.1), "bf16": (2e-2, 1e-1, 20.0, 0.1, 1.0)}
 STRICT_BITS = ("bf16x3", "mixed")
 
 
