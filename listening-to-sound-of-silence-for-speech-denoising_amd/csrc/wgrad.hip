@@ -17,6 +17,7 @@
 // that a deterministic reduce kernel folds into the OIHW gradient (no atomics).
 #include "sos_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef sos_half_t bf16x8 __attribute__((ext_vector_type(8)));   // 8 storage-type (bf16, or fp16 in the SOS_F16 build) MFMA operands
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -24,6 +25,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define WG_WAVES 8            // waves per workgroup (512 threads, two per SIMD)
 #define WG_THREADS (WG_WAVES * 64)
+#ifndef SOS_WGRAD_PIPE
+#define SOS_WGRAD_PIPE 0      // 1: register double-buffered k-step pipeline of the 25-tap kernels (measured SLOWER)
+#endif
 #define WG_PAIRS 4            // (tap, n-tile) pairs per wave; x MT m-tiles = accumulator tiles per wave
 
 // Ablation switches (SOS_WGRAD_DBG bit mask: 1 no prefetch DMA, 8 DMA lanes all out of range, 16 ... all offset 0)
@@ -320,6 +324,84 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
         const WgTile onext = st.origin_of(more ? step + 1 : step);
         const bool prefetch = p.dbuf && more;
         const unsigned gb = sbase + cur * p.bufbytes, xb = gb + gbytes;
+        if constexpr (BAL && SOS_WGRAD_PIPE) {
+            // ---- software pipeline over the k-steps (round 3).  The counted waits of the loop below do not survive hipcc's
+            // scheduler (the MFMAs sink below them: every k-step waited for ALL of its reads before its first MFMA, and the
+            // in-order MFMA issue of a k-step -- 9..10 x 32 cycles -- then kept the wave from issuing the next reads: LDS
+            // latency and MFMA issue were serial, the MFMA pipe 57 % busy).  Here the fragments are double buffered in
+            // registers: the reads of k-step ks + 1 are issued BEFORE the MFMAs of ks, whose operands landed during the
+            // MFMAs of ks - 1; one wait per k-step, pinned with scheduling barriers.
+            struct Frag { u32x4 av[MT], bv[NP]; };
+            Frag F0, F1;
+            u32x4 avx, bvx;               // the wave's part of the 25th tap: read at the top of ITS k-step, used last (8 registers, not 16)
+            auto rd2 = [&](const unsigned a0addr, const unsigned a1addr) {
+                const uint2 lo = lds_tr(a0addr), hi = lds_tr(a1addr);
+                return u32x4{lo.x, lo.y, hi.x, hi.y};
+            };
+            auto issue_reads = [&](const int ks, Frag& F) {
+                const unsigned ga = (gb + (unsigned)ks * 1024u) + glane;
+                const unsigned xk = xb + (unsigned)__builtin_amdgcn_readlane((int)ppk, ks);
+                { const uint2 lo = lds_tr(ga), hi = lds_tr_off<256>(ga); F.av[0] = u32x4{lo.x, lo.y, hi.x, hi.y}; }
+                if constexpr (MT >= 2) { const uint2 lo = lds_tr_off<16384>(ga), hi = lds_tr_off<16384 + 256>(ga); F.av[1] = u32x4{lo.x, lo.y, hi.x, hi.y}; }
+                if constexpr (MT >= 3) { const uint2 lo = lds_tr_off<32768>(ga), hi = lds_tr_off<32768 + 256>(ga); F.av[2] = u32x4{lo.x, lo.y, hi.x, hi.y}; }
+#pragma unroll
+                for (int u = 0; u < NP; ++u) F.bv[u] = rd2(xlane0 + (xk + toff[u]), xlane1 + (xk + toff[u]));
+            };
+            // hx / last are compile-time tags: the k-loop below exists twice (waves with / without a part of the 25th tap) and
+            // only the last k-step is peeled (two full copies of the loop, one per wave kind, made hipcc spill 483 registers)
+            auto kstep = [&](auto last, const int ks, Frag& C, Frag& N) {
+                constexpr bool LAST = decltype(last)::value;
+                uint2 ent = make_uint2(0u, 0u);
+                const int di = ks * nlight + lw;                      // this wave's DMA instruction in this k-step
+                const bool dma = prefetch && lw >= 0 && di < ninstr;
+                if (dma) ent = lds_read64(st.entry_addr(di));          // ahead of the next reads: it returns before them
+                if (hasx) {
+                    const unsigned gax = (gb + (unsigned)ks * 1024u) + glane + (unsigned)wave * 16384u;
+                    const unsigned xk = xb + (unsigned)__builtin_amdgcn_readlane((int)ppk, ks);
+                    const uint2 lo = lds_tr(gax), hi = lds_tr_off<256>(gax);
+                    avx = u32x4{lo.x, lo.y, hi.x, hi.y};
+                    bvx = rd2(xlane0 + (xk + toffx), xlane1 + (xk + toffx));
+                }
+                if constexpr (!LAST) issue_reads(ks + 1, N);
+                __builtin_amdgcn_sched_barrier(0);
+                // LDS returns in order: when no more than the reads issued in THIS k-step are outstanding, `ent` and C (issued
+                // a k-step ago) have landed.  lgkmcnt is a 4-bit counter: 15 = "at most 15 outstanding".
+                constexpr int NOUT = LAST ? 0 : 2 * (MT + NP);
+                if (hasx) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ent) : "n"(NOUT + 4 > 15 ? 15 : NOUT + 4));
+                else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ent) : "n"(NOUT));
+#pragma unroll
+                for (int a = 0; a < MT; ++a) asm volatile("" : "+v"(C.av[a]));
+#pragma unroll
+                for (int u = 0; u < NP; ++u) asm volatile("" : "+v"(C.bv[u]));
+                __builtin_amdgcn_sched_barrier(0);
+                if (dma) st.issue(di, ent, onext, cur ^ 1);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const bf16x8 bfr = __builtin_bit_cast(bf16x8, C.bv[u]);
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+                        acc[a][u] = SOS_MFMA_32x32x16(__builtin_bit_cast(bf16x8, C.av[a]), bfr, acc[a][u], 0, 0, 0);
+                }
+                if (hasx) {          // its four reads were the first of this k-step: landed once only the next k-step's are outstanding
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(avx), "+v"(bvx) : "n"(LAST ? 0 : 2 * (MT + NP)));
+                    accx = SOS_MFMA_32x32x16(__builtin_bit_cast(bf16x8, avx), __builtin_bit_cast(bf16x8, bvx), accx, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            {
+                constexpr std::false_type more_t{};
+                constexpr std::true_type last_t{};
+                issue_reads(0, F0);
+#pragma unroll 1
+                for (int ks = 0; ks < 14; ks += 2) {
+                    kstep(more_t, ks, F0, F1);
+                    kstep(more_t, ks + 1, F1, F0);
+                }
+                kstep(more_t, 14, F0, F1);
+                kstep(last_t, 15, F1, F0);
+            }
+        } else {
 #pragma unroll 1
         for (int ks = 0; ks < 16; ++ks) {
             uint2 ent = make_uint2(0u, 0u);
@@ -390,6 +472,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             if constexpr (BAL) {
                 if (hasx) accx = SOS_MFMA_32x32x16(__builtin_bit_cast(bf16x8, avx), __builtin_bit_cast(bf16x8, bvx), accx, 0, 0, 0);
             }
+        }
         }
         if (p.dbuf) {
             cur ^= 1;
@@ -887,7 +970,24 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
                 if (one + tabb > lds_max) continue;
                 const int db = 2 * one + tabb <= lds_max;
                 const double steps = (double)((Hc + TH - 1) / TH) * ((Wc + TW - 1) / TW) * ((d->dil_w + NC - 1) / NC);
-                const double cost = steps * (256.0 * taps + (db ? 1.0 : 6.0) * NC * PH * PW);
+                // LDS bank conflicts of the transposed X reads (16x16x32 kernel, 32-byte pixel pitch): a 32-lane group reads 8
+                // tile pixels x 32 B, pixel pp on banks 8 (pp mod 8) ..; with TW = 4 and PW = 8 (5x5 taps) the two tile rows of
+                // a group alias (SQ_LDS_BANK_CONFLICT was 42 % of the LDS-active cycles of the 48 -> 48 gradient, whose
+                // cheapest tile by step count is 64 x 4): count the worst multiplicity and charge the MFMA term for it
+                double conflict = 1.0;
+                if (use16) {
+                    int worst = 1;
+                    for (int grp = 0; grp < 4; ++grp) {            // pixels 8 grp .. 8 grp + 7 of a 32-pixel k-step
+                        int cnt[8] = {0};
+                        for (int e = 0; e < 8; ++e) {
+                            const int k = 8 * grp + e;
+                            const int pp = ((k >> (lth + ltw)) * PH + ((k >> ltw) & (TH - 1)) * d->stride) * PW + (k & (TW - 1)) * d->stride;
+                            if (++cnt[pp & 7] > worst) worst = cnt[pp & 7];
+                        }
+                    }
+                    conflict = 1.0 + 0.3 * (worst - 1);
+                }
+                const double cost = steps * (256.0 * taps * conflict + (db ? 1.0 : 6.0) * NC * PH * PW);
                 if (cost < best) { best = cost; bnc = NC; bth = lth; btw = ltw; bdb = db; p.bufbytes = (int)one; p.npixp = npixp; }
             }
         }

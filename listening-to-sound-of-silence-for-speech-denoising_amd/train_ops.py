@@ -517,9 +517,12 @@ def up_forward_train(lp, src, dst, c_off, x3):
                out_dtype=raw.dtype_code, sb=raw.H * raw.W * row, sh=2 * raw.W * row, sw=2 * row, sc=1,
                cout_store=lp["cout"], third=raw.cs, Ho=src.H, Wo=src.W, out_elem_offset=(ph * raw.W + pw) * row)
     # batch statistics over the UNCROPPED output (the reference resizes after the block), then crop
-    yfull = E.Act(raw.B, raw.H, raw.W, cs, x3, dev, zero=cs > E.pad_to(lp["cout"], 8))
-    saved = E.bn_train(raw, 0, lp["cout"], lp["bn"], L.ACT_PRELU, lp["prelu"].weight, yfull, 0)
-    copy_crop(yfull, 0, dst, c_off, lp["cout"])
+    if (dst.H, dst.W) == (raw.H, raw.W):            # nothing to crop (up1.1: 2 x 128 x 89 = 256 x 178): straight into the concat buffer
+        saved = E.bn_train(raw, 0, lp["cout"], lp["bn"], L.ACT_PRELU, lp["prelu"].weight, dst, c_off)
+    else:
+        yfull = E.Act(raw.B, raw.H, raw.W, cs, x3, dev, zero=cs > E.pad_to(lp["cout"], 8))
+        saved = E.bn_train(raw, 0, lp["cout"], lp["bn"], L.ACT_PRELU, lp["prelu"].weight, yfull, 0)
+        copy_crop(yfull, 0, dst, c_off, lp["cout"])
     return dict(kind="up", lp=lp, src=src, dst=dst, c_off=c_off, raw=raw, saved=saved)
 
 
@@ -528,13 +531,22 @@ class GradBufs:
     producers accumulate into it (skip connections fan in)."""
 
     def __init__(self, x3):
-        self.x3, self.bufs = x3, {}
+        self.x3, self.bufs, self.written = x3, {}, {}
 
     def of(self, act):
         k = id(act)
         if k not in self.bufs:
             self.bufs[k] = E.Act(act.B, act.H, act.W, act.cs, self.x3, act.t.device, zero=True)
         return self.bufs[k]
+
+    def first_write(self, act, c_off, C):
+        """True when no producer has written channels [c_off, c_off + C) of grad(act) yet: that producer may STORE instead of
+        accumulate (one read pass of the tensor less: the fold / conv epilogue then does not re-read the zeros).  The
+        slice counts as written from now on."""
+        iv = self.written.setdefault(id(act), [])
+        fresh = all(c_off + C <= a or b <= c_off for a, b in iv)
+        iv.append((c_off, c_off + C))
+        return fresh
 
 
 def _reflect_dgrad(lp, d_raw, src, cin_off, gb, x3):
@@ -557,7 +569,7 @@ def _reflect_dgrad(lp, d_raw, src, cin_off, gb, x3):
             E.conv(d_raw, 0, d_raw.cs, w, Mh, Mw, lp["cin"], one, zero, L.ACT_NONE, out=dpad.t, out_dtype=dpad.dtype_code,
                    sb=dpad.H * dpad.W * row, sh=2 * dpad.W * row, sw=2 * row, sc=1, cout_store=cin_cs, third=dpad.cs,
                    pad=(Mh - 1, Mw - 1), Ho=Ho, Wo=Wo, out_elem_offset=(ph * dpad.W + pw) * row)
-    reflect_fold(dpad, H, W, p, gb.of(src), cin_off, lp["cin"], accumulate=True)
+    reflect_fold(dpad, H, W, p, gb.of(src), cin_off, lp["cin"], accumulate=not gb.first_write(src, cin_off, lp["cin"]))
 
 
 _INV_PERM = {}           # (concat permutation, device) -> its inverse as a device index tensor
@@ -592,10 +604,14 @@ def down_backward(t, gb, grads, name, x3, need_src_grad=True):
 def up_backward(t, gb, grads, name, x3):
     lp, raw, src = t["lp"], t["raw"], t["src"]
     dev = raw.t.device
-    dy_full = E.Act(raw.B, raw.H, raw.W, raw.cs, x3, dev, zero=raw.cs > E.pad_to(lp["cout"], 8))
-    copy_crop(gb.of(t["dst"]), t["c_off"], dy_full, 0, lp["cout"])
+    gdst = gb.of(t["dst"])
+    if (gdst.H, gdst.W) == (raw.H, raw.W):          # nothing was cropped in the forward pass (up1.1: 2 x 128 x 89): no copy
+        dy_full, dy_off = gdst, t["c_off"]
+    else:                                           # zero-pad the cropped rows / columns back (mid.8: 128 x 90 -> 128 x 89)
+        dy_full, dy_off = E.Act(raw.B, raw.H, raw.W, raw.cs, x3, dev, zero=raw.cs > E.pad_to(lp["cout"], 8)), 0
+        copy_crop(gdst, t["c_off"], dy_full, 0, lp["cout"])
     d_raw = E.Act(raw.B, raw.H, raw.W, raw.cs, x3, dev, zero=raw.cs > E.pad_to(lp["cout"], 8))
-    dgamma, dbeta, dslope = bn_bwd(dy_full, 0, raw, 0, lp["cout"], t["saved"], lp["bn"].weight, L.ACT_PRELU,
+    dgamma, dbeta, dslope = bn_bwd(dy_full, dy_off, raw, 0, lp["cout"], t["saved"], lp["bn"].weight, L.ACT_PRELU,
                                    lp["prelu"].weight, d_raw)
     grads[f"{name}.block.1.weight"], grads[f"{name}.block.1.bias"], grads[f"{name}.block.2.weight"] = dgamma, dbeta, dslope
     dw = torch.empty_like(lp["ct"].weight, dtype=torch.float32)                      # (Cin, Cout, 3, 3)
@@ -604,4 +620,4 @@ def up_backward(t, gb, grads, name, x3):
     gsrc = gb.of(src)
     one, zero = ones_zeros(lp["wd"].shape[1], dev)
     E.conv_to_act(d_raw, 0, d_raw.cs, lp["wd"], 3, 3, lp["cin"], one, zero, L.ACT_NONE, gsrc, cout_store=lp["cin"],
-                  stride=2, pad=(1, 1), Ho=src.H, Wo=src.W, accumulate=True)
+                  stride=2, pad=(1, 1), Ho=src.H, Wo=src.W, accumulate=not gb.first_write(src, 0, lp["cin"]))

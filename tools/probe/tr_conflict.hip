@@ -38,18 +38,15 @@ int main() {
     int *d16, *d64; long long* dout;
     hipMalloc(&d16, 256); hipMalloc(&d64, 256); hipMalloc(&dout, 8192 * 8);
     hipMemcpy(d16, h16, 256, hipMemcpyHostToDevice); hipMemcpy(d64, h64, 256, hipMemcpyHostToDevice);
-    const int reps = 200;
-    for (int nw = 1; nw <= 8; nw *= 2) {
-        for (int pat = 0; pat < 2; ++pat) {
-            printf("%d wave(s)/CU, pitch %d:", nw, pat ? 64 : 32);
-            for (int s = 0; s < 9; ++s) {
-                const int shift = s * (pat ? 64 : 32);
-                k<<<1, 64 * nw, 65536>>>(pat ? d64 : d16, shift, dout, reps);
-                hipDeviceSynchronize();
-                long long t; hipMemcpy(&t, dout, 8, hipMemcpyDeviceToHost);
-                printf(" %5.2f", (double)t / (reps * NREAD));
-            }
-            printf("   (cycles per wave-read; shift = 0..8 pixels)\n");
+    const int reps = 20;
+    // one dispatch per (pattern, shift): under `rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS` the CSV rows are in this order
+    for (int pat = 0; pat < 2; ++pat) {
+        for (int s = 0; s < 24; ++s) {
+            const int shift = s * (pat ? 64 : 32);
+            k<<<1, 512, 65536>>>(pat ? d64 : d16, shift, dout, reps);
+            hipDeviceSynchronize();
+            long long t; hipMemcpy(&t, dout, 8, hipMemcpyDeviceToHost);
+            printf("pitch %d shift %2d pixels: %5.2f cycles per wave-read (8 waves)\n", pat ? 64 : 32, s, (double)t / (reps * NREAD));
         }
     }
     return 0;

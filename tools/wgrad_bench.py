@@ -4,7 +4,9 @@ import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+import sos_amd
 from sos_amd import _lib as L, engine as E
+sos_amd.set_precision(os.environ.get('SOS_PRECISION', 'bf16'))
 SHAPES = [("ctx96 d1x1", 256, 178, 96, 96, (5, 5), (1, 1), 1), ("ctx96 d8x1", 256, 178, 96, 96, (5, 5), (8, 1), 1),
           ("ctx96 d32x32", 256, 178, 96, 96, (5, 5), (32, 32), 1), ("ctx48 d1x1", 256, 178, 48, 48, (5, 5), (1, 1), 1),
           ("inp 256 3x3", 64, 45, 256, 256, (3, 3), (1, 1), 1), ("inp 128 5x5", 128, 89, 128, 128, (5, 5), (1, 1), 1),
@@ -14,9 +16,10 @@ a = ap.parse_args()
 dev = torch.device("cuda"); B = 64
 for name, H, W, cin, cout, k, dil, st in SHAPES:
     if a.only and a.only not in name: continue
-    x = E.Act(B, H, W, cin, False, dev); x.t.normal_()
+    zero = os.environ.get('SOS_BENCH_ZERO') == '1'       # all-zero operands: same instruction stream, no toggling (power A/B)
+    x = E.Act(B, H, W, cin, False, dev); x.t.zero_() if zero else x.t.normal_()
     Ho, Wo = (H + st - 1) // st, (W + st - 1) // st
-    g = E.Act(B, Ho, Wo, E.pad_to(cout, 16), False, dev); g.t.normal_()
+    g = E.Act(B, Ho, Wo, E.pad_to(cout, 16), False, dev); g.t.zero_() if zero else g.t.normal_()
     dw = torch.empty(cout, cin, k[0], k[1], device=dev)
     pad = ((k[0] - 1) // 2 * dil[0], (k[1] - 1) // 2 * dil[1])
     run = lambda: E.wgrad(g, 0, cout, x, 0, cin, k[0], k[1], dw, stride=st, dil=dil, pad=pad)
