@@ -738,8 +738,11 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
     }
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.wgt, 0, (unsigned)((long long)p.kh * p.kw * tap_stride * 2), 0x00020000);
+    // hi|hi|lo three-pass mode: the contraction also runs over p.nchunks = 3 channel SEGMENTS (activation thirds x the
+    // weight's [hi|lo|hi] K ranges); segment `sg` shifts the weight source by sg * cin channels
+    unsigned segk = 0;
     auto dma_window = [&](const int w, const int buf) {
-        const unsigned woff = (unsigned)((long long)w * 2 * tap_stride * 2);
+        const unsigned woff = (unsigned)((long long)w * 2 * tap_stride * 2) + segk;
 #pragma unroll
         for (int u = 0; u < WPW; ++u) {
             const int i = wv + 4 * u;
@@ -760,9 +763,13 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
     const __amdgpu_buffer_rsrc_t in_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + in_b * p.in_cs), 0, (unsigned)(p.H * p.W * p.in_cs) * 2u, 0x00020000);
     build_pixel_table(p, pixtab, tid, hin0, win0, rw0, Wl, wgather);
+    for (int sg = 0; sg < p.nchunks; ++sg) {
+    // (first segment: publishes the pixel table; later ones: every wave has passed the last window's barrier, i.e. is done
+    // reading the patch and the slabs)
     __syncthreads();
+    segk = (unsigned)(sg * p.cin * 2);
     if (!CDBG(1)) stage_patch_dma<CPR, false>(p, patch, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc,
-                                (unsigned)(p.cin_off * 2));
+                                (unsigned)((p.cin_off + sg * p.seg_stride) * 2));
     if (!CDBG(8)) dma_window(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's patch pieces have landed
     __syncthreads();
@@ -805,6 +812,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    }
 
     if (CDBG(4)) return;
     // ---- epilogue: D[m = cout][n = pixel]: lane = pixel + 16 * (cout / 4), register = cout % 4
@@ -812,6 +820,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
     const bool partial = ROWS > p.cout, sig = p.act == SOS_ACT_SIGMOID;
     const float sn = p.act == SOS_ACT_RELU ? 0.f : (p.act == SOS_ACT_PRELU ? slope : 1.f);   // max(y,0) + sn*min(y,0)
     const bool raw = !p.scale && p.act == SOS_ACT_NONE;          // training forward convs, data gradients
+    const bool x3out = p.out_dtype == SOS_DT_BF16X3;
 #pragma unroll
     for (int nt = 0; nt < NT16; ++nt) {
         const int co = nt * 16 + 4 * g;                   // 4 consecutive channels co..co+3
@@ -838,10 +847,15 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
                 for (int e = 0; e < 4; ++e) v[e] = (co + e < p.cout) ? v[e] : 0.f;
             }
             const int m = wave * 64 + pt * 16 + l15;
-            *(uint2*)(smem + m * OROW + co * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            const unsigned h01 = pack2bf(v[0], v[1]), h23 = pack2bf(v[2], v[3]);
+            *(uint2*)(smem + m * OROW + co * 2) = make_uint2(h01, h23);
+            if (x3out) {              // hi|hi|lo output: the low parts go to the second staging plane
+                *(uint2*)(smem + 256 * OROW + m * OROW + co * 2) =
+                    make_uint2(pack2bf(v[0] - sos_lo2f(h01), v[1] - sos_hi2f(h01)), pack2bf(v[2] - sos_lo2f(h23), v[3] - sos_hi2f(h23)));
+            }
         }
     }
-    store_staged_tile<NT16 * 2, OROW>(p, smem, tid, b, 0, ho_base, wo_base, rw0, false, Wo);
+    store_staged_tile<NT16 * 2, OROW>(p, smem, tid, b, 0, ho_base, wo_base, rw0, x3out, Wo);
 #endif
 }
 
@@ -905,7 +919,9 @@ static size_t lds_bytes(int npix, int nt, int ks) {           // ks >= 100: sing
 static inline int nseg_eff(const sos_conv_desc* d) { return d->in_nseg * (d->t_taps > 1 ? d->t_taps : 1); }
 
 static int nt16_for(const sos_conv_desc* d) {
-    if (d->in_nseg != 1 || d->t_taps > 1 || d->out_dtype != SOS_DT_BF16 || d->out_sc != 1 || (d->cin != 16 && d->cin != 48)) return 0;
+    // plain 16-bit in -> out, or the three-segment hi|hi|lo mode in -> out (the parity-precision detector of 'mixed')
+    const bool plain = d->in_nseg == 1 && d->out_dtype == SOS_DT_BF16, x3 = d->in_nseg == 3 && d->out_dtype == SOS_DT_BF16X3;
+    if (!(plain || x3) || d->t_taps > 1 || d->out_sc != 1 || (d->cin != 16 && d->cin != 48)) return 0;
     if (d->cout <= 16) return 1;
     if (d->cout > 32 && d->cout <= 48) return 3;
     return 0;
@@ -954,7 +970,7 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
                 for (int single = 0; single < 2; ++single) {
                     const size_t lds = lds_bytes16(npix, nt16, k16, single);
                     if (lds > LDS_LIMIT) continue;
-                    double per_block = 0.75 * (256.0 * taps * k16 + 3.0 * npix * k16 + 40.0 * (6 + taps / 2));
+                    double per_block = 0.75 * nseg_eff(d) * (256.0 * taps * k16 + 3.0 * npix * k16 + 40.0 * (6 + taps / 2));
                     if (lds > LDS_LIMIT / 2) per_block *= 1.3;
                     else if (lds <= LDS_LIMIT / 3) per_block *= 0.95;
                     out.push_back({NC, lth, ltw, single ? -1 : 0, blocks * per_block});
@@ -1161,9 +1177,9 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
         const bool single = c.ks < 0;
         const int nt16 = nt16_for(d), ks16 = d->cin / 16;
         if (!nt16) { sos_set_error("sos_conv2d_fwd: internal: 16-row tiling for an ineligible shape"); return SOS_EINVAL; }
-        p.cps = 1; p.nchunks = 1;
+        p.cps = 1; p.nchunks = nseg_eff(d);              // channel segments (3 in the hi|hi|lo mode), whole cin per segment
         size_t lds16 = lds_bytes16(p.npix, nt16, ks16, single);
-        const size_t stage16 = (size_t)256 * (nt16 * 32 + 16) + 1024 + (d->stats ? 16384 : 0);
+        const size_t stage16 = (size_t)256 * (nt16 * 32 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + 1024 + (d->stats ? 16384 : 0);
         if (stage16 > lds16) lds16 = stage16;
         conv_kernel_t k = nullptr;
 #define SOS_C16(NTV, KSV)                                                                        \

@@ -65,14 +65,14 @@ def _load_tune_cache():
         # the shipped table first, then the user's cache file of THIS library (X for the bf16 build, X.f16 for the fp16
         # build) laid over it if it exists; a user file this build cannot read is reported and ignored
         user = None if not _TUNE_CACHE else _TUNE_CACHE + ("" if which == "bf16" else ".f16")
-        if _os.environ.get("SOS_CONV_TUNE_TABLE", "1") != "0":      # =0: cost-model picks only (A/B of the table itself)
+        if _os.environ.get("SOS_CONV_TUNE_TABLE", "1") != "0":      # =0: without the shipped table (A/B of the table itself; re-tuning)
             n = L.lib().sos_conv2d_tune_load(SHIPPED_TUNE_TABLE.encode())
             if n < 0:
                 raise RuntimeError("sos_conv2d_tune_load: " + (L.lib().sos_last_error() or b"").decode())
-            if user and _os.path.exists(user):
-                if L.lib().sos_conv2d_tune_load(user.encode()) < 0:
-                    import warnings
-                    warnings.warn("SOS_CONV_TUNE_CACHE %s ignored: %s" % (user, (L.lib().sos_last_error() or b"").decode()))
+        if user and _os.path.exists(user):
+            if L.lib().sos_conv2d_tune_load(user.encode()) < 0:
+                import warnings
+                warnings.warn("SOS_CONV_TUNE_CACHE %s ignored: %s" % (user, (L.lib().sos_last_error() or b"").decode()))
         if AUTOTUNE and user and int(_os.environ.get("RANK", "0")) == 0:
             import atexit
             h = L.lib()

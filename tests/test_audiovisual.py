@@ -218,3 +218,44 @@ def test_full_size_variant_properties_60x224x224():
         assert abs(losses[0] - losses[1]) < 2e-3 * abs(losses[0])
     finally:
         sos_amd.set_precision("bf16")
+
+
+@pytest.mark.gpu
+def test_configs4_per_gpu_share_32_clips_trains():
+    """BASELINE configs[4] is batch 128 on 4 GPUs = 32 clips per GPU (60 frames of 224 x 224 + the 2 x 256 x 178 spectrogram
+    each: 56 GiB of tape on one MI355X).  Run THAT per-GPU share through one real training step in fp16 (the timed mode of
+    tools/av_bench.py): the batch of 16 clips repeated twice has the loss of the 16-clip batch (BatchNorm moments are those of
+    the half batch up to the f32 summation order), every parameter gets a finite gradient, a second identical step from the
+    same weights is bit-identical (no atomics, fixed tilings), and the Adam step moves the weights."""
+    import sos_amd
+    from sos_amd import agent
+    from sos_amd.detector import networks as dnet
+    B = 32
+    free, _ = torch.cuda.mem_get_info()
+    if free < 90 * (1 << 30):
+        pytest.skip("needs ~60 GiB of free HBM")
+    s16 = spec_input(930, 16, 178).cuda()
+    v16 = video_input(931, 16, 60, 224, 224).cuda()
+    lab16 = (spec_input(932, 16, 60, 1)[:, 0, 0] > 0).float().cuda()
+    sos_amd.set_precision("fp16")
+    try:
+        res = []
+        for reps in (1, 2, 2):
+            torch.manual_seed(1)
+            ag = agent.DetectorAgent(dnet.get_network(video=True), lr=1e-3)
+            w0 = ag.net.encoder_video[1].block[0].weight.detach().clone()
+            batch = {"audio": s16.repeat(reps, 1, 1, 1), "frames": v16.repeat(reps, 1, 1, 1, 1), "label": lab16.repeat(reps, 1)}
+            assert batch["frames"].shape[0] == 16 * reps
+            _, l1 = ag.train_func(batch)
+            grads = {n: p.grad.detach().clone() for n, p in ag.net.named_parameters()}
+            assert all(bool(torch.isfinite(g).all()) for g in grads.values())
+            assert not torch.equal(w0, ag.net.encoder_video[1].block[0].weight.detach())
+            res.append((float(l1["bce"]), grads))
+            del ag, batch
+            torch.cuda.empty_cache()
+        print("configs[4] per-GPU share: loss at 16 clips", res[0][0], "at 32 (the same 16 twice)", res[1][0])
+        assert res[1][1]["fc1.2.weight"].shape == (1, 100) and B == 32
+        assert abs(res[0][0] - res[1][0]) < 2e-3 * abs(res[0][0])
+        assert res[1][0] == res[2][0] and all(torch.equal(res[1][1][n], res[2][1][n]) for n in res[1][1])
+    finally:
+        sos_amd.set_precision("bf16")

@@ -17,12 +17,26 @@ OUT = os.path.join(ROOT, "gpurun_out", "tune_table_gfx950.txt")
 os.makedirs(os.path.dirname(OUT), exist_ok=True)
 os.environ["SOS_CONV_TUNE"] = "1"
 os.environ["SOS_CONV_TUNE_CACHE"] = OUT
+os.environ["SOS_CONV_TUNE_TABLE"] = "0"        # only the table being built (OUT), never the shipped one underneath
 EXTEND_AV = "--extend-av" in sys.argv        # keep the committed table, add the audio-visual variant's shapes
+RETUNE_X3 = "--retune-x3" in sys.argv        # keep the committed table, re-measure the three-segment shapes the 16-row kernel now takes
+SHIPPED = os.path.join(ROOT, "listening-to-sound-of-silence-for-speech-denoising_amd", "tune_table_gfx950.txt")
 if os.path.exists(OUT):
     os.remove(OUT)
 if EXTEND_AV:
     import shutil
-    shutil.copy(os.path.join(ROOT, "listening-to-sound-of-silence-for-speech-denoising_amd", "tune_table_gfx950.txt"), OUT)
+    shutil.copy(SHIPPED, OUT)
+if RETUNE_X3:
+    # shape key columns (conv.hip, shape_key): 4 cin, 5 segments, 14 out dtype (1 = hi|hi|lo), 15 dense NHWC, 18 cout
+    lines = open(SHIPPED).read().splitlines()
+    keep = [lines[0]]
+    for ln in lines[1:]:
+        v = ln.split()
+        elig = len(v) >= 23 and v[5] == "3" and v[4] in ("16", "48") and v[14] == "1" and v[15] == "1" and (int(v[18]) <= 16 or 32 < int(v[18]) <= 48)
+        if not elig:
+            keep.append(ln)
+    open(OUT, "w").write("\n".join(keep) + "\n")
+    print("dropped", len(lines) - len(keep), "entries to re-measure")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -69,7 +83,28 @@ def av_workloads():
     torch.cuda.synchronize()
 
 
+def x3_detector_workloads():
+    """The detector in the three-pass mode (what 'mixed' runs): inference at the table's batch sizes + a training step."""
+    for B in (64, 32, 16, 8, 4, 2, 1):
+        torch.manual_seed(0)
+        det = dnet.get_network().cuda().eval()
+        S = torch.randn(B, 2, 256, 178, device="cuda")
+        with torch.no_grad():
+            det(S, 60)
+        if B in (64, 2, 1):
+            agent.DetectorAgent(det.train(), lr=1e-3).train_func({"audio": S, "label": (torch.rand(B, 60, device="cuda") > 0.3).float()})
+        torch.cuda.synchronize()
+        print("re-tuned bf16x3 detector, B =", B, flush=True)
+
+
 def main():
+    if RETUNE_X3:
+        sos_amd.set_precision("bf16x3")
+        x3_detector_workloads()
+        from sos_amd import _lib
+        _lib.lib().sos_conv2d_tune_save(OUT.encode())
+        print("wrote", OUT, sum(1 for _ in open(OUT)) - 1, "entries")
+        return
     if EXTEND_AV:
         sos_amd.set_precision("fp16")
         av_workloads()
