@@ -48,6 +48,7 @@ PROFILER = None
 import os as _os
 import threading as _threading
 AUTOTUNE = _os.environ.get("SOS_CONV_TUNE", "0") == "1"
+TUNE_CANDIDATES = int(_os.environ.get("SOS_CONV_TUNE_CANDIDATES", "8"))     # best-ranked tilings of the cost model that get timed
 SHIPPED_TUNE_TABLE = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tune_table_gfx950.txt")
 _tuned = set()
 _tune_lock = _threading.Lock()
@@ -383,10 +384,10 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
                 real_out = d.out
                 d.out = scratch.data_ptr() + out_elem_offset * esize
                 d.accumulate = 0
-                L.check(L.lib().sos_conv2d_tune(C.byref(d), 8, 3, None, L.stream_ptr()), "sos_conv2d_tune")
+                L.check(L.lib().sos_conv2d_tune(C.byref(d), TUNE_CANDIDATES, 3, None, L.stream_ptr()), "sos_conv2d_tune")
                 d.out, d.accumulate = real_out, 1
             else:
-                L.check(L.lib().sos_conv2d_tune(C.byref(d), 8, 3, None, L.stream_ptr()), "sos_conv2d_tune")
+                L.check(L.lib().sos_conv2d_tune(C.byref(d), TUNE_CANDIDATES, 3, None, L.stream_ptr()), "sos_conv2d_tune")
     end = None
     if PROFILER is not None:
         # ragged batches: only the clips' own columns are algorithmic work (valid_cols = their sum)

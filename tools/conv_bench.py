@@ -29,6 +29,12 @@ SHAPES = [
     ("inp 256->256 3x3 d16", 64, 45, 256, 256, (3, 3), (16, 16), 1, 1),
     ("inp 256->128 3x3", 128, 89, 256, 128, (3, 3), (1, 1), 1, 1),
     ("inp 128->64 3x3", 256, 178, 128, 64, (3, 3), (1, 1), 1, 1),
+    # data gradients of the U-Net's reflect-padded blocks: full correlation of d_raw (fwd cout channels) with the flipped
+    # weights onto the PADDED domain (train_ops._reflect_dgrad): zero padding (k-1)*dil, output (H + 2p) x (W + 2p), no epilogue
+    ("dgrad up2.0 64->128 3x3", 256, 178, 64, 128, (3, 3), (1, 1), 1, "dgrad"),
+    ("dgrad up1.0 128->256 3x3", 128, 89, 128, 256, (3, 3), (1, 1), 1, "dgrad"),
+    ("dgrad down2.1 128->128 5x5", 128, 89, 128, 128, (5, 5), (1, 1), 1, "dgrad"),
+    ("dgrad mid 256->256 3x3 d2", 64, 45, 256, 256, (3, 3), (2, 2), 1, "dgrad"),
 ]
 
 
@@ -51,14 +57,21 @@ def main():
         else:
             src.t.normal_()
         Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+        dgrad = pm == "dgrad"
+        if dgrad:
+            pm = 0
+            Ho, Wo = H + (k[0] - 1) * dil[0], W + (k[1] - 1) * dil[1]
         dst = E.Act(B, Ho, Wo, E.pad_to(cout, 16), False, dev)
         w = E.pack_weight(torch.randn(cout, cin, k[0], k[1], device=dev) * (0.0 if zmode in ('1', 'w') else 0.05), cin, False)
         scale = torch.ones(w.shape[1], device=dev)
         shift = torch.zeros(w.shape[1], device=dev)
         pad = ((k[0] - 1) // 2 * dil[0], (k[1] - 1) // 2 * dil[1])
+        if dgrad:
+            pad = ((k[0] - 1) * dil[0], (k[1] - 1) * dil[1])
 
         def run():
-            E.conv_to_act(src, 0, cin, w, k[0], k[1], cout, scale, shift, L.ACT_RELU, dst, cout_store=dst.cs,
+            E.conv_to_act(src, 0, cin, w, k[0], k[1], cout, None if dgrad else scale, None if dgrad else shift,
+                          L.ACT_NONE if dgrad else L.ACT_RELU, dst, cout_store=dst.cs,
                           stride=stride, dil=dil, pad=pad, pad_mode=pm, Ho=Ho, Wo=Wo)
         import time
         t_end = time.time() + a.warm

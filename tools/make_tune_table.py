@@ -26,6 +26,7 @@ if os.path.exists(OUT):
 if EXTEND_AV:
     import shutil
     shutil.copy(SHIPPED, OUT)
+    shutil.copy(SHIPPED, OUT + ".f16")       # the fp16 build reads / writes its own cache file (engine._load_tune_cache)
 if RETUNE_X3:
     # shape key columns (conv.hip, shape_key): 4 cin, 5 segments, 14 out dtype (1 = hi|hi|lo), 15 dense NHWC, 18 cout
     lines = open(SHIPPED).read().splitlines()

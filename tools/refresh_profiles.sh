@@ -13,9 +13,9 @@ python tools/wgrad_bench.py > $O/wgrad_bench.txt 2>&1
 python tools/lstm_bench.py > $O/lstm_bench.txt 2>&1
 python tools/bn_bench.py > $O/bn_bench.txt 2>&1
 python tools/frontend_bench.py > $O/frontend_bench.txt 2>&1
-rocprofv3 --kernel-trace --stats -d $O/prof_train -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_train.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/prof_infer -o t -- python bench.py --mode infer --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_infer.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/prof_ragged -o t -- python bench.py --mode infer-ragged --steps 2 --warmup 1 --no-cpu-baseline > $O/prof_ragged.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_train -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $O/prof_train.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_infer -o t -- python bench.py --mode infer --steps 5 --warmup 1 --no-cpu-baseline --no-secondary > $O/prof_infer.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_ragged -o t -- python bench.py --mode infer-ragged --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $O/prof_ragged.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | tr ' ' '_')
   rocprofv3 --pmc $c --kernel-include-regex conv_mfma -d $O/pmc_$n -o p --output-format csv -- python tools/conv_bench.py --only "ctx96 d1x1" --iters 3 --warm 0.05 > $O/pmc_$n.log 2>&1
@@ -39,10 +39,10 @@ print(json.dumps(out))
 PY
 cp $O/pmc_conv96.json profiles/${R}_pmc_conv96.json     # bench.py reports this record as roofline.traffic
 python bench.py --steps 10 --warmup 3 > $O/bench_train_fp16.json 2> $O/bench_train_fp16.err
-python bench.py --precision bf16 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_train_bf16.json 2> $O/bench_train_bf16.err
-python bench.py --precision bf16x3 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_train_bf16x3.json 2> $O/bench_train_bf16x3.err
-python bench.py --mode infer --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_infer_fp16.json 2> $O/bench_infer_fp16.err
-python bench.py --mode infer-ragged --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_ragged_fp16.json 2> $O/bench_ragged_fp16.err
+python bench.py --precision bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench_train_bf16.json 2> $O/bench_train_bf16.err
+python bench.py --precision bf16x3 --steps 6 --warmup 2 --no-cpu-baseline --no-secondary > $O/bench_train_bf16x3.json 2> $O/bench_train_bf16x3.err
+python bench.py --mode infer --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench_infer_fp16.json 2> $O/bench_infer_fp16.err
+python bench.py --mode infer-ragged --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/bench_ragged_fp16.json 2> $O/bench_ragged_fp16.err
 for m in train infer ragged; do python profiles/summarize_rocpd.py $(find $O/prof_$m -name "*.db" | head -1) $O/${m}_kernels.md > /dev/null 2>&1; done
 find $O -name "*.db" -delete            # the summaries stay; gpurun copies at most 64 MiB back
 for f in $O/bench_*.json; do echo $f; cut -c1-420 $f; done
