@@ -16,7 +16,11 @@
 // walks a slice of the pixels (split-K); partial sums go to a [ksplit][taps][M][N] fp32 buffer
 // that a deterministic reduce kernel folds into the OIHW gradient (no atomics).
 #include "sos_common.h"
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 typedef sos_half_t bf16x8 __attribute__((ext_vector_type(8)));   // 8 storage-type (bf16, or fp16 in the SOS_F16 build) MFMA operands
@@ -56,7 +60,18 @@ struct WgParams {
     int tT, tcin, tpad;       // temporal taps (tT = 0: off): frames per clip, channels per frame, temporal padding
     int ntg, taps_all;        // kernels with more taps than one workgroup holds (7x7): ntg workgroups own kh tap ROWS each
                               // (kh / kw above are then the group's), taps_all = taps of the whole kernel
+    int kord;                 // order of the 256 tile pixels along the contraction: 0 = (class, row, column), 1 = (class, column,
+                              // row).  A k-step (16 / 32 consecutive tile pixels) none of whose pixels lies inside the image is
+                              // skipped, so the order decides WHICH border pixels cost nothing: whole rows below the image (0) or
+                              // whole columns right of it (1); the host counts both and keeps the cheaper
 };
+
+// tile pixel e (k order) -> (class, row i, column j)
+__device__ __host__ __forceinline__ void wg_decode(int e, int logTH, int logTW, int kord, int& cls, int& i, int& j) {
+    cls = e >> (logTH + logTW);
+    if (kord) { i = e & ((1 << logTH) - 1); j = (e >> logTH) & ((1 << logTW) - 1); }
+    else { j = e & ((1 << logTW) - 1); i = (e >> logTW) & ((1 << logTH) - 1); }
+}
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -134,11 +149,11 @@ struct WgStage {
         gimg_bytes = (unsigned)p.Hg * p.Wg * p.g_cs * 2; ximg_bytes = (unsigned)p.Hx * p.Wx * p.x_cs * 2;
         reflect = p.pad_mode == SOS_PAD_REFLECT;
         // ---- tile-invariant pixel table
-        const int lsh = p.logTW + p.logTH;
         for (int e = tid; e < 256 + p.npixp; e += WG_THREADS) {
             unsigned r = 0u, c = 0x7fff7fffu;                     // invalid: always out of range
             if (e < 256) {
-                const int j = e & (TW - 1), i = (e >> p.logTW) & (TH - 1), cls = e >> lsh;
+                int j, i, cls;
+                wg_decode(e, p.logTH, p.logTW, p.kord, cls, i, j);
                 const int hrel = i * p.dh, wrel = cls + j * p.dw;
                 r = (unsigned)((hrel * p.Wg + wrel) * p.g_cs * 2);
                 c = (unsigned)hrel | ((unsigned)wrel << 16);
@@ -274,7 +289,6 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     const int g4 = lane >> 4, s16 = lane & 15;
     const int chan_off = (16 * (g4 & 1) + 4 * (s16 & 3)) * 2;    // byte offset of this lane's 4-channel run
     const int krow = 8 * (g4 >> 1) + (s16 >> 2);                 // pixel (k) inside a 16-pixel k-step; +4 for 2nd read
-    const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTH) - 1, lsh = p.logTW + p.logTH;
 
     const WgStage<2, NTB> st(p, smem, tid, MT, NTB, m0, n0, tg);
     const int ninstr = st.ninstr;
@@ -306,17 +320,36 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     const int nlight = WG_WAVES - heavy, lw = wave - heavy;       // lw < 0: this wave issues no DMA in the k-loop
 
     // patch pixel of tile pixel k (k-order = (class, row, column) of the 256-pixel tile)
-    auto pp_of = [&](int k) { return ((k >> lsh) * p.PH + ((k >> p.logTW) & THm) * p.stride) * p.PW + (k & TWm) * p.stride; };
+    auto pp_of = [&](int k) {
+        int c, i, j;
+        wg_decode(k, p.logTH, p.logTW, p.kord, c, i, j);
+        return (c * p.PH + i * p.stride) * p.PW + j * p.stride;
+    };
     const unsigned glane = (unsigned)(krow * 64 + chan_off);
     const unsigned xlane0 = (unsigned)(pp_of(krow) * 64 + chan_off), xlane1 = (unsigned)(pp_of(krow + 4) * 64 + chan_off);
 
     const unsigned ppk = (unsigned)pp_of((lane & 15) * 16) * 64u;      // lane ks: X-image byte offset of k-step ks
+    // lane ks: image-relative coordinates of the FIRST pixel of k-step ks.  Validity falls monotonically along rows, columns
+    // and classes and a k-step is an aligned block of the pixel index, so a k-step holds a pixel inside the image exactly
+    // when its first pixel is inside: one compare + ballot per tile gives the mask of the k-steps worth multiplying
+    // (the others would add G = 0 rows: skipping them changes no bit of the result).
+    int kfh, kfw;
+    {
+        int c, i, j;
+        wg_decode((lane & 15) * 16, p.logTH, p.logTW, p.kord, c, i, j);
+        kfh = i * p.dh; kfw = c + j * p.dw;
+    }
 
     const int step0 = split * p.steps_per_split;
     const int step1 = min(step0 + p.steps_per_split, p.nsteps);
     int cur = 0;
     __syncthreads();                               // pixel table complete
-    if (step0 < step1) st.issue_all(st.origin_of(step0), 0);
+    int cgh0 = 0, cgw0 = 0;                        // origin of the tile being multiplied
+    if (step0 < step1) {
+        const WgTile o0 = st.origin_of(step0);
+        cgh0 = o0.gh0; cgw0 = o0.gw0;
+        st.issue_all(o0, 0);
+    }
     for (int step = step0; step < step1; ++step) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // tile `step` has landed in buffer `cur`; buffer cur^1 is free
@@ -324,6 +357,9 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
         const WgTile onext = st.origin_of(more ? step + 1 : step);
         const bool prefetch = p.dbuf && more;
         const unsigned gb = sbase + cur * p.bufbytes, xb = gb + gbytes;
+        unsigned kmask = (unsigned)__builtin_amdgcn_ballot_w64(cgh0 + kfh < p.Hg && cgw0 + kfw < p.Wg) & 0xffffu;   // wave-uniform
+        if (WDBG(32)) kmask = 0xffffu;
+        cgh0 = onext.gh0; cgw0 = onext.gw0;
         if constexpr (BAL && SOS_WGRAD_PIPE) {
             // ---- software pipeline over the k-steps (round 3).  The counted waits of the loop below do not survive hipcc's
             // scheduler (the MFMAs sink below them: every k-step waited for ALL of its reads before its first MFMA, and the
@@ -402,10 +438,13 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
                 kstep(last_t, 15, F1, F0);
             }
         } else {
+        int it = 0;                                 // k-steps done: the DMA slots of the next tile are counted in these
 #pragma unroll 1
-        for (int ks = 0; ks < 16; ++ks) {
+        for (; kmask; ++it) {
+            const int ks = __builtin_ctz(kmask);
+            kmask &= kmask - 1;
             uint2 ent = make_uint2(0u, 0u);
-            const int di = ks * nlight + lw;                      // this wave's DMA instruction in this k-step
+            const int di = it * nlight + lw;                      // this wave's DMA instruction in this k-step
             const bool dma = prefetch && lw >= 0 && di < ninstr;
             if (dma) ent = lds_read64(st.entry_addr(di));
             // k = 16 ks + krow: the bits of 16 ks and of krow (< 16) are disjoint, so the patch pixel of k is
@@ -471,6 +510,14 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
             }
             if constexpr (BAL) {
                 if (hasx) accx = SOS_MFMA_32x32x16(__builtin_bit_cast(bf16x8, avx), __builtin_bit_cast(bf16x8, bvx), accx, 0, 0, 0);
+            }
+        }
+        // border tile with skipped k-steps: the DMA slots those k-steps would have carried
+        if (prefetch && lw >= 0) {
+            for (int di = it * nlight + lw; di < ninstr; di += nlight) {
+                uint2 ent = lds_read64(st.entry_addr(di));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent));
+                st.issue(di, ent, onext, cur ^ 1);
             }
         }
         }
@@ -539,7 +586,6 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
     const int g4 = lane >> 4, s16 = lane & 15;
     const int krow = 4 * g4 + (s16 >> 2);                         // tile pixel of the first read inside the k-step; +16 second
     const int colb = (s16 & 3) * 8;
-    const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTH) - 1, lsh = p.logTW + p.logTH;
 
     const WgStage<1, N16> st(p, smem, tid, M16, N16, 0, 0);
     const int ninstr = st.ninstr;
@@ -562,16 +608,31 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
         toff[f] = (unsigned)((ta * p.PW + tb) * 32);
     }
     const unsigned toffe = (unsigned)(((tap_e / p.kw) * p.PW + (tap_e % p.kw)) * 32);
-    auto pp_of = [&](int k) { return ((k >> lsh) * p.PH + ((k >> p.logTW) & THm) * p.stride) * p.PW + (k & TWm) * p.stride; };
+    auto pp_of = [&](int k) {
+        int c, i, j;
+        wg_decode(k, p.logTH, p.logTW, p.kord, c, i, j);
+        return (c * p.PH + i * p.stride) * p.PW + j * p.stride;
+    };
     const unsigned glane = (unsigned)(krow * 32 + colb);
     const unsigned xlane0 = (unsigned)(pp_of(krow) * 32 + colb), xlane1 = (unsigned)(pp_of(krow + 16) * 32 + colb);
     const unsigned ppk = (unsigned)pp_of((lane & 7) * 32) * 32u;        // lane ks: X-image byte offset of k-step ks
+    int kfh, kfw;                                                       // lane ks: first pixel of k-step ks (see wgrad_kernel)
+    {
+        int c, i, j;
+        wg_decode((lane & 7) * 32, p.logTH, p.logTW, p.kord, c, i, j);
+        kfh = i * p.dh; kfw = c + j * p.dw;
+    }
 
     const int step0 = split * p.steps_per_split;
     const int step1 = min(step0 + p.steps_per_split, p.nsteps);
     int cur = 0;
     __syncthreads();                               // pixel table complete
-    if (step0 < step1) st.issue_all(st.origin_of(step0), 0);
+    int cgh0 = 0, cgw0 = 0;                        // origin of the tile being multiplied
+    if (step0 < step1) {
+        const WgTile o0 = st.origin_of(step0);
+        cgh0 = o0.gh0; cgw0 = o0.gw0;
+        st.issue_all(o0, 0);
+    }
     for (int step = step0; step < step1; ++step) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // tile `step` has landed in buffer `cur`; buffer cur^1 is free
@@ -579,10 +640,16 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
         const WgTile onext = st.origin_of(more ? step + 1 : step);
         const bool prefetch = p.dbuf && more;
         const unsigned gb = sbase + cur * p.bufbytes, xb = gb + gbytes;
+        unsigned kmask = (unsigned)__builtin_amdgcn_ballot_w64(cgh0 + kfh < p.Hg && cgw0 + kfw < p.Wg) & 0xffu;   // wave-uniform
+        if (WDBG(32)) kmask = 0xffu;
+        cgh0 = onext.gh0; cgw0 = onext.gw0;
+        int it = 0;
 #pragma unroll 1
-        for (int ks = 0; ks < 8; ++ks) {
+        for (; kmask; ++it) {
+            const int ks = __builtin_ctz(kmask);
+            kmask &= kmask - 1;
             if (prefetch) {                        // the next tile: 8 waves x 8 k-steps DMA slots (more rounds if the patch is big)
-                for (int di = ks * WG_WAVES + wave; di < ninstr; di += 8 * WG_WAVES) {
+                for (int di = it * WG_WAVES + wave; di < ninstr; di += 8 * WG_WAVES) {
                     uint2 ent = lds_read64(st.entry_addr(di));
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent));
                     st.issue(di, ent, onext, cur ^ 1);
@@ -641,6 +708,14 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
                     acce[n] = SOS_MFMA_16x16x32(__builtin_bit_cast(bf16x8, ae), __builtin_bit_cast(bf16x8, be[n]),
                                                                       acce[n], 0, 0, 0);
             }
+        }
+        if (prefetch) {                            // the DMA slots of skipped k-steps
+            for (; it < 8; ++it)
+                for (int di = it * WG_WAVES + wave; di < ninstr; di += 8 * WG_WAVES) {
+                    uint2 ent = lds_read64(st.entry_addr(di));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent));
+                    st.issue(di, ent, onext, cur ^ 1);
+                }
         }
         if (p.dbuf) {
             cur ^= 1;
@@ -850,11 +925,12 @@ static int wg_gemm_split(int ntiles, int K, int64_t plane_bytes, int cap) {
 // ksplit <= 0 in the descriptor = automatic: one workgroup per CU (MI355X: 256) over (pixel split, m-group, n-group),
 // bounded by 256 MB of partial sums.
 static const int WG_NCU = 256;
+static const int WG_MAXSPLIT = 1024;      // several workgroups per CU for gradients whose tiles are short (see sos_conv2d_wgrad)
 static int wg_max_split(const sos_wgrad_desc* d) {
     const int64_t Mp = (d->M + 31) / 32 * 32, Np = (d->N + 31) / 32 * 32;
     const int64_t per = (int64_t)d->kh * d->kw * Mp * Np * 4;
     const int64_t cap = ((int64_t)256 << 20) / per;
-    return (int)(cap < 1 ? 1 : (cap > WG_NCU ? WG_NCU : cap));
+    return (int)(cap < 1 ? 1 : (cap > WG_MAXSPLIT ? WG_MAXSPLIT : cap));
 }
 
 extern "C" int64_t sos_wgrad_workspace_bytes(const sos_wgrad_desc* d) {
@@ -948,58 +1024,115 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     // small channel counts: the 16x16x32 kernel owns all of dW in one workgroup (no padding to 32)
     const int m16 = (d->M + 15) / 16, n16 = (d->N + 15) / 16;
     const bool use16 = !temporal && p.ntg == 1 && m16 == 3 && n16 == 3 && (taps == 25 || taps == 9) && !getenv("SOS_WGRAD_NO16");
-    // pixel tile (NC x TH x TW = 256): fewest k-steps among the shapes whose operands fit LDS (double
-    // buffered, <= 16 DMA slots, if possible); shrink the channel tile if none fits
+    // pixel tile (NC x TH x TW = 256) and the order of its pixels along the contraction: fewest k-steps THAT HOLD A PIXEL OF THE
+    // IMAGE (the kernels skip the others) among the shapes whose operands fit LDS (double buffered if possible); shrink the
+    // channel tile if none fits.  The choice depends on the shape only and is cached (the exact count walks every tile).
     const size_t lds_max = 160 * 1024;
-    for (;;) {
-        double best = 1e300;
-        int bnc = 0, bth = 0, btw = 0, bdb = 0;
-        for (int lnc = 0; lnc <= 6; ++lnc) {
-            const int NC = 1 << lnc;
-            if (NC > 1 && (d->stride > 1 || NC > d->dil_w || d->dil_w % NC)) break;
-            for (int lth = 0; lth + lnc <= 8; ++lth) {
-                const int ltw = 8 - lnc - lth;
-                if (ltw < 2) continue;
-                const int TH = 1 << lth, TW = 1 << ltw;
-                const int PH = (TH - 1) * d->stride + khg, PW = (TW - 1) * d->stride + d->kw;
-                if ((TH - 1 + d->kh) * d->dil_h >= 0x7fff || (d->stride * NC + (PW - 1) * d->dil_w) >= 0x7fff) continue;
-                const int npixp = use16 ? (NC * PH * PW + 31) / 32 * 32 : (NC * PH * PW + 15) / 16 * 16;
-                const size_t one = use16 ? ((size_t)256 * 32 * m16 + (size_t)npixp * 32 * n16 + 1023) / 1024 * 1024
-                                         : ((size_t)256 * 64 * mt + (size_t)npixp * 64 * ntb + 1023) / 1024 * 1024;
-                const size_t tabb = (size_t)(256 + npixp) * 8;
-                if (one + tabb > lds_max) continue;
-                const int db = 2 * one + tabb <= lds_max;
-                const double steps = (double)((Hc + TH - 1) / TH) * ((Wc + TW - 1) / TW) * ((d->dil_w + NC - 1) / NC);
-                // LDS bank conflicts of the transposed X reads (16x16x32 kernel, 32-byte pixel pitch): a 32-lane group reads 8
-                // tile pixels x 32 B, pixel pp on banks 8 (pp mod 8) ..; with TW = 4 and PW = 8 (5x5 taps) the two tile rows of
-                // a group alias (SQ_LDS_BANK_CONFLICT was 42 % of the LDS-active cycles of the 48 -> 48 gradient, whose
-                // cheapest tile by step count is 64 x 4): count the worst multiplicity and charge the MFMA term for it
-                double conflict = 1.0;
-                if (use16) {
-                    int worst = 1;
-                    for (int grp = 0; grp < 4; ++grp) {            // pixels 8 grp .. 8 grp + 7 of a 32-pixel k-step
-                        int cnt[8] = {0};
-                        for (int e = 0; e < 8; ++e) {
-                            const int k = 8 * grp + e;
-                            const int pp = ((k >> (lth + ltw)) * PH + ((k >> ltw) & (TH - 1)) * d->stride) * PW + (k & (TW - 1)) * d->stride;
-                            if (++cnt[pp & 7] > worst) worst = cnt[pp & 7];
-                        }
-                    }
-                    conflict = 1.0 + 0.3 * (worst - 1);
-                }
-                const double cost = steps * (256.0 * taps * conflict + (db ? 1.0 : 6.0) * NC * PH * PW);
-                if (cost < best) { best = cost; bnc = NC; bth = lth; btw = ltw; bdb = db; p.bufbytes = (int)one; p.npixp = npixp; }
-            }
-        }
-        if (bnc) { p.NC = bnc; p.logTH = bth; p.logTW = btw; p.dbuf = bdb; break; }
-        if (ntb == 1 || use16) { sos_set_error("sos_conv2d_wgrad: patch does not fit LDS"); return SOS_ENOSPC; }
-        ntb >>= 1;
+    const int kpix = use16 ? 32 : 16;              // tile pixels per k-step
+    struct TileCfg { int nc, lth, ltw, db, kord, bufbytes, npixp, ntb; };
+    struct TileKey {
+        int v[16];
+        bool operator<(const TileKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
+    };
+    static std::mutex tile_mu;
+    static std::map<TileKey, TileCfg> tile_cache;
+    const TileKey tkey = {{d->Hg, d->Wg, d->kh, d->kw, d->stride, d->dil_h, d->dil_w, mt, ntb, use16 ? 1 : 0, khg, m16, n16, 0, 0, 0}};
+    TileCfg tc;
+    bool cached = false;
+    {
+        std::lock_guard<std::mutex> lk(tile_mu);
+        auto f = tile_cache.find(tkey);
+        if (f != tile_cache.end()) { tc = f->second; cached = true; }
     }
+    const char* force = getenv("SOS_WGRAD_TILE");  // experiments: "nc,lth,ltw,kord"
+    if (!cached || force) {
+        int fnc = -1, fth = -1, ftw = -1, fko = -1;
+        if (force) sscanf(force, "%d,%d,%d,%d", &fnc, &fth, &ftw, &fko);
+        int ntb_try = ntb;
+        for (;;) {
+            double best = 1e300;
+            tc.nc = 0;
+            for (int lnc = 0; lnc <= 6; ++lnc) {
+                const int NC = 1 << lnc;
+                if (NC > 1 && (d->stride > 1 || NC > d->dil_w || d->dil_w % NC)) break;
+                for (int lth = 0; lth + lnc <= 8; ++lth) {
+                    const int ltw = 8 - lnc - lth;
+                    if (ltw < 2) continue;
+                    if (force && fnc > 0 && (NC != fnc || lth != fth || ltw != ftw)) continue;
+                    const int TH = 1 << lth, TW = 1 << ltw;
+                    const int PH = (TH - 1) * d->stride + khg, PW = (TW - 1) * d->stride + d->kw;
+                    if ((TH - 1 + d->kh) * d->dil_h >= 0x7fff || (d->stride * NC + (PW - 1) * d->dil_w) >= 0x7fff) continue;
+                    const int npixp = use16 ? (NC * PH * PW + 31) / 32 * 32 : (NC * PH * PW + 15) / 16 * 16;
+                    const size_t one = use16 ? ((size_t)256 * 32 * m16 + (size_t)npixp * 32 * n16 + 1023) / 1024 * 1024
+                                             : ((size_t)256 * 64 * mt + (size_t)npixp * 64 * ntb_try + 1023) / 1024 * 1024;
+                    const size_t tabb = (size_t)(256 + npixp) * 8;
+                    if (one + tabb > lds_max) continue;
+                    const int db = 2 * one + tabb <= lds_max;
+                    const int tiles_h = (Hc + TH - 1) / TH, tiles_w = (Wc + TW - 1) / TW, ngw = (d->dil_w + NC - 1) / NC;
+                    const double ntiles = (double)d->dil_h * ngw * tiles_h * tiles_w;
+                    for (int kord = 0; kord < 2; ++kord) {
+                        if (force && fko >= 0 && kord != fko) continue;
+                        // Cost of one image in k-step units, calibrated on MI355X with tools/probe/wgrad_tile_sweep.py (round 3: every
+                        // tile x order of the 96- and 48-channel layers timed; this model's pick is within 1.1 % of the best measured
+                        // one on each).  A tile multiplies its k-steps that hold a pixel of the image (first pixel of the k-step
+                        // inside); meanwhile the DMA of the NEXT tile runs, `kb` k-steps per KB of operand image whether its pixels
+                        // are inside or not -- so a border tile that keeps 2 of its k-steps still takes its successor's fetch time
+                        // (double buffered: the longer of the two; single buffered: a fraction of the fetch is exposed) -- plus a
+                        // fixed barrier / drain cost per tile.  The 16x16x32 kernel's k-step is 32 pixels x 9 tiles per tap and
+                        // fetches 48-channel operands: its DMA term weighs more (the former bank-conflict term of that kernel is
+                        // subsumed: the sweep ranks its tiles correctly without it).
+                        const double kb = use16 ? 0.15 : 0.04, sbf = use16 ? 0.3 : 0.5, fixed = use16 ? 1.5 : 1.0;
+                        const double dma = (double)one / 1024.0 * kb;
+                        double cost = 0.0;
+                        for (int rh = 0; rh < d->dil_h; ++rh)
+                            for (int gw = 0; gw < ngw; ++gw)
+                                for (int ti = 0; ti < tiles_h; ++ti)
+                                    for (int tj = 0; tj < tiles_w; ++tj) {
+                                        const int gh0 = rh + ti * TH * d->dil_h, gw0 = gw * NC + tj * TW * d->dil_w;
+                                        int nks = 0;
+                                        for (int ks = 0; ks < 256 / kpix; ++ks) {
+                                            int c, i, j;
+                                            wg_decode(ks * kpix, lth, ltw, kord, c, i, j);
+                                            if (gh0 + i * d->dil_h < d->Hg && gw0 + c + j * d->dil_w < d->Wg) ++nks;
+                                        }
+                                        cost += db ? (nks > dma ? nks : dma) : nks + sbf * dma;
+                                    }
+                        cost += fixed * ntiles;
+                        if (cost < best) { best = cost; tc = TileCfg{NC, lth, ltw, db, kord, (int)one, npixp, ntb_try}; }
+                    }
+                }
+            }
+            if (tc.nc) break;
+            if (ntb_try == 1 || use16) { sos_set_error("sos_conv2d_wgrad: patch does not fit LDS"); return SOS_ENOSPC; }
+            ntb_try >>= 1;
+        }
+        if (getenv("SOS_WGRAD_VERBOSE"))
+            fprintf(stderr, "sos_conv2d_wgrad: %dx%d k%dx%d s%d d%dx%d M%d N%d %s-> NC=%d TH=%d TW=%d order=%d dbuf=%d ntb=%d lds=%d\n", d->Hg, d->Wg,
+                    d->kh, d->kw, d->stride, d->dil_h, d->dil_w, d->M, d->N, use16 ? "(16x16x32) " : "", tc.nc, 1 << tc.lth, 1 << tc.ltw,
+                    tc.kord, tc.db, tc.ntb, tc.bufbytes);
+        if (!force) {
+            std::lock_guard<std::mutex> lk(tile_mu);
+            tile_cache[tkey] = tc;
+        }
+    }
+    ntb = tc.ntb;
+    p.NC = tc.nc; p.logTH = tc.lth; p.logTW = tc.ltw; p.dbuf = tc.db; p.kord = tc.kord; p.bufbytes = tc.bufbytes; p.npixp = tc.npixp;
     {
         const int TH = 1 << p.logTH, TW = 1 << p.logTW;
         p.tiles_h = (Hc + TH - 1) / TH; p.tiles_w = (Wc + TW - 1) / TW; p.ngw = (d->dil_w + p.NC - 1) / p.NC;
         p.PH = (TH - 1) * d->stride + khg; p.PW = (TW - 1) * d->stride + d->kw;
         p.npix = p.NC * p.PH * p.PW;
+    }
+    // workgroups per CU: one (its own double-buffered DMA pipeline covers the fetch of the next tile) unless a tile is so
+    // short that the fetch latency of a tile exceeds its MFMA time -- then several co-resident workgroups cover each other
+    // (measured: the 96 -> 8 / 48 -> 4 1x1 heads, two MFMAs per k-step and workgroup: 0.456 -> 0.338 / 0.239 -> 0.185 ms with
+    // two workgroups per CU; the thin 5x5 / 1x7 first layers, whose double buffers no longer fit then, get slower)
+    int occ = is_flat && mt * ntb <= 2 ? 2 : 1;
+    { const char* e = getenv("SOS_WGRAD_OCC"); if (e && atoi(e) >= 1 && atoi(e) <= 4) occ = atoi(e); }
+    if (occ > 1) {
+        const size_t tabb = (size_t)(256 + p.npixp) * 8;
+        while (occ > 1 && (size_t)p.bufbytes + tabb > lds_max / occ) --occ;
+        if (occ > 1 && 2 * (size_t)p.bufbytes + tabb > lds_max / occ) p.dbuf = 0;
     }
     const size_t lds = (size_t)p.bufbytes * (p.dbuf ? 2 : 1) + (size_t)(256 + p.npixp) * 8;
     { const char* e = getenv("SOS_WGRAD_DBG"); p.dbg = e ? atoi(e) : 0; }
@@ -1007,7 +1140,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     int ksplit = d->ksplit;
     if (ksplit <= 0) {
         const int groups = use16 ? 1 : mgroups * ((ntiles_n + ntb - 1) / ntb) * p.ntg;
-        ksplit = WG_NCU / groups;
+        ksplit = occ * WG_NCU / groups;
         if (ksplit < 1) ksplit = 1;
         const int cap = wg_max_split(d);
         if (ksplit > cap) ksplit = cap;
@@ -1019,7 +1152,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     p.xcdmap = 0;
     if (!use16 && d->ksplit <= 0 && p.ny * p.nz > 1 && p.ny * p.nz <= 16 && !getenv("SOS_WGRAD_NOXCD")) {
         // one workgroup per CU: an XCD (32 CUs) takes floor(32 / groups) splits, all groups of a split on one XCD
-        const int per_xcd = 32 / (p.ny * p.nz);
+        const int per_xcd = occ * 32 / (p.ny * p.nz);
         int ks8 = 8 * per_xcd;
         if (ks8 > p.nsteps) ks8 = p.nsteps / 8 * 8;
         const int cap = wg_max_split(d) / 8 * 8;

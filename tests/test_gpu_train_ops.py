@@ -97,6 +97,12 @@ CASES = [
     ("16: 5x5 48x48", 48, 48, (5, 5), 1, (1, 1), (2, 2), "zeros", 37, 50),
     ("16: 5x5 dil(4,4) 48x40", 48, 40, (5, 5), 1, (4, 4), (8, 8), "zeros", 30, 41),
     ("16: 3x3 reflect 40x48", 40, 48, (3, 3), 1, (1, 1), (1, 1), "reflect", 21, 35),
+    # round 3: k-steps without a pixel inside the image are skipped; shapes whose cheapest tile walks its pixels column-major
+    # (few strided columns per residue class) and whose border tiles lose whole k-steps
+    ("5x5 dil(16,16) 96x96", 96, 96, (5, 5), 1, (16, 16), (32, 32), "zeros", 64, 45),
+    ("5x5 dil(16,1) 96x64", 96, 64, (5, 5), 1, (16, 1), (32, 2), "zeros", 40, 51),
+    ("16: 5x5 dil(16,16) 48x48", 48, 48, (5, 5), 1, (16, 16), (32, 32), "zeros", 64, 45),
+    ("16: 5x5 dil(32,32) 48x48", 48, 48, (5, 5), 1, (32, 32), (64, 64), "zeros", 70, 81),
 ]
 
 
@@ -120,6 +126,30 @@ def test_conv_weight_grad(case, mode_x3):
     err = rel_err(dw.cpu(), w.grad)
     print(case[0], "x3" if x3 else "bf16", "wgrad rel err", err)
     assert err < (2e-4 if x3 else 2e-5 + 1e-3)
+
+
+@pytest.mark.parametrize("tile", ["1,4,4,0", "1,4,4,1", "1,6,2,1", "1,2,6,0", "2,3,4,1", "4,4,2,1", "4,4,2,0"])
+@pytest.mark.parametrize("ch", [96, 48])
+def test_conv_weight_grad_forced_tiles(tile, ch, monkeypatch):
+    """Every (residue classes, tile height, tile width, pixel order) of the weight-gradient kernels gives the same gradient:
+    the tile and the order of its pixels along the contraction (row- or column-major, which decides the border k-steps that
+    are skipped) are performance choices only.  SOS_WGRAD_TILE = "classes,log2 TH,log2 TW,order" forces one."""
+    from sos_amd import engine as E
+    monkeypatch.setenv("SOS_WGRAD_TILE", tile)
+    B, H, W, k, dil = 2, 37, 45, (5, 5), (4, 4)
+    pad = (8, 8)
+    x = torch.from_numpy(hashed(51, (B, ch, H, W)).astype(np.float32))
+    xa, xheld = _act_from_nchw(x, False)
+    w = torch.zeros(ch, ch, 5, 5, requires_grad=True)
+    y = F.conv2d(xheld, w, None, 1, pad, dil)
+    g = torch.from_numpy(hashed(52, tuple(y.shape)).astype(np.float32))
+    ga, gheld = _act_from_nchw(g, False)
+    y.backward(gheld)
+    dw = torch.empty(ch, ch, 5, 5, dtype=torch.float32, device="cuda")
+    E.wgrad(ga, 0, ch, xa, 0, ch, 5, 5, dw, dil=dil, pad=pad)
+    err = rel_err(dw.cpu(), w.grad)
+    print(tile, ch, "wgrad rel err", err)
+    assert err < 2e-5 + 1e-3
 
 
 def test_conv_transpose_weight_grad(mode_x3):

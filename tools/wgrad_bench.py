@@ -10,14 +10,25 @@ sos_amd.set_precision(os.environ.get('SOS_PRECISION', 'bf16'))
 SHAPES = [("ctx96 d1x1", 256, 178, 96, 96, (5, 5), (1, 1), 1), ("ctx96 d8x1", 256, 178, 96, 96, (5, 5), (8, 1), 1),
           ("ctx96 d32x32", 256, 178, 96, 96, (5, 5), (32, 32), 1), ("ctx48 d1x1", 256, 178, 48, 48, (5, 5), (1, 1), 1),
           ("inp 256 3x3", 64, 45, 256, 256, (3, 3), (1, 1), 1), ("inp 128 5x5", 128, 89, 128, 128, (5, 5), (1, 1), 1),
-          ("inp 64->128 s2", 256, 178, 64, 128, (5, 5), (1, 1), 2), ("lstm proj 3072->1600", 1, 178, 3072, 1600, (1, 1), (1, 1), 1)]
+          ("inp 64->128 s2", 256, 178, 64, 128, (5, 5), (1, 1), 2), ("lstm proj 3072->1600", 1, 178, 3072, 1600, (1, 1), (1, 1), 1),
+          # round 3: the dilated layers (border k-steps skipped), the 7x1 layers and the thin first / last layers
+          ("ctx96 d2x2", 256, 178, 96, 96, (5, 5), (2, 2), 1), ("ctx96 d4x4", 256, 178, 96, 96, (5, 5), (4, 4), 1),
+          ("ctx96 d8x8", 256, 178, 96, 96, (5, 5), (8, 8), 1), ("ctx96 d16x16", 256, 178, 96, 96, (5, 5), (16, 16), 1),
+          ("ctx96 d16x1", 256, 178, 96, 96, (5, 5), (16, 1), 1), ("ctx96 d32x1", 256, 178, 96, 96, (5, 5), (32, 1), 1),
+          ("ctx48 d16x16", 256, 178, 48, 48, (5, 5), (16, 16), 1), ("ctx48 d32x32", 256, 178, 48, 48, (5, 5), (32, 32), 1),
+          ("ctx96 7x1", 256, 178, 96, 96, (7, 1), (1, 1), 1), ("ctx48 7x1", 256, 178, 48, 48, (7, 1), (1, 1), 1),
+          ("thin 2->96 1x7", 256, 178, 2, 96, (1, 7), (1, 1), 1), ("thin 2->48 1x7", 256, 178, 2, 48, (1, 7), (1, 1), 1),
+          ("thin 2->64 5x5", 256, 178, 2, 64, (5, 5), (1, 1), 1), ("thin 64->2 5x5", 256, 178, 64, 2, (5, 5), (1, 1), 1),
+          ("thin 96->8 1x1", 256, 178, 96, 8, (1, 1), (1, 1), 1), ("thin 48->4 1x1", 256, 178, 48, 4, (1, 1), (1, 1), 1),
+          ("inp 256 3x3 d16", 64, 45, 256, 256, (3, 3), (16, 16), 1), ("inp 256 3x3 d8", 64, 45, 256, 256, (3, 3), (8, 8), 1),
+          ("inp 64->128 3x3", 256, 178, 64, 128, (3, 3), (1, 1), 1), ("inp 128->256 3x3", 128, 89, 128, 256, (3, 3), (1, 1), 1)]
 ap = argparse.ArgumentParser(); ap.add_argument("--only", default=""); ap.add_argument("--iters", type=int, default=10); ap.add_argument("--warm", type=float, default=0.3)
 a = ap.parse_args()
 dev = torch.device("cuda"); B = 64
 for name, H, W, cin, cout, k, dil, st in SHAPES:
     if a.only and a.only not in name: continue
     zero = os.environ.get('SOS_BENCH_ZERO') == '1'       # all-zero operands: same instruction stream, no toggling (power A/B)
-    x = E.Act(B, H, W, cin, False, dev); x.t.zero_() if zero else x.t.normal_()
+    x = E.Act(B, H, W, E.pad_to(cin, 16), False, dev); x.t.zero_() if zero else x.t.normal_()
     Ho, Wo = (H + st - 1) // st, (W + st - 1) // st
     g = E.Act(B, Ho, Wo, E.pad_to(cout, 16), False, dev); g.t.zero_() if zero else g.t.normal_()
     dw = torch.empty(cout, cin, k[0], k[1], device=dev)
