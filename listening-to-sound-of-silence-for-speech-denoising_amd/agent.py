@@ -318,6 +318,9 @@ class BaseAgent(object):
         self.optimizer.zero_grad(set_to_none=True)
         if self.bucketer is not None:
             self.bucketer.reset()
+        gate = getattr(self, "backward_gate", None)
+        if gate is not None:           # train_concurrent: this model's backward waits for the big model's heavy phase to end
+            torch.cuda.current_stream().wait_event(gate)
         loss.backward()
         if self.bucketer is not None:
             self.bucketer.finalize()
@@ -342,30 +345,45 @@ def train_concurrent(jobs):
     """One training step of several independent agents (the reference trains its two models in two separate
     processes), each on its own HIP stream: [(agent, batch), ...] -> [(outputs, losses), ...].
     Put the big model first.  If its network announces the end of its heavy backward phase (`after_stage2_backward` of
-    denoiser.networks.JointModel), the other agents' streams wait for that point: their steps then run under the big
+    denoiser.networks.JointModel), the other agents' backward + optimizer wait for that point: they then run under the big
     model's U-Net backward and optimizer -- many medium-sized, partly HBM-bound kernels that leave room -- instead of
     time-sharing the chip with its chip-filling 96-channel convolutions (which made every such kernel ~8 % longer and
-    gave nothing back: 485 vs 477 utt/s fully overlapped vs back to back).  SOS_STREAM_OVERLAP=full
+    gave nothing back: 485 vs 477 utt/s fully overlapped vs back to back).  If it also announces the
+    start of its BiLSTM (`before_lstm_forward`), the other agents' FORWARD starts there: the recurrence (8 workgroups
+    stepping through T frames), the FC head, the losses and their backward up to the encoders' keep the chip mostly idle
+    for ~4 ms per step (round 3; SOS_STREAM_OVERLAP=gated is the round-2 schedule: whole step behind the backward gate).
+    SOS_STREAM_OVERLAP=full
     restores the unconstrained overlap."""
     cur = torch.cuda.current_stream()
     outs = []
-    gate = None
+    gate = gate_f = None
+    mode = os.environ.get("SOS_STREAM_OVERLAP", "split")
     for k, (ag, data) in enumerate(jobs):
         if getattr(ag, "stream", None) is None:
-            ag.stream = torch.cuda.Stream(device=ag.device)
+            prio = -1 if (k == 0 and os.environ.get("SOS_STREAM_PRIO") == "1") else 0     # A/B: big model on a high-priority stream
+            ag.stream = torch.cuda.Stream(device=ag.device, priority=prio)
         ag.stream.wait_stream(cur)
         net = getattr(ag, "net", None)
-        if k == 0 and len(jobs) > 1 and getattr(net, "ANNOUNCES_STAGE2_BACKWARD", False) and os.environ.get("SOS_STREAM_OVERLAP") != "full":
+        ag.backward_gate = None
+        if k == 0 and len(jobs) > 1 and getattr(net, "ANNOUNCES_STAGE2_BACKWARD", False) and mode != "full":
             gate = torch.cuda.Event()
             net.after_stage2_backward = gate.record          # runs inside backward: records on this agent's stream
+            if mode == "split" and getattr(net, "ANNOUNCES_LSTM_FORWARD", False):
+                gate_f = torch.cuda.Event()
+                net.before_lstm_forward = gate_f.record      # runs inside forward, once the encoders are enqueued
+        elif gate_f is not None:
+            ag.stream.wait_event(gate_f)                     # forward: under the big model's BiLSTM / FC head window
+            ag.backward_gate = gate                          # backward + optimizer: under its U-Net backward
         elif gate is not None:
             ag.stream.wait_event(gate)
         try:
             with torch.cuda.stream(ag.stream):
                 outs.append(ag.train_func(data))
         finally:
+            ag.backward_gate = None
             if k == 0 and gate is not None:
                 net.after_stage2_backward = None
+                net.before_lstm_forward = None
     for ag, _ in jobs:
         cur.wait_stream(ag.stream)
     return outs

@@ -1084,17 +1084,20 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
                         const double kb = use16 ? 0.15 : 0.04, sbf = use16 ? 0.3 : 0.5, fixed = use16 ? 1.5 : 1.0;
                         const double dma = (double)one / 1024.0 * kb;
                         double cost = 0.0;
+                        const int nk = 256 / kpix;
+                        int kh_rel[16], kw_rel[16];                       // first pixel of every k-step, relative to the tile origin
+                        for (int ks = 0; ks < nk; ++ks) {
+                            int c, i, j;
+                            wg_decode(ks * kpix, lth, ltw, kord, c, i, j);
+                            kh_rel[ks] = i * d->dil_h; kw_rel[ks] = c + j * d->dil_w;
+                        }
                         for (int rh = 0; rh < d->dil_h; ++rh)
                             for (int gw = 0; gw < ngw; ++gw)
                                 for (int ti = 0; ti < tiles_h; ++ti)
                                     for (int tj = 0; tj < tiles_w; ++tj) {
                                         const int gh0 = rh + ti * TH * d->dil_h, gw0 = gw * NC + tj * TW * d->dil_w;
                                         int nks = 0;
-                                        for (int ks = 0; ks < 256 / kpix; ++ks) {
-                                            int c, i, j;
-                                            wg_decode(ks * kpix, lth, ltw, kord, c, i, j);
-                                            if (gh0 + i * d->dil_h < d->Hg && gw0 + c + j * d->dil_w < d->Wg) ++nks;
-                                        }
+                                        for (int ks = 0; ks < nk; ++ks) nks += (gh0 + kh_rel[ks] < d->Hg) & (gw0 + kw_rel[ks] < d->Wg);
                                         cost += db ? (nks > dma ? nks : dma) : nks + sbf * dma;
                                     }
                         cost += fixed * ntiles;

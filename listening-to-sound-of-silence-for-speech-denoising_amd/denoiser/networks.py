@@ -312,7 +312,7 @@ class ContextAggNet(nn.Module):
                     fc0=TO.linear_train_plan(self.fc[0], 400, x3), fc2=TO.linear_train_plan(self.fc[2], E.pad_to(600, 16), x3),
                     fc4=TO.linear_train_plan(self.fc[4], E.pad_to(600, 16), x3))
 
-    def forward_train(self, plan, x, n, x3):
+    def forward_train(self, plan, x, n, x3, before_lstm=None):
         dev = x.device
         B, _, F, T = x.shape
         nseg = 3 if x3 else 1
@@ -321,6 +321,8 @@ class ContextAggNet(nn.Module):
         fs = dict(t=feat, row=nseg * nfeat, third=nfeat, H=F, W=T, Wo=T, gather=None, x3=x3)
         tx = TO.encoder_forward_train(plan["enc_x"], E.pack_input(x, x3), dict(fs, c_off=0), x3)
         tn = TO.encoder_forward_train(plan["enc_n"], E.pack_input(n, x3), dict(fs, c_off=8), x3)
+        if before_lstm is not None:    # agent.train_concurrent: the recurrence, the FC head and their backward leave the chip
+            before_lstm()              # mostly idle (8 workgroups stepping through T frames): another model's forward may start
         h, tl = TO.lstm_forward_train(plan["lstm"], (feat, B, 1, T, nfeat, nseg), B, T, x3, dev)
         f0, f2, f4 = plan["fc0"], plan["fc2"], plan["fc4"]
         a0 = E.Act(B, 1, T, E.pad_to(600, 16), x3, dev)
@@ -382,6 +384,7 @@ class JointModel(nn.Module):
     """M2/networks.py:208-217: n_pred = stage1(n, x); out = stage2(x, n_pred); returns both."""
 
     ANNOUNCES_STAGE2_BACKWARD = True     # _backward_scaled calls self.after_stage2_backward() (agent.train_concurrent's gate)
+    ANNOUNCES_LSTM_FORWARD = True        # _forward_train calls self.before_lstm_forward() once both encoders are enqueued
 
     def __init__(self, config):
         super().__init__()
@@ -402,7 +405,7 @@ class JointModel(nn.Module):
         plan = self._tcache.get(self, self._build_train_plan)
         x3 = plan["x3"]
         n_pred, t1 = self.stage1.forward_train(plan["s1"], n, x, x3)
-        out, t2 = self.stage2.forward_train(plan["s2"], x, n_pred, x3)
+        out, t2 = self.stage2.forward_train(plan["s2"], x, n_pred, x3, before_lstm=getattr(self, "before_lstm_forward", None))
         return (n_pred, out), dict(plan=plan, t1=t1, t2=t2, x3=x3, mode=get_precision())
 
     def _backward(self, tape, g_npred, g_out):
