@@ -174,6 +174,19 @@ typedef struct sos_conv_desc {
      * clip.  The contraction index is (range s < in_nseg, dt, channel): weights [kh*kw][cout_pad][in_nseg*t_taps*cin].
      * t_taps <= 1: plain 2-D convolution.  Replaces a materialised time-stacked input (sos_time_stack). */
     int32_t t_frames, t_taps, t_pad;
+    /* optional REFLECTION-PAD FOLD of the output (backward of ReflectionPad2d in DownConvBlock, M2/networks.py:105: the data
+     * gradient of a reflect-padded conv is a full correlation onto the PADDED domain [H+2p][W+2p] whose border cells add to the
+     * interior cell they mirror).  fold_pad = p > 0: output pixel (ho, wo) is cell (hp, wp) = (ho*fold_sy + fold_oy,
+     * wo*fold_sx + fold_ox) of the padded domain (sy = sx = 1, oy = ox = 0 for a stride-1 layer; 2 and the phase for the four
+     * phase convolutions of a stride-2 layer).  Interior cells (p <= hp < p + fold_H, p <= wp < p + fold_W) are written -- with
+     * `accumulate`: added -- straight to `out` as pixel (hp - p, wp - p) of the dense [B][fold_H][fold_W] NHWC tensor that
+     * out_sb / out_sw / out_c_off / out_third describe (out_sh is ignored); border cells are stored to the padded scratch tensor
+     * fold_pad_out, dense [B][fold_H+2p][fold_W+2p][fold_row] with the channels from 0 (thirds fold_third apart), which
+     * sos_reflect_fold_border then adds onto `out`.  Only the border of the scratch tensor is ever touched.  16-bit NHWC outputs
+     * (out_sc == 1) without fused statistics only. */
+    void* fold_pad_out;
+    int32_t fold_pad, fold_H, fold_W, fold_sy, fold_oy, fold_sx, fold_ox, fold_row;
+    int64_t fold_third;
 } sos_conv_desc;
 
 int sos_conv2d_fwd(const sos_conv_desc* desc /* host pointer */, sos_stream_t stream);
@@ -356,6 +369,10 @@ int sos_gather_pack_multi(const sos_pack_entry* entries, int n_entries, const in
  * gradient `padded` ([B][H+2pad][W+2pad]) onto the [B][H][W] interior. */
 int sos_reflect_fold(const sos_view* padded, int H, int W, int pad, const sos_view* out, int accumulate,
                      sos_stream_t stream);
+/* second half of a convolution launched with sos_conv_desc.fold_pad: out += the BORDER cells of `padded` folded onto the
+ * interior cells they mirror (the interior cells were written by the convolution itself).  Touches only the pixels of `out`
+ * within `pad` of an edge and the border of `padded`. */
+int sos_reflect_fold_border(const sos_view* padded, int H, int W, int pad, const sos_view* out, sos_stream_t stream);
 /* copy a channel slice between NHWC grids [B][Hs][Ws] -> [B][Hd][Wd]: overlap copied, rest of dst zeroed
  * (the crop that stands in for F.interpolate(out, skip.size()) at M2/networks.py:199-203, and its backward). */
 int sos_copy_crop(const sos_view* src, int Hs, int Ws, const sos_view* dst, int Hd, int Wd, sos_stream_t stream);

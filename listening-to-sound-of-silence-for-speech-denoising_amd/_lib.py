@@ -34,6 +34,9 @@ class ConvDesc(C.Structure):
         ("stats", C.c_void_p), ("stats_c", C.c_int32),
         ("wl_tab", C.c_void_p), ("wo_tab", C.c_void_p), ("w_gather_stride", C.c_int32),
         ("t_frames", C.c_int32), ("t_taps", C.c_int32), ("t_pad", C.c_int32),
+        ("fold_pad_out", C.c_void_p),
+        ("fold_pad", C.c_int32), ("fold_H", C.c_int32), ("fold_W", C.c_int32), ("fold_sy", C.c_int32), ("fold_oy", C.c_int32),
+        ("fold_sx", C.c_int32), ("fold_ox", C.c_int32), ("fold_row", C.c_int32), ("fold_third", C.c_int64),
     ]
 
 
@@ -57,7 +60,7 @@ class WgradDesc(C.Structure):
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 ADAM_CHUNK = 16384          # SOS_ADAM_CHUNK of include/sos_hip.h
 GUARD_FLOATS = 5            # SOS_GUARD_FLOATS
-EXPECTED_ABI = 4            # sos_abi_version() of the library these argument lists were written for
+EXPECTED_ABI = 5            # sos_abi_version() of the library these argument lists were written for
 
 # name -> argtypes, exactly the prototypes of include/sos_hip.h
 SIGNATURES = {
@@ -91,6 +94,7 @@ SIGNATURES = {
     "sos_pack_grad_f32": [_P, _P, _I, _L, _L, _I, _L, _L, _L, C.POINTER(View), _P, _P],
     "sos_feat_to_nhwc": [C.POINTER(View), _I, _I, _I, _I, _P, _P, C.POINTER(View), _P],
     "sos_reflect_fold": [C.POINTER(View), _I, _I, _I, C.POINTER(View), _I, _P],
+    "sos_reflect_fold_border": [C.POINTER(View), _I, _I, _I, C.POINTER(View), _P],
     "sos_copy_crop": [C.POINTER(View), _I, _I, C.POINTER(View), _I, _I, _P],
     "sos_lstm_bidir_bwd": [_P, _I, _I, _L, _P, _P, _P, _P, _L, _L, _I, _P, _P],
     "sos_mse_loss": [_P, _P, _L, _F, _P, _P, _P, _P],

@@ -647,6 +647,9 @@ extern "C" int sos_feat_to_nhwc(const sos_view* feat, int B, int H, int W, int W
 // Backward of ReflectionPad2d(pad) (DownConvBlock, M2/networks.py:105): the gradient w.r.t. the
 // padded tensor [B][H+2p][W+2p] is folded back, every border cell adding to the interior cell it
 // mirrors.  out (+)= fold(padded).
+// border_only: the interior cell (h + pad, w + pad) has already been written to `out` by the convolution (sos_conv_desc.fold_pad);
+// only pixels with a mirrored border cell are touched, and those cells are ADDED to what is there.
+template <bool BORDER_ONLY>
 __global__ __launch_bounds__(256) void reflect_fold_kernel(View pd, int H, int W, int pad, View out, int accumulate,
                                                            long long total) {
     const int CG = (out.C + 7) / 8;
@@ -664,11 +667,13 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(View pd, int H, int W
         vs[nv++] = w + pad;
         if (w >= 1 && w <= pad) vs[nv++] = pad - w;
         if (w >= W - 1 - pad && w <= W - 2) vs[nv++] = 2 * (W - 1) - w + pad;
+        if (BORDER_ONLY && nu == 1 && nv == 1) continue;
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
         for (int a = 0; a < nu; ++a)
             for (int c = 0; c < nv; ++c) {
+                if (BORDER_ONLY && a == 0 && c == 0) continue;
                 float f[8];
                 load8(pd, (b * Hp + us[a]) * Wp + vs[c], cg * 8, f);
 #pragma unroll
@@ -696,9 +701,24 @@ extern "C" int sos_reflect_fold(const sos_view* padded, int H, int W, int pad, c
         return SOS_EINVAL;
     }
     const long long total = out->npix * ((out->C + 7) / 8);
-    hipLaunchKernelGGL(reflect_fold_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, to_view(padded), H, W,
+    hipLaunchKernelGGL(reflect_fold_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, to_view(padded), H, W,
                        pad, to_view(out), accumulate, total);
     return sos_check_launch("sos_reflect_fold");
+}
+
+extern "C" int sos_reflect_fold_border(const sos_view* padded, int H, int W, int pad, const sos_view* out, sos_stream_t stream) {
+    int rc = check_view(padded, "sos_reflect_fold_border");
+    if (!rc) rc = check_view(out, "sos_reflect_fold_border");
+    if (rc) return rc;
+    if (H < 1 || W < 1 || pad < 1 || pad >= H || pad >= W || out->npix % ((long long)H * W) ||
+        padded->npix != out->npix / ((long long)H * W) * (H + 2 * pad) * (W + 2 * pad) || padded->C < out->C) {
+        sos_set_error("sos_reflect_fold_border: bad geometry");
+        return SOS_EINVAL;
+    }
+    const long long total = out->npix * ((out->C + 7) / 8);
+    hipLaunchKernelGGL(reflect_fold_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, to_view(padded), H, W,
+                       pad, to_view(out), 1, total);
+    return sos_check_launch("sos_reflect_fold_border");
 }
 
 // copy a channel slice between two NHWC pixel grids of different size: the overlap

@@ -68,6 +68,12 @@ struct ConvParams {
     int nblk;               // grid.x
     int lmap;               // lane -> pixel relabelling inside a 32-pixel column tile (0: natural order)
     int dbg;                // SOS_CONV_DBG ablation mask (0 in production)
+    // reflection-pad fold of the output (sos_conv_desc.fold_*): output pixel (ho, wo) is cell (ho*fsy + foy, wo*fsx + fox) of
+    // the padded domain; interior cells go to `out` as pixel (hp - fP, wp - fP) of a dense [B][fH][fW] tensor (pitch sw),
+    // border cells to out2 ([B][fH + 2 fP][fW + 2 fP], pitch frow)
+    void* out2;
+    int fP, fH, fW, fsy, foy, fsx, fox, frow;
+    long long fthird;
 };
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* p) {
@@ -141,7 +147,14 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
         const int cls = m >> (p.logTW + p.logTH);
         const int ho = ho_base + i * p.dh;
         const int wo = wo_base + cls + j * p.dw;
-        otab[m] = (ho < p.Ho && wo < Wo && (cls == 0 || rw0 + cls < p.dw)) ? ho * (int)p.sh + wo * (int)p.sw : -1;
+        const bool ok = ho < p.Ho && wo < Wo && (cls == 0 || rw0 + cls < p.dw);
+        int off = ho * (int)p.sh + wo * (int)p.sw;
+        if (p.fP) {          // reflection-pad fold: interior cells of the padded domain -> `out`; border cells -> out2, coded as -2 - offset
+            const int hp = ho * p.fsy + p.foy, wp = wo * p.fsx + p.fox;
+            const bool inner = hp >= p.fP && hp < p.fP + p.fH && wp >= p.fP && wp < p.fP + p.fW;
+            off = inner ? ((hp - p.fP) * p.fW + (wp - p.fP)) * (int)p.sw : -2 - (hp * (p.fW + 2 * p.fP) + wp) * p.frow;
+        }
+        otab[m] = ok ? off : -1;
     }
     __syncthreads();
     if (p.stats) {
@@ -182,18 +195,20 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
     }
     // ---- cooperative store: consecutive lanes write consecutive 16-byte pieces of a pixel's
     // channel run (and consecutive pixels of a tile row are adjacent in memory when dil_w == 1).
-    bf16_t* op = (bf16_t*)p.out + (long long)b * p.sb + p.c_off + n0;
-    const int ish = (int)p.sh, isw = (int)p.sw, ith = (int)p.third;
+    bf16_t* opm = (bf16_t*)p.out + (long long)b * p.sb + p.c_off + n0;
+    // fold mode: the padded scratch tensor (border cells), channels from 0
+    bf16_t* op2 = p.fP ? (bf16_t*)p.out2 + (long long)b * (p.fH + 2 * p.fP) * (p.fW + 2 * p.fP) * p.frow + n0 : nullptr;
     if (!x3 && !p.accum && ((p.cout_store - n0) & 7) == 0) {          // common case: whole 8-channel pieces, plain store
         const int npiece = min(PPX, (p.cout_store - n0) >> 3);
 #pragma unroll 4
         for (int idx = tid; idx < 256 * PPX; idx += 256) {
             const int m = idx / PPX, q = idx - m * PPX;
             const int off = otab[m];
-            if (q < npiece && off >= 0) {
+            if (q < npiece && off != -1) {
                 // streamed output (read back only after the whole tensor is written): non-temporal store, +0.9 % on inference
                 typedef unsigned u32x4nt __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(*(const u32x4nt*)(ost_hi + m * OROW + q * 16), (u32x4nt*)(op + off + q * 8));
+                bf16_t* dst = off >= 0 ? opm + off : op2 + (-2 - off);
+                __builtin_nontemporal_store(*(const u32x4nt*)(ost_hi + m * OROW + q * 16), (u32x4nt*)(dst + q * 8));
             }
         }
         return;
@@ -203,18 +218,17 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
         const int m = idx / PPX, q = idx - m * PPX;
         const int co = n0 + q * 8;
         if (co >= p.cout_store) continue;
-        const int j = m & (TW - 1);
-        const int i = (m >> p.logTW) & (TH - 1);
-        const int cls = m >> (p.logTW + p.logTH);
-        const int ho = ho_base + i * p.dh;
-        const int wo = wo_base + cls + j * p.dw;
-        if (!(ho < p.Ho && wo < Wo && (cls == 0 || rw0 + cls < p.dw))) continue;
-        const int o = ho * ish + wo * isw + q * 8;
+        const int off = otab[m];
+        if (off == -1) continue;
+        const bool border = off < 0;                  // fold mode: a border cell of the padded scratch tensor (plain store)
+        bf16_t* op = border ? op2 : opm;
+        const int o = (border ? -2 - off : off) + q * 8;
+        const int ith = border ? (int)p.fthird : (int)p.third;
         uint4 hv = *(const uint4*)(ost_hi + m * OROW + q * 16);
         if (co + 8 <= p.cout_store) {
             uint4 lv = make_uint4(0u, 0u, 0u, 0u);
             if (x3) lv = *(const uint4*)(ost_lo + m * OROW + q * 16);
-            if (p.accum) {
+            if (p.accum && !border) {
                 // gradient fan-in: new = old + this, re-split into hi (+ lo)
                 const uint4 oh = *(const uint4*)(op + o);
                 uint4 ol = make_uint4(0u, 0u, 0u, 0u);
@@ -1104,6 +1118,16 @@ static int validate(const sos_conv_desc* d) {
         sos_set_error("sos_conv2d_fwd: one input image exceeds 4 GB");
         return SOS_ENOSPC;
     }
+    if (d->fold_pad < 0 || (d->fold_pad > 0 && (!d->fold_pad_out || d->fold_H < 1 || d->fold_W < 1 || d->fold_sy < 1 || d->fold_sx < 1 ||
+                                               d->fold_oy < 0 || d->fold_ox < 0 || d->fold_row < d->cout_store || d->fold_row % 8 ||
+                                               d->out_dtype == SOS_DT_F32 || d->out_sc != 1 || d->stats || d->wl_tab ||
+                                               (d->Ho - 1) * d->fold_sy + d->fold_oy >= d->fold_H + 2 * d->fold_pad ||
+                                               (d->Wo - 1) * d->fold_sx + d->fold_ox >= d->fold_W + 2 * d->fold_pad ||
+                                               (int64_t)(d->fold_H + 2 * d->fold_pad) * (d->fold_W + 2 * d->fold_pad) * d->fold_row >= 0x7ffffff0ll ||
+                                               (int64_t)d->fold_H * d->fold_W * d->out_sw >= 0x7ffffff0ll))) {
+        sos_set_error("sos_conv2d_fwd: bad reflection-pad fold (16-bit dense NHWC outputs inside the padded domain only)");
+        return SOS_EINVAL;
+    }
     if (d->pad_mode == SOS_PAD_REFLECT && (d->pad_top >= d->H || d->pad_left >= d->Wl)) {
         sos_set_error("sos_conv2d_fwd: reflect pad %d/%d needs a larger input (%dx%d)", d->pad_top, d->pad_left, d->H, d->Wl);
         return SOS_EINVAL;
@@ -1149,6 +1173,8 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     p.stats = d->stats; p.stats_c = d->stats_c;
     p.wl_tab = d->wl_tab; p.wo_tab = d->wo_tab; p.wg_stride = d->w_gather_stride;
     p.act = d->act; p.accum = d->accumulate; p.sb = d->out_sb; p.sh = d->out_sh; p.sw = d->out_sw; p.sc = d->out_sc; p.third = d->out_third;
+    p.out2 = d->fold_pad_out; p.fP = d->fold_pad; p.fH = d->fold_H; p.fW = d->fold_W; p.fsy = d->fold_sy; p.foy = d->fold_oy;
+    p.fsx = d->fold_sx; p.fox = d->fold_ox; p.frow = d->fold_row; p.fthird = d->fold_third;
     // c.ks encodes: k-steps per chunk (% 100), + 100 single slab buffer, + 1000 * n-tiles per workgroup (0: default)
     const int nt = c.ks >= 1000 ? c.ks / 1000 : nt_for(d);
     const int ks_enc = c.ks >= 1000 ? c.ks % 1000 : c.ks;

@@ -330,12 +330,14 @@ def fold_bn(bn, cout_pad):
 def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dtype, sb, sh, sw, sc,
          Ho, Wo, c_off=0, cout_store=None, third=0, stride=1, dil=(1, 1), pad=(0, 0), pad_mode=L.PAD_ZERO,
          slope=None, w_gather=None, out_elem_offset=0, in_dims=None, accumulate=False, stats_c=0, wl_tab=None,
-         wo_tab=None, wg_stride=0, valid_cols=None, temporal=None):
+         wo_tab=None, wg_stride=0, valid_cols=None, temporal=None, fold=None):
     """Fill a sos_conv_desc and enqueue sos_conv2d_fwd.  `src` is an Act (or a (tensor,B,H,W,cs,nseg)
     view described by in_dims).  stats_c > 0: also return the fused BatchNorm partial sums of the first stats_c
     output channels as (partial [2][stats_c][tiles], tiles) for sos_bn_finalize.  temporal = (frames per clip, kt): the
     B images are clips of consecutive frames and the contraction also runs over kt neighbouring frames (Conv3d with
-    temporal stride 1, padding (kt - 1) // 2); `cin` stays the channels of ONE frame."""
+    temporal stride 1, padding (kt - 1) // 2); `cin` stays the channels of ONE frame.  fold = (padded scratch Act, pad, H, W,
+    sy, oy, sx, ox): reflection-pad fold of the output (sos_conv_desc.fold_*): `out` / sb / sw then describe the dense
+    [B][H][W] gradient tensor the interior cells go to."""
     d = L.ConvDesc()
     if in_dims is None:
         t, B, H, W, cs, nseg = src.t, src.B, src.H, src.W, src.cs, src.nseg
@@ -371,8 +373,13 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
         d.t_frames, d.t_taps, d.t_pad = temporal[0], temporal[1], (temporal[1] - 1) // 2
     if wl_tab is not None:                # ragged batch: per-image logical input width / valid output width (sos_hip.h)
         d.wl_tab, d.wo_tab, d.w_gather_stride = wl_tab.data_ptr(), wo_tab.data_ptr(), wg_stride
+    if fold is not None:
+        fa, fp, fH, fW, fsy, foy, fsx, fox = fold
+        d.fold_pad_out, d.fold_pad, d.fold_H, d.fold_W = fa.t.data_ptr(), fp, fH, fW
+        d.fold_sy, d.fold_oy, d.fold_sx, d.fold_ox = fsy, foy, fsx, fox
+        d.fold_row, d.fold_third = fa.nseg * fa.cs, fa.cs
     _load_tune_cache()
-    if AUTOTUNE:
+    if AUTOTUNE and fold is None:          # (a folded launch shares its tiling with the plain data-gradient launch of the same shape)
         key = (B, H, W, d.Wl, cin, d.in_nseg, d.cout_pad, cout, kh, kw, stride, dil, Ho, Wo, out_dtype, sc == 1, pad_mode,
                w_gather is not None, d.t_taps)
         if key not in _tuned and not torch.cuda.is_current_stream_capturing():

@@ -614,27 +614,55 @@ class GradBufs:
         return self.of(act)
 
 
+def reflect_fold_border(padded, H, W, pad, dst, dst_off, C):
+    pv, ov = E.view(padded, 0, C), E.view(dst, dst_off, C)
+    L.check(L.lib().sos_reflect_fold_border(ctypes.byref(pv), H, W, pad, ctypes.byref(ov), L.stream_ptr()), "sos_reflect_fold_border")
+
+
+FOLD_FUSED = os.environ.get("SOS_FOLD_FUSED", "1") != "0"      # A/B: 0 = padded-domain gradient + a full fold pass (rounds 1-2)
+
+
 def _reflect_dgrad(lp, d_raw, src, cin_off, gb, x3):
-    """Data gradient of ReflectionPad2d + (strided / dilated) valid conv: zero-padded full
-    correlation onto the padded domain, then fold the border back (accumulating into grad(src))."""
+    """Data gradient of ReflectionPad2d + (strided / dilated) valid conv: zero-padded full correlation onto the padded
+    domain whose border cells are folded back onto the interior cells they mirror (accumulating into grad(src)).
+    Round 3: the convolution writes the INTERIOR cells straight into grad(src) (sos_conv_desc.fold_*) and only the border
+    cells into a padded scratch tensor, which sos_reflect_fold_border adds on: the fold no longer reads the whole padded
+    gradient and re-writes the whole tensor (3.0 ms of HBM passes per training step at B = 64)."""
     dev = d_raw.t.device
     p, k, d = lp["pad"], lp["k"], lp["dil"]
     H, W = src.H, src.W
     cin_cs = E.pad_to(lp["cin"], 16)
-    dpad = E.Act(src.B, H + 2 * p, W + 2 * p, cin_cs, x3, dev, zero=lp["stride"] != 1)
+    fused = FOLD_FUSED and lp["cin"] % 8 == 0 and p > 0
+    dst = gb.of(src)
+    accumulate = not gb.first_write(src, cin_off, lp["cin"])
+    dpad = E.Act(src.B, H + 2 * p, W + 2 * p, cin_cs, x3, dev, zero=(lp["stride"] != 1 and not fused))
+    drow = dst.nseg * dst.cs
     if lp["stride"] == 1:
         one, zero = ones_zeros(lp["wd"].shape[1], dev)
-        E.conv_to_act(d_raw, 0, d_raw.cs, lp["wd"], k, k, lp["cin"], one, zero, L.ACT_NONE, dpad, cout_store=cin_cs,
-                      dil=(d, d), pad=((k - 1) * d, (k - 1) * d), Ho=dpad.H, Wo=dpad.W)
+        if fused:
+            E.conv(d_raw, 0, d_raw.cs, lp["wd"], k, k, lp["cin"], one, zero, L.ACT_NONE, out=dst.t, out_dtype=dst.dtype_code,
+                   sb=H * W * drow, sh=0, sw=drow, sc=1, c_off=cin_off, cout_store=lp["cin"], third=dst.cs, dil=(d, d),
+                   pad=((k - 1) * d, (k - 1) * d), Ho=dpad.H, Wo=dpad.W, accumulate=accumulate, fold=(dpad, p, H, W, 1, 0, 1, 0))
+        else:
+            E.conv_to_act(d_raw, 0, d_raw.cs, lp["wd"], k, k, lp["cin"], one, zero, L.ACT_NONE, dpad, cout_store=cin_cs,
+                          dil=(d, d), pad=((k - 1) * d, (k - 1) * d), Ho=dpad.H, Wo=dpad.W)
     else:
         row = dpad.nseg * dpad.cs
         for (ph, pw), (w, Mh, Mw) in lp["wd_phases"].items():
             Ho, Wo = (dpad.H - ph + 1) // 2, (dpad.W - pw + 1) // 2
             one, zero = ones_zeros(w.shape[1], dev)
-            E.conv(d_raw, 0, d_raw.cs, w, Mh, Mw, lp["cin"], one, zero, L.ACT_NONE, out=dpad.t, out_dtype=dpad.dtype_code,
-                   sb=dpad.H * dpad.W * row, sh=2 * dpad.W * row, sw=2 * row, sc=1, cout_store=cin_cs, third=dpad.cs,
-                   pad=(Mh - 1, Mw - 1), Ho=Ho, Wo=Wo, out_elem_offset=(ph * dpad.W + pw) * row)
-    reflect_fold(dpad, H, W, p, gb.of(src), cin_off, lp["cin"], accumulate=not gb.first_write(src, cin_off, lp["cin"]))
+            if fused:
+                E.conv(d_raw, 0, d_raw.cs, w, Mh, Mw, lp["cin"], one, zero, L.ACT_NONE, out=dst.t, out_dtype=dst.dtype_code,
+                       sb=H * W * drow, sh=0, sw=drow, sc=1, c_off=cin_off, cout_store=lp["cin"], third=dst.cs,
+                       pad=(Mh - 1, Mw - 1), Ho=Ho, Wo=Wo, accumulate=accumulate, fold=(dpad, p, H, W, 2, ph, 2, pw))
+            else:
+                E.conv(d_raw, 0, d_raw.cs, w, Mh, Mw, lp["cin"], one, zero, L.ACT_NONE, out=dpad.t, out_dtype=dpad.dtype_code,
+                       sb=dpad.H * dpad.W * row, sh=2 * dpad.W * row, sw=2 * row, sc=1, cout_store=cin_cs, third=dpad.cs,
+                       pad=(Mh - 1, Mw - 1), Ho=Ho, Wo=Wo, out_elem_offset=(ph * dpad.W + pw) * row)
+    if fused:
+        reflect_fold_border(dpad, H, W, p, dst, cin_off, lp["cin"])
+    else:
+        reflect_fold(dpad, H, W, p, dst, cin_off, lp["cin"], accumulate=accumulate)
 
 
 _INV_PERM = {}           # (concat permutation, device) -> its inverse as a device index tensor
