@@ -47,6 +47,7 @@ PROFILER = None
 # regenerates the shipped file.
 import os as _os
 import threading as _threading
+FLATTEN_1X1 = _os.environ.get("SOS_FLATTEN_1X1", "1") != "0"      # A/B switch of the batch-flattened 1x1 layers (conv())
 AUTOTUNE = _os.environ.get("SOS_CONV_TUNE", "0") == "1"
 TUNE_CANDIDATES = int(_os.environ.get("SOS_CONV_TUNE_CANDIDATES", "8"))     # best-ranked tilings of the cost model that get timed
 SHIPPED_TUNE_TABLE = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tune_table_gfx950.txt")
@@ -343,6 +344,13 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
         t, B, H, W, cs, nseg = src.t, src.B, src.H, src.W, src.cs, src.nseg
     else:
         t, B, H, W, cs, nseg = in_dims
+    # 1x1 layers over single-row images (Linear layers, LSTM input projections: H = 1, W = T frames): the batch is one long
+    # row -- full 256-pixel tiles instead of one ragged tile per clip (T = 178: 70 % of a tile, the detector's T = 60: 23 %)
+    Bp, Wop = B, Wo                       # (the profiler's signature keeps the layer's own dimensions)
+    if (FLATTEN_1X1 and kh == 1 and kw == 1 and stride == 1 and pad == (0, 0) and H == 1 and Ho == 1 and Wo == W and B > 1
+            and w_gather is None and wl_tab is None and temporal is None and fold is None and not stats_c and sb == Wo * sw
+            and B * W * nseg * cs * 2 < 0xfff00000):
+        B, W, Wo = 1, B * W, B * Wo
     d.in_ = t.data_ptr()
     d.B, d.H, d.W = B, H, W
     d.in_cs = nseg * cs
@@ -398,9 +406,9 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
     end = None
     if PROFILER is not None:
         # ragged batches: only the clips' own columns are algorithmic work (valid_cols = their sum)
-        cols = B * Wo if valid_cols is None else valid_cols
+        cols = Bp * Wop if valid_cols is None else valid_cols
         kin = d.in_nseg * max(1, d.t_taps) * cin
-        sig = ("conv", kh, kw, dil[0], dil[1], stride, kin, cout, B, Ho, Wo) + (() if valid_cols is None else ("ragged", cols))
+        sig = ("conv", kh, kw, dil[0], dil[1], stride, kin, cout, Bp, Ho, Wop) + (() if valid_cols is None else ("ragged", cols))
         end = PROFILER.bracket(sig, 2.0 * Ho * cols * cout * kin * kh * kw)
     stats = None
     if stats_c:
