@@ -675,8 +675,16 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
 // These per-lane offsets are window invariant.  One barrier per TWO taps; an odd last tap gets a zero slab.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NT16, int KS, bool SB>
-__global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {     // 2 (3: single slab buffer) workgroups per CU
+// MODE 0: two window-slab buffers, the next window's DMA issued at the start of a window (lands in ~600 cycles of MFMAs or
+// is waited for); 1: ONE buffer refilled behind a barrier (three workgroups per CU cover each other's refill latency);
+// 2 (round 3, an A/B switch only: SOS_CONV16_MODE=2): a RING OF THREE buffers, the DMA of window w + 2 issued at the start of
+// window w, counted vmcnt waits, one barrier per window, two workgroups per CU (66 KB).  Written on the hypothesis that the
+// per-window refill wait is what holds mode 1 at 52 % MFMA-pipe busy; MEASURED SLOWER (48 -> 48 5x5 at B = 64: 0.410 ms
+// against 0.348 ms in mode 1 and 0.395 ms in mode 0; the ISA shows no wait inside the window): what the kernel needs is the
+// third resident workgroup, i.e. more waves to cover the fragment reads' LDS latency (7 ds_read_b128 per 12 MFMAs keep the
+// LDS pipe ~55 % busy), not a hidden refill.
+template <int NT16, int KS, int MODE>
+__global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvParams p) {
 #if __HIP_DEVICE_COMPILE__
     constexpr int KC = 16 * KS, G8 = 2 * KS;     // channels / 8-channel groups per tap
     // unpadded row pitches: lanes 16..31 of a fragment read address the SAME 16 rows as lanes 0..15, 16 bytes further
@@ -688,12 +696,15 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
     constexpr int TPIECES = ROWS * CPR, WPIECES = 2 * TPIECES;
     // the double-buffered variant fills the window slab by LDS-DMA (whole 1 KB instructions; the slab image is piece-linear)
     constexpr int WINSTR = (WPIECES + 63) / 64, WPW = (WINSTR + 3) / 4;
+    constexpr bool SB = MODE == 1;
+    constexpr int NBUF = MODE == 1 ? 1 : (MODE == 2 ? 3 : 2);
+    static_assert(MODE != 2 || WPW <= 3, "ring mode: the counted vmcnt waits cover at most three DMA instructions per wave and window");
     constexpr int WBYTES = SB ? 2 * TAPBYTES : WINSTR * 1024;
     constexpr int OROW = NT16 * 32 + 16;          // bytes per staged output pixel row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
     const int boff0 = p.npix * PSTRIDE;
-    unsigned* pixtab = (unsigned*)(smem + boff0 + (SB ? 1 : 2) * WBYTES);
+    unsigned* pixtab = (unsigned*)(smem + boff0 + NBUF * WBYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
 
@@ -785,12 +796,16 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
     if (!CDBG(1)) stage_patch_dma<CPR, false>(p, patch, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc,
                                 (unsigned)((p.cin_off + sg * p.seg_stride) * 2));
     if (!CDBG(8)) dma_window(0, 0);
+    if constexpr (MODE == 2) { if (nwin > 1 && !CDBG(8)) dma_window(1, 1); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's patch pieces have landed
     __syncthreads();
 
+    int ring = 0;                                         // MODE 2: buffer of window w (w mod 3 without the division)
     for (int w = 0; w < nwin; ++w) {
-        const int cur = SB ? 0 : (w & 1);
-        if constexpr (!SB) { if (w + 1 < nwin && !CDBG(8)) dma_window(w + 1, cur ^ 1); }       // next window's slab (lands while the MFMAs run)
+        const int cur = MODE == 2 ? ring : (SB ? 0 : (w & 1));
+        if constexpr (MODE == 0) { if (w + 1 < nwin && !CDBG(8)) dma_window(w + 1, cur ^ 1); }       // next window's slab (lands while the MFMAs run)
+        // ring: window w + 2 into the buffer window w - 1 was read from (every wave has passed the barrier that closed it)
+        if constexpr (MODE == 2) { if (w + 2 < nwin && !CDBG(8)) dma_window(w + 2, ring == 0 ? 2 : ring - 1); }
         __builtin_amdgcn_sched_barrier(0);
         const int t0 = 2 * w, t1 = min(2 * w + 1, ntaps - 1);
         const int toff0 = ((t0 / p.kw) * p.PW + (t0 % p.kw)) * PSTRIDE;
@@ -823,7 +838,18 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void conv16_kernel(ConvParams p) {
             __syncthreads();
             if (w + 1 < nwin && !CDBG(8)) dma_window(w + 1, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (MODE == 2) {
+            // window w + 1 must have landed; this wave's pieces of window w + 2 (issued above: instructions wv, wv + 4, ...
+            // of WINSTR) may stay in flight
+            const int mine = (w + 2 < nwin && !CDBG(8)) ? (WINSTR - wv + 3) / 4 : 0;
+            if (mine >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (mine == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (mine == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ring = ring == 2 ? 0 : ring + 1;
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
     }
     }
@@ -940,10 +966,10 @@ static int nt16_for(const sos_conv_desc* d) {
     if (d->cout > 32 && d->cout <= 48) return 3;
     return 0;
 }
-static size_t lds_bytes16(int npix, int nt16, int ks, bool single) {
+static size_t lds_bytes16(int npix, int nt16, int ks, int mode) {     // mode 0: two slab buffers, 1: one, 2: ring of three
     const size_t row = (size_t)ks * 32;            // unpadded pitches
-    const size_t slab = single ? (size_t)2 * nt16 * 16 * row : ((size_t)2 * nt16 * 16 * 2 * ks + 63) / 64 * 1024;   // WBYTES
-    return (size_t)npix * row + (single ? 1 : 2) * slab + (size_t)npix * 4;
+    const size_t slab = mode == 1 ? (size_t)2 * nt16 * 16 * row : ((size_t)2 * nt16 * 16 * 2 * ks + 63) / 64 * 1024;   // WBYTES
+    return (size_t)npix * row + (mode == 1 ? 1 : (mode == 2 ? 3 : 2)) * slab + (size_t)npix * 4;
 }
 
 // One tiling choice: NC residue classes x (1<<lth) x (1<<ltw) pixels, 16*ks channels per chunk (ks == 0: the
@@ -981,13 +1007,14 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
             const long long th = (Hc + TH - 1) / TH, tw = (Wc + TW - 1) / TW, ngw = (d->dil_w + NC - 1) / NC;
             const double blocks = (double)th * tw * ngw * d->dil_h;
             if (const int nt16 = nt16_for(d)) {               // 16-row kernel on the same pixel tiling (ks 0: double, -1: single slab)
-                for (int single = 0; single < 2; ++single) {
-                    const size_t lds = lds_bytes16(npix, nt16, k16, single);
+                // (the ring-of-three schedule, mode 2, is never a candidate: measured slower, see conv16_kernel; SOS_CONV16_MODE=2 forces it)
+                for (int mode = 0; mode < 2; ++mode) {
+                    const size_t lds = lds_bytes16(npix, nt16, k16, mode);
                     if (lds > LDS_LIMIT) continue;
                     double per_block = 0.75 * nseg_eff(d) * (256.0 * taps * k16 + 3.0 * npix * k16 + 40.0 * (6 + taps / 2));
                     if (lds > LDS_LIMIT / 2) per_block *= 1.3;
                     else if (lds <= LDS_LIMIT / 3) per_block *= 0.95;
-                    out.push_back({NC, lth, ltw, single ? -1 : 0, blocks * per_block});
+                    out.push_back({NC, lth, ltw, -mode, blocks * per_block});
                 }
             }
             for (int ks : kscand) {
@@ -1199,24 +1226,27 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
         static const char* nomap = getenv("SOS_CONV_NO_LANE_MAP");          // A/B switch
         if (!nomap) p.lmap = pick_lane_map(p, (ks_enc % 100) * 32 + 16);
     }
-    if (c.ks <= 0) {                                     // 16-row kernel (ks 0: double-buffered slab, -1: single)
-        const bool single = c.ks < 0;
+    if (c.ks <= 0) {                                     // 16-row kernel (ks 0: double-buffered slab, -1: single, -2: ring of three)
+        int mode = -c.ks;
+        { static const char* e = getenv("SOS_CONV16_MODE"); if (e) mode = atoi(e); }      // A/B: force a slab mode
         const int nt16 = nt16_for(d), ks16 = d->cin / 16;
         if (!nt16) { sos_set_error("sos_conv2d_fwd: internal: 16-row tiling for an ineligible shape"); return SOS_EINVAL; }
         p.cps = 1; p.nchunks = nseg_eff(d);              // channel segments (3 in the hi|hi|lo mode), whole cin per segment
-        size_t lds16 = lds_bytes16(p.npix, nt16, ks16, single);
+        if (mode < 0 || mode > 2 || lds_bytes16(p.npix, nt16, ks16, mode) > LDS_LIMIT) mode = -c.ks;
+        size_t lds16 = lds_bytes16(p.npix, nt16, ks16, mode);
         const size_t stage16 = (size_t)256 * (nt16 * 32 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + 1024 + (d->stats ? 16384 : 0);
         if (stage16 > lds16) lds16 = stage16;
         conv_kernel_t k = nullptr;
 #define SOS_C16(NTV, KSV)                                                                        \
-        if (nt16 == NTV && ks16 == KSV) k = single ? conv16_kernel<NTV, KSV, true> : conv16_kernel<NTV, KSV, false>;
+        if (nt16 == NTV && ks16 == KSV) k = mode == 1 ? conv16_kernel<NTV, KSV, 1> : (mode == 2 ? conv16_kernel<NTV, KSV, 2> : conv16_kernel<NTV, KSV, 0>);
         SOS_C16(1, 1) SOS_C16(1, 3) SOS_C16(3, 1) SOS_C16(3, 3)
 #undef SOS_C16
         static sos_device_once attr16;
         (void)sos_per_device_once(attr16, [] {
 #define SOS_C16A(NTV, KSV)                                                                                                        \
-            (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);  \
-            (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+            (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);  \
+            (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);  \
+            (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
             SOS_C16A(1, 1) SOS_C16A(1, 3) SOS_C16A(3, 1) SOS_C16A(3, 3)
 #undef SOS_C16A
             return (int)SOS_OK;

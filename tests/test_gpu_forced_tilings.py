@@ -22,3 +22,15 @@ def test_network_parity_with_forced_candidate(k):
                         os.path.join(ROOT, "tests", "test_gpu_train_nets.py"), "-k", "not train_step"], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_network_parity_with_forced_16_row_slab_mode(mode):
+    """The 16-row conv kernel's three weight-slab schedules (two buffers, one buffer refilled behind a barrier, ring of three
+    with the DMA two windows ahead) are performance choices: the network parity tests pass with each forced for every
+    16-row launch (SOS_CONV16_MODE; a mode whose buffers do not fit falls back to the tiling's own)."""
+    env = dict(os.environ, SOS_CONV16_MODE=str(mode))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_nets.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_train_nets.py"), "-k", "not train_step"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
