@@ -61,7 +61,7 @@ struct ConvParams {
     int wg_stride;
     long long sb, sh, sw, sc, third;
     // tiling
-    int NC, logTH, logTW, PH, PW;
+    int NC, TH, TW, PH, PW;  // pixel tile: NC residue classes x TH x TW strided pixels (<= 256 slots; any integers since round 3)
     int nchunks;            // cin / (16*KS)
     int npix;               // NC*PH*PW
     int tiles_h, tiles_w, ngw;
@@ -75,6 +75,16 @@ struct ConvParams {
     int fP, fH, fW, fsy, foy, fsx, fox, frow;
     long long fthird;
 };
+
+// pixel slot m (0..255) of a tile -> (residue class, row, column); slots with cls >= NC are dead (tiles of NC x TH x TW < 256
+// pixels: dilation 32 leaves 8 x 5.6 strided pixels per class -- 5 classes x 8 x 6 = 240 slots instead of 4 x 8 x 8 with a
+// quarter of every MFMA column tile on padding).  Per-tile work only: the divisions never reach a tap loop.
+__host__ __device__ __forceinline__ void tile_decode(int m, int TH, int TW, int& cls, int& i, int& j) {
+    const int r = m / TW;
+    j = m - r * TW;
+    cls = r / TH;
+    i = r - cls * TH;
+}
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* p) {
     return __builtin_bit_cast(bf16x8, *(const uint4*)p);
@@ -135,19 +145,17 @@ template <int PPX, int OROW>
 __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* smem, const int tid, const int b, const int n0,
                                                   const int ho_base, const int wo_base, const int rw0, const bool x3,
                                                   const int Wo) {
-    const int TH = 1 << p.logTH, TW = 1 << p.logTW;
     char* ost_hi = smem;
     char* ost_lo = smem + 256 * OROW;
     // element offset of every tile pixel inside its output image (-1: outside), one entry per thread
     int* otab = (int*)(smem + 256 * OROW * (x3 ? 2 : 1));
     {
         const int m = tid;
-        const int j = m & (TW - 1);
-        const int i = (m >> p.logTW) & (TH - 1);
-        const int cls = m >> (p.logTW + p.logTH);
+        int cls, i, j;
+        tile_decode(m, p.TH, p.TW, cls, i, j);
         const int ho = ho_base + i * p.dh;
         const int wo = wo_base + cls + j * p.dw;
-        const bool ok = ho < p.Ho && wo < Wo && (cls == 0 || rw0 + cls < p.dw);
+        const bool ok = cls < p.NC && ho < p.Ho && wo < Wo && (cls == 0 || rw0 + cls < p.dw);
         int off = ho * (int)p.sh + wo * (int)p.sw;
         if (p.fP) {          // reflection-pad fold: interior cells of the padded domain -> `out`; border cells -> out2, coded as -2 - offset
             const int hp = ho * p.fsy + p.foy, wp = wo * p.fsx + p.fox;
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
     const int b = t;
     const int n0 = blockIdx.y * BROWS;
 
-    const int TH = 1 << p.logTH, TW = 1 << p.logTW;
+    const int TH = p.TH, TW = p.TW;
     const int rw0 = gw * p.NC;
     // first output row/col (class 0 of the group) of this tile, and the input coordinate of patch (0,0)
     const int ho_base = rh + ti * TH * p.dh;
@@ -338,9 +346,9 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = wave * 64 + mt * 32 + lpix;
-        const int j = m & (TW - 1);
-        const int i = (m >> p.logTW) & (TH - 1);
-        const int cls = m >> (p.logTW + p.logTH);
+        int cls, i, j;
+        tile_decode(m, TH, TW, cls, i, j);
+        if (cls >= p.NC) cls = i = j = 0;          // dead slot: reads a valid patch pixel, its column is never stored
         abase[mt] = ((cls * p.PH + i * p.stride) * p.PW + j * p.stride) * PSTRIDE + lhi * 16;
     }
     const int bfrag_off = l31 * BSTRIDE + lhi * 16;
@@ -532,13 +540,12 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = wave * 64 + mt * 32 + lpix;
-        const int j = m & (TW - 1);
-        const int i = (m >> p.logTW) & (TH - 1);
-        const int cls = m >> (p.logTW + p.logTH);
+        int cls, i, j;
+        tile_decode(m, TH, TW, cls, i, j);
         const int ho = ho_base + i * p.dh;
         const int wo = wo_base + cls + j * p.dw;
         mrow[mt] = m * OROW;
-        pix_ok[mt] = ho < p.Ho && wo < Wo && (cls == 0 || rw0 + cls < p.dw);
+        pix_ok[mt] = cls < p.NC && ho < p.Ho && wo < Wo && (cls == 0 || rw0 + cls < p.dw);
         obase[mt] = (long long)b * p.sb + (long long)ho * p.sh + (long long)wo * p.sw;
     }
     // Common case (bf16 NHWC output, ReLU / PReLU / linear): the activation is the branch-free
@@ -720,7 +727,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
     const int ti = t % p.tiles_h; t /= p.tiles_h;
     const int rh = t % p.dh; t /= p.dh;
     const int b = t;
-    const int TH = 1 << p.logTH, TW = 1 << p.logTW;
+    const int TH = p.TH, TW = p.TW;
     const int rw0 = gw * p.NC;
     const int ho_base = rh + ti * TH * p.dh, wo_base = rw0 + tj * TW * p.dw;
     const int hin0 = ho_base * p.stride - p.pad_t, win0 = wo_base * p.stride - p.pad_l;
@@ -736,7 +743,9 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
         const int m = wave * 64 + pt * 16 + l15;
-        const int j = m & (TW - 1), i = (m >> p.logTW) & (TH - 1), cls = m >> (p.logTW + p.logTH);
+        int cls, i, j;
+        tile_decode(m, TH, TW, cls, i, j);
+        if (cls >= p.NC) cls = i = j = 0;          // dead slot (see conv_mfma_kernel)
         pbase[pt] = ((cls * p.PH + i * p.stride) * p.PW + j * p.stride) * PSTRIDE;
     }
     // per-lane, window-invariant fragment offsets of the BW K-blocks
@@ -975,9 +984,16 @@ static size_t lds_bytes16(int npix, int nt16, int ks, int mode) {     // mode 0:
 // One tiling choice: NC residue classes x (1<<lth) x (1<<ltw) pixels, 16*ks channels per chunk (ks == 0: the
 // 16-row kernel, whole cin in one chunk).
 struct ConvCfg {
-    int NC, lth, ltw, ks;
+    int NC, lth, ltw, ks;     // lth / ltw < 16: log2 of the tile height / width; >= 16: the (non-power-of-two) size + 16 (tdim())
     double cost;
 };
+
+static inline int tdim(int l) { return l < 16 ? 1 << l : l - 16; }      // tile size of an encoded ConvCfg.lth / ltw
+static inline int tenc(int v) {                                           // and back (powers of two keep their log2)
+    for (int l = 0; l < 16; ++l)
+        if ((1 << l) == v) return l;
+    return v + 16;
+}
 
 static int nt_for(const sos_conv_desc* d) {
     // output-channel tiles per block: as many as fit (<= 4), balanced over the n-blocks
@@ -996,48 +1012,71 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
     const int taps = d->kh * d->kw;
     static const int kscand[] = {8, 6, 5, 4, 3, 2, 1};
     const int k16 = d->cin / 16;
+    auto add_tile = [&](const int NC, const int TH, const int TW) {
+        const int PH = (TH - 1) * d->stride + d->kh, PW = (TW - 1) * d->stride + d->kw;
+        const int npix = NC * PH * PW;
+        const long long th = (Hc + TH - 1) / TH, tw = (Wc + TW - 1) / TW, ngw = (d->dil_w + NC - 1) / NC;
+        const double blocks = (double)th * tw * ngw * d->dil_h;
+        if (const int nt16 = nt16_for(d)) {               // 16-row kernel on the same pixel tiling (ks 0: double, -1: single slab)
+            // (the ring-of-three schedule, mode 2, is never a candidate: measured slower, see conv16_kernel; SOS_CONV16_MODE=2 forces it)
+            for (int mode = 0; mode < 2; ++mode) {
+                const size_t lds = lds_bytes16(npix, nt16, k16, mode);
+                if (lds > LDS_LIMIT) continue;
+                double per_block = 0.75 * nseg_eff(d) * (256.0 * taps * k16 + 3.0 * npix * k16 + 40.0 * (6 + taps / 2));
+                if (lds > LDS_LIMIT / 2) per_block *= 1.3;
+                else if (lds <= LDS_LIMIT / 3) per_block *= 0.95;
+                out.push_back({NC, tenc(TH), tenc(TW), -mode, blocks * per_block});
+            }
+        }
+        for (int ks : kscand) {
+            if (k16 % ks) continue;
+            const size_t lds = lds_bytes(npix, nt, ks);
+            if (lds > LDS_LIMIT) continue;
+            const int nchunks = nseg_eff(d) * k16 / ks;
+            double per_block = 256.0 * taps * nchunks * ks + 3.0 * npix * nchunks * ks + 40.0 * nchunks * (6 + taps);
+            if (lds > LDS_LIMIT / 2) per_block *= 1.3;     // a lone workgroup per CU hides nothing
+            out.push_back({NC, tenc(TH), tenc(TW), ks, blocks * per_block});
+            // single slab buffer: worth it only when it lets a third workgroup into the CU
+            const size_t lds1 = lds_bytes(npix, nt, ks + 100);
+            // (three n-tiles: the instance sits at the 168-register limit of three waves per SIMD -- ks >= 3 spills, 65-342 registers:
+            // 11 ms instead of 1.5 on the 96 -> 96 layer; never a candidate)
+            if ((nt <= 2 ? ks <= 4 : (nt == 3 && ks <= 2)) && lds1 <= LDS_LIMIT / 3 && lds > LDS_LIMIT / 3)
+                out.push_back({NC, tenc(TH), tenc(TW), ks + 100, blocks * per_block * 0.93});
+            // 128 output channels per workgroup need ~400 registers and > 80 KB of LDS (one workgroup per CU): two
+            // n-blocks of 64 stage the patch twice but fit two or three workgroups (ks + 2000)
+            if (nt == 4) {
+                const size_t lds2 = lds_bytes(npix, 2, ks);
+                if (lds2 <= LDS_LIMIT / 2)
+                    out.push_back({NC, tenc(TH), tenc(TW), ks + 2000, blocks * 2.0 * (128.0 * taps * nchunks * ks + 3.0 * npix * nchunks * ks + 40.0 * nchunks * (6 + taps)) * 0.9});
+            }
+        }
+    };
     for (int lnc = 0; lnc <= 8; ++lnc) {
         const int NC = 1 << lnc;
         if (NC > 1 && (d->stride > 1 || NC > d->dil_w)) break;
-        for (int lth = 0; lth + lnc <= 8; ++lth) {
-            const int ltw = 8 - lnc - lth;
-            const int TH = 1 << lth, TW = 1 << ltw;
-            const int PH = (TH - 1) * d->stride + d->kh, PW = (TW - 1) * d->stride + d->kw;
-            const int npix = NC * PH * PW;
-            const long long th = (Hc + TH - 1) / TH, tw = (Wc + TW - 1) / TW, ngw = (d->dil_w + NC - 1) / NC;
-            const double blocks = (double)th * tw * ngw * d->dil_h;
-            if (const int nt16 = nt16_for(d)) {               // 16-row kernel on the same pixel tiling (ks 0: double, -1: single slab)
-                // (the ring-of-three schedule, mode 2, is never a candidate: measured slower, see conv16_kernel; SOS_CONV16_MODE=2 forces it)
-                for (int mode = 0; mode < 2; ++mode) {
-                    const size_t lds = lds_bytes16(npix, nt16, k16, mode);
-                    if (lds > LDS_LIMIT) continue;
-                    double per_block = 0.75 * nseg_eff(d) * (256.0 * taps * k16 + 3.0 * npix * k16 + 40.0 * (6 + taps / 2));
-                    if (lds > LDS_LIMIT / 2) per_block *= 1.3;
-                    else if (lds <= LDS_LIMIT / 3) per_block *= 0.95;
-                    out.push_back({NC, lth, ltw, -mode, blocks * per_block});
-                }
+        for (int lth = 0; lth + lnc <= 8; ++lth) add_tile(NC, 1 << lth, 1 << (8 - lnc - lth));
+    }
+    // Non-power-of-two tiles (round 3) for images whose strided extent per residue class is small: dilation 32 leaves 8 x 5.6
+    // strided pixels per class, the U-Net's padded-domain gradients at dilation 16 6 x 4.8 -- 8-wide power-of-two tiles put a
+    // quarter to a half of every MFMA column tile on padding.  Candidates: the strided height / width cut into 1..3 equal
+    // parts, as many whole residue classes as fit 256 slots.  SOS_CONV_NPOT=0 removes them (A/B).
+    static const char* npot_env = getenv("SOS_CONV_NPOT");
+    if (!(npot_env && atoi(npot_env) == 0) && d->stride == 1 && (Hc <= 48 || Wc <= 48)) {
+        for (int ph = 1; ph <= 3; ++ph)
+            for (int pw = 1; pw <= 3; ++pw) {
+                const int TH = (Hc + ph - 1) / ph, TW = (Wc + pw - 1) / pw;
+                if (TH < 1 || TW < 2 || TH * TW > 256 || TH > 64 || TW > 64) continue;
+                int NC = 256 / (TH * TW);
+                if (NC > d->dil_w) NC = d->dil_w;
+                if (NC < 1) continue;
+                // fewer classes when the last group of a row of classes would be mostly empty
+                const int ngw = (d->dil_w + NC - 1) / NC;
+                NC = (d->dil_w + ngw - 1) / ngw;
+                const bool pow2 = (TH & (TH - 1)) == 0 && (TW & (TW - 1)) == 0 && (NC & (NC - 1)) == 0 && NC * TH * TW == 256;
+                if (pow2) continue;                       // already in the list above
+                if (NC * TH * TW < 160) continue;         // no better than a power-of-two tile with padding
+                add_tile(NC, TH, TW);
             }
-            for (int ks : kscand) {
-                if (k16 % ks) continue;
-                const size_t lds = lds_bytes(npix, nt, ks);
-                if (lds > LDS_LIMIT) continue;
-                const int nchunks = nseg_eff(d) * k16 / ks;
-                double per_block = 256.0 * taps * nchunks * ks + 3.0 * npix * nchunks * ks + 40.0 * nchunks * (6 + taps);
-                if (lds > LDS_LIMIT / 2) per_block *= 1.3;     // a lone workgroup per CU hides nothing
-                out.push_back({NC, lth, ltw, ks, blocks * per_block});
-                // single slab buffer: worth it only when it lets a third workgroup into the CU
-                const size_t lds1 = lds_bytes(npix, nt, ks + 100);
-                if (nt <= 3 && ks <= 4 && lds1 <= LDS_LIMIT / 3 && lds > LDS_LIMIT / 3)
-                    out.push_back({NC, lth, ltw, ks + 100, blocks * per_block * 0.93});
-                // 128 output channels per workgroup need ~400 registers and > 80 KB of LDS (one workgroup per CU): two
-                // n-blocks of 64 stage the patch twice but fit two or three workgroups (ks + 2000)
-                if (nt == 4) {
-                    const size_t lds2 = lds_bytes(npix, 2, ks);
-                    if (lds2 <= LDS_LIMIT / 2)
-                        out.push_back({NC, lth, ltw, ks + 2000, blocks * 2.0 * (128.0 * taps * nchunks * ks + 3.0 * npix * nchunks * ks + 40.0 * nchunks * (6 + taps)) * 0.9});
-                }
-            }
-        }
     }
     std::sort(out.begin(), out.end(), [](const ConvCfg& a, const ConvCfg& b) { return a.cost < b.cost; });
     return out;
@@ -1168,7 +1207,7 @@ static int validate(const sos_conv_desc* d) {
 static int pick_lane_map(const ConvParams& p, int pstride) {
     static const int grp[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
                                    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
-    const int TW = 1 << p.logTW, TH = 1 << p.logTH;
+    const int TW = p.TW, TH = p.TH;
     int best = 0, best_cost = 1 << 30;
     for (int mode = 0; mode < 3; ++mode) {
         if (mode == 2 && TW != 8) continue;
@@ -1178,7 +1217,9 @@ static int pick_lane_map(const ConvParams& p, int pstride) {
             for (int k = 0; k < 16; ++k) {
                 const int l = grp[g][k];
                 const int lp = mode == 0 ? l : (mode == 1 ? g * 16 + k : (g + 2 * (k >> 3)) * 8 + (k & 7));
-                const int j = lp & (TW - 1), i = (lp >> p.logTW) & (TH - 1), cls = lp >> (p.logTW + p.logTH);
+                int cls, i, j;
+                tile_decode(lp, TH, TW, cls, i, j);
+                if (cls >= p.NC) cls = i = j = 0;
                 const int off = ((cls * p.PH + i * p.stride) * p.PW + j * p.stride) * pstride;
                 worst = std::max(worst, ++cnt[(off >> 4) & 15]);
             }
@@ -1207,8 +1248,9 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     const int ks_enc = c.ks >= 1000 ? c.ks % 1000 : c.ks;
     const int nby = (d->cout_pad / 32 + nt - 1) / nt;
     const int Hc = (d->Ho + d->dil_h - 1) / d->dil_h, Wc = (d->Wo + d->dil_w - 1) / d->dil_w;
-    p.NC = c.NC; p.logTH = c.lth; p.logTW = c.ltw;
-    const int TH = 1 << c.lth, TW = 1 << c.ltw;
+    const int TH = tdim(c.lth), TW = tdim(c.ltw);
+    p.NC = c.NC; p.TH = TH; p.TW = TW;
+    if (c.NC < 1 || TH < 1 || TW < 1 || c.NC * TH * TW > 256) { sos_set_error("sos_conv2d_fwd: internal: tile %d x %d x %d", c.NC, TH, TW); return SOS_EINVAL; }
     p.PH = (TH - 1) * d->stride + d->kh; p.PW = (TW - 1) * d->stride + d->kw;
     p.npix = p.NC * p.PH * p.PW;
     p.cps = c.ks > 0 ? d->cin / (16 * (ks_enc % 100)) : 1;
@@ -1273,7 +1315,7 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
 
 static long long tiles_of(const sos_conv_desc* d, const ConvCfg& c) {
     const int Hc = (d->Ho + d->dil_h - 1) / d->dil_h, Wc = (d->Wo + d->dil_w - 1) / d->dil_w;
-    const int TH = 1 << c.lth, TW = 1 << c.ltw;
+    const int TH = tdim(c.lth), TW = tdim(c.ltw);
     return (long long)d->B * d->dil_h * ((Hc + TH - 1) / TH) * ((d->dil_w + c.NC - 1) / c.NC) * ((Wc + TW - 1) / TW);
 }
 
@@ -1307,8 +1349,8 @@ extern "C" int sos_conv2d_fwd(const sos_conv_desc* d, sos_stream_t stream) {
     }
     const size_t pick = force ? (size_t)atol(force) % cfgs.size() : 0;
     if (getenv("SOS_CONV_LIST"))      // debugging aid: the chosen candidate of the cost-ordered list
-        fprintf(stderr, "sos_conv2d_fwd: cfg %zu/%zu NC=%d TH=%d TW=%d ks=%d\n", pick, cfgs.size(), cfgs[pick].NC, 1 << cfgs[pick].lth,
-                1 << cfgs[pick].ltw, cfgs[pick].ks);
+        fprintf(stderr, "sos_conv2d_fwd: cfg %zu/%zu NC=%d TH=%d TW=%d ks=%d\n", pick, cfgs.size(), cfgs[pick].NC, tdim(cfgs[pick].lth),
+                tdim(cfgs[pick].ltw), cfgs[pick].ks);
     return launch_cfg(d, cfgs[pick], (hipStream_t)stream);
 }
 

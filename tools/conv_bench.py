@@ -35,6 +35,8 @@ SHAPES = [
     ("dgrad up1.0 128->256 3x3", 128, 89, 128, 256, (3, 3), (1, 1), 1, "dgrad"),
     ("dgrad down2.1 128->128 5x5", 128, 89, 128, 128, (5, 5), (1, 1), 1, "dgrad"),
     ("dgrad mid 256->256 3x3 d2", 64, 45, 256, 256, (3, 3), (2, 2), 1, "dgrad"),
+    ("dgrad mid 256->256 3x3 d8", 64, 45, 256, 256, (3, 3), (8, 8), 1, "dgrad"),
+    ("dgrad mid 256->256 3x3 d16", 64, 45, 256, 256, (3, 3), (16, 16), 1, "dgrad"),
 ]
 
 

@@ -18,8 +18,11 @@ os.makedirs(os.path.dirname(OUT), exist_ok=True)
 os.environ["SOS_CONV_TUNE"] = "1"
 os.environ["SOS_CONV_TUNE_CACHE"] = OUT
 os.environ["SOS_CONV_TUNE_TABLE"] = "0"        # only the table being built (OUT), never the shipped one underneath
+os.environ["SOS_FOLD_FUSED"] = "0"             # the U-Net's folded data-gradient launches are never timed (their output is live): tune
+                                               # the unfused launches of the SAME shape keys instead
 EXTEND_AV = "--extend-av" in sys.argv        # keep the committed table, add the audio-visual variant's shapes
 RETUNE_X3 = "--retune-x3" in sys.argv        # keep the committed table, re-measure the three-segment shapes the 16-row kernel now takes
+RETUNE_NPOT = "--retune-npot" in sys.argv    # keep the committed table, re-measure the shapes that gained non-power-of-two tile candidates
 SHIPPED = os.path.join(ROOT, "listening-to-sound-of-silence-for-speech-denoising_amd", "tune_table_gfx950.txt")
 if os.path.exists(OUT):
     os.remove(OUT)
@@ -37,6 +40,20 @@ if RETUNE_X3:
         if not elig:
             keep.append(ln)
     open(OUT, "w").write("\n".join(keep) + "\n")
+    print("dropped", len(lines) - len(keep), "entries to re-measure")
+
+if RETUNE_NPOT:
+    # shape key columns (conv.hip, shape_key): 9 stride, 10 dil_h, 11 dil_w, 12 Ho, 13 Wo.  enumerate_cfgs adds the non-power-of-two
+    # tiles for stride-1 shapes whose strided extent per residue class is <= 48 in either direction
+    lines = open(SHIPPED).read().splitlines()
+    keep = [lines[0]]
+    for ln in lines[1:]:
+        v = [int(x) for x in ln.split()]
+        hc, wc = -(-v[12] // v[10]), -(-v[13] // v[11])
+        if not (v[9] == 1 and (hc <= 48 or wc <= 48) and v[12] > 1):
+            keep.append(ln)
+    for path in (OUT, OUT + ".f16"):
+        open(path, "w").write("\n".join(keep) + "\n")
     print("dropped", len(lines) - len(keep), "entries to re-measure")
 
 import numpy as np  # noqa: E402
@@ -103,6 +120,21 @@ def main():
         sos_amd.set_precision("bf16x3")
         x3_detector_workloads()
         from sos_amd import _lib
+        _lib.lib().sos_conv2d_tune_save(OUT.encode())
+        print("wrote", OUT, sum(1 for _ in open(OUT)) - 1, "entries")
+        return
+    if RETUNE_NPOT:
+        for prec, batches in (("bf16", (64, 32, 16, 8, 4, 2, 1)), ("bf16x3", (64, 2, 1))):
+            sos_amd.set_precision(prec)
+            for B in batches:
+                workloads(B)
+                print("re-tuned", prec, "B =", B, flush=True)
+        sos_amd.set_precision("bf16x3")
+        x3_detector_workloads()
+        sos_amd.set_precision("fp16")
+        av_workloads()
+        from sos_amd import _lib
+        sos_amd.set_precision("bf16")
         _lib.lib().sos_conv2d_tune_save(OUT.encode())
         print("wrote", OUT, sum(1 for _ in open(OUT)) - 1, "entries")
         return
