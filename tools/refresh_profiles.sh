@@ -5,7 +5,7 @@
 #   rocprofv3 --kernel-trace --stats summaries of the train / infer / ragged benches,
 #   the HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs) of the dominant conv kernel,
 #   the micro-benchmarks.  Every process loads the shipped tiling table: nothing is tuned here.
-R=${1:-r02}
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/refresh; mkdir -p $O
 python tools/conv_bench.py > $O/conv_bench.txt 2>&1
@@ -41,8 +41,11 @@ cp $O/pmc_conv96.json profiles/${R}_pmc_conv96.json     # bench.py reports this 
 python bench.py --steps 10 --warmup 3 > $O/bench_train_fp16.json 2> $O/bench_train_fp16.err
 python bench.py --precision bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench_train_bf16.json 2> $O/bench_train_bf16.err
 python bench.py --precision bf16x3 --steps 6 --warmup 2 --no-cpu-baseline --no-secondary > $O/bench_train_bf16x3.json 2> $O/bench_train_bf16x3.err
-python bench.py --mode infer --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench_infer_fp16.json 2> $O/bench_infer_fp16.err
-python bench.py --mode infer-ragged --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/bench_ragged_fp16.json 2> $O/bench_ragged_fp16.err
+python bench.py --mode infer --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench_infer_mixed.json 2> $O/bench_infer_mixed.err
+python bench.py --mode infer --precision fp16 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench_infer_fp16.json 2> $O/bench_infer_fp16.err
+python bench.py --mode infer-ragged --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/bench_ragged_mixed.json 2> $O/bench_ragged_mixed.err
+bash tools/probe/steady_families.sh > $O/steady_families.txt 2>&1
+bash tools/probe/low_occupancy.sh > $O/low_occupancy.txt 2>&1
 for m in train infer ragged; do python profiles/summarize_rocpd.py $(find $O/prof_$m -name "*.db" | head -1) $O/${m}_kernels.md > /dev/null 2>&1; done
 find $O -name "*.db" -delete            # the summaries stay; gpurun copies at most 64 MiB back
 for f in $O/bench_*.json; do echo $f; cut -c1-420 $f; done
