@@ -681,6 +681,9 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
 // weight fragment (from the window's [2 taps][rows][cin] slab) and the pixel fragment (patch shifted by THAT tap).
 // These per-lane offsets are window invariant.  One barrier per TWO taps; an odd last tap gets a zero slab.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef SOS_C16_UPFRONT
+#define SOS_C16_UPFRONT 0
+#endif
 
 // MODE 0: two window-slab buffers, the next window's DMA issued at the start of a window (lands in ~600 cycles of MFMAs or
 // is waited for); 1: ONE buffer refilled behind a barrier (three workgroups per CU cover each other's refill latency);
@@ -828,6 +831,30 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) fb[buf][pt] = lds_frag(patch + pbase[pt] + po);
         };
+#if SOS_C16_UPFRONT
+        // experiment (round 3): every fragment of the window's BW K-blocks requested up front (7 BW ds_read_b128 in flight), the
+        // MFMAs of block kb wait only for their own operands (LDS returns in order)
+        bf16x8 ga[BW][NT16], gb[BW][4];
+#pragma unroll
+        for (int kb = 0; kb < BW; ++kb) {
+#pragma unroll
+            for (int nt = 0; nt < NT16; ++nt) ga[kb][nt] = lds_frag(slab + aoff[kb] + nt * 16 * BSTRIDE);
+            const int po = (tap1[kb] ? toff1 : toff0) + coff[kb];
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) gb[kb][pt] = lds_frag(patch + pbase[pt] + po);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < BW; ++kb) {
+#pragma unroll
+            for (int nt = 0; nt < NT16; ++nt)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+                    acc[pt][nt] = SOS_MFMA_16x16x32(ga[kb][nt], gb[kb][pt], acc[pt][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        (void)fa; (void)fb; (void)read_block;
+#else
         read_block(0, 0);
 #pragma unroll
         for (int kb = 0; kb < BW; ++kb) {
@@ -841,6 +868,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
                     acc[pt][nt] = SOS_MFMA_16x16x32(fa[cb][nt], fb[cb][pt], acc[pt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+#endif
         if constexpr (SB) {
             // single buffer: refilled behind a barrier; the DMA's latency is covered by the two other workgroups of the
             // CU, and the LDS pipe is spared the ds_write_b128s of a register path (48->48 5x5: 0.356 -> 0.340 ms)

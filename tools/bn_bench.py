@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from sos_amd import _lib as L, engine as E
-dev = torch.device("cuda"); B, H, W, C = 64, 256, 178, int(os.environ.get("BN_C", "96"))
+dev = torch.device("cuda"); B, C = 64, int(os.environ.get("BN_C", "96"))
+H, W = int(os.environ.get("BN_H", "256")), int(os.environ.get("BN_W", "178"))      # BN_C / BN_H / BN_W: the U-Net's tensors
 x = E.Act(B, H, W, C, False, dev); x.t.normal_()
 dy = E.Act(B, H, W, C, False, dev); dy.t.normal_()
 dx = E.Act(B, H, W, C, False, dev)
