@@ -10,6 +10,14 @@
 #include "sos_common.h"
 #include <stdlib.h>
 
+#ifndef SOS_BN_BWD_ALIGNED
+#define SOS_BN_BWD_ALIGNED 0      // 1: backward passes with pixel lanes spanning whole 128-byte lines like the forward ones -- measured (round 3,
+                                  // tools/probe/bn_ab.sh): 96 ch 570 vs 562 us, 48 ch 275 vs 282 us for reduce + apply: inside the noise, not adopted
+#endif
+#ifndef SOS_BN_RED_U
+#define SOS_BN_RED_U 2            // 16-byte loads in flight per thread and operand in bn_bwd_reduce (4: 0-7 % slower)
+#endif
+
 struct View {
     bf16_t* ptr;
     long long npix;
@@ -360,10 +368,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(View dy, View x, con
                                                             const float* __restrict__ invstd, int act,
                                                             const float* __restrict__ slope_p,
                                                             float* __restrict__ partial) {
-    constexpr int BN_U = 2;
+    constexpr int BN_U = SOS_BN_RED_U;
     __shared__ float red[256 * 24];
     const int CG = (x.C + 7) / 8;
-    const int PL = 256 / CG;
+    const int PL = SOS_BN_BWD_ALIGNED ? bn_pl(CG, x.row) : 256 / CG;      // pixel lanes spanning whole 128-byte lines (see bn_pl)
     const int tid = threadIdx.x;
     const int cg = tid % CG, pl = tid / CG;
     const float slope = slope_p ? slope_p[0] : 0.f;
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View x, cons
                                                            const float* __restrict__ cc, View dx) {
     constexpr int BN_U = 2;
     const int CG = (x.C + 7) / 8;
-    const int PL = 256 / CG;
+    const int PL = SOS_BN_BWD_ALIGNED ? bn_pl(CG, x.row) : 256 / CG;
     const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
     if (pl >= PL) return;
     const float slope = slope_p ? slope_p[0] : 0.f;
@@ -527,7 +535,7 @@ extern "C" int sos_bn_bwd(const sos_view* dy, const sos_view* x, const float* sc
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, partial, nblk, C, (double)x->npix, gamma, invstd,
                        dgamma, dbeta, dslope ? coef + 3 * C : nullptr, coef, coef + C, coef + 2 * C, out_scale);
     if (dslope) hipLaunchKernelGGL(slope_sum_kernel, dim3(1), dim3(256), 0, s, coef + 3 * C, C, dslope);
-    const int PLh = 256 / ((C + 7) / 8);
+    const int PLh = SOS_BN_BWD_ALIGNED ? bn_pl((C + 7) / 8, x->row) : 256 / ((C + 7) / 8);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((x->npix + PLh - 1) / PLh * 256)), dim3(256), 0, s, to_view(dy),
                        to_view(x), scale, shift, mean, invstd, act, slope, coef, coef + C, coef + 2 * C, to_view(dx));
     return sos_check_launch("sos_bn_bwd");
