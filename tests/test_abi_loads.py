@@ -96,3 +96,18 @@ def test_lstm_gate_permutation_is_consistent():
         for j in range(H):
             for q in range(4):
                 assert int(perm[d * 4 * H + 4 * j + q]) == d * 4 * H + q * H + j
+
+
+def test_bench_picks_the_dominant_signature_by_work_not_by_warm_up_time():
+    """bench.py's roofline leg: the dominant launch signature is the one carrying the most algorithmic FLOPs (per launch x
+    launches), whatever one-time host work inflated the HIP-event brackets of other signatures during warm-up (a run once
+    reported a 15 TFLOP/s first-layer gradient as dominant: roofline.frac 0.005)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    summ = {("conv", 5, 5, 1, 1, 1, 96, 96, 64, 256, 178): dict(flops=1.344e12, launches=12, total_ms=14.0, avg_ms=1.17),
+            ("conv", 5, 5, 2, 2, 1, 96, 96, 64, 256, 178): dict(flops=1.344e12, launches=6, total_ms=7.2, avg_ms=1.2),
+            ("wgrad", 1, 7, 1, 1, 1, 48, 2, 64, 256, 178): dict(flops=3.9e9, launches=6, total_ms=900.0, avg_ms=150.0)}
+    assert bench._dominant(summ) == ("conv", 5, 5, 1, 1, 1, 96, 96, 64, 256, 178)

@@ -275,3 +275,33 @@ def test_temporal_taps_conv_and_gradients_match_conv3d(kt, stride, mode_x3):
         e = rel_err(gotx, xr.grad)
         print("temporal dgrad", e)
         assert e < (3e-5 if x3 else 1e-2)
+
+
+@pytest.mark.parametrize("T,cin,cout", [(178, 3072, 1600), (60, 2048, 800), (178, 400, 600)])
+def test_flattened_1x1_layers_are_bit_identical(T, cin, cout, monkeypatch):
+    """1x1 layers over single-row images (LSTM input projections, FC head) run over the batch as ONE pixel row (engine.conv):
+    a tiling choice only -- every output pixel's contraction order is unchanged, so the outputs are bit-identical to the
+    per-clip launch (SOS_FLATTEN_1X1=0)."""
+    from sos_amd import engine as E, _lib as L
+    sos_amd = pytest.importorskip("sos_amd")
+    sos_amd.set_precision("fp16")
+    try:
+        dev = torch.device("cuda")
+        B = 5
+        torch.manual_seed(3)
+        w = E.pack_weight(lambda: torch.randn(cout, cin, 1, 1, device=dev) * 0.05, E.pad_to(cin, 16), False)
+        src = E.Act(B, 1, T, E.pad_to(cin, 16), False, dev)
+        src.t.normal_()
+        scale = E.pad_vec(torch.ones(cout, device=dev), w.shape[1], 1.0)
+        shift = E.pad_vec(torch.zeros(cout, device=dev), w.shape[1])
+        outs = []
+        for flat in (True, False):
+            monkeypatch.setattr(E, "FLATTEN_1X1", flat)
+            dst = E.Act(B, 1, T, E.pad_to(cout, 16), False, dev, zero=True)
+            E.conv_to_act(src, 0, E.pad_to(cin, 16), w, 1, 1, cout, scale, shift, L.ACT_RELU, dst, cout_store=dst.cs, Ho=1, Wo=T)
+            outs.append(dst.t.clone())
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+        assert float(outs[0].float().abs().max()) > 0
+    finally:
+        sos_amd.set_precision("bf16")
