@@ -1029,7 +1029,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     // channel tile if none fits.  The choice depends on the shape only and is cached (the exact count walks every tile).
     const size_t lds_max = 160 * 1024;
     const int kpix = use16 ? 32 : 16;              // tile pixels per k-step
-    struct TileCfg { int nc, lth, ltw, db, kord, bufbytes, npixp, ntb; };
+    struct TileCfg { int nc, lth, ltw, db, kord, bufbytes, npixp, ntb, pw; };
     struct TileKey {
         int v[16];
         bool operator<(const TileKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
@@ -1062,16 +1062,21 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
                     const int TH = 1 << lth, TW = 1 << ltw;
                     const int PH = (TH - 1) * d->stride + khg, PW = (TW - 1) * d->stride + d->kw;
                     if ((TH - 1 + d->kh) * d->dil_h >= 0x7fff || (d->stride * NC + (PW - 1) * d->dil_w) >= 0x7fff) continue;
-                    const int npixp = use16 ? (NC * PH * PW + 31) / 32 * 32 : (NC * PH * PW + 15) / 16 * 16;
-                    const size_t one = use16 ? ((size_t)256 * 32 * m16 + (size_t)npixp * 32 * n16 + 1023) / 1024 * 1024
-                                             : ((size_t)256 * 64 * mt + (size_t)npixp * 64 * ntb_try + 1023) / 1024 * 1024;
-                    const size_t tabb = (size_t)(256 + npixp) * 8;
-                    if (one + tabb > lds_max) continue;
-                    const int db = 2 * one + tabb <= lds_max;
                     const int tiles_h = (Hc + TH - 1) / TH, tiles_w = (Wc + TW - 1) / TW, ngw = (d->dil_w + NC - 1) / NC;
                     const double ntiles = (double)d->dil_h * ngw * tiles_h * tiles_w;
                     for (int kord = 0; kord < 2; ++kord) {
                         if (force && fko >= 0 && kord != fko) continue;
+                        // Column-major order: the pixels a transposed read gathers are consecutive ROWS of the patch, PWl pixel
+                        // pitches apart; with an even PWl their 64-byte (32-byte) runs land on the same banks (PW = 12: 768 B = 0 mod
+                        // 256 -- SQ_LDS_BANK_CONFLICT was 59 % of the LDS-active cycles of the 96 -> 96 gradient), with an odd one
+                        // they tile the 64 banks.  One more (never multiplied) patch column buys that.
+                        const int PWl = (kord == 1 && (PW & 1) == 0 && !getenv("SOS_WGRAD_EVEN_PITCH")) ? PW + 1 : PW;
+                        const int npixp = use16 ? (NC * PH * PWl + 31) / 32 * 32 : (NC * PH * PWl + 15) / 16 * 16;
+                        const size_t one = use16 ? ((size_t)256 * 32 * m16 + (size_t)npixp * 32 * n16 + 1023) / 1024 * 1024
+                                                 : ((size_t)256 * 64 * mt + (size_t)npixp * 64 * ntb_try + 1023) / 1024 * 1024;
+                        const size_t tabb = (size_t)(256 + npixp) * 8;
+                        if (one + tabb > lds_max) continue;
+                        const int db = 2 * one + tabb <= lds_max;
                         // Cost of one image in k-step units, calibrated on MI355X with tools/probe/wgrad_tile_sweep.py (round 3: every
                         // tile x order of the 96- and 48-channel layers timed; this model's pick is within 1.1 % of the best measured
                         // one on each).  A tile multiplies its k-steps that hold a pixel of the image (first pixel of the k-step
@@ -1101,7 +1106,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
                                         cost += db ? (nks > dma ? nks : dma) : nks + sbf * dma;
                                     }
                         cost += fixed * ntiles;
-                        if (cost < best) { best = cost; tc = TileCfg{NC, lth, ltw, db, kord, (int)one, npixp, ntb_try}; }
+                        if (cost < best) { best = cost; tc = TileCfg{NC, lth, ltw, db, kord, (int)one, npixp, ntb_try, PWl}; }
                     }
                 }
             }
@@ -1110,9 +1115,9 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
             ntb_try >>= 1;
         }
         if (getenv("SOS_WGRAD_VERBOSE"))
-            fprintf(stderr, "sos_conv2d_wgrad: %dx%d k%dx%d s%d d%dx%d M%d N%d %s-> NC=%d TH=%d TW=%d order=%d dbuf=%d ntb=%d lds=%d\n", d->Hg, d->Wg,
+            fprintf(stderr, "sos_conv2d_wgrad: %dx%d k%dx%d s%d d%dx%d M%d N%d %s-> NC=%d TH=%d TW=%d order=%d dbuf=%d ntb=%d lds=%d pitch=%d\n", d->Hg, d->Wg,
                     d->kh, d->kw, d->stride, d->dil_h, d->dil_w, d->M, d->N, use16 ? "(16x16x32) " : "", tc.nc, 1 << tc.lth, 1 << tc.ltw,
-                    tc.kord, tc.db, tc.ntb, tc.bufbytes);
+                    tc.kord, tc.db, tc.ntb, tc.bufbytes, tc.pw);
         if (!force) {
             std::lock_guard<std::mutex> lk(tile_mu);
             tile_cache[tkey] = tc;
@@ -1123,7 +1128,7 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     {
         const int TH = 1 << p.logTH, TW = 1 << p.logTW;
         p.tiles_h = (Hc + TH - 1) / TH; p.tiles_w = (Wc + TW - 1) / TW; p.ngw = (d->dil_w + p.NC - 1) / p.NC;
-        p.PH = (TH - 1) * d->stride + khg; p.PW = (TW - 1) * d->stride + d->kw;
+        p.PH = (TH - 1) * d->stride + khg; p.PW = tc.pw;        // patch pitch: (TW - 1) stride + kw, + 1 when that keeps it odd
         p.npix = p.NC * p.PH * p.PW;
     }
     // workgroups per CU: one (its own double-buffered DMA pipeline covers the fetch of the next tile) unless a tile is so

@@ -9,7 +9,7 @@ import sos_amd
 from sos_amd import engine as E
 sos_amd.set_precision(os.environ.get('SOS_PRECISION', 'bf16'))
 SH = {"ctx96 d1x1": (96, (5, 5), (1, 1)), "ctx96 d4x4": (96, (5, 5), (4, 4)), "ctx96 d16x16": (96, (5, 5), (16, 16)),
-      "ctx96 d32x32": (96, (5, 5), (32, 32)), "ctx48 d1x1": (48, (5, 5), (1, 1)), "ctx48 d4x4": (48, (5, 5), (4, 4)),
+      "ctx96 d32x32": (96, (5, 5), (32, 32)), "ctx96 d8x8": (96, (5, 5), (8, 8)), "ctx96 d2x2": (96, (5, 5), (2, 2)), "ctx48 d1x1": (48, (5, 5), (1, 1)), "ctx48 d4x4": (48, (5, 5), (4, 4)),
       "ctx48 d8x8": (48, (5, 5), (8, 8)), "ctx48 d16x16": (48, (5, 5), (16, 16)), "ctx48 d32x32": (48, (5, 5), (32, 32)),
       "ctx48 d32x1": (48, (5, 5), (32, 1)), "ctx96 7x1": (96, (7, 1), (1, 1)), "ctx48 7x1": (48, (7, 1), (1, 1)),
       # U-Net: (cin, cout, k, dil, stride, H, W)
