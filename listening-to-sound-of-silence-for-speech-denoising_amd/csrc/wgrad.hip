@@ -168,12 +168,34 @@ struct WgStage {
             *(uint2*)(smem + (tab - (unsigned)(uintptr_t)smem) + e * 8) = make_uint2(r, c);
         }
     }
-    __device__ __forceinline__ WgTile origin_of(int step) const {
+    // Position of a pixel tile in the walk (tile column fastest, then tile row, class group, row class, image).  The kernels
+    // decompose their FIRST step with divisions and then advance by carries: origin_of(step) cost four scalar divisions
+    // (~150 SALU) per tile and wave, right behind the tile's barrier (SQ counters: 4.5 SALU per MFMA in wgrad_kernel).
+    struct Walk { int tj, ti, gw, rh, t; };
+    __device__ __forceinline__ Walk walk_init(int step) const {
+        Walk w;
         int t = step;
-        const int tj = t % p.tiles_w; t /= p.tiles_w;
-        const int ti = t % p.tiles_h; t /= p.tiles_h;
-        const int gw = t % p.ngw; t /= p.ngw;
-        const int rh = t % p.dh; t /= p.dh;
+        w.tj = t % p.tiles_w; t /= p.tiles_w;
+        w.ti = t % p.tiles_h; t /= p.tiles_h;
+        w.gw = t % p.ngw; t /= p.ngw;
+        w.rh = t % p.dh; t /= p.dh;
+        w.t = t;
+        return w;
+    }
+    __device__ __forceinline__ void walk_next(Walk& w) const {
+        if (++w.tj < p.tiles_w) return;
+        w.tj = 0;
+        if (++w.ti < p.tiles_h) return;
+        w.ti = 0;
+        if (++w.gw < p.ngw) return;
+        w.gw = 0;
+        if (++w.rh < p.dh) return;
+        w.rh = 0;
+        ++w.t;
+    }
+    __device__ __forceinline__ WgTile origin_of(int step) const { return origin_at(walk_init(step)); }
+    __device__ __forceinline__ WgTile origin_at(const Walk& wk) const {
+        const int tj = wk.tj, ti = wk.ti, gw = wk.gw, rh = wk.rh, t = wk.t;
         WgTile o;
         o.gh0 = rh + ti * TH * p.dh; o.gw0 = gw * p.NC + tj * TW * p.dw;
         o.xh0 = o.gh0 * p.stride - p.pad_t + xrow; o.xw0 = o.gw0 * p.stride - p.pad_l;
@@ -345,8 +367,9 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
     int cur = 0;
     __syncthreads();                               // pixel table complete
     int cgh0 = 0, cgw0 = 0;                        // origin of the tile being multiplied
+    auto wk = st.walk_init(step0 < step1 ? step0 : 0);
     if (step0 < step1) {
-        const WgTile o0 = st.origin_of(step0);
+        const WgTile o0 = st.origin_at(wk);
         cgh0 = o0.gh0; cgw0 = o0.gw0;
         st.issue_all(o0, 0);
     }
@@ -354,7 +377,8 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // tile `step` has landed in buffer `cur`; buffer cur^1 is free
         const bool more = step + 1 < step1 && !WDBG(1);
-        const WgTile onext = st.origin_of(more ? step + 1 : step);
+        if (more) st.walk_next(wk);
+        const WgTile onext = st.origin_at(wk);
         const bool prefetch = p.dbuf && more;
         const unsigned gb = sbase + cur * p.bufbytes, xb = gb + gbytes;
         unsigned kmask = (unsigned)__builtin_amdgcn_ballot_w64(cgh0 + kfh < p.Hg && cgw0 + kfw < p.Wg) & 0xffffu;   // wave-uniform
@@ -628,8 +652,9 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
     int cur = 0;
     __syncthreads();                               // pixel table complete
     int cgh0 = 0, cgw0 = 0;                        // origin of the tile being multiplied
+    auto wk = st.walk_init(step0 < step1 ? step0 : 0);
     if (step0 < step1) {
-        const WgTile o0 = st.origin_of(step0);
+        const WgTile o0 = st.origin_at(wk);
         cgh0 = o0.gh0; cgw0 = o0.gw0;
         st.issue_all(o0, 0);
     }
@@ -637,7 +662,8 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // tile `step` has landed in buffer `cur`; buffer cur^1 is free
         const bool more = step + 1 < step1 && !WDBG(1);
-        const WgTile onext = st.origin_of(more ? step + 1 : step);
+        if (more) st.walk_next(wk);
+        const WgTile onext = st.origin_at(wk);
         const bool prefetch = p.dbuf && more;
         const unsigned gb = sbase + cur * p.bufbytes, xb = gb + gbytes;
         unsigned kmask = (unsigned)__builtin_amdgcn_ballot_w64(cgh0 + kfh < p.Hg && cgw0 + kfw < p.Wg) & 0xffu;   // wave-uniform
