@@ -684,6 +684,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SOS_C16_UPFRONT
 #define SOS_C16_UPFRONT 0
 #endif
+#ifndef SOS_C16_XPF
+#define SOS_C16_XPF 0       // 1: the next window's first pixel fragments requested before the barrier that closes a window (experiment: inside the noise)
+#endif
 
 // MODE 0: two window-slab buffers, the next window's DMA issued at the start of a window (lands in ~600 cycles of MFMAs or
 // is waited for); 1: ONE buffer refilled behind a barrier (three workgroups per CU cover each other's refill latency);
@@ -814,6 +817,16 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
     __syncthreads();
 
     int ring = 0;                                         // MODE 2: buffer of window w (w mod 3 without the division)
+#if SOS_C16_XPF
+    // pixel fragments of the NEXT window's first K-block: requested before the barrier(s) that close a window (the patch does
+    // not change inside a segment), so that behind the barrier only the three weight fragments are still to be read
+    bf16x8 fbn[4];
+    {
+        const int po = (tap1[0] ? __builtin_amdgcn_readlane(tapoff16, min(1, ntaps - 1)) : __builtin_amdgcn_readlane(tapoff16, 0)) + coff[0];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) fbn[pt] = lds_frag(patch + pbase[pt] + po);
+    }
+#endif
     for (int w = 0; w < nwin; ++w) {
         const int cur = MODE == 2 ? ring : (SB ? 0 : (w & 1));
         if constexpr (MODE == 0) { if (w + 1 < nwin && !CDBG(8)) dma_window(w + 1, cur ^ 1); }       // next window's slab (lands while the MFMAs run)
@@ -857,7 +870,12 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
         __builtin_amdgcn_sched_barrier(0);
         (void)fa; (void)fb; (void)read_block;
 #else
+#if SOS_C16_XPF
+#pragma unroll
+        for (int nt = 0; nt < NT16; ++nt) fa[0][nt] = lds_frag(slab + aoff[0] + nt * 16 * BSTRIDE);
+#else
         read_block(0, 0);
+#endif
 #pragma unroll
         for (int kb = 0; kb < BW; ++kb) {
             const int cb = kb & 1;
@@ -866,10 +884,24 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
 #pragma unroll
             for (int nt = 0; nt < NT16; ++nt)
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt)
+                for (int pt = 0; pt < 4; ++pt) {
+#if SOS_C16_XPF
+                    acc[pt][nt] = SOS_MFMA_16x16x32(fa[cb][nt], kb == 0 ? fbn[pt] : fb[cb][pt], acc[pt][nt], 0, 0, 0);
+#else
                     acc[pt][nt] = SOS_MFMA_16x16x32(fa[cb][nt], fb[cb][pt], acc[pt][nt], 0, 0, 0);
+#endif
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
+#if SOS_C16_XPF
+        if (w + 1 < nwin) {
+            const int t0n = __builtin_amdgcn_readlane(tapoff16, 2 * w + 2);
+            const int t1n = __builtin_amdgcn_readlane(tapoff16, min(2 * w + 3, ntaps - 1));
+            const int po = (tap1[0] ? t1n : t0n) + coff[0];
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) fbn[pt] = lds_frag(patch + pbase[pt] + po);
+        }
+#endif
 #endif
         if constexpr (SB) {
             // single buffer: refilled behind a barrier; the DMA's latency is covered by the two other workgroups of the
