@@ -60,7 +60,7 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(runs=3):
+def cpu_baseline(runs=5):
     """The oracle (CPU restatement of the reference path, torch fp32 + numpy f64) timed on the host cores with the
     protocol SURVEY.md 8-d / BASELINE.md 3 fix: BASELINE configs[0] = ONE 2 s clip through the whole inference pipeline
     (STFT -> detector -> bits->mask -> STFT -> JointModel -> mask apply -> ISTFT), 1 warm-up, median of `runs` runs --
@@ -354,12 +354,16 @@ def main():
         audio_seconds = wl.audio_seconds
         # HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs, FETCH_SIZE doubled per the gfx950 correction); null when the signature has no PMC record
-        traffic = None
+        traffic = traffic_source = None
         try:
             import glob
-            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv96.json")))[-1]))   # latest round
+            pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv96.json")))[-1]      # latest round
+            pmc = json.load(open(pmc_path))
             if dom[0] == "conv" and tuple(dom[1:8]) == (5, 5, 1, 1, 1, 96, 96) and dom[8] == 64:
                 traffic = pmc["hbm_bytes_per_launch"]
+                # (PMC counters cannot be collected inside this timed run: the field is READ from the committed pass)
+                traffic_source = ("profiles/" + os.path.basename(pmc_path) + " (stand-alone rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the "
+                                  "same launch signature, tools/refresh_profiles.sh; not measured in this run)")
         except Exception:
             pass
         line = {
@@ -385,7 +389,7 @@ def main():
                        "realtime_factor": value * audio_seconds / B,
                        "end_to_end_tflops": value * gflop / 1e3 / n_gpus},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": ("wgrad_kernel " if dom[0] == "wgrad" else "conv_mfma_kernel ") + str(dom),
                          "launches": prof["launches"],
                          "avg_ms": prof["avg_ms"], "flops_per_launch": prof["flops"]},
@@ -398,11 +402,12 @@ def main():
             for key, mode, prec, b, k, w, fr in (("infer_mixed_utt_s", "infer", "mixed", 64, 10, 3, None),
                                                  ("infer_fp16_utt_s", "infer", "fp16", 64, 10, 3, None),
                                                  ("ragged_mixed_clips_s", "infer-ragged", "mixed", 256, 3, 1, None),
+                                                 ("ragged_mixed_hipgraph_clips_s", "infer-ragged", "mixed", 256, 3, 1, "graph"),
                                                  ("train_bf16_utt_s", "train", "bf16", 64, 10, 3, None),
                                                  ("train_mixed_utt_s", "train", "mixed", 64, 10, 3, None),
                                                  ("train_fp16_16khz_2x256x251_utt_s", "train", "fp16", 64, 5, 2, 251)):
                 try:
-                    w2 = Workload(mode, prec, b, rank, frames=fr)
+                    w2 = Workload(mode, prec, b, rank, frames=None if fr == "graph" else fr, graph=fr == "graph")
                     dt2, _, _ = run_timed(w2, k, w, barrier, profile=False)
                     sec[key] = round(b * k / dt2, 1)
                     if mode == "infer-ragged":
@@ -412,9 +417,55 @@ def main():
                 except Exception as e:        # a secondary line never takes the headline down
                     sec[key] = None
                     sec[key + "_error"] = repr(e)[:200]
+            # the audio-visual variant's per-GPU share of BASELINE configs[4] (32 clips of 60 x 224 x 224 frames + audio): one
+            # training step of the detector with its video branch
+            try:
+                sos_amd.set_precision("fp16")
+                from sos_amd import agent as _agent
+                from sos_amd.detector import networks as _dnet
+                torch.manual_seed(0)
+                ag = _agent.DetectorAgent(_dnet.get_network(video=True), lr=1e-3)
+                bav = {"audio": torch.randn(32, 2, 256, 178, device="cuda"), "frames": torch.rand(32, 3, 60, 224, 224, device="cuda"),
+                       "label": (torch.rand(32, 60, device="cuda") > 0.3).float()}
+                for _ in range(2):
+                    ag.train_func(bav)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    ag.train_func(bav)
+                barrier()
+                sec["audiovisual_train_fp16_b32_clips_s"] = round(32 * 3 / (time.perf_counter() - t0), 1)
+                del ag, bav
+                torch.cuda.empty_cache()
+            except Exception as e:
+                sec["audiovisual_train_fp16_b32_clips_s"] = None
+                sec["audiovisual_train_fp16_b32_clips_s_error"] = repr(e)[:200]
+            # the data-parallel gradient path on this one GPU (a 1-rank RCCL group: every bucket gathered and all-reduced,
+            # one communicator per model): what the bucket copies + collective launches cost the headline step
+            try:
+                import torch.distributed as dist1
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(_free_port()))
+                os.environ["SOS_FORCE_BUCKETS"] = "1"
+                dist1.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+                try:
+                    w2 = Workload("train", "fp16", 64, rank)
+                    dt2, _, _ = run_timed(w2, 10, 3, barrier, profile=False)
+                    sec["train_fp16_forced_buckets_utt_s"] = round(64 * 10 / dt2, 1)
+                    del w2
+                finally:
+                    dist1.destroy_process_group()
+                    os.environ.pop("SOS_FORCE_BUCKETS", None)
+                torch.cuda.empty_cache()
+            except Exception as e:
+                sec["train_fp16_forced_buckets_utt_s"] = None
+                sec["train_fp16_forced_buckets_utt_s_error"] = repr(e)[:200]
             sec["note"] = ("same box, after the headline loop: infer = B=64 2 s clips x 10 steps; ragged = BASELINE configs[3], B=256 "
-                           "U(1 s,10 s) x 3 steps; train_* = the headline workload in another precision x 10 steps; train_fp16_16khz_2x256x251 = SURVEY.md 8-d's "
-                           "secondary (BASELINE-literal 16 kHz / STFT 512-128, Nyquist dropped) spectrogram geometry, 1.41x the FLOPs per clip, throughput only")
+                           "U(1 s,10 s) x 3 steps (eager launches / replayed hipGraphs); train_* = the headline workload in another precision x 10 steps; "
+                           "train_fp16_16khz_2x256x251 = SURVEY.md 8-d's secondary (BASELINE-literal 16 kHz / STFT 512-128, Nyquist dropped) spectrogram "
+                           "geometry, 1.41x the FLOPs per clip, throughput only; audiovisual_train = the detector with its video branch at BASELINE "
+                           "configs[4]'s per-GPU share (32 clips of 60 x 224 x 224 frames) x 3 steps; train_fp16_forced_buckets = the headline "
+                           "workload with the data-parallel gradient path forced in a world of one (1-rank RCCL groups, one per model)")
             line["secondary"] = sec
             sos_amd.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:

@@ -119,6 +119,15 @@ int sos_threshold_bits(const float* logits, int64_t n, float threshold, uint8_t*
 int sos_pack_nchw_to_nhwc(const float* in, int64_t B, int C, int64_t H, int64_t W, void* out, int cs,
                           int dtype, const float* mul /* optional device scalar multiplied in (loss scale) */,
                           sos_stream_t stream);
+/* The same boundary pack with the kw HORIZONTAL TAPS of the first conv layer folded into the channel axis: stored channel
+ * t*C + c of pixel (h, w) = in[b][c][h][w + t - pad_left] (t < kw; outside the clip: zero for SOS_PAD_ZERO, mirrored for
+ * SOS_PAD_REFLECT; channels >= kw*C zero).  The first block of every encoder (Conv2d(2, nf, (1,7)), M1/networks.py:120-128,
+ * M2/networks.py:72-80) and of the U-Net (DownConvBlock(2, 64, 5, 1), M2/networks.py:158,165) then runs as a kh x 1 layer over
+ * kw*C real channels with the weight w'[o][t*C + c][a][0] = w[o][c][a][t] -- 14 or 10 of the 16 stored channels real instead
+ * of 2, at no extra byte.  clip_w: optional device [B] (ragged batch: clip b has clip_w[b] <= W columns, its border is taken
+ * at ITS end, columns past it are written as zeros).  cs (per third) % 8 == 0 and >= kw*C. */
+int sos_pack_nchw_wtaps(const float* in, int64_t B, int C, int64_t H, int64_t W, int kw, int pad_left, int pad_mode,
+                        const int32_t* clip_w, void* out, int cs, int dtype, const float* mul, sos_stream_t stream);
 
 /* ---- a6,a8,a9 (+ a7/a10/a11 heads): Conv2d (zero or reflect pad, stride,
  * dilation) / ConvTranspose2d phases / Linear, fused with folded BatchNorm or bias
@@ -345,7 +354,9 @@ int sos_scale_f32(float* x, int64_t n, const float* s /* device scalar */, sos_s
 #define SOS_GUARD_FLOATS 5
 #define SOS_GUARD_GROWTH 200
 int sos_grad_guard(const float* g, int64_t n, float* guard, int finalize, sos_stream_t stream);
-/* skip: optional device scalar (the guard's [0]): a non-zero value turns the launch into a no-op */
+/* skip: optional device pointer to the guard state: a non-zero [0] turns the launch into a no-op, and once [3] (steps skipped so
+ * far) is non-zero the bias corrections are taken at step - [3], the number of updates actually APPLIED (`step` counts attempts;
+ * torch.cuda.amp.GradScaler semantics: a skipped update does not advance the optimizer's step) */
 int sos_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int64_t step, float grad_scale, const float* skip, sos_stream_t stream);
 

@@ -60,7 +60,7 @@ class WgradDesc(C.Structure):
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 ADAM_CHUNK = 16384          # SOS_ADAM_CHUNK of include/sos_hip.h
 GUARD_FLOATS = 5            # SOS_GUARD_FLOATS
-EXPECTED_ABI = 5            # sos_abi_version() of the library these argument lists were written for
+EXPECTED_ABI = 6            # sos_abi_version() of the library these argument lists were written for
 
 # name -> argtypes, exactly the prototypes of include/sos_hip.h
 SIGNATURES = {
@@ -81,6 +81,7 @@ SIGNATURES = {
     "sos_add_signals_f32": [_P, _P, _P, _L, _I, _L, _F, _P, _P, _P, _P],
     "sos_storage_dtype": [],
     "sos_pack_nchw_to_nhwc": [_P, _L, _I, _L, _L, _P, _I, _I, _P, _P],
+    "sos_pack_nchw_wtaps": [_P, _L, _I, _L, _L, _I, _I, _I, _P, _P, _I, _I, _P, _P],
     "sos_conv2d_fwd": [C.POINTER(ConvDesc), _P],
     "sos_conv2d_tune": [C.POINTER(ConvDesc), _I, _I, C.POINTER(C.c_float), _P],
     "sos_conv2d_tune_save": [C.c_char_p],

@@ -155,8 +155,10 @@ class FusedAdam(torch.optim.Optimizer):
         if self.guard is not None and work:
             # one pass over the flat gradients (65 MB for the denoiser: ~15 us): any Inf / NaN -> found = 1, the Adam
             # kernels return at once, exp_avg / exp_avg_sq / the weights stay as they are, and the loss-scale target backs
-            # off.  Decided on the device: no host synchronisation.  (The host-side step counters still advance: the bias
-            # correction of later steps sees one step more than was applied.)
+            # off.  Decided on the device: no host synchronisation.  The host-side step counters count ATTEMPTS; the guard's
+            # [3] counts the skipped ones on the device and the Adam kernels take their bias corrections at attempts - skipped,
+            # i.e. at the number of updates actually applied (GradScaler semantics).  save_ckpt folds the two into the applied
+            # count and stores the guard's back-off state next to the optimizer's.
             for k, (_, _, ent) in enumerate(work):
                 L.check(L.lib().sos_grad_guard(L.ptr(ent["flat_g"]), ent["flat_g"].numel(), L.ptr(self.guard),
                                                1 if k == len(work) - 1 else 0, L.stream_ptr()), "sos_grad_guard")
@@ -279,23 +281,42 @@ class BaseAgent(object):
         self.clock = TrainClock()
         self.model_dir = model_dir
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        broadcast_module_state(self.net)
+        force = dist.is_initialized() and os.environ.get("SOS_FORCE_BUCKETS") == "1"
+        # One process group -- i.e. one RCCL communicator with its own stream -- PER MODEL: with the default group both models'
+        # buckets queue on one communicator stream and the detector's 9 MB all-reduce waits behind the denoiser's 65 MB
+        # (train_concurrent runs the two backward passes side by side).  Every rank constructs its agents in the same order,
+        # so the new_group calls match up.  SOS_SHARED_GROUP=1: the default group for every model (A/B).
+        self.group = None
+        if dist.is_initialized() and (self.world > 1 or force) and os.environ.get("SOS_SHARED_GROUP") != "1":
+            self.group = dist.new_group()
+        broadcast_module_state(self.net, group=self.group)
         self.optimizer = FusedAdam(self.net.parameters(), lr)
         self.optimizer.grad_scale = 1.0 / self.world
         from .engine import guard_state
         self.optimizer.guard = guard_state(self.net)
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, lr_step_size)
-        force = dist.is_initialized() and os.environ.get("SOS_FORCE_BUCKETS") == "1"
-        self.bucketer = GradBucketer(list(self.net.named_parameters())) if (self.world > 1 or force) else None
+        self.bucketer = GradBucketer(list(self.net.named_parameters()), group=self.group) if (self.world > 1 or force) else None
         self.net.grad_sink_factory = (lambda: GradSink(self.bucketer)) if self.bucketer is not None else None
 
     # -- checkpoints: M1/agent.py:62-100
     def save_ckpt(self, name=None):
         path = os.path.join(self.model_dir, f"ckpt_epoch{self.clock.epoch}.pth" if name is None else f"{name}.pth")
+        # the reference's four keys (M1/agent.py:62-78) + the overflow guard of the fp16 mode.  The optimizer's `step` entries
+        # are written as APPLIED updates (attempts minus the steps the device-side guard skipped) and the guard's skipped-step
+        # count as zero, so the pair stays consistent for this trainer and `step` means what it means to torch.optim.Adam.
+        from .engine import guard_state
+        guard = guard_state(self.net).detach().cpu().clone()          # (a host sync: checkpoints are outside the step loop)
+        skipped = float(guard[3])
+        osd = self.optimizer.state_dict()
+        if skipped:
+            osd = dict(osd, state={k: (dict(v, step=v["step"] - skipped) if "step" in v else v) for k, v in osd["state"].items()})
+        guard[3] = 0.0
+        guard[0] = 0.0
         torch.save({"clock": self.clock.make_checkpoint(),
                     "model_state_dict": {k: v.detach().cpu() for k, v in self.net.state_dict().items()},
-                    "optimizer_state_dict": self.optimizer.state_dict(),
-                    "scheduler_state_dict": self.scheduler.state_dict()}, path)
+                    "optimizer_state_dict": osd,
+                    "scheduler_state_dict": self.scheduler.state_dict(),
+                    "overflow_guard": guard}, path)
         return path
 
     def load_ckpt(self, name=None):
@@ -311,6 +332,11 @@ class BaseAgent(object):
                 st["step"] = st["step"].detach().cpu()
         self.scheduler.load_state_dict(ck["scheduler_state_dict"])
         self.clock.restore_checkpoint(ck["clock"])
+        from .engine import guard_state
+        g = guard_state(self.net)
+        g.zero_()                                    # a reference checkpoint has no guard entry: full loss scale, nothing skipped
+        if ck.get("overflow_guard") is not None:     # resumed fp16 run: the loss-scale back-off it had reached
+            g.copy_(ck["overflow_guard"].to(g.device, torch.float32))
 
     # -- M1/agent.py:101-130
     def update_network(self, loss_dict):

@@ -124,6 +124,14 @@ def encoder_plan(enc, x3):
     plan = []
     for i, blk in enumerate(enc):
         conv, bn = blk.block[0], blk.block[1]
+        wf = E.wfold_spec(conv, conv.padding[1], L.PAD_ZERO) if i == 0 else None
+        if wf is not None:      # horizontal taps on the channel axis (engine.wfold_spec): a kh x 1 layer over kw * I channels
+            cin_store = E.pad_to(wf["kw"] * wf["I"], 16)
+            w = E.pack_weight(lambda: wf["fold"](conv.weight.detach().float()), cin_store, x3)
+            scale, shift = E.fold_bn(bn, w.shape[1])
+            plan.append(dict(w=w, scale=scale, shift=shift, kh=conv.kernel_size[0], kw=1, dil=(conv.dilation[0], 1),
+                             pad=(conv.padding[0], 0), cout=conv.out_channels, cin_store=cin_store, wtaps=wf["wtaps"]))
+            continue
         cin_store = E.pad_to(conv.in_channels, 16)
         w = E.pack_weight(conv.weight, cin_store, x3)
         scale, shift = E.fold_bn(bn, w.shape[1])
@@ -131,6 +139,13 @@ def encoder_plan(enc, x3):
                          dil=tuple(conv.dilation), pad=tuple(conv.padding), cout=conv.out_channels,
                          cin_store=cin_store))
     return plan
+
+
+def pack_encoder_input(plan, x, x3, rag=None, mul=None):
+    """The f32 NCHW module input of an encoder stack as the Act its first block reads (with the first block's horizontal
+    taps on the channel axis when the plan says so)."""
+    wt = plan[0].get("wtaps")
+    return E.pack_input(x, x3, mul=mul, wtaps=wt, clip_w=(rag.level(0) if (rag is not None and wt is not None) else None))
 
 
 def run_encoder(plan, a, feat, feat_row, feat_third, feat_c_off, x3, w_gather=None, T_out=None, rag=None, rag_out=None):

@@ -130,16 +130,22 @@ __device__ __forceinline__ void stage_patch_dma(const ConvParams& p, char* patch
     // ds_read + s_waitcnt lgkmcnt(0) per instruction put ~11 serial LDS round trips per wave and chunk at the head of every
     // tile -- 20 % of a wave's life on the 3x3 / 7x1 layers, whose tiles hold 250-320 MFMAs per wave instead of 900).
     for (int i0 = wave; i0 < ninstr; i0 += 16) {
-        unsigned ent[4];
+        unsigned ent[4], ta[4];
         int qq[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int L = (i0 + 4 * u) * 64 + lane;
             const int pix = L / RP;
             qq[u] = L - pix * RP;
-            asm volatile("ds_read_b32 %0, %1" : "=v"(ent[u]) : "v"(tab_addr + (unsigned)min(pix, p.npix - 1) * 4u));
+            ta[u] = tab_addr + (unsigned)min(pix, p.npix - 1) * 4u;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent[0]), "+v"(ent[1]), "+v"(ent[2]), "+v"(ent[3]));
+        // ONE asm statement: the four requests and their wait cannot be separated, and the early-clobber outputs cannot share a
+        // register with an address that a later request still needs (as separate statements the compiler was free to copy or
+        // spill an `ent` register between its ds_read and the wait -- ADVICE r3)
+        asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(ent[0]), "=&v"(ent[1]), "=&v"(ent[2]), "=&v"(ent[3])
+                     : "v"(ta[0]), "v"(ta[1]), "v"(ta[2]), "v"(ta[3])
+                     : "memory");
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + 4 * u;
@@ -1269,6 +1275,12 @@ static int validate(const sos_conv_desc* d) {
                                                (int64_t)d->fold_H * d->fold_W * d->out_sw >= 0x7ffffff0ll))) {
         sos_set_error("sos_conv2d_fwd: bad reflection-pad fold (16-bit dense NHWC outputs inside the padded domain only)");
         return SOS_EINVAL;
+    }
+    // the staged (16-bit, channel-contiguous) store path keeps a pixel's offset inside its image in 32 bits
+    if (d->out_dtype != SOS_DT_F32 && d->out_sc == 1 && !d->fold_pad &&
+        (int64_t)(d->Ho - 1) * d->out_sh + (int64_t)(d->Wo - 1) * d->out_sw + d->out_c_off + d->cout_store >= 0x7ffffff0ll) {
+        sos_set_error("sos_conv2d_fwd: one output image spans more than 2^31 elements (Ho=%d Wo=%d)", d->Ho, d->Wo);
+        return SOS_ENOSPC;
     }
     if (d->pad_mode == SOS_PAD_REFLECT && (d->pad_top >= d->H || d->pad_left >= d->Wl)) {
         sos_set_error("sos_conv2d_fwd: reflect pad %d/%d needs a larger input (%dx%d)", d->pad_top, d->pad_left, d->H, d->Wl);

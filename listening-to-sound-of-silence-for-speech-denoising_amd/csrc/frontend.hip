@@ -344,3 +344,69 @@ extern "C" int sos_pack_nchw_to_nhwc(const float* in, int64_t B, int C, int64_t 
                        (bf16_t*)out, cs, x3, mul);
     return sos_check_launch("sos_pack_nchw_to_nhwc");
 }
+
+// ------------------------------------------- NCHW f32 -> NHWC with the horizontal taps of the first conv layer on the channel axis
+// The first block of every encoder / of the U-Net reads 2 channels (M1/networks.py:120-128, M2/networks.py:72-80,158,165):
+// on the MFMA kernels a tap contracts 16 stored channels of which 2 are real.  Folding the kw horizontal taps into the
+// channel axis HERE (channel t*C + c of pixel (h, w) = in[c][h][w + t - pad_left], zero or reflected outside the clip) costs
+// no extra byte -- a pixel is 16 stored channels either way -- and turns the kh x kw layer into a kh x 1 layer over kw*C
+// real channels (1x7: ONE tap with 14 of 16 channels real; 5x5: 5 taps with 10 of 16), for the forward conv and for its
+// weight gradient alike.
+__global__ void pack_wtaps_kernel(const float* __restrict__ in, int C, int H, int W, int64_t total, bf16_t* __restrict__ out,
+                                  int cs, int x3, int kw, int pad_l, int reflect, const int* __restrict__ clip_w,
+                                  const float* __restrict__ mul_p) {
+    const int third = x3 ? cs / 3 : cs;                  // multiple of 8, >= kw * C
+    const float mul = mul_p ? mul_p[0] : 1.f;
+    const int64_t HW = (int64_t)H * W;
+    const int kc = kw * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW, r = i - b * HW;
+        const int h = (int)(r / W), w = (int)(r - (int64_t)h * W);
+        const int Wc = clip_w ? clip_w[b] : W;
+        const float* ip = in + b * C * HW + (int64_t)h * W;
+        bf16_t* o = out + i * cs;
+        for (int c0 = 0; c0 < third; c0 += 8) {
+            unsigned hw4[4], lw4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k = c0 + 2 * e + u;
+                    float x = 0.f;
+                    if (k < kc && w < Wc) {
+                        const int t = k / C, c = k - t * C;
+                        int ws = w + t - pad_l;
+                        if (reflect) ws = reflect_index(ws, Wc);
+                        if (ws >= 0 && ws < Wc) x = ip[(int64_t)c * HW + ws] * mul;
+                    }
+                    v[u] = x;
+                }
+                hw4[e] = pack2bf(v[0], v[1]);
+                lw4[e] = pack2bf(v[0] - sos_lo2f(hw4[e]), v[1] - sos_hi2f(hw4[e]));
+            }
+            const uint4 hv = make_uint4(hw4[0], hw4[1], hw4[2], hw4[3]);
+            *(uint4*)(o + c0) = hv;
+            if (x3) {
+                *(uint4*)(o + c0 + third) = hv;
+                *(uint4*)(o + c0 + 2 * third) = make_uint4(lw4[0], lw4[1], lw4[2], lw4[3]);
+            }
+        }
+    }
+}
+
+extern "C" int sos_pack_nchw_wtaps(const float* in, int64_t B, int C, int64_t H, int64_t W, int kw, int pad_left, int pad_mode,
+                                   const int32_t* clip_w, void* out, int cs, int dtype, const float* mul, sos_stream_t stream) {
+    const int x3 = dtype == SOS_DT_BF16X3;
+    const int third = x3 ? cs / 3 : cs;
+    if (!in || !out || B < 1 || C < 1 || H < 1 || W < 1 || kw < 1 || pad_left < 0 || pad_left >= kw || (dtype != SOS_DT_BF16 && !x3) ||
+        (x3 && cs % 3) || third % 8 || third < kw * C || H * W >= 0x7fffffffll ||
+        (pad_mode != SOS_PAD_ZERO && pad_mode != SOS_PAD_REFLECT) || (pad_mode == SOS_PAD_REFLECT && pad_left >= W)) {
+        sos_set_error("sos_pack_nchw_wtaps: bad args (C=%d kw=%d pad=%d cs=%d)", C, kw, pad_left, cs);
+        return SOS_EINVAL;
+    }
+    const int64_t total = B * H * W;
+    hipLaunchKernelGGL(pack_wtaps_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, in, C, (int)H, (int)W, total,
+                       (bf16_t*)out, cs, x3, kw, pad_left, pad_mode == SOS_PAD_REFLECT ? 1 : 0, clip_w, mul);
+    return sos_check_launch("sos_pack_nchw_wtaps");
+}

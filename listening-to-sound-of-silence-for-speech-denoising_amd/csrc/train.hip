@@ -160,10 +160,23 @@ extern "C" int sos_grad_guard(const float* g, int64_t n, float* guard, int final
     return sos_check_launch("sos_grad_guard");
 }
 
+// Bias corrections count APPLIED updates (torch.cuda.amp.GradScaler does not advance `step` on a skipped update): the host's
+// step counter counts attempts; the guard's [3] holds the steps skipped so far ON THE DEVICE, so the corrections are
+// re-derived here from step - skipped whenever a step has ever been skipped (otherwise the host's values stand, bit for bit).
+__device__ __forceinline__ void adam_applied_steps(const float* __restrict__ skip, float step, float b1, float b2, float& bc1,
+                                                   float& bc2_sqrt) {
+    if (skip && skip[3] != 0.f) {
+        const float applied = fmaxf(step - skip[3], 1.f);
+        bc1 = 1.0f - powf(b1, applied);
+        bc2_sqrt = sqrtf(1.0f - powf(b2, applied));
+    }
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
-                            float bc1, float bc2_sqrt, float gscale, const float* __restrict__ skip) {
+                            float bc1, float bc2_sqrt, float gscale, const float* __restrict__ skip, float step) {
     if (skip && skip[0] != 0.f) return;
+    adam_applied_steps(skip, step, b1, b2, bc1, bc2_sqrt);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float gi = g[i] * gscale;
         const float pi = p[i];
@@ -187,7 +200,7 @@ extern "C" int sos_adam_step(float* p, const float* g, float* m, float* v, int64
     long long gb = (n + 255) / 256;
     if (gb > 2048) gb = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr,
-                       beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale, skip);
+                       beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale, skip, (float)step);
     return sos_check_launch("sos_adam_step");
 }
 
@@ -198,8 +211,9 @@ extern "C" int sos_adam_step(float* p, const float* g, float* m, float* v, int64
 struct AdamTensor { float* p; const float* g; float* m; float* v; long long n; };
 __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTensor* __restrict__ tab, const int2* __restrict__ chunks,
                                                          float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                         float bc2_sqrt, float gscale, const float* __restrict__ skip) {
+                                                         float bc2_sqrt, float gscale, const float* __restrict__ skip, float step) {
     if (skip && skip[0] != 0.f) return;         // overflow guard: the whole step is dropped (uniform over the grid)
+    adam_applied_steps(skip, step, b1, b2, bc1, bc2_sqrt);
     const int2 c = chunks[blockIdx.x];
     const AdamTensor t = tab[c.x];
     const long long lo = (long long)c.y * SOS_ADAM_CHUNK;
@@ -229,7 +243,7 @@ extern "C" int sos_adam_multi_step(const sos_adam_tensor* tensors, int n_tensors
     const float bc2 = 1.0f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream,
                        (const AdamTensor*)tensors, (const int2*)chunks, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
-                       grad_scale, skip);
+                       grad_scale, skip, (float)step);
     return sos_check_launch("sos_adam_multi_step");
 }
 

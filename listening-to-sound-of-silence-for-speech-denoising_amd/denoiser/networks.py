@@ -51,10 +51,18 @@ class UpConvBlock(nn.Module):
         raise RuntimeError("UpConvBlock is executed by InpaintNet through libsos_hip")
 
 
-def _down_plan(blk, x3, in_perm=None):
+def _down_plan(blk, x3, in_perm=None, first=False):
+    """first=True: the block reads the 2-channel module input -- its horizontal taps may sit on the channel axis
+    (engine.wfold_spec): the plan then describes a k x 1 layer and carries `wtaps` for the boundary pack."""
     conv = blk.block[1]
-    cin_store = E.pad_to(conv.in_channels, 16)
-    w = E.pack_weight(conv.weight, cin_store, x3, in_perm)
+    k0 = conv.kernel_size[0]
+    wf = E.wfold_spec(conv, (k0 - 1) // 2 * conv.dilation[0], L.PAD_REFLECT) if (first and in_perm is None) else None
+    if wf is not None:
+        cin_store = E.pad_to(wf["kw"] * wf["I"], 16)
+        w = E.pack_weight(lambda: wf["fold"](conv.weight.detach().float()), cin_store, x3)
+    else:
+        cin_store = E.pad_to(conv.in_channels, 16)
+        w = E.pack_weight(conv.weight, cin_store, x3, in_perm)
     has_bn = len(blk.block) > 2 and isinstance(blk.block[2], nn.BatchNorm2d)
     if has_bn:
         scale, shift = E.fold_bn(blk.block[2], w.shape[1])
@@ -63,8 +71,10 @@ def _down_plan(blk, x3, in_perm=None):
         shift = E.pad_vec(conv.bias, w.shape[1])
     prelu = blk.block[-1] if isinstance(blk.block[-1], nn.PReLU) else None
     k = conv.kernel_size[0]
-    return dict(w=w, scale=scale, shift=shift, k=k, stride=conv.stride[0], dil=conv.dilation[0],
-                pad=(k - 1) // 2 * conv.dilation[0], cout=conv.out_channels, cin_store=cin_store,
+    pad = (k - 1) // 2 * conv.dilation[0]
+    return dict(w=w, scale=scale, shift=shift, k=k, kw=1 if wf is not None else k, stride=conv.stride[0], dil=conv.dilation[0],
+                pad=pad, pad_w=0 if wf is not None else pad, cout=conv.out_channels, cin_store=cin_store,
+                wtaps=wf["wtaps"] if wf is not None else None,
                 slope=prelu.weight.detach().float() if prelu is not None else None,
                 act=L.ACT_PRELU if prelu is not None else L.ACT_NONE)
 
@@ -93,9 +103,9 @@ def _up_plan(blk, x3):
 
 def _run_down(lp, src, cin_off, dst, c_off, Ho, Wo, rk=None):
     """rk: ragged-batch keywords (engine.Ragged.kw): the clips' own input / output widths."""
-    E.conv_to_act(src, cin_off, lp["cin_store"], lp["w"], lp["k"], lp["k"], lp["cout"], lp["scale"], lp["shift"],
+    E.conv_to_act(src, cin_off, lp["cin_store"], lp["w"], lp["k"], lp["kw"], lp["cout"], lp["scale"], lp["shift"],
                   lp["act"], dst, c_off=c_off, cout_store=lp["cout"], stride=lp["stride"], dil=(lp["dil"], lp["dil"]),
-                  pad=(lp["pad"], lp["pad"]), pad_mode=L.PAD_REFLECT, slope=lp["slope"], Ho=Ho, Wo=Wo, **(rk or {}))
+                  pad=(lp["pad"], lp["pad_w"]), pad_mode=L.PAD_REFLECT, slope=lp["slope"], Ho=Ho, Wo=Wo, **(rk or {}))
 
 
 def _run_up(lp, src, dst, c_off, rag=None, lsrc=0, ldst=0):
@@ -145,8 +155,8 @@ class InpaintNet(nn.Module):
     def build_plan(self, x3):
         perm_up1 = list(range(128, 256)) + list(range(0, 128))   # buffer order [down4 | out] vs cat([out, down4])
         return dict(
-            down1=_down_plan(self.down1[0], x3), down2_0=_down_plan(self.down2[0], x3),
-            down2_1=_down_plan(self.down2[1], x3), down3=_down_plan(self.down3[0], x3),
+            down1=_down_plan(self.down1[0], x3, first=True), down2_0=_down_plan(self.down2[0], x3),
+            down2_1=_down_plan(self.down2[1], x3), down3=_down_plan(self.down3[0], x3, first=True),
             down4_0=_down_plan(self.down4[0], x3), down4_1=_down_plan(self.down4[1], x3),
             mid=[_down_plan(self.mid[i], x3) for i in range(8)], mid8=_up_plan(self.mid[8], x3),
             up1_0=_down_plan(self.up1[0], x3, perm_up1), up1_1=_up_plan(self.up1[1], x3),
@@ -161,7 +171,9 @@ class InpaintNet(nn.Module):
         B, _, H, W = x.shape
         H1, W1 = (H + 1) // 2, (W + 1) // 2          # after the 5x5 stride-2 reflect-padded convs
         H2, W2 = (H1 + 1) // 2, (W1 + 1) // 2        # after the 3x3 stride-2 one
-        ax, ay = E.pack_input(x, x3), E.pack_input(y, x3)
+        cw = rag.level(0) if rag is not None else None
+        ax = E.pack_input(x, x3, wtaps=plan["down1"]["wtaps"], clip_w=cw if plan["down1"]["wtaps"] else None)
+        ay = E.pack_input(y, x3, wtaps=plan["down3"]["wtaps"], clip_w=cw if plan["down3"]["wtaps"] else None)
         d1 = E.Act(B, H, W, 64, x3, dev)
         U2 = E.Act(B, H, W, 128, x3, dev)            # [up1.1 out | down3]
         X = E.Act(B, H1, W1, 384, x3, dev)           # [down2 | down4 | mid.8 out]
@@ -194,8 +206,8 @@ class InpaintNet(nn.Module):
     def build_train_plan(self, x3):
         perm_up1 = list(range(128, 256)) + list(range(0, 128))
         P = TO.down_train_plan
-        return dict(down1=P(self.down1[0], x3), down2_0=P(self.down2[0], x3), down2_1=P(self.down2[1], x3),
-                    down3=P(self.down3[0], x3), down4_0=P(self.down4[0], x3), down4_1=P(self.down4[1], x3),
+        return dict(down1=P(self.down1[0], x3, first=True), down2_0=P(self.down2[0], x3), down2_1=P(self.down2[1], x3),
+                    down3=P(self.down3[0], x3, first=True), down4_0=P(self.down4[0], x3), down4_1=P(self.down4[1], x3),
                     mid=[P(self.mid[i], x3) for i in range(8)], mid8=TO.up_train_plan(self.mid[8], x3),
                     up1_0=P(self.up1[0], x3, perm_up1), up1_1=TO.up_train_plan(self.up1[1], x3),
                     up2_0=P(self.up2[0], x3), up2_1=_down_plan(self.up2[1], x3),
@@ -207,7 +219,8 @@ class InpaintNet(nn.Module):
         B, _, H, W = x.shape
         H1, W1 = (H + 1) // 2, (W + 1) // 2
         H2, W2 = (H1 + 1) // 2, (W1 + 1) // 2
-        ax, ay = E.pack_input(x, x3), E.pack_input(y, x3)
+        ax = E.pack_input(x, x3, wtaps=plan["down1"].get("wtaps"))
+        ay = E.pack_input(y, x3, wtaps=plan["down3"].get("wtaps"))
         d1 = E.Act(B, H, W, 64, x3, dev)
         U2 = E.Act(B, H, W, 128, x3, dev)
         X = E.Act(B, H1, W1, 384, x3, dev)
@@ -289,8 +302,8 @@ class ContextAggNet(nn.Module):
         # ragged: rows of frames past a clip's end stay zero (finite) -- the FC head runs over all rows
         feat = (torch.empty if rag is None else torch.zeros)((B, T, nseg * nfeat), dtype=E.act_dtype(), device=dev)
         lengths = rag.level(0) if rag is not None else None
-        CN.run_encoder(plan["enc_x"], E.pack_input(x, x3), feat, nseg * nfeat, nfeat, 0, x3, rag=rag)
-        CN.run_encoder(plan["enc_n"], E.pack_input(n, x3), feat, nseg * nfeat, nfeat, 8, x3, rag=rag)
+        CN.run_encoder(plan["enc_x"], CN.pack_encoder_input(plan["enc_x"], x, x3, rag), feat, nseg * nfeat, nfeat, 0, x3, rag=rag)
+        CN.run_encoder(plan["enc_n"], CN.pack_encoder_input(plan["enc_n"], n, x3, rag), feat, nseg * nfeat, nfeat, 8, x3, rag=rag)
         h = CN.run_lstm(plan["lstm"], (feat, B, 1, T, nfeat, nseg), B, T, x3, dev, lengths=lengths)
         f0, f2, f4 = plan["fc0"], plan["fc2"], plan["fc4"]
         a0 = E.Act(B, 1, T, E.pad_to(600, 16), x3, dev)
@@ -319,8 +332,8 @@ class ContextAggNet(nn.Module):
         nfeat = 12 * F
         feat = torch.empty((B, T, nseg * nfeat), dtype=E.act_dtype(), device=dev)
         fs = dict(t=feat, row=nseg * nfeat, third=nfeat, H=F, W=T, Wo=T, gather=None, x3=x3)
-        tx = TO.encoder_forward_train(plan["enc_x"], E.pack_input(x, x3), dict(fs, c_off=0), x3)
-        tn = TO.encoder_forward_train(plan["enc_n"], E.pack_input(n, x3), dict(fs, c_off=8), x3)
+        tx = TO.encoder_forward_train(plan["enc_x"], CN.pack_encoder_input(plan["enc_x"], x, x3), dict(fs, c_off=0), x3)
+        tn = TO.encoder_forward_train(plan["enc_n"], CN.pack_encoder_input(plan["enc_n"], n, x3), dict(fs, c_off=8), x3)
         if before_lstm is not None:    # agent.train_concurrent: the recurrence, the FC head and their backward leave the chip
             before_lstm()              # mostly idle (8 workgroups stepping through T frames): another model's forward may start
         h, tl = TO.lstm_forward_train(plan["lstm"], (feat, B, 1, T, nfeat, nseg), B, T, x3, dev)

@@ -84,7 +84,7 @@ class AudioVisualNet(nn.Module):
         B, _, F, T = s.shape
         nseg = 3 if x3 else 1
         nfeat = 8 * F + self.video_feat
-        a = E.pack_input(s, x3)
+        a = CN.pack_encoder_input(plan["enc"], s, x3)
         feat = torch.empty((B, n, nseg * nfeat), dtype=E.act_dtype(), device=dev)
         gather = CN.nearest_index(T, n, dev)
         fspec = dict(t=feat, row=nseg * nfeat, third=nfeat, c_off=0, H=F, W=T, Wo=n, gather=gather, x3=x3)
@@ -161,7 +161,7 @@ class AudioVisualNet(nn.Module):
         x3 = plan["x3"]
         dev = s.device
         B, _, F, T = s.shape
-        a = E.pack_input(s, x3)
+        a = CN.pack_encoder_input(plan["enc"], s, x3, rag)
         nseg = 3 if x3 else 1
         nfeat = 8 * F + self.video_feat
         lengths = None

@@ -38,6 +38,18 @@ class LaunchProfiler:
 
 PROFILER = None
 
+# SOS_LAUNCH_LOG=<file>: one line per conv / weight-gradient launch, in enqueue order: "conv|<signature>" / "wgrad|<signature>".
+# profiles/summarize_rocpd.py joins it with the rocprofv3 kernel trace of the same process (the k-th conv-family dispatch is the
+# k-th "conv" line), so that the per-kernel table has one row per (kernel, layer signature) and the roofline fraction of the
+# dominant SIGNATURE is recomputable from profiles/ (VERDICT r3 #6).  Off by default: no file, no overhead.
+_LAUNCH_LOG = None
+if _os.environ.get("SOS_LAUNCH_LOG"):
+    _LAUNCH_LOG = open(_os.environ["SOS_LAUNCH_LOG"], "a", buffering=1)
+
+
+def _log_launch(kind, sig, flops):
+    _LAUNCH_LOG.write("%s|%s|%.6g\n" % (kind, ",".join(str(v) for v in sig[1:]), flops))
+
 # Conv tilings.  By default every process loads the SHIPPED table (tune_table_gfx950.txt, measured once on an MI355X for
 # the BASELINE shapes) and uses the deterministic cost-model pick for any other shape: two processes -- or two ranks of
 # one data-parallel job -- therefore run identical tilings, i.e. identical summation orders and bit-identical results.
@@ -178,16 +190,42 @@ def guard_state(net):
     return g
 
 
-def pack_input(x, x3=None, mul=None):
-    """f32 NCHW module input -> Act with cs = 16 (sos_pack_nchw_to_nhwc); `mul`: optional device scalar (loss scale)."""
+WFOLD = _os.environ.get("SOS_WFOLD", "1") != "0"       # A/B switch: horizontal taps of the 2-channel first layers on the channel axis
+
+
+def pack_input(x, x3=None, mul=None, wtaps=None, clip_w=None):
+    """f32 NCHW module input -> Act with cs = 16 (sos_pack_nchw_to_nhwc); `mul`: optional device scalar (loss scale).
+    wtaps = (kw, pad_left, pad_mode): the horizontal taps of the first conv layer folded into the channel axis
+    (sos_pack_nchw_wtaps, see wfold_spec); clip_w: int32 device [B], the clips' own widths of a ragged batch."""
     L.require_cuda(x)
     x3 = is_x3() if x3 is None else x3
     x = x.contiguous().float()
     B, Cc, H, W = x.shape
+    if wtaps is not None:
+        kw, pad_left, pad_mode = wtaps
+        a = Act(B, H, W, pad_to(kw * Cc, 16), x3, x.device)
+        L.check(L.lib().sos_pack_nchw_wtaps(L.ptr(x), B, Cc, H, W, kw, pad_left, pad_mode, L.ptr(clip_w), L.ptr(a.t),
+                                            a.nseg * a.cs, a.dtype_code, L.ptr(mul), L.stream_ptr()), "sos_pack_nchw_wtaps")
+        return a
     a = Act(B, H, W, pad_to(Cc, 16), x3, x.device)
     L.check(L.lib().sos_pack_nchw_to_nhwc(L.ptr(x), B, Cc, H, W, L.ptr(a.t), a.nseg * a.cs, a.dtype_code,
                                           L.ptr(mul), L.stream_ptr()), "sos_pack_nchw_to_nhwc")
     return a
+
+
+def wfold_spec(conv, pad_left, pad_mode):
+    """A first layer whose input is the 2-channel module input (Conv2d(2, nf, (1,7)) of the encoders, M1/networks.py:120-128 /
+    M2/networks.py:72-80; DownConvBlock(2, 64, 5, 1) of the U-Net, M2/networks.py:158,165): on the MFMA kernels a tap contracts
+    16 stored channels of which 2 are real.  With the kw horizontal taps folded into the channel axis by the boundary pack
+    (sos_pack_nchw_wtaps: stored channel t*I + c = x[c][h][w + t - pad_left]) the layer is a kh x 1 conv over kw*I real channels
+    with w'[o][t*I + c][a][0] = w[o][c][a][t]: 14 (1x7) or 10 (5x5) of 16 channels real, 1/kw of the taps -- forward conv and
+    weight gradient alike.  Returns None when the layer does not qualify, else dict(kw, I, wtaps, fold(w), unfold(dw'))."""
+    O, I, kh, kw = conv.weight.shape
+    if (not WFOLD or kw < 2 or kw * I > 16 or conv.dilation[1] != 1 or conv.stride[1] != 1 or conv.stride[0] != 1):
+        return None
+    return dict(kw=kw, I=I, wtaps=(kw, pad_left, pad_mode),
+                fold=lambda w: w.permute(0, 3, 1, 2).reshape(O, kw * I, kh, 1),
+                unfold=lambda dw: dw.reshape(O, kw, I, kh).permute(0, 2, 3, 1).contiguous())
 
 
 def pack_weight(w, cin_store, x3, in_perm=None):
@@ -349,7 +387,7 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
     Bp, Wop = B, Wo                       # (the profiler's signature keeps the layer's own dimensions)
     if (FLATTEN_1X1 and kh == 1 and kw == 1 and stride == 1 and pad == (0, 0) and H == 1 and Ho == 1 and Wo == W and B > 1
             and w_gather is None and wl_tab is None and temporal is None and fold is None and not stats_c and sb == Wo * sw
-            and B * W * nseg * cs * 2 < 0xfff00000):
+            and B * W * nseg * cs * 2 < 0xfff00000 and B * Wo * sw < 0x7ffffff0):     # (input bytes and output offsets stay 32-bit)
         B, W, Wo = 1, B * W, B * Wo
     d.in_ = t.data_ptr()
     d.B, d.H, d.W = B, H, W
@@ -387,29 +425,34 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
         d.fold_sy, d.fold_oy, d.fold_sx, d.fold_ox = fsy, foy, fsx, fox
         d.fold_row, d.fold_third = fa.nseg * fa.cs, fa.cs
     _load_tune_cache()
-    if AUTOTUNE and fold is None:          # (a folded launch shares its tiling with the plain data-gradient launch of the same shape)
+    if AUTOTUNE:
+        # (folded data-gradient launches are tuned like any other shape: with the fused fold -- the default -- the plain
+        # padded-domain launch they used to share a tiling with no longer happens)
         key = (B, H, W, d.Wl, cin, d.in_nseg, d.cout_pad, cout, kh, kw, stride, dil, Ho, Wo, out_dtype, sc == 1, pad_mode,
                w_gather is not None, d.t_taps)
         if key not in _tuned and not torch.cuda.is_current_stream_capturing():
             _tuned.add(key)
-            if accumulate:
-                # the tuner launches the kernel many times: never let it accumulate into the real
-                # gradient buffer -- tune a non-accumulating copy of the descriptor on scratch output
+            if accumulate or fold is not None:
+                # the tuner launches the kernel many times: never let it accumulate into (or store interior cells over) the
+                # real gradient buffer -- tune a non-accumulating copy of the descriptor on scratch output
                 scratch = torch.empty_like(out)
-                real_out = d.out
+                real_out, real_acc = d.out, d.accumulate
                 d.out = scratch.data_ptr() + out_elem_offset * esize
                 d.accumulate = 0
                 L.check(L.lib().sos_conv2d_tune(C.byref(d), TUNE_CANDIDATES, 3, None, L.stream_ptr()), "sos_conv2d_tune")
-                d.out, d.accumulate = real_out, 1
+                d.out, d.accumulate = real_out, real_acc
             else:
                 L.check(L.lib().sos_conv2d_tune(C.byref(d), TUNE_CANDIDATES, 3, None, L.stream_ptr()), "sos_conv2d_tune")
     end = None
-    if PROFILER is not None:
+    if PROFILER is not None or _LAUNCH_LOG is not None:
         # ragged batches: only the clips' own columns are algorithmic work (valid_cols = their sum)
         cols = Bp * Wop if valid_cols is None else valid_cols
         kin = d.in_nseg * max(1, d.t_taps) * cin
         sig = ("conv", kh, kw, dil[0], dil[1], stride, kin, cout, Bp, Ho, Wop) + (() if valid_cols is None else ("ragged", cols))
-        end = PROFILER.bracket(sig, 2.0 * Ho * cols * cout * kin * kh * kw)
+        if _LAUNCH_LOG is not None:
+            _log_launch("conv", sig, 2.0 * Ho * cols * cout * kin * kh * kw)
+        if PROFILER is not None:
+            end = PROFILER.bracket(sig, 2.0 * Ho * cols * cout * kin * kh * kw)
     stats = None
     if stats_c:
         tiles = L.lib().sos_conv2d_tile_count(C.byref(d))
@@ -665,9 +708,12 @@ def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0,
         d.scale = scale
         d.scale_dev = gs.inv.data_ptr() if gs.inv is not None else None
         end = None
-        if PROFILER is not None:
+        if PROFILER is not None or _LAUNCH_LOG is not None:
             sig = ("wgrad", kh, kw, dil[0], dil[1], stride, M, N, g.B, g.H, g.W)
-            end = PROFILER.bracket(sig, 2.0 * g.B * g.H * g.W * M * N * kh * kw)
+            if _LAUNCH_LOG is not None:
+                _log_launch("wgrad", sig, 2.0 * g.B * g.H * g.W * M * N * kh * kw)
+            if PROFILER is not None:
+                end = PROFILER.bracket(sig, 2.0 * g.B * g.H * g.W * M * N * kh * kw)
         L.check(L.lib().sos_conv2d_wgrad(ctypes.byref(d), L.stream_ptr()), "sos_conv2d_wgrad")
         if end is not None:
             end.record()

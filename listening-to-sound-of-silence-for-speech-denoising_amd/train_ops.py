@@ -95,8 +95,21 @@ def _side_stream(dev, cur):
 
 def encoder_train_plan(enc, x3):
     plan = []
-    for blk in enc:
+    for i, blk in enumerate(enc):
         conv, bn = blk.block[0], blk.block[1]
+        wf = E.wfold_spec(conv, conv.padding[1], L.PAD_ZERO) if i == 0 else None
+        if wf is not None:
+            # first block: horizontal taps on the channel axis (engine.wfold_spec) -- forward conv and weight gradient see a
+            # kh x 1 layer over kw * I channels; the data gradient (encoder_n only: the stage-1 prediction) keeps the layer's
+            # own geometry (`dg`), it contracts the 48 output channels
+            cin_store = E.pad_to(wf["kw"] * wf["I"], 16)
+            plan.append(dict(w=E.pack_weight(lambda conv=conv, wf=wf: wf["fold"](conv.weight.detach().float()), cin_store, x3),
+                             wd=dgrad_weight(conv.weight, x3), conv=conv, bn=bn, kh=conv.kernel_size[0], kw=1,
+                             dil=(conv.dilation[0], 1), pad=(conv.padding[0], 0), cout=conv.out_channels,
+                             cin=wf["kw"] * wf["I"], cin_store=cin_store, wtaps=wf["wtaps"], unfold=wf["unfold"],
+                             dg=dict(kh=conv.kernel_size[0], kw=conv.kernel_size[1], dil=tuple(conv.dilation),
+                                     pad=tuple(conv.padding), cin=conv.in_channels)))
+            continue
         cin_store = E.pad_to(conv.in_channels, 16)
         plan.append(dict(w=E.pack_weight(conv.weight, cin_store, x3), wd=dgrad_weight(conv.weight, x3), conv=conv, bn=bn,
                          kh=conv.kernel_size[0], kw=conv.kernel_size[1], dil=tuple(conv.dilation),
@@ -152,28 +165,30 @@ def _encoder_backward(plan, tape, dy, grads, prefix, x3, need_input_grad, dev, c
         dgamma, dbeta, _ = bn_bwd(dy, 0, raw, 0, lp["cout"], tp["saved"], lp["bn"].weight, L.ACT_RELU, None, d_raw)
         grads[f"{prefix}.{i}.block.1.weight"] = dgamma
         grads[f"{prefix}.{i}.block.1.bias"] = dbeta
+        dw_shape = (lp["cout"], lp["cin"], lp["kh"], lp["kw"])       # (the folded first block: (O, kw * I, kh, 1), un-folded below)
         if side is not None:
             # the weight gradient (MFMA bound, one workgroup per CU) depends only on d_raw and the block's input: it runs on
             # a side stream under the data gradient + the BatchNorm backward passes of the block below (HBM bound)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                dw = torch.empty_like(lp["conv"].weight, dtype=torch.float32)
+                dw = torch.empty(dw_shape, dtype=torch.float32, device=dev)
                 E.wgrad(d_raw, 0, lp["cout"], tp["inp"], 0, lp["cin"], lp["kh"], lp["kw"], dw, dil=lp["dil"], pad=lp["pad"], gs=gs)
             d_raw.t.record_stream(side)
             dw.record_stream(cur)
         else:
-            dw = torch.empty_like(lp["conv"].weight, dtype=torch.float32)
+            dw = torch.empty(dw_shape, dtype=torch.float32, device=dev)
             E.wgrad(d_raw, 0, lp["cout"], tp["inp"], 0, lp["cin"], lp["kh"], lp["kw"], dw, dil=lp["dil"], pad=lp["pad"])
-        grads[f"{prefix}.{i}.block.0.weight"] = dw
+        grads[f"{prefix}.{i}.block.0.weight"] = lp["unfold"](dw) if "unfold" in lp else dw
         if i == 0 and not need_input_grad:
             break
         inp = tp["inp"]
         d_in = E.Act(inp.B, inp.H, inp.W, inp.cs, x3, dev)
         one, zero = ones_zeros(lp["wd"].shape[1], dev)
+        dg = lp.get("dg", lp)           # geometry of the data gradient: the layer's own (a folded first block keeps it in `dg`)
         # "same" convs: pad' = dil*(k-1) - pad == pad
-        E.conv_to_act(d_raw, 0, d_raw.cs, lp["wd"], lp["kh"], lp["kw"], lp["cin"], one, zero, L.ACT_NONE, d_in,
-                      cout_store=inp.cs, dil=lp["dil"],
-                      pad=(lp["dil"][0] * (lp["kh"] - 1) - lp["pad"][0], lp["dil"][1] * (lp["kw"] - 1) - lp["pad"][1]),
+        E.conv_to_act(d_raw, 0, d_raw.cs, lp["wd"], dg["kh"], dg["kw"], dg["cin"], one, zero, L.ACT_NONE, d_in,
+                      cout_store=inp.cs, dil=dg["dil"],
+                      pad=(dg["dil"][0] * (dg["kh"] - 1) - dg["pad"][0], dg["dil"][1] * (dg["kw"] - 1) - dg["pad"][1]),
                       Ho=inp.H, Wo=inp.W)
         dy = d_in
     return dy
@@ -483,8 +498,10 @@ def copy_crop(src, src_off, dst, dst_off, C):
             "sos_copy_crop")
 
 
-def down_train_plan(blk, x3, in_perm=None):
-    """DownConvBlock: block.0 ReflectionPad2d, block.1 Conv2d, [block.2 BN, block.3 PReLU]."""
+def down_train_plan(blk, x3, in_perm=None, first=False):
+    """DownConvBlock: block.0 ReflectionPad2d, block.1 Conv2d, [block.2 BN, block.3 PReLU].  first=True: the block reads the
+    2-channel module input and needs no input gradient -- its horizontal taps may sit on the channel axis (engine.wfold_spec):
+    forward conv and weight gradient then see a k x 1 layer over kw * I channels (`kw` = 1, `pad_w` = 0, `wtaps` for the pack)."""
     import torch.nn as nn
     conv = blk.block[1]
     has_bn = len(blk.block) > 2 and isinstance(blk.block[2], nn.BatchNorm2d)
@@ -494,9 +511,15 @@ def down_train_plan(blk, x3, in_perm=None):
     cout_cs = E.pad_to(conv.out_channels, 16)
     wf = lambda: conv.weight.detach().float()                                    # noqa: E731
     wperm = lambda: wf() if in_perm is None else wf()[:, in_perm]                 # noqa: E731
+    fold = E.wfold_spec(conv, (k - 1) // 2 * d, L.PAD_REFLECT) if (first and in_perm is None) else None
+    if fold is not None:
+        cin_store = E.pad_to(fold["kw"] * fold["I"], 16)
+        return dict(w=E.pack_weight(lambda: fold["fold"](wf()), cin_store, x3), conv=conv, bn=blk.block[2] if has_bn else None,
+                    prelu=prelu, k=k, kw=1, stride=s, dil=d, pad=(k - 1) // 2 * d, pad_w=0, cout=conv.out_channels,
+                    cin=fold["kw"] * fold["I"], cin_store=cin_store, in_perm=None, wtaps=fold["wtaps"], unfold=fold["unfold"])
     plan = dict(w=E.pack_weight(wf, cin_store, x3, in_perm), conv=conv, bn=blk.block[2] if has_bn else None, prelu=prelu,
-                k=k, stride=s, dil=d, pad=(k - 1) // 2 * d, cout=conv.out_channels, cin=conv.in_channels,
-                cin_store=cin_store, in_perm=in_perm)
+                k=k, kw=k, stride=s, dil=d, pad=(k - 1) // 2 * d, pad_w=(k - 1) // 2 * d, cout=conv.out_channels,
+                cin=conv.in_channels, cin_store=cin_store, in_perm=in_perm)
     if s == 1:
         plan["wd"] = E.pack_weight(lambda: wperm().flip(2, 3).transpose(0, 1).contiguous(), cout_cs, x3)
     else:
@@ -535,8 +558,8 @@ def down_forward_train(lp, src, cin_off, dst, c_off, Ho, Wo, x3):
     cs = E.pad_to(lp["cout"], 16)
     one, zero = ones_zeros(lp["w"].shape[1], dev)
     raw = E.Act(src.B, Ho, Wo, cs, x3, dev)
-    E.conv_to_act(src, cin_off, lp["cin_store"], lp["w"], lp["k"], lp["k"], lp["cout"], one, zero, L.ACT_NONE, raw,
-                  cout_store=cs, stride=lp["stride"], dil=(lp["dil"], lp["dil"]), pad=(lp["pad"], lp["pad"]),
+    E.conv_to_act(src, cin_off, lp["cin_store"], lp["w"], lp["k"], lp["kw"], lp["cout"], one, zero, L.ACT_NONE, raw,
+                  cout_store=cs, stride=lp["stride"], dil=(lp["dil"], lp["dil"]), pad=(lp["pad"], lp["pad_w"]),
                   pad_mode=L.PAD_REFLECT, Ho=Ho, Wo=Wo)
     saved = E.bn_train(raw, 0, lp["cout"], lp["bn"], L.ACT_PRELU, lp["prelu"].weight, dst, c_off)
     return dict(kind="down", lp=lp, src=src, cin_off=cin_off, dst=dst, c_off=c_off, raw=raw, saved=saved)
@@ -635,6 +658,11 @@ def _reflect_dgrad(lp, d_raw, src, cin_off, gb, x3):
     fused = FOLD_FUSED and lp["cin"] % 8 == 0 and p > 0
     dst = gb.of(src)
     accumulate = not gb.first_write(src, cin_off, lp["cin"])
+    if not fused and not accumulate and lp["cin"] % 8:
+        # sos_reflect_fold STORES whole 8-channel groups: a slice that is not a multiple of 8 inside a wider gradient buffer
+        # would zero up to 7 neighbouring channels -- zero the slice and accumulate instead
+        gb._zero(src, cin_off, cin_off + lp["cin"])
+        accumulate = True
     dpad = E.Act(src.B, H + 2 * p, W + 2 * p, cin_cs, x3, dev, zero=(lp["stride"] != 1 and not fused))
     drow = dst.nseg * dst.cs
     if lp["stride"] == 1:
@@ -675,9 +703,11 @@ def down_backward(t, gb, grads, name, x3, need_src_grad=True):
     dgamma, dbeta, dslope = bn_bwd(gb.read(t["dst"], t["c_off"], lp["cout"]), t["c_off"], raw, 0, lp["cout"], t["saved"],
                                    lp["bn"].weight, L.ACT_PRELU, lp["prelu"].weight, d_raw)
     grads[f"{name}.block.2.weight"], grads[f"{name}.block.2.bias"], grads[f"{name}.block.3.weight"] = dgamma, dbeta, dslope
-    dw = torch.empty_like(lp["conv"].weight, dtype=torch.float32)
-    E.wgrad(d_raw, 0, lp["cout"], t["src"], t["cin_off"], lp["cin"], lp["k"], lp["k"], dw, stride=lp["stride"],
-            dil=(lp["dil"], lp["dil"]), pad=(lp["pad"], lp["pad"]), pad_mode=L.PAD_REFLECT)
+    dw = torch.empty((lp["cout"], lp["cin"], lp["k"], lp["kw"]), dtype=torch.float32, device=dev)
+    E.wgrad(d_raw, 0, lp["cout"], t["src"], t["cin_off"], lp["cin"], lp["k"], lp["kw"], dw, stride=lp["stride"],
+            dil=(lp["dil"], lp["dil"]), pad=(lp["pad"], lp["pad_w"]), pad_mode=L.PAD_REFLECT)
+    if "unfold" in lp:                      # first block with its horizontal taps on the channel axis: back to (O, I, kh, kw)
+        dw = lp["unfold"](dw)
     if lp["in_perm"] is not None:           # dw is in the stored channel order; undo the concat permutation
         key = (tuple(lp["in_perm"]), str(dw.device))
         inv = _INV_PERM.get(key)
@@ -691,6 +721,8 @@ def down_backward(t, gb, grads, name, x3, need_src_grad=True):
         dw = dw[:, inv].contiguous()
     grads[f"{name}.block.1.weight"] = dw
     if need_src_grad:
+        if "unfold" in lp:
+            raise RuntimeError("down_backward: a block planned with first=True (folded horizontal taps) has no input gradient")
         _reflect_dgrad(lp, d_raw, t["src"], t["cin_off"], gb, x3)
 
 

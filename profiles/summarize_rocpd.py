@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd sqlite database (kernel trace) into a per-kernel table.
-usage: summarize_rocpd.py results.db [out.md]"""
+usage: summarize_rocpd.py results.db [out.md [launch_log]]"""
 import sqlite3
 import sys
 
@@ -29,6 +29,32 @@ lines = [f"total kernel time {tot:.2f} ms over {sum(r[6] for r in rows)} dispatc
          "| kernel | blocks.x | grid.y | LDS B | vgpr | agpr | calls | total ms | % | avg us | min us |", "|---|---|---|---|---|---|---|---|---|---|---|"]
 for r in rows[:60]:
     lines.append(f"| {r[0][:90]} | {r[1]} | {r[2]} | {r[3]} | {r[4]} | {r[5]} | {r[6]} | {r[7]:.2f} | {100*r[7]/tot:.1f} | {r[8]:.1f} | {r[9]:.1f} |")
+# ---- one row per (kernel, layer signature): join with the engine's launch log (SOS_LAUNCH_LOG, one line per conv / wgrad launch
+# in enqueue order): the k-th dispatch of the conv family (conv_mfma_kernel / conv16_kernel) is the k-th "conv" line, the k-th
+# dispatch of the weight-gradient family (wgrad_kernel / wgrad16_kernel / wgrad_gemm_kernel; not the reduce) the k-th "wgrad" line
+if len(sys.argv) > 3:
+    log = [ln.rstrip("\n").split("|") for ln in open(sys.argv[3]) if "|" in ln]
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
+    order = "dispatch_id" if "dispatch_id" in cols else "start"
+    for kind, pat in (("conv", r"conv_mfma_kernel|conv16_kernel"), ("wgrad", r"wgrad_kernel|wgrad16_kernel|wgrad_gemm_kernel")):
+        disp = [r for r in c.execute(f"select name, end-start from kernels order by {order}").fetchall() if re.search(pat, r[0])]
+        ents = [e for e in log if e[0] == kind]
+        lines += ["", f"### {kind} launches by layer signature ({len(disp)} dispatches, {len(ents)} logged launches)"]
+        if len(disp) != len(ents):
+            lines.append("(counts differ: the log and the trace are not from the same process -- no per-signature rows)")
+            continue
+        agg = {}
+        for (name, ns), (_, sig, flops) in zip(disp, ents):
+            m = re.search(r"(conv_mfma_kernel|conv16_kernel|wgrad16_kernel|wgrad_gemm_kernel|wgrad_kernel)(<[^>]*>)?", name)
+            a = agg.setdefault((m.group(0) if m else name[:40], sig), [0, 0.0, 1e30, float(flops)])
+            a[0] += 1
+            a[1] += ns
+            a[2] = min(a[2], ns)
+        hdr = "kh,kw,dil_h,dil_w,stride,cin,cout,B,Ho,Wo" if kind == "conv" else "kh,kw,dil_h,dil_w,stride,M,N,B,Hg,Wg"
+        lines += [f"| kernel | signature ({hdr}) | calls | total ms | avg us | min us | TFLOP/s (avg) | of 2.5 PF |", "|---|---|---|---|---|---|---|---|"]
+        for (kn, sig), a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
+            tf = a[3] / (a[1] / a[0] * 1e-9) / 1e12
+            lines.append(f"| {kn} | {sig} | {a[0]} | {a[1] / 1e6:.2f} | {a[1] / a[0] / 1e3:.1f} | {a[2] / 1e3:.1f} | {tf:.0f} | {tf / 2500:.3f} |")
 txt = "\n".join(lines)
 print(txt)
 if len(sys.argv) > 2:

@@ -359,6 +359,56 @@ def test_overflow_guard_skips_the_step_on_the_device():
         sos_amd.set_precision("bf16")
 
 
+def test_skipped_steps_do_not_advance_adams_bias_correction(tmp_path):
+    """torch.cuda.amp.GradScaler does not advance the optimizer's step on a skipped update.  FusedAdam's host counter
+    counts attempts; the guard's skipped-step count lives on the device and the kernel takes its bias corrections at
+    attempts - skipped: after [finite, Inf, finite] the parameters equal torch.optim.Adam's after TWO steps on the finite
+    gradients.  save_ckpt stores the applied count and the guard's back-off state; load_ckpt restores both."""
+    from sos_amd import agent, engine
+    torch.manual_seed(3)
+    net = torch.nn.Linear(7, 5).cuda()
+    ref = torch.nn.Linear(7, 5)
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    opt = agent.FusedAdam(net.parameters(), lr=1e-2)
+    opt.guard = engine.guard_state(net)
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    gs = [{n: torch.randn_like(p) for n, p in ref.named_parameters()} for _ in range(2)]
+
+    def step(g, poison=False):
+        for n, p in net.named_parameters():
+            p.grad = g[n].cuda().clone()
+            if poison:
+                p.grad.view(-1)[0] = float("inf")
+        opt.step()
+
+    step(gs[0])
+    step(gs[1], poison=True)            # skipped on the device
+    step(gs[1])
+    for g in gs:
+        for n, p in ref.named_parameters():
+            p.grad = g[n].clone()
+        ropt.step()
+    torch.cuda.synchronize()
+    assert opt.guard.cpu().tolist()[3] == 1.0
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert float((p.detach().cpu() - q.detach()).abs().max()) < 2e-6, n       # (with attempts = 3: 1.2e-4 off)
+    # checkpoint: applied steps + the guard's back-off; a fresh agent resumes with both
+    class _A(agent.BaseAgent):
+        pass
+    ag = _A(torch.nn.Linear(7, 5), lr=1e-2, model_dir=str(tmp_path))
+    ag.net.load_state_dict(net.state_dict())
+    ag.optimizer.load_state_dict(opt.state_dict())
+    engine.guard_state(ag.net).copy_(opt.guard)
+    ag.save_ckpt("latest")
+    ck = torch.load(str(tmp_path / "latest.pth"))
+    assert all(float(v["step"]) == 2.0 for v in ck["optimizer_state_dict"]["state"].values())
+    assert ck["overflow_guard"].tolist()[:4] == [0.0, 0.5, 1.0, 0.0]        # {found, back-off, finite steps since, skipped}
+    ag2 = _A(torch.nn.Linear(7, 5), lr=1e-2, model_dir=str(tmp_path))
+    ag2.load_ckpt("latest")
+    assert engine.guard_state(ag2.net).cpu().tolist()[:4] == [0.0, 0.5, 1.0, 0.0]
+    assert all(int(st["step"]) == 2 for st in ag2.optimizer.state.values())
+
+
 def test_backward_after_an_optimizer_step_is_refused():
     """A training tape is valid for the weights its forward ran with (the packed weights are refreshed in place): forward,
     optimizer step, backward of the OLD forward raises instead of silently mixing old activations with new weights."""

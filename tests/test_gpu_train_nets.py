@@ -125,9 +125,13 @@ def test_denoiser_train_step_matches_reference_autograd(golden, precision):
         sos_amd.set_precision("bf16")
 
 
-def test_encoder_block_backward_exact():
-    """Three Conv2d+BN(train)+ReLU blocks (dilated 5x5, 5x5, 1x1) forward + backward through the HIP
-    kernels vs torch autograd on the same weights: every gradient within 1e-4 (bf16x3)."""
+@pytest.mark.parametrize("first", [(5, 5), (1, 7)], ids=["first5x5", "first1x7"])
+@pytest.mark.parametrize("wfold", [True, False], ids=["wfold", "plain"])
+def test_encoder_block_backward_exact(first, wfold, monkeypatch):
+    """Three Conv2d+BN(train)+ReLU blocks (dilated 5x5 or 1x7, 5x5, 1x1) forward + backward through the HIP
+    kernels vs torch autograd on the same weights: every gradient within 1e-4 (bf16x3).  The first block reads 2 channels:
+    with `wfold` its horizontal taps sit on the channel axis (engine.wfold_spec: k x 1 forward conv and weight gradient over
+    kw * 2 channels, un-folded weight gradient, data gradient in the layer's own geometry); `plain` is the unfolded layer."""
     import torch.nn.functional as F
     from sos_amd import engine as E, train_ops as TO, common_nets as CN
     from test_gpu_train_ops import _act_to_nchw
@@ -137,13 +141,15 @@ def test_encoder_block_backward_exact():
         x3 = True
         torch.manual_seed(0)
         B, H, W = 2, 32, 24
-        enc = CN.make_encoder([(5, 5), (5, 5)], [(2, 1), (1, 1)], nf=48, outf=8)
-        ref = CN.make_encoder([(5, 5), (5, 5)], [(2, 1), (1, 1)], nf=48, outf=8)
+        monkeypatch.setattr(E, "WFOLD", wfold)
+        enc = CN.make_encoder([first, (5, 5)], [(2, 1) if first == (5, 5) else (1, 1), (1, 1)], nf=48, outf=8)
+        ref = CN.make_encoder([first, (5, 5)], [(2, 1) if first == (5, 5) else (1, 1), (1, 1)], nf=48, outf=8)
         ref.load_state_dict(enc.state_dict())
         enc = enc.cuda().train()
         x = torch.from_numpy(hashed(5, (B, 2, H, W)).astype(np.float32))
         plan = TO.encoder_train_plan(enc, x3)
-        a = E.pack_input(x.cuda(), x3)
+        assert ("wtaps" in plan[0]) == wfold
+        a = CN.pack_encoder_input(plan, x.cuda(), x3)
         nfeat = 8 * H
         feat = torch.empty((B, W, 3 * nfeat), dtype=torch.bfloat16, device="cuda")
         fspec = dict(t=feat, row=3 * nfeat, third=nfeat, c_off=0, H=H, W=W, Wo=W, gather=None, x3=x3)

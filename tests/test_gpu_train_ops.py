@@ -203,6 +203,77 @@ def test_down_block_input_gradient(case, accumulate, mode_x3):
     assert rel_err(grads["b.block.1.weight"], ref.block[1].weight.grad) < (2e-4 if x3 else 1e-1)
 
 
+@pytest.mark.parametrize("reflect", [False, True], ids=["zero", "reflect"])
+@pytest.mark.parametrize("ragged", [False, True], ids=["dense", "ragged"])
+def test_pack_wtaps_matches_a_shifted_gather(mode_x3, reflect, ragged):
+    """sos_pack_nchw_wtaps (horizontal taps of the 2-channel first layers on the channel axis): stored channel t*C + c of pixel
+    (h, w) is x[c][h][w + t - pad] -- zero or mirrored outside the clip, at the clip's OWN end in a ragged batch -- rounded to the
+    storage type exactly like the plain boundary pack (bit-identical values; the low parts in the three-pass mode)."""
+    from sos_amd import engine as E, _lib as L
+    x3 = mode_x3
+    B, Cc, H, W, kw = 3, 2, 9, 21, 7 if not reflect else 5
+    pad = (kw - 1) // 2
+    x = torch.from_numpy(hashed(91, (B, Cc, H, W)).astype(np.float32))
+    widths = [21, 13, 17] if ragged else [W] * B
+    cw = torch.tensor(widths, dtype=torch.int32, device="cuda") if ragged else None
+    a = E.pack_input(x.cuda(), x3, wtaps=(kw, pad, L.PAD_REFLECT if reflect else L.PAD_ZERO), clip_w=cw)
+    assert a.cs == 16 and a.t.shape[-1] == (48 if x3 else 16)
+    want = torch.zeros(B, H, W, 16)
+    for b in range(B):
+        Wc = widths[b]
+        for t in range(kw):
+            for w in range(Wc):
+                ws = w + t - pad
+                if reflect:
+                    ws = -ws if ws < 0 else (2 * (Wc - 1) - ws if ws >= Wc else ws)
+                if 0 <= ws < Wc:
+                    want[b, :, w, t * Cc:(t + 1) * Cc] = x[b, :, :, ws].t()
+    st = E.act_dtype()
+    hi = want.to(st)
+    got = a.t.cpu()
+    assert torch.equal(got[..., :16], hi)
+    if x3:
+        assert torch.equal(got[..., 16:32], hi)
+        assert torch.equal(got[..., 32:], (want - hi.float()).to(st))
+
+
+def test_first_down_block_with_folded_taps(mode_x3):
+    """DownConvBlock(2, 64, 5, 1) -- down1 / down3 of the U-Net (M2/networks.py:158,165) -- with its horizontal taps on the channel
+    axis (train_ops.down_train_plan(first=True)): raw conv output, BatchNorm + PReLU output and the un-folded weight gradient
+    against torch on the same (storage-rounded) input."""
+    from sos_amd import engine as E, train_ops as TO
+    from sos_amd.denoiser.networks import DownConvBlock
+    x3 = mode_x3
+    torch.manual_seed(2)
+    blk = DownConvBlock(2, 64, 5, 1)
+    ref = DownConvBlock(2, 64, 5, 1)
+    ref.load_state_dict(blk.state_dict())
+    blk = blk.cuda().train()
+    B, H, W = 2, 19, 23
+    x = torch.from_numpy(hashed(7, (B, 2, H, W)).astype(np.float32))
+    lp = TO.down_train_plan(blk, x3, first=True)
+    assert lp["kw"] == 1 and lp["cin"] == 10 and lp["wtaps"][0] == 5
+    xa = E.pack_input(x.cuda(), x3, wtaps=lp["wtaps"])
+    st = E.act_dtype()
+    xheld = x.to(st).float() + ((x - x.to(st).float()).to(st).float() if x3 else 0)
+    dst = E.Act(B, H, W, 64, x3, torch.device("cuda"))
+    t = TO.down_forward_train(lp, xa, 0, dst, 0, H, W, x3)
+    xr = xheld.clone().requires_grad_(True)
+    yr = ref.block(xr)
+    tol = 3e-5 if x3 else 2e-2
+    assert rel_err(_act_to_nchw(dst, 64), yr.detach()) < tol
+    g = torch.from_numpy(hashed(8, tuple(yr.shape)).astype(np.float32))
+    ga, gheld = _act_from_nchw(g, x3)
+    yr.backward(gheld)
+    gb = TO.GradBufs(x3)
+    gb.bufs[id(dst)] = ga
+    gb.written[id(dst)] = [(0, 64)]
+    grads = {}
+    TO.down_backward(t, gb, grads, "b", x3, need_src_grad=False)
+    assert grads["b.block.1.weight"].shape == ref.block[1].weight.shape
+    assert rel_err(grads["b.block.1.weight"], ref.block[1].weight.grad) < (2e-4 if x3 else 1e-1)
+
+
 def test_conv_transpose_weight_grad(mode_x3):
     """ConvTranspose2d(k3,s2,p1,output_padding=1): roles swap (G = layer input, X = output grad)."""
     from sos_amd import engine as E, _lib as L

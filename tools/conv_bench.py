@@ -37,6 +37,15 @@ SHAPES = [
     ("dgrad mid 256->256 3x3 d2", 64, 45, 256, 256, (3, 3), (2, 2), 1, "dgrad"),
     ("dgrad mid 256->256 3x3 d8", 64, 45, 256, 256, (3, 3), (8, 8), 1, "dgrad"),
     ("dgrad mid 256->256 3x3 d16", 64, 45, 256, 256, (3, 3), (16, 16), 1, "dgrad"),
+    # round 4: the 2-channel first layers, as stored (16 channels per tap, 2 real) and with their horizontal taps folded into the
+    # channel axis by the boundary pack (engine.wfold_spec: 14 / 10 of 16 channels real, 1 / kw of the taps); TFLOP/s of the
+    # STORED contraction -- compare the milliseconds
+    ("thin 2->96 1x7 stored", 256, 178, 16, 96, (1, 7), (1, 1), 1, 0),
+    ("thin 2->96 folded 1x1", 256, 178, 16, 96, (1, 1), (1, 1), 1, 0),
+    ("thin 2->48 1x7 stored", 256, 178, 16, 48, (1, 7), (1, 1), 1, 0),
+    ("thin 2->48 folded 1x1", 256, 178, 16, 48, (1, 1), (1, 1), 1, 0),
+    ("thin 2->64 5x5 stored", 256, 178, 16, 64, (5, 5), (1, 1), 1, 1),
+    ("thin 2->64 folded 5x1", 256, 178, 16, 64, (5, 1), (1, 1), 1, 1),
 ]
 
 

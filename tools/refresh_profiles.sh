@@ -5,7 +5,7 @@
 #   rocprofv3 --kernel-trace --stats summaries of the train / infer / ragged benches,
 #   the HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs) of the dominant conv kernel,
 #   the micro-benchmarks.  Every process loads the shipped tiling table: nothing is tuned here.
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/refresh; mkdir -p $O
 python tools/conv_bench.py > $O/conv_bench.txt 2>&1
@@ -13,7 +13,8 @@ python tools/wgrad_bench.py > $O/wgrad_bench.txt 2>&1
 python tools/lstm_bench.py > $O/lstm_bench.txt 2>&1
 python tools/bn_bench.py > $O/bn_bench.txt 2>&1
 python tools/frontend_bench.py > $O/frontend_bench.txt 2>&1
-rocprofv3 --kernel-trace --stats -d $O/prof_train -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $O/prof_train.log 2>&1
+rm -f $O/launch_train.log
+SOS_LAUNCH_LOG=$O/launch_train.log rocprofv3 --kernel-trace --stats -d $O/prof_train -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $O/prof_train.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_infer -o t -- python bench.py --mode infer --steps 5 --warmup 1 --no-cpu-baseline --no-secondary > $O/prof_infer.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_ragged -o t -- python bench.py --mode infer-ragged --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $O/prof_ragged.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
@@ -46,6 +47,7 @@ python bench.py --mode infer --precision fp16 --steps 20 --warmup 3 --no-cpu-bas
 python bench.py --mode infer-ragged --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/bench_ragged_mixed.json 2> $O/bench_ragged_mixed.err
 bash tools/probe/steady_families.sh > $O/steady_families.txt 2>&1
 bash tools/probe/low_occupancy.sh > $O/low_occupancy.txt 2>&1
-for m in train infer ragged; do python profiles/summarize_rocpd.py $(find $O/prof_$m -name "*.db" | head -1) $O/${m}_kernels.md > /dev/null 2>&1; done
+python profiles/summarize_rocpd.py $(find $O/prof_train -name "*.db" | head -1) $O/train_kernels.md $O/launch_train.log > /dev/null 2>&1
+for m in infer ragged; do python profiles/summarize_rocpd.py $(find $O/prof_$m -name "*.db" | head -1) $O/${m}_kernels.md > /dev/null 2>&1; done
 find $O -name "*.db" -delete            # the summaries stay; gpurun copies at most 64 MiB back
 for f in $O/bench_*.json; do echo $f; cut -c1-420 $f; done

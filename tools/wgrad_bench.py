@@ -21,7 +21,10 @@ SHAPES = [("ctx96 d1x1", 256, 178, 96, 96, (5, 5), (1, 1), 1), ("ctx96 d8x1", 25
           ("thin 2->64 5x5", 256, 178, 2, 64, (5, 5), (1, 1), 1), ("thin 64->2 5x5", 256, 178, 64, 2, (5, 5), (1, 1), 1),
           ("thin 96->8 1x1", 256, 178, 96, 8, (1, 1), (1, 1), 1), ("thin 48->4 1x1", 256, 178, 48, 4, (1, 1), (1, 1), 1),
           ("inp 256 3x3 d16", 64, 45, 256, 256, (3, 3), (16, 16), 1), ("inp 256 3x3 d8", 64, 45, 256, 256, (3, 3), (8, 8), 1),
-          ("inp 64->128 3x3", 256, 178, 64, 128, (3, 3), (1, 1), 1), ("inp 128->256 3x3", 128, 89, 128, 256, (3, 3), (1, 1), 1)]
+          ("inp 64->128 3x3", 256, 178, 64, 128, (3, 3), (1, 1), 1), ("inp 128->256 3x3", 128, 89, 128, 256, (3, 3), (1, 1), 1),
+          # round 4: the thin first layers with their horizontal taps on the channel axis (engine.wfold_spec): compare the ms with the "thin" rows
+          ("fold 14->96 1x1", 256, 178, 14, 96, (1, 1), (1, 1), 1), ("fold 14->48 1x1", 256, 178, 14, 48, (1, 1), (1, 1), 1),
+          ("fold 10->64 5x1", 256, 178, 10, 64, (5, 1), (1, 1), 1)]
 ap = argparse.ArgumentParser(); ap.add_argument("--only", default=""); ap.add_argument("--iters", type=int, default=10); ap.add_argument("--warm", type=float, default=0.3)
 a = ap.parse_args()
 dev = torch.device("cuda"); B = 64
