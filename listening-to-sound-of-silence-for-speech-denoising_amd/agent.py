@@ -202,14 +202,28 @@ class GradBucketer:
 
     def reset(self):
         self.buckets, self.cur, self.cur_fill, self.handles, self.views = [], None, 0, [], {}
-        self.pending = ([], [])
+        self.pending, self.pending_streams = ([], []), []
+
+    def _flush_pending(self):
+        """ONE batched copy of the pending gradients into their bucket views, on the current stream.  Gradients produced on
+        another stream (the denoiser's branch streams, denoiser/networks.py) are waited for, and their memory is kept from
+        the caching allocator until this stream's copy has run."""
+        if not self.pending[0]:
+            return
+        if any(st is not None for st in self.pending_streams):          # (gloo CPU tests: no streams)
+            cur = torch.cuda.current_stream()
+            for st in {s_ for s_ in self.pending_streams if s_ is not None and s_ != cur}:
+                cur.wait_stream(st)
+            for g, st in zip(self.pending[1], self.pending_streams):
+                if st is not None and st != cur:
+                    g.record_stream(cur)
+        torch._foreach_copy_(self.pending[0], self.pending[1])
+        self.pending, self.pending_streams = ([], []), []
 
     def _launch(self, flat, fill):
         # the bucket's gradients are gathered with ONE batched copy (a copy per tensor was 322 launches per step), then
         # its all-reduce starts while the backward pass goes on
-        if self.pending[0]:
-            torch._foreach_copy_(self.pending[0], self.pending[1])
-            self.pending = ([], [])
+        self._flush_pending()
         if self.collective:
             self.handles.append(dist.all_reduce(flat[:fill], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -227,6 +241,7 @@ class GradBucketer:
         v = self.cur[self.cur_fill:self.cur_fill + n]
         self.pending[0].append(v)
         self.pending[1].append(g.reshape(-1))
+        self.pending_streams.append(torch.cuda.current_stream() if g.is_cuda else None)
         self.cur_fill += n
         self.views[name] = v.view(self.shapes[name])
         return self.views[name]
@@ -236,9 +251,8 @@ class GradBucketer:
         1/world average is applied by the optimizer's grad_scale)."""
         if self.cur is not None and self.cur_fill:
             self._launch(self.cur, self.cur_fill)
-        elif self.pending[0]:
-            torch._foreach_copy_(self.pending[0], self.pending[1])
-            self.pending = ([], [])
+        else:
+            self._flush_pending()
         for h in self.handles:
             h.wait()
         for name, v in self.views.items():
@@ -247,7 +261,7 @@ class GradBucketer:
 
     def reset_keep_views(self):
         self.cur, self.cur_fill, self.handles, self.buckets, self.views = None, 0, [], [], {}
-        self.pending = ([], [])
+        self.pending, self.pending_streams = ([], []), []
 
 
 class GradSink(dict):

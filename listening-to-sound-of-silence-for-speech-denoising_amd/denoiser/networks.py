@@ -325,15 +325,32 @@ class ContextAggNet(nn.Module):
                     fc0=TO.linear_train_plan(self.fc[0], 400, x3), fc2=TO.linear_train_plan(self.fc[2], E.pad_to(600, 16), x3),
                     fc4=TO.linear_train_plan(self.fc[4], E.pad_to(600, 16), x3))
 
-    def forward_train(self, plan, x, n, x3, before_lstm=None):
+    def forward_train(self, plan, x, n, x3, before_lstm=None, side=None):
+        """n: the stage-1 prediction, or a zero-argument callable producing it (JointModel passes stage 1's training forward).
+        side: optional HIP stream for the branch [n() -> encoder_n] -- it does not depend on encoder_x (M2/networks.py:214-217:
+        only encoder_n consumes n_pred), so the U-Net and the 48-channel stack run beside the 96-channel stack and join at the
+        BiLSTM.  Same kernels in the same order per branch: bit-identical to the one-stream schedule."""
         dev = x.device
         B, _, F, T = x.shape
         nseg = 3 if x3 else 1
         nfeat = 12 * F
         feat = torch.empty((B, T, nseg * nfeat), dtype=E.act_dtype(), device=dev)
         fs = dict(t=feat, row=nseg * nfeat, third=nfeat, H=F, W=T, Wo=T, gather=None, x3=x3)
-        tx = TO.encoder_forward_train(plan["enc_x"], CN.pack_encoder_input(plan["enc_x"], x, x3), dict(fs, c_off=0), x3)
-        tn = TO.encoder_forward_train(plan["enc_n"], CN.pack_encoder_input(plan["enc_n"], n, x3), dict(fs, c_off=8), x3)
+        n_extra = None
+        if side is not None:
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)                     # the inputs, the refreshed weights and `feat` exist
+            with torch.cuda.stream(side):
+                if callable(n):
+                    n, n_extra = n()
+                tn = TO.encoder_forward_train(plan["enc_n"], CN.pack_encoder_input(plan["enc_n"], n, x3), dict(fs, c_off=8), x3)
+            tx = TO.encoder_forward_train(plan["enc_x"], CN.pack_encoder_input(plan["enc_x"], x, x3), dict(fs, c_off=0), x3)
+            cur.wait_stream(side)                     # join: the feature matrix is complete
+        else:
+            if callable(n):
+                n, n_extra = n()
+            tx = TO.encoder_forward_train(plan["enc_x"], CN.pack_encoder_input(plan["enc_x"], x, x3), dict(fs, c_off=0), x3)
+            tn = TO.encoder_forward_train(plan["enc_n"], CN.pack_encoder_input(plan["enc_n"], n, x3), dict(fs, c_off=8), x3)
         if before_lstm is not None:    # agent.train_concurrent: the recurrence, the FC head and their backward leave the chip
             before_lstm()              # mostly idle (8 workgroups stepping through T frames): another model's forward may start
         h, tl = TO.lstm_forward_train(plan["lstm"], (feat, B, 1, T, nfeat, nseg), B, T, x3, dev)
@@ -347,11 +364,14 @@ class ContextAggNet(nn.Module):
         out = torch.empty((B, 2, F, T), dtype=torch.float32, device=dev)
         E.conv(a1, 0, f4["cin_store"], f4["w"], 1, 1, 2 * F, f4["scale"], f4["shift"], L.ACT_SIGMOID, out=out,
                out_dtype=L.DT_F32, sb=2 * F * T, sh=0, sw=1, sc=T, Ho=1, Wo=T)
-        return out, dict(tx=tx, tn=tn, tl=tl, h=h, a0=a0, a1=a1, out=out, dims=(B, F, T))
+        return out, dict(tx=tx, tn=tn, tl=tl, h=h, a0=a0, a1=a1, out=out, dims=(B, F, T), n=n, n_extra=n_extra)
 
-    def backward(self, plan, tape, g_out, grads, x3, prefix="stage2"):
+    def backward(self, plan, tape, g_out, grads, x3, prefix="stage2", side=None, tail=None, before_join=None):
         """g_out: f32 (B,2,F,T) gradient of the mask.  Returns the Act gradient of encoder_n's
-        2-channel input (the stage-1 prediction)."""
+        2-channel input (the stage-1 prediction).
+        side: optional HIP stream for the branch [encoder_n backward -> tail(d_n)] (tail = the rest of the chain that hangs off
+        encoder_n's input gradient: JointModel passes stage 1's backward); encoder_x's backward runs beside it on the current
+        stream, which then calls before_join() and waits for the side stream before returning."""
         B, F, T = tape["dims"]
         dev = g_out.device
         nseg = 3 if x3 else 1
@@ -366,10 +386,29 @@ class ContextAggNet(nn.Module):
         dh = TO.linear_backward(plan["fc0"], tape["h"], dz0, grads, f"{prefix}.fc.0", x3, dev)
         dfeat = TO.lstm_backward(plan["lstm"], tape["tl"], dh, grads, f"{prefix}.lstm", B, T, x3, dev)
         nfeat = 12 * F
+        if side is not None:
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)                     # dfeat exists
+            with torch.cuda.stream(side):
+                dyn = TO.feat_grad_to_nhwc(dfeat, nseg * nfeat, nfeat, 8, 4, B, F, T, T, x3)
+                d_n = TO.encoder_backward(plan["enc_n"], tape["tn"], dyn, grads, f"{prefix}.encoder_n", x3, need_input_grad=True)
+                if tail is not None:
+                    tail(d_n)
+            dyx = TO.feat_grad_to_nhwc(dfeat, nseg * nfeat, nfeat, 0, 8, B, F, T, T, x3)
+            TO.encoder_backward(plan["enc_x"], tape["tx"], dyx, grads, f"{prefix}.encoder_x", x3)
+            if before_join is not None:
+                before_join()
+            # `dfeat` (allocated on the current stream, read on the side stream) stays referenced until here: the caching
+            # allocator may hand its memory out again only after the join below has been enqueued
+            cur.wait_stream(side)
+            return d_n
         dyx = TO.feat_grad_to_nhwc(dfeat, nseg * nfeat, nfeat, 0, 8, B, F, T, T, x3)
         TO.encoder_backward(plan["enc_x"], tape["tx"], dyx, grads, f"{prefix}.encoder_x", x3)
         dyn = TO.feat_grad_to_nhwc(dfeat, nseg * nfeat, nfeat, 8, 4, B, F, T, T, x3)
-        return TO.encoder_backward(plan["enc_n"], tape["tn"], dyn, grads, f"{prefix}.encoder_n", x3, need_input_grad=True)
+        d_n = TO.encoder_backward(plan["enc_n"], tape["tn"], dyn, grads, f"{prefix}.encoder_n", x3, need_input_grad=True)
+        if tail is not None:
+            tail(d_n)
+        return d_n
 
     def forward(self, x, n):
         raise RuntimeError("call ContextAggNet through JointModel (libsos_hip path)")
@@ -414,11 +453,27 @@ class JointModel(nn.Module):
         x3 = E.is_x3()
         return dict(x3=x3, s1=self.stage1.build_train_plan(x3), s2=self.stage2.build_train_plan(x3))
 
+    # SOS_BRANCH_STREAMS=1: the branch [stage 1 -> encoder_n] (forward) / [encoder_n -> stage 1] (backward) on a side stream
+    # beside encoder_x (HBM-bound BatchNorm passes and the low-efficiency U-Net launches of one branch under
+    # the MFMA-bound 96-channel convolutions of the other).  Same kernels, same order per branch: bit-identical results.
+    BRANCH_STREAMS = __import__("os").environ.get("SOS_BRANCH_STREAMS", "0") == "1"
+
+    def _side_stream(self, dev):
+        if not self.BRANCH_STREAMS or torch.cuda.is_current_stream_capturing():
+            return None
+        cur = torch.cuda.current_stream(dev)
+        key = (dev.index, cur.cuda_stream)
+        ss = self.__dict__.setdefault("_side_streams", {})
+        if key not in ss:
+            ss[key] = torch.cuda.Stream(device=dev)
+        return ss[key]
+
     def _forward_train(self, x, n):
         plan = self._tcache.get(self, self._build_train_plan)
         x3 = plan["x3"]
-        n_pred, t1 = self.stage1.forward_train(plan["s1"], n, x, x3)
-        out, t2 = self.stage2.forward_train(plan["s2"], x, n_pred, x3, before_lstm=getattr(self, "before_lstm_forward", None))
+        out, t2 = self.stage2.forward_train(plan["s2"], x, lambda: self.stage1.forward_train(plan["s1"], n, x, x3), x3,
+                                            before_lstm=getattr(self, "before_lstm_forward", None), side=self._side_stream(x.device))
+        n_pred, t1 = t2.pop("n"), t2.pop("n_extra")
         return (n_pred, out), dict(plan=plan, t1=t1, t2=t2, x3=x3, mode=get_precision())
 
     def _backward(self, tape, g_npred, g_out):
@@ -437,14 +492,23 @@ class JointModel(nn.Module):
         B, F, T = tape["t2"]["dims"]
         if g_out is None:
             g_out = torch.zeros((B, 2, F, T), dtype=torch.float32, device=dev)
-        d_np = self.stage2.backward(plan["s2"], tape["t2"], g_out, grads, x3)          # Act [B,F,T,16]
+        def stage1_tail(d_np):                                                          # d_np: Act [B,F,T,16]
+            if g_npred is not None:
+                direct = E.pack_input(g_npred, x3, mul=E.cur_gs().mul)                     # loss gradient on n_pred
+                TO.reflect_fold(direct, F, T, 0, d_np, 0, 2, accumulate=True)              # pad 0: plain add
+            self.stage1.backward(plan["s1"], tape["t1"], d_np, grads, x3)
+
+        side = self._side_stream(dev)
         hook = getattr(self, "after_stage2_backward", None)
-        if hook is not None:           # agent.train_concurrent: another model's step may start here (see there)
-            hook()
-        if g_npred is not None:
-            direct = E.pack_input(g_npred, x3, mul=E.cur_gs().mul)                     # loss gradient on n_pred
-            TO.reflect_fold(direct, F, T, 0, d_np, 0, 2, accumulate=True)              # pad 0: plain add
-        self.stage1.backward(plan["s1"], tape["t1"], d_np, grads, x3)
+        if side is None:
+            d_np = self.stage2.backward(plan["s2"], tape["t2"], g_out, grads, x3)
+            if hook is not None:       # agent.train_concurrent: another model's step may start here (see there)
+                hook()
+            stage1_tail(d_np)
+        else:
+            # branch streams: stage 1's backward hangs off encoder_n's on the side stream; the gate of the other model's
+            # backward is recorded behind encoder_x's backward on this stream, as in the one-stream schedule
+            self.stage2.backward(plan["s2"], tape["t2"], g_out, grads, x3, side=side, tail=stage1_tail, before_join=hook)
         return grads
 
     def forward(self, x, n, rag=None):

@@ -38,6 +38,16 @@ class LaunchProfiler:
 
 PROFILER = None
 
+# Conv tilings.  By default every process loads the SHIPPED table (tune_table_gfx950.txt, measured once on an MI355X for
+# the BASELINE shapes) and uses the deterministic cost-model pick for any other shape: two processes -- or two ranks of
+# one data-parallel job -- therefore run identical tilings, i.e. identical summation orders and bit-identical results.
+# SOS_CONV_TUNE=1 opts into timing-based autotuning of shapes the table does not hold (sos_conv2d_tune synchronises, so
+# it is skipped while a stream capture is in progress); SOS_CONV_TUNE_CACHE=<file> replaces the shipped table and, with
+# autotuning on, receives the tuned table at exit (rank 0 only, written atomically).  tools/make_tune_table.py
+# regenerates the shipped file.
+import os as _os
+import threading as _threading
+
 # SOS_LAUNCH_LOG=<file>: one line per conv / weight-gradient launch, in enqueue order: "conv|<signature>" / "wgrad|<signature>".
 # profiles/summarize_rocpd.py joins it with the rocprofv3 kernel trace of the same process (the k-th conv-family dispatch is the
 # k-th "conv" line), so that the per-kernel table has one row per (kernel, layer signature) and the roofline fraction of the
@@ -50,15 +60,6 @@ if _os.environ.get("SOS_LAUNCH_LOG"):
 def _log_launch(kind, sig, flops):
     _LAUNCH_LOG.write("%s|%s|%.6g\n" % (kind, ",".join(str(v) for v in sig[1:]), flops))
 
-# Conv tilings.  By default every process loads the SHIPPED table (tune_table_gfx950.txt, measured once on an MI355X for
-# the BASELINE shapes) and uses the deterministic cost-model pick for any other shape: two processes -- or two ranks of
-# one data-parallel job -- therefore run identical tilings, i.e. identical summation orders and bit-identical results.
-# SOS_CONV_TUNE=1 opts into timing-based autotuning of shapes the table does not hold (sos_conv2d_tune synchronises, so
-# it is skipped while a stream capture is in progress); SOS_CONV_TUNE_CACHE=<file> replaces the shipped table and, with
-# autotuning on, receives the tuned table at exit (rank 0 only, written atomically).  tools/make_tune_table.py
-# regenerates the shipped file.
-import os as _os
-import threading as _threading
 FLATTEN_1X1 = _os.environ.get("SOS_FLATTEN_1X1", "1") != "0"      # A/B switch of the batch-flattened 1x1 layers (conv())
 AUTOTUNE = _os.environ.get("SOS_CONV_TUNE", "0") == "1"
 TUNE_CANDIDATES = int(_os.environ.get("SOS_CONV_TUNE_CANDIDATES", "8"))     # best-ranked tilings of the cost model that get timed

@@ -96,9 +96,12 @@ def test_agents_train_step_and_checkpoint(tmp_path):
         ag3.load_ckpt(99)
 
 
-def test_train_concurrent_matches_serial():
+@pytest.mark.parametrize("branch", [False, True], ids=["two-streams", "branch-streams"])
+def test_train_concurrent_matches_serial(branch, monkeypatch):
     """The two models trained on two HIP streams (agent.train_concurrent) end up bit-identical to back-to-back
-    training: the kernels are deterministic and the agents share no mutable device state."""
+    training: the kernels are deterministic and the agents share no mutable device state.  branch-streams: the denoiser
+    additionally runs its [stage 1 -> encoder_n] branch on a side stream beside encoder_x (JointModel.BRANCH_STREAMS), forward
+    and backward -- same kernels in the same order per branch, so still bit-identical to the serial schedule."""
     import sos_amd
     from sos_amd import agent
     from sos_amd.common import MyConfig
@@ -118,10 +121,13 @@ def test_train_concurrent_matches_serial():
 
     d1, j1 = make()
     d2, j2 = make()
-    for _ in range(2):
+    for _ in range(3):
+        monkeypatch.setattr(jnet.JointModel, "BRANCH_STREAMS", False)
         d1.train_func(bd); j1.train_func(bj)
+        monkeypatch.setattr(jnet.JointModel, "BRANCH_STREAMS", branch)
         agent.train_concurrent([(j2, bj), (d2, bd)])
     torch.cuda.synchronize()
+    assert bool(j2.net.__dict__.get("_side_streams")) == branch
     for a, b in ((d1, d2), (j1, j2)):
         for (k, p), (_, q) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
             assert torch.equal(p, q), k
@@ -169,15 +175,18 @@ print("RCCL_PATH_OK", n)
 """
 
 
-def test_bucketed_all_reduce_path_on_rccl_world_of_one():
+@pytest.mark.parametrize("branch", ["0", "1"], ids=["two-streams", "branch-streams"])
+def test_bucketed_all_reduce_path_on_rccl_world_of_one(branch):
     """The multi-GPU gradient path (GradBucketer: flat buckets, async all_reduce on the RCCL stream issued from the
-    two model streams, wait, Adam on the bucket views) with backend 'nccl' in a world of one, where the all-reduce
-    is the identity: parameters after two steps are bit-identical to the single-process path."""
+    two model streams -- one communicator per model --, wait, Adam on the bucket views) with backend 'nccl' in a world of one,
+    where the all-reduce is the identity: parameters after two steps are bit-identical to the single-process path.
+    branch-streams: gradients are produced on the denoiser's side stream as well (the bucketer waits for the producing stream
+    before its batched copy)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SOS_ROOT=root, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+               MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0", SOS_BRANCH_STREAMS=branch)
     r = subprocess.run([sys.executable, "-c", _RCCL_CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, r.stdout[-3000:]
