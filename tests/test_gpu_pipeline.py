@@ -11,11 +11,27 @@ from oracle import nets as onet
 
 pytestmark = pytest.mark.gpu
 
-# waveform bound (||a-b||_inf / ||b||_inf) of a denoiser that STORES activations and weights in IEEE half: the storage
-# format's rounding (2^-12 per element) through 15-30 stacked conv blocks, the BiLSTM and the mask's 10 * logit() gives
-# 1-3e-3 on these clips -- tools/probe/precision_study.py reproduces the same figure on the f32 oracle with nothing but
-# .half() round trips inserted, i.e. the kernels add nothing beyond the format (observed on the GPU: 1.1e-3 .. 4.8e-3)
+# Waveform bound (||a-b||_inf / ||b||_inf) of a denoiser that STORES activations and weights in IEEE half.  The bound is
+# COMPUTED per clip (round 4): the f32 oracle with nothing but .half() round trips at the kernels' storage points
+# (tests/storage_model.py) deviates from the f32 oracle by m (1-3e-3 on these clips: the rounding of the 27 conv blocks' WEIGHTS
+# of stage 2 alone gives 3e-3 on the reconstructed spectrogram, the BiLSTM input projection 1.8e-3, the FC head 6e-4 --
+# tools/probe/precision_study.py jm; no single stage carries it, so no cheap parity-precision tail exists); the HIP waveform must
+# lie within WAVE_MODEL_FACTOR x m of the oracle: the kernels add nothing beyond the format.  WAVE_TOL_FP16 caps it from above.
 WAVE_TOL_FP16 = 6e-3
+WAVE_MODEL_FACTOR = 2.0
+
+
+def _model_wave_deviation(sd2, wave, bits, y_ref):
+    """Waveform deviation of the storage model (IEEE-half round trips at the denoiser's storage points, f32 everything else,
+    the given frame decisions) from the f32 oracle waveform y_ref."""
+    from storage_model import q, storage_model
+    mask = ofe.convert_bitstreammask_to_audiomask(wave, 14000 / 30.0, list(bits))
+    S = torch.from_numpy(ofe.fast_stft(wave).transpose(2, 0, 1)[None].astype(np.float32))
+    Sn = torch.from_numpy(ofe.fast_stft(wave * mask).transpose(2, 0, 1)[None].astype(np.float32))
+    with storage_model(torch.float16), torch.no_grad():
+        _, crm = onet.joint_forward(sd2, q(S), q(Sn))
+    y = ofe.fast_istft(ofe.fast_icRM_sigmoid(S[0].permute(1, 2, 0).numpy(), crm[0].permute(1, 2, 0).numpy()))
+    return float(np.max(np.abs(y - y_ref)) / np.max(np.abs(y_ref)))
 
 
 def _oracle_chain(sd1, sd2, wave, n_frames, bits=None):
@@ -104,6 +120,10 @@ def test_pipeline_matches_oracle_and_si_sdr(precision):
         # bf16x3 is the parity mode (north_star 1e-3); plain bf16 carries 0.5-2e-2 per-layer rounding noise whose sum
         # depends on the summation order of the conv tilings (observed 1.6e-2 .. 5.9e-2 here)
         assert err < err_tol
+        if precision in ("mixed", "fp16"):
+            m = _model_wave_deviation(sd2, raw["mixed"][i], bits, y)
+            print(precision, "clip", i, "  storage-model waveform deviation", m, " HIP / model", err / m)
+            assert err < WAVE_MODEL_FACTOR * m + 1e-4
         # fidelity of the HIP waveform w.r.t. the oracle's waveform, as an SI-SDR (dB)
         fid = ofe.si_sdr(out, y)
         assert fid > fid_min, fid
@@ -188,7 +208,7 @@ def test_ragged_one_launch_1s_and_10s_vs_oracle():
     lens = [140000, 14000, 28123, 97531, 14000 + 157, 51800]
     waves = [_long_wave(300 + 10 * i, n) for i, n in enumerate(lens)]
     clips = [torch.from_numpy(w).cuda() for w in waves]
-    for precision, tol_single, tol_oracle in (("bf16x3", 2e-4, 1e-3), ("mixed", 1e-2, 1e-2)):
+    for precision, tol_single, tol_oracle in (("bf16x3", 2e-4, 1e-3), ("mixed", 1e-2, WAVE_TOL_FP16)):
         sos_amd.set_precision(precision)
         try:
             outs, extra = pipeline.denoise_ragged(det, jm, clips, return_all=True)
@@ -210,6 +230,10 @@ def test_ragged_one_launch_1s_and_10s_vs_oracle():
                 err = np.abs(yg - y).max() / max(np.abs(y).max(), 1e-9)
                 print(precision, "ragged vs oracle, clip", i, "len", lens[i], "rel err", err)
                 assert err < tol_oracle
+                if precision == "mixed":            # computed bound (see _model_wave_deviation)
+                    m = _model_wave_deviation(sd2, waves[i], bits, y)
+                    print("   storage-model waveform deviation", m, " HIP / model", err / m)
+                    assert err < WAVE_MODEL_FACTOR * m + 1e-4
         finally:
             sos_amd.set_precision("bf16")
 

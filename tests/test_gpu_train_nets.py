@@ -23,6 +23,20 @@ DET_TOL_FP16, JM_TOL_FP16 = 0.1, 0.15
 SLOPE_TOL = {"bf16x3": 1e-3, "fp16": 5e-3, "bf16": 2e-2}
 
 
+def _model_deviation(which, precision, x, n, nfr, g):
+    """Deviation from the reference goldens of the storage model (tests/storage_model.py: the f32 oracle with round trips
+    through the 16-bit storage type at the kernels' storage points) on the train-mode forward of the detector ('det':
+    logits) or the denoiser ('jm': n_pred, mask)."""
+    from storage_model import q, storage_dtype, storage_model
+    with storage_model(storage_dtype(precision)), torch.no_grad():
+        if which == "det":
+            sd = onet.closed_form_state(onet.detector_spec(), seed=1)
+            return rel_err(onet.detector_forward(sd, q(x), nfr, training=True), g["train_det_logits"])
+        sd = onet.closed_form_state(onet.joint_spec(), seed=2)
+        n_pred, mask = onet.joint_forward(sd, q(x), q(n), training=True)
+        return rel_err(n_pred, g["train_n_pred"]), rel_err(mask, g["train_mask"])
+
+
 def _check_grads(named_params, gradnorm, gradhead, tol, label, slope_scale=None):
     worst = 0.0
     bad = []
@@ -74,7 +88,15 @@ def test_detector_train_step_matches_reference_autograd(golden, precision):
         tol = {"bf16x3": 2e-2, "fp16": DET_TOL_FP16, "bf16": 0.25}[precision]
         e_lo = rel_err(logits, g["train_det_logits"])
         print(precision, "train logits rel err", e_lo, "loss", float(loss), "ref", float(g["train_bce"]))
-        assert e_lo < {"bf16x3": 1e-3, "fp16": 2e-2, "bf16": 0.1}[precision]
+        if precision == "bf16x3":
+            assert e_lo < 1e-3
+        else:
+            # 16-bit storage: the bound is COMPUTED -- the f32 oracle with nothing but round trips through the storage type at
+            # the kernels' storage points (tests/storage_model.py) deviates from the reference by e_model; the kernels may
+            # add nothing beyond the format: within 2x of that model's own deviation
+            e_model = _model_deviation("det", precision, x.cpu(), None, nfr, g)
+            print(precision, "  storage-model logits deviation", e_model, " HIP / model", e_lo / e_model)
+            assert e_lo < 2.0 * e_model + 1e-4
         worst, med = _check_grads(list(det.named_parameters()), g["train_det_gradnorm"], g["train_det_gradhead"], tol, precision)
         print(precision, "worst grad err", worst, "median", med)
         assert med < {"bf16x3": 2e-3, "fp16": 2e-2, "bf16": 8e-2}[precision]
@@ -112,7 +134,12 @@ def test_denoiser_train_step_matches_reference_autograd(golden, precision):
         x3 = precision == "bf16x3"
         e1, e2 = rel_err(n_pred, g["train_n_pred"]), rel_err(out, g["train_mask"])
         print(precision, "train n_pred/mask rel err", e1, e2, "losses", float(l1), float(l2), "ref", float(g["train_l1"]), float(g["train_l2"]))
-        assert max(e1, e2) < {"bf16x3": 1e-3, "fp16": 1.5e-2, "bf16": 0.1}[precision]
+        if precision == "bf16x3":
+            assert max(e1, e2) < 1e-3
+        else:       # computed bound, see the detector test
+            m1, m2 = _model_deviation("jm", precision, x.cpu(), n.cpu(), None, g)
+            print(precision, "  storage-model n_pred / mask deviation", m1, m2, " HIP / model", e1 / m1, e2 / m2)
+            assert e1 < 2.0 * m1 + 1e-4 and e2 < 2.0 * m2 + 1e-4
         ltol = {"bf16x3": 1e-3, "fp16": 5e-3, "bf16": 5e-2}[precision]
         assert abs(float(l1) / float(g["train_l1"]) - 1) < ltol
         assert abs(float(l2) / float(g["train_l2"]) - 1) < ltol

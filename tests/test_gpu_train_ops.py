@@ -196,11 +196,80 @@ def test_down_block_input_gradient(case, accumulate, mode_x3):
     grads = {}
     TO.down_backward(t, gb, grads, "b", x3)
     err = rel_err(_act_to_nchw(gb.of(xa), cin), expect)
-    print(case, "accumulate" if accumulate else "store", "x3" if x3 else "16-bit", "d_in rel err", err)
-    # (the three-pass mode is the correctness check: a wrong fold is an O(1) error on the border pixels; the 16-bit modes carry
-    # the rounding of d_raw through the BatchNorm backward: 6e-2 observed in bfloat16 with the unfused fold as well)
-    assert err < (3e-4 if x3 else 1e-1)
-    assert rel_err(grads["b.block.1.weight"], ref.block[1].weight.grad) < (2e-4 if x3 else 1e-1)
+    err_w = rel_err(grads["b.block.1.weight"], ref.block[1].weight.grad)
+    print(case, "accumulate" if accumulate else "store", "x3" if x3 else "16-bit", "d_in rel err", err, "dw rel err", err_w)
+    if x3:      # the three-pass mode is the logic check: a wrong fold is an O(1) error on the border pixels
+        assert err < 3e-4 and err_w < 2e-4
+        return
+    # 16-bit modes: the bound is COMPUTED.  The same block in f32 with nothing but round trips through the storage type where
+    # the kernels store (weights, raw conv output, block output; their gradients d_y, d_raw, d_in -- tests/storage_model.py)
+    # deviates from f32 autograd by m / m_w: the kernels may add nothing beyond the format -- within 2x of the model's own
+    # deviation (a 5 % scaling bug in the fold or the BatchNorm backward is 10-50x that)
+    from oracle import nets as onet
+    from storage_model import q, storage_model
+    import sos_amd
+    dt = torch.float16 if sos_amd.get_precision() == "fp16" else torch.bfloat16
+    sdm = {"b.block.1.weight": ref.block[1].weight.detach().clone().requires_grad_(True),
+           "b.block.2.weight": ref.block[2].weight.detach().clone(), "b.block.2.bias": ref.block[2].bias.detach().clone(),
+           "b.block.3.weight": ref.block[3].weight.detach().clone()}
+    with storage_model(dt):
+        xm = xheld.clone().requires_grad_(True)
+        onet.down_block(xm, sdm, "b", k, s, d, True).backward(gheld)
+        m_in = xm.grad if not accumulate else q(xm.grad + pheld)
+    m, m_w = rel_err(m_in, expect), rel_err(sdm["b.block.1.weight"].grad, ref.block[1].weight.grad)
+    print("   storage model: d_in", m, "dw", m_w, " HIP / model", err / m, err_w / m_w)
+    assert err < 2.0 * m + 1e-4 and err_w < 2.0 * m_w + 1e-4
+
+
+def test_loss_scale_is_exact_under_power_of_two_rescaling():
+    """fp16 mode: the backward pass carries a power-of-two loss scale chosen on the device from max|g| of the entering gradient
+    (sos_amax_f32 + sos_loss_scale), multiplied in where f32 gradients become 16-bit (sos_pack_nchw_to_nhwc `mul`) and divided out
+    where parameter gradients leave (sos_wgrad_desc.scale_dev, sos_bn_bwd out_scale).  The pass is linear, so rescaling the entering
+    gradient by 2^+-6 must change NOTHING but the scale: the stored (scaled) activation gradients are the same bits, S moves by
+    exactly 2^-+6, and every parameter gradient is exactly 2^+-6 times the unscaled run's (VERDICT r3 #3c)."""
+    import sos_amd
+    from sos_amd import engine as E, train_ops as TO
+    from sos_amd.denoiser.networks import DownConvBlock
+    sos_amd.set_precision("fp16")
+    try:
+        torch.manual_seed(4)
+        cin, cout, k, s, d, H, W = 64, 64, 3, 1, 2, 21, 26
+        blk = DownConvBlock(cin, cout, k, s, dilation=d).cuda().train()
+        x = torch.from_numpy(hashed(13, (2, cin, H, W)).astype(np.float32))
+        xa, _ = _act_from_nchw(x, False)
+        lp = TO.down_train_plan(blk, False)
+        dst = E.Act(2, H, W, cout, False, torch.device("cuda"))
+        t = TO.down_forward_train(lp, xa, 0, dst, 0, H, W, False)
+        g = torch.from_numpy(hashed(14, (2, cout, H, W)).astype(np.float32)) * 3e-3       # (small: unscaled it would sit in half's subnormals)
+        res = {}
+        for c in (1.0, 2.0 ** -6, 2.0 ** 6):
+            gc = (g * c).cuda()
+            with E.backward_scale(gc) as gs:
+                ga = E.pack_input(gc, False, mul=gs.mul)
+                gb = TO.GradBufs(False)
+                gb.bufs[id(dst)] = ga
+                gb.written[id(dst)] = [(0, cout)]
+                grads = {}
+                TO.down_backward(t, gb, grads, "b", False)
+                res[c] = (float(gs.mul), ga.t.clone(), gb.of(xa).t.clone(), {n: v.clone() for n, v in grads.items()})
+        S1, ga1, din1, gr1 = res[1.0]
+        assert S1 >= 2.0 ** 14                      # max|g| = 3e-3 -> S = 2^16: the scale is doing something
+        for c in (2.0 ** -6, 2.0 ** 6):
+            S, ga, din, gr = res[c]
+            assert S == S1 / c, (S, S1, c)
+            assert torch.equal(ga, ga1) and torch.equal(din, din1)          # the scaled 16-bit gradients: the same bits
+            for n in gr1:
+                assert torch.equal(gr[n], gr1[n] * c), n                    # parameter gradients: exactly c x
+        # and the unscaled run agrees with f32 autograd to the format's accuracy (the loss scale is what keeps 3e-3 * 2^-8-sized
+        # gradient elements out of half's subnormal range)
+        ref = DownConvBlock(cin, cout, k, s, dilation=d)
+        ref.load_state_dict({kk: v.cpu() for kk, v in blk.state_dict().items()})
+        xr = x.half().float().requires_grad_(True)
+        ref.train()
+        ref.block(xr).backward(g)
+        assert rel_err(gr1["b.block.1.weight"], ref.block[1].weight.grad) < 2e-2
+    finally:
+        sos_amd.set_precision("bf16")
 
 
 @pytest.mark.parametrize("reflect", [False, True], ids=["zero", "reflect"])
