@@ -161,16 +161,15 @@ __device__ __forceinline__ void stage_patch_dma(const ConvParams& p, char* patch
 // ---- cooperative store of the staged bf16 output tile ([256 pixels][OROW bytes] in LDS at smem, the lo
 // plane of the hi|hi|lo mode behind it): consecutive lanes write consecutive 16-byte pieces of a pixel's channel
 // run (and consecutive pixels of a tile row are adjacent in memory when dil_w == 1).  PPX = 16-byte pieces per pixel.
-template <int PPX, int OROW>
+template <int PPX, int OROW, int SLOTS = 256>
 __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* smem, const int tid, const int b, const int n0,
                                                   const int ho_base, const int wo_base, const int rw0, const bool x3,
                                                   const int Wo) {
     char* ost_hi = smem;
-    char* ost_lo = smem + 256 * OROW;
-    // element offset of every tile pixel inside its output image (-1: outside), one entry per thread
-    int* otab = (int*)(smem + 256 * OROW * (x3 ? 2 : 1));
-    {
-        const int m = tid;
+    char* ost_lo = smem + SLOTS * OROW;
+    // element offset of every tile pixel inside its output image (-1: outside), SLOTS / 256 entries per thread
+    int* otab = (int*)(smem + SLOTS * OROW * (x3 ? 2 : 1));
+    for (int m = tid; m < SLOTS; m += 256) {
         int cls, i, j;
         tile_decode(m, p.TH, p.TW, cls, i, j);
         const int ho = ho_base + i * p.dh;
@@ -194,7 +193,7 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
         if (pl < PL) {
-            for (int m = pl; m < 256; m += PL) {
+            for (int m = pl; m < SLOTS; m += PL) {
                 if (otab[m] < 0) continue;
                 const uint4 hv = *(const uint4*)(ost_hi + m * OROW + cg * 16);
                 uint4 lv = make_uint4(0u, 0u, 0u, 0u);
@@ -209,7 +208,7 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
                 }
             }
         }
-        float* red = (float*)(smem + 256 * OROW * (x3 ? 2 : 1) + 1024);
+        float* red = (float*)(smem + SLOTS * OROW * (x3 ? 2 : 1) + SLOTS * 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s[e]; red[tid * 16 + 8 + e] = q[e]; }
         __syncthreads();
@@ -229,7 +228,7 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
     if (!x3 && !p.accum && ((p.cout_store - n0) & 7) == 0) {          // common case: whole 8-channel pieces, plain store
         const int npiece = min(PPX, (p.cout_store - n0) >> 3);
 #pragma unroll 4
-        for (int idx = tid; idx < 256 * PPX; idx += 256) {
+        for (int idx = tid; idx < SLOTS * PPX; idx += 256) {
             const int m = idx / PPX, q = idx - m * PPX;
             const int off = otab[m];
             if (q < npiece && off != -1) {
@@ -242,7 +241,7 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
         return;
     }
 #pragma unroll 4
-    for (int idx = tid; idx < 256 * PPX; idx += 256) {
+    for (int idx = tid; idx < SLOTS * PPX; idx += 256) {
         const int m = idx / PPX, q = idx - m * PPX;
         const int co = n0 + q * 8;
         if (co >= p.cout_store) continue;
@@ -716,8 +715,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // against 0.348 ms in mode 1 and 0.395 ms in mode 0; the ISA shows no wait inside the window): what the kernel needs is the
 // third resident workgroup, i.e. more waves to cover the fragment reads' LDS latency (7 ds_read_b128 per 12 MFMAs keep the
 // LDS pipe ~55 % busy), not a hidden refill.
-template <int NT16, int KS, int MODE>
-__global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvParams p) {
+// PT: 16-pixel column tiles per wave.  4: a 256-pixel workgroup (three per CU in MODE 1).  8 (round 4): a wave owns 128 pixels x
+// all NT16 * 16 output channels -- NT16 + 8 fragment reads per 8 NT16 MFMAs instead of NT16 + 4 per 4 NT16 (48 channels: 11 per 24
+// instead of 7 per 12 ds_read_b128), and a 512-pixel workgroup streams every window slab once for twice the pixels (half the
+// L2 -> LDS weight traffic and half the barriers per pixel); 96 accumulator registers, two workgroups per CU.
+template <int NT16, int KS, int MODE, int PT = 4>
+__global__ __launch_bounds__(256, (MODE == 1 && PT == 4) ? 3 : 2) void conv16_kernel(ConvParams p) {
 #if __HIP_DEVICE_COMPILE__
     constexpr int KC = 16 * KS, G8 = 2 * KS;     // channels / 8-channel groups per tap
     // unpadded row pitches: lanes 16..31 of a fragment read address the SAME 16 rows as lanes 0..15, 16 bytes further
@@ -734,6 +737,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
     static_assert(MODE != 2 || WPW <= 3, "ring mode: the counted vmcnt waits cover at most three DMA instructions per wave and window");
     constexpr int WBYTES = SB ? 2 * TAPBYTES : WINSTR * 1024;
     constexpr int OROW = NT16 * 32 + 16;          // bytes per staged output pixel row
+    constexpr int SLOTS = 64 * PT;                // pixel slots of the workgroup's tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
     const int boff0 = p.npix * PSTRIDE;
@@ -764,11 +768,11 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
     }
     const int* wgather = p.wgather ? p.wgather + (long long)b * p.wg_stride : nullptr;
 
-    // per-lane pixel operand base (tap (0,0)) of the wave's four 16-pixel column tiles
-    int pbase[4];
+    // per-lane pixel operand base (tap (0,0)) of the wave's PT 16-pixel column tiles
+    int pbase[PT];
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-        const int m = wave * 64 + pt * 16 + l15;
+    for (int pt = 0; pt < PT; ++pt) {
+        const int m = wave * (16 * PT) + pt * 16 + l15;
         int cls, i, j;
         tile_decode(m, TH, TW, cls, i, j);
         if (cls >= p.NC) cls = i = j = 0;          // dead slot (see conv_mfma_kernel)
@@ -812,9 +816,9 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
         }
     };
 
-    f32x4 acc[4][NT16];
+    f32x4 acc[PT][NT16];
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt)
+    for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
         for (int nt = 0; nt < NT16; ++nt) acc[pt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -840,11 +844,11 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
 #if SOS_C16_XPF
     // pixel fragments of the NEXT window's first K-block: requested before the barrier(s) that close a window (the patch does
     // not change inside a segment), so that behind the barrier only the three weight fragments are still to be read
-    bf16x8 fbn[4];
+    bf16x8 fbn[PT];
     {
         const int po = (tap1[0] ? __builtin_amdgcn_readlane(tapoff16, min(1, ntaps - 1)) : __builtin_amdgcn_readlane(tapoff16, 0)) + coff[0];
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) fbn[pt] = lds_frag(patch + pbase[pt] + po);
+        for (int pt = 0; pt < PT; ++pt) fbn[pt] = lds_frag(patch + pbase[pt] + po);
     }
 #endif
     for (int w = 0; w < nwin; ++w) {
@@ -858,25 +862,25 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
         const int toff0 = __builtin_amdgcn_readlane(tapoff16, 2 * w);
         const int toff1 = __builtin_amdgcn_readlane(tapoff16, min(2 * w + 1, ntaps - 1));
         const char* slab = smem + boff0 + cur * WBYTES;
-        bf16x8 fa[2][NT16], fb[2][4];
+        bf16x8 fa[2][NT16], fb[2][PT];
         auto read_block = [&](const int kb, const int buf) {
 #pragma unroll
             for (int nt = 0; nt < NT16; ++nt) fa[buf][nt] = lds_frag(slab + aoff[kb] + nt * 16 * BSTRIDE);
             const int po = (tap1[kb] ? toff1 : toff0) + coff[kb];
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) fb[buf][pt] = lds_frag(patch + pbase[pt] + po);
+            for (int pt = 0; pt < PT; ++pt) fb[buf][pt] = lds_frag(patch + pbase[pt] + po);
         };
 #if SOS_C16_UPFRONT
         // experiment (round 3): every fragment of the window's BW K-blocks requested up front (7 BW ds_read_b128 in flight), the
         // MFMAs of block kb wait only for their own operands (LDS returns in order)
-        bf16x8 ga[BW][NT16], gb[BW][4];
+        bf16x8 ga[BW][NT16], gb[BW][PT];
 #pragma unroll
         for (int kb = 0; kb < BW; ++kb) {
 #pragma unroll
             for (int nt = 0; nt < NT16; ++nt) ga[kb][nt] = lds_frag(slab + aoff[kb] + nt * 16 * BSTRIDE);
             const int po = (tap1[kb] ? toff1 : toff0) + coff[kb];
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) gb[kb][pt] = lds_frag(patch + pbase[pt] + po);
+            for (int pt = 0; pt < PT; ++pt) gb[kb][pt] = lds_frag(patch + pbase[pt] + po);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -884,7 +888,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
 #pragma unroll
             for (int nt = 0; nt < NT16; ++nt)
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt)
+                for (int pt = 0; pt < PT; ++pt)
                     acc[pt][nt] = SOS_MFMA_16x16x32(ga[kb][nt], gb[kb][pt], acc[pt][nt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -904,7 +908,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
 #pragma unroll
             for (int nt = 0; nt < NT16; ++nt)
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) {
+                for (int pt = 0; pt < PT; ++pt) {
 #if SOS_C16_XPF
                     acc[pt][nt] = SOS_MFMA_16x16x32(fa[cb][nt], kb == 0 ? fbn[pt] : fb[cb][pt], acc[pt][nt], 0, 0, 0);
 #else
@@ -919,7 +923,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
             const int t1n = __builtin_amdgcn_readlane(tapoff16, min(2 * w + 3, ntaps - 1));
             const int po = (tap1[0] ? t1n : t0n) + coff[0];
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) fbn[pt] = lds_frag(patch + pbase[pt] + po);
+            for (int pt = 0; pt < PT; ++pt) fbn[pt] = lds_frag(patch + pbase[pt] + po);
         }
 #endif
 #endif
@@ -960,7 +964,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
         if (p.scale) { sc4 = *(const float4*)(p.scale + co); sh4 = *(const float4*)(p.shift + co); }
         const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
+        for (int pt = 0; pt < PT; ++pt) {
             float v[4];
             if (raw) {
 #pragma unroll
@@ -977,16 +981,16 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void conv16_kernel(ConvPara
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = (co + e < p.cout) ? v[e] : 0.f;
             }
-            const int m = wave * 64 + pt * 16 + l15;
+            const int m = wave * (16 * PT) + pt * 16 + l15;
             const unsigned h01 = pack2bf(v[0], v[1]), h23 = pack2bf(v[2], v[3]);
             *(uint2*)(smem + m * OROW + co * 2) = make_uint2(h01, h23);
             if (x3out) {              // hi|hi|lo output: the low parts go to the second staging plane
-                *(uint2*)(smem + 256 * OROW + m * OROW + co * 2) =
+                *(uint2*)(smem + SLOTS * OROW + m * OROW + co * 2) =
                     make_uint2(pack2bf(v[0] - sos_lo2f(h01), v[1] - sos_hi2f(h01)), pack2bf(v[2] - sos_lo2f(h23), v[3] - sos_hi2f(h23)));
             }
         }
     }
-    store_staged_tile<NT16 * 2, OROW>(p, smem, tid, b, 0, ho_base, wo_base, rw0, x3out, Wo);
+    store_staged_tile<NT16 * 2, OROW, SLOTS>(p, smem, tid, b, 0, ho_base, wo_base, rw0, x3out, Wo);
 #endif
 }
 
@@ -1094,6 +1098,25 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
     const int taps = d->kh * d->kw;
     static const int kscand[] = {8, 6, 5, 4, 3, 2, 1};
     const int k16 = d->cin / 16;
+    // 16-row kernel with 512-pixel workgroups (conv16_kernel<.., PT = 8>; ks -4: double, -5: single slab): the wave owns 128
+    // pixels x all output channels; candidates are the tiles of <= 512 slots whose patch still lets two workgroups into a CU
+    // (or one, for the tuner to reject)
+    auto add_tile16x = [&](const int NC, const int TH, const int TW) {
+        const int nt16 = nt16_for(d);
+        if (!nt16 || NC * TH * TW > 512 || NC * TH * TW <= 256) return;
+        const int PH = (TH - 1) * d->stride + d->kh, PW = (TW - 1) * d->stride + d->kw;
+        const int npix = NC * PH * PW;
+        const long long th = (Hc + TH - 1) / TH, tw = (Wc + TW - 1) / TW, ngw = (d->dil_w + NC - 1) / NC;
+        const double blocks = (double)th * tw * ngw * d->dil_h;
+        const size_t stage = (size_t)512 * (nt16 * 32 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + 2048 + 16384;
+        for (int mode = 0; mode < 2; ++mode) {
+            const size_t lds = std::max(lds_bytes16(npix, nt16, k16, mode), stage);
+            if (lds > LDS_LIMIT) continue;
+            double per_block = 0.75 * nseg_eff(d) * (0.9 * 512.0 * taps * k16 + 3.0 * npix * k16 + 40.0 * (6 + taps / 2));
+            if (lds > LDS_LIMIT / 2) per_block *= 1.3;
+            out.push_back({NC, tenc(TH), tenc(TW), -4 - mode, blocks * per_block});
+        }
+    };
     auto add_tile = [&](const int NC, const int TH, const int TW) {
         const int PH = (TH - 1) * d->stride + d->kh, PW = (TW - 1) * d->stride + d->kw;
         const int npix = NC * PH * PW;
@@ -1137,6 +1160,19 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
         const int NC = 1 << lnc;
         if (NC > 1 && (d->stride > 1 || NC > d->dil_w)) break;
         for (int lth = 0; lth + lnc <= 8; ++lth) add_tile(NC, 1 << lth, 1 << (8 - lnc - lth));
+    }
+    static const char* no512 = getenv("SOS_CONV16_NO512");          // A/B switch: without the 512-pixel workgroups of the 16-row kernel
+    if (nt16_for(d) && d->stride == 1 && !(no512 && atoi(no512))) {
+        for (int lnc = 0; lnc <= 6; ++lnc) {
+            const int NC = 1 << lnc;
+            if (NC > 1 && NC > d->dil_w) break;
+            for (int lth = 1; lth + lnc <= 7; ++lth) {
+                const int TH = 1 << lth, TWf = 512 / (NC * TH);
+                // the full 512 slots and the next narrower even widths (a 16 x 32 tile's 69 KB patch + slab + table is 1 KB over
+                // half a CU's LDS; 16 x 30 fits two workgroups)
+                for (int TW = TWf; TW >= TWf - 4 && TW >= 4; TW -= 2) add_tile16x(NC, TH, TW);
+            }
+        }
     }
     // Non-power-of-two tiles (round 3) for images whose strided extent per residue class is small: dilation 32 leaves 8 x 5.6
     // strided pixels per class, the U-Net's padded-domain gradients at dilation 16 6 x 4.8 -- 8-wide power-of-two tiles put a
@@ -1338,7 +1374,8 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     const int Hc = (d->Ho + d->dil_h - 1) / d->dil_h, Wc = (d->Wo + d->dil_w - 1) / d->dil_w;
     const int TH = tdim(c.lth), TW = tdim(c.ltw);
     p.NC = c.NC; p.TH = TH; p.TW = TW;
-    if (c.NC < 1 || TH < 1 || TW < 1 || c.NC * TH * TW > 256) { sos_set_error("sos_conv2d_fwd: internal: tile %d x %d x %d", c.NC, TH, TW); return SOS_EINVAL; }
+    const bool pt8 = c.ks <= -4;                          // 16-row kernel, 512-pixel workgroup
+    if (c.NC < 1 || TH < 1 || TW < 1 || c.NC * TH * TW > (pt8 ? 512 : 256)) { sos_set_error("sos_conv2d_fwd: internal: tile %d x %d x %d", c.NC, TH, TW); return SOS_EINVAL; }
     p.PH = (TH - 1) * d->stride + d->kh; p.PW = (TW - 1) * d->stride + d->kw;
     p.npix = p.NC * p.PH * p.PW;
     p.cps = c.ks > 0 ? d->cin / (16 * (ks_enc % 100)) : 1;
@@ -1356,19 +1393,22 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
         static const char* nomap = getenv("SOS_CONV_NO_LANE_MAP");          // A/B switch
         if (!nomap) p.lmap = pick_lane_map(p, (ks_enc % 100) * 32 + 16);
     }
-    if (c.ks <= 0) {                                     // 16-row kernel (ks 0: double-buffered slab, -1: single, -2: ring of three)
-        int mode = -c.ks;
-        { static const char* e = getenv("SOS_CONV16_MODE"); if (e) mode = atoi(e); }      // A/B: force a slab mode
+    if (c.ks <= 0) {                                     // 16-row kernel (ks 0: double-buffered slab, -1: single, -2: ring of three; -4 / -5: 512-pixel workgroups)
+        int mode = pt8 ? -c.ks - 4 : -c.ks;
+        if (!pt8) { static const char* e = getenv("SOS_CONV16_MODE"); if (e) mode = atoi(e); }      // A/B: force a slab mode
         const int nt16 = nt16_for(d), ks16 = d->cin / 16;
         if (!nt16) { sos_set_error("sos_conv2d_fwd: internal: 16-row tiling for an ineligible shape"); return SOS_EINVAL; }
         p.cps = 1; p.nchunks = nseg_eff(d);              // channel segments (3 in the hi|hi|lo mode), whole cin per segment
-        if (mode < 0 || mode > 2 || lds_bytes16(p.npix, nt16, ks16, mode) > LDS_LIMIT) mode = -c.ks;
+        if (mode < 0 || mode > (pt8 ? 1 : 2) || lds_bytes16(p.npix, nt16, ks16, mode) > LDS_LIMIT) mode = pt8 ? -c.ks - 4 : -c.ks;
         size_t lds16 = lds_bytes16(p.npix, nt16, ks16, mode);
-        const size_t stage16 = (size_t)256 * (nt16 * 32 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + 1024 + (d->stats ? 16384 : 0);
+        const size_t slots = pt8 ? 512 : 256;
+        const size_t stage16 = slots * (nt16 * 32 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + slots * 4 + (d->stats ? 16384 : 0);
         if (stage16 > lds16) lds16 = stage16;
+        if (lds16 > LDS_LIMIT) { sos_set_error("sos_conv2d_fwd: internal: 16-row tile needs %zu bytes of LDS", lds16); return SOS_EINVAL; }
         conv_kernel_t k = nullptr;
 #define SOS_C16(NTV, KSV)                                                                        \
-        if (nt16 == NTV && ks16 == KSV) k = mode == 1 ? conv16_kernel<NTV, KSV, 1> : (mode == 2 ? conv16_kernel<NTV, KSV, 2> : conv16_kernel<NTV, KSV, 0>);
+        if (nt16 == NTV && ks16 == KSV) k = pt8 ? (mode == 1 ? conv16_kernel<NTV, KSV, 1, 8> : conv16_kernel<NTV, KSV, 0, 8>)     \
+                                                : (mode == 1 ? conv16_kernel<NTV, KSV, 1> : (mode == 2 ? conv16_kernel<NTV, KSV, 2> : conv16_kernel<NTV, KSV, 0>));
         SOS_C16(1, 1) SOS_C16(1, 3) SOS_C16(3, 1) SOS_C16(3, 3)
 #undef SOS_C16
         static sos_device_once attr16;
@@ -1376,7 +1416,9 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
 #define SOS_C16A(NTV, KSV)                                                                                                        \
             (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);  \
             (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);  \
-            (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+            (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);  \
+            (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);  \
+            (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
             SOS_C16A(1, 1) SOS_C16A(1, 3) SOS_C16A(3, 1) SOS_C16A(3, 3)
 #undef SOS_C16A
             return (int)SOS_OK;
@@ -1407,8 +1449,18 @@ static long long tiles_of(const sos_conv_desc* d, const ConvCfg& c) {
     return (long long)d->B * d->dil_h * ((Hc + TH - 1) / TH) * ((d->dil_w + c.NC - 1) / c.NC) * ((Wc + TW - 1) / TW);
 }
 
+// SOS_CONV16_FORCE512=1 (testing): every shape the 16-row kernel takes runs its cheapest 512-pixel-workgroup candidate (ks -5 / -4)
+static bool forced_512(const sos_conv_desc* d, ConvCfg* out) {
+    static const char* f512 = getenv("SOS_CONV16_FORCE512");
+    if (!(f512 && atoi(f512)) || !nt16_for(d)) return false;
+    for (const ConvCfg& e : enumerate_cfgs(d))
+        if (e.ks <= -4) { *out = e; return true; }
+    return false;
+}
+
 extern "C" int64_t sos_conv2d_tile_count(const sos_conv_desc* d) {
     if (validate(d)) return -1;
+    { ConvCfg c5; if (forced_512(d, &c5)) return tiles_of(d, c5); }
     static const char* force = getenv("SOS_CONV_FORCE_CFG");
     if (!force) {
         ConvCfg c;
@@ -1423,6 +1475,7 @@ extern "C" int64_t sos_conv2d_tile_count(const sos_conv_desc* d) {
 extern "C" int sos_conv2d_fwd(const sos_conv_desc* d, sos_stream_t stream) {
     int rc = validate(d);
     if (rc) return rc;
+    { ConvCfg c5; if (forced_512(d, &c5)) return launch_cfg(d, c5, (hipStream_t)stream); }
     // SOS_CONV_FORCE_CFG=k (testing): use the k-th candidate tiling (mod count) instead of the tuned one
     static const char* force = getenv("SOS_CONV_FORCE_CFG");
     if (!force) {

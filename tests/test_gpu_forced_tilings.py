@@ -34,3 +34,15 @@ def test_network_parity_with_forced_16_row_slab_mode(mode):
                         os.path.join(ROOT, "tests", "test_gpu_train_nets.py"), "-k", "not train_step"], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_network_parity_with_forced_512_pixel_16_row_workgroups():
+    """Round 4: the 16-row conv kernel with 512-pixel workgroups (a wave owns 128 pixels x all output channels; conv16_kernel<.., PT = 8>)
+    is a tiling candidate the table may or may not pick per shape: the network parity tests (forward of both networks, the
+    fp16 / bf16 / three-pass modes, the exact encoder-block backward) pass with it forced for every eligible launch
+    (SOS_CONV16_FORCE512=1), single- and double-buffered slab."""
+    env = dict(os.environ, SOS_CONV16_FORCE512="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_nets.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_train_nets.py"), "-k", "not train_step"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -23,6 +23,8 @@ os.environ["SOS_FOLD_FUSED"] = "0"             # the U-Net's folded data-gradien
 EXTEND_AV = "--extend-av" in sys.argv        # keep the committed table, add the audio-visual variant's shapes
 RETUNE_X3 = "--retune-x3" in sys.argv        # keep the committed table, re-measure the three-segment shapes the 16-row kernel now takes
 RETUNE_NPOT = "--retune-npot" in sys.argv    # keep the committed table, re-measure the shapes that gained non-power-of-two tile candidates
+RETUNE_16ROW = "--retune-16row" in sys.argv  # keep the committed table, re-measure the 16- / 48-channel-input shapes (round 4: the 16-row
+                                             # kernel's 512-pixel workgroups; the first layers with their horizontal taps on the channel axis)
 SHIPPED = os.path.join(ROOT, "listening-to-sound-of-silence-for-speech-denoising_amd", "tune_table_gfx950.txt")
 if os.path.exists(OUT):
     os.remove(OUT)
@@ -40,6 +42,14 @@ if RETUNE_X3:
         if not elig:
             keep.append(ln)
     open(OUT, "w").write("\n".join(keep) + "\n")
+    print("dropped", len(lines) - len(keep), "entries to re-measure")
+
+if RETUNE_16ROW:
+    os.environ.setdefault("SOS_CONV_TUNE_CANDIDATES", "48")       # the 512-pixel candidates sit anywhere in the cost-ordered list
+    lines = open(SHIPPED).read().splitlines()
+    keep = [lines[0]] + [ln for ln in lines[1:] if ln.split()[4] not in ("16", "48")]      # column 4: cin (conv.hip, shape_key)
+    for path in (OUT, OUT + ".f16"):
+        open(path, "w").write("\n".join(keep) + "\n")
     print("dropped", len(lines) - len(keep), "entries to re-measure")
 
 if RETUNE_NPOT:
@@ -120,6 +130,19 @@ def main():
         sos_amd.set_precision("bf16x3")
         x3_detector_workloads()
         from sos_amd import _lib
+        _lib.lib().sos_conv2d_tune_save(OUT.encode())
+        print("wrote", OUT, sum(1 for _ in open(OUT)) - 1, "entries")
+        return
+    if RETUNE_16ROW:
+        for prec, batches in (("bf16", (64, 32, 16, 8, 4, 2, 1)), ("bf16x3", (64, 2, 1))):
+            sos_amd.set_precision(prec)
+            for B in batches:
+                workloads(B)
+                print("re-tuned", prec, "B =", B, flush=True)
+        sos_amd.set_precision("bf16x3")
+        x3_detector_workloads()
+        from sos_amd import _lib
+        sos_amd.set_precision("bf16")
         _lib.lib().sos_conv2d_tune_save(OUT.encode())
         print("wrote", OUT, sum(1 for _ in open(OUT)) - 1, "entries")
         return
