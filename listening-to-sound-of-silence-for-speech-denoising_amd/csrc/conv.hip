@@ -1161,8 +1161,13 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
         if (NC > 1 && (d->stride > 1 || NC > d->dil_w)) break;
         for (int lth = 0; lth + lnc <= 8; ++lth) add_tile(NC, 1 << lth, 1 << (8 - lnc - lth));
     }
-    static const char* no512 = getenv("SOS_CONV16_NO512");          // A/B switch: without the 512-pixel workgroups of the 16-row kernel
-    if (nt16_for(d) && d->stride == 1 && !(no512 && atoi(no512))) {
+    // 512-pixel workgroups of the 16-row kernel: OPT-IN (SOS_CONV16_512=1, or SOS_CONV16_FORCE512=1 of the tests).  Round 4
+    // measured them slower on every 5x5 shape (48 -> 48 at B = 64: 0.396 vs 0.369 ms forced against the table's 256-pixel tile on
+    // the same box; a re-tune over 48 candidates per shape kept the 256-pixel tiles for all but two B = 8 1x1 heads): the
+    // kernel wants its third resident workgroup more than fewer fragment reads per MFMA.
+    static const char* en512 = getenv("SOS_CONV16_512");
+    static const char* f512e = getenv("SOS_CONV16_FORCE512");
+    if (nt16_for(d) && d->stride == 1 && ((en512 && atoi(en512)) || (f512e && atoi(f512e)))) {
         for (int lnc = 0; lnc <= 6; ++lnc) {
             const int NC = 1 << lnc;
             if (NC > 1 && NC > d->dil_w) break;

@@ -84,7 +84,9 @@ def test_agents_train_step_and_checkpoint(tmp_path):
     ag2.clock.tick()
     path = ag2.save_ckpt()
     ck = torch.load(path, map_location="cpu")
-    assert set(ck.keys()) == {"clock", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict"}
+    # the reference's four keys (M1/agent.py:62-78) + the fp16 mode's overflow-guard state (round 4: a resumed run keeps its
+    # loss-scale back-off; a reference-side loader indexes the four keys by name and never sees the fifth)
+    assert set(ck.keys()) == {"clock", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "overflow_guard"}
     assert list(ck["model_state_dict"].keys()) == [k for k, _, _ in onet.joint_spec()]
     assert ck["clock"] == {"epoch": 1, "minibatch": 1, "step": 1}
     jm2 = jnet.get_network(MyConfig())

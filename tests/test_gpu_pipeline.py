@@ -208,7 +208,7 @@ def test_ragged_one_launch_1s_and_10s_vs_oracle():
     lens = [140000, 14000, 28123, 97531, 14000 + 157, 51800]
     waves = [_long_wave(300 + 10 * i, n) for i, n in enumerate(lens)]
     clips = [torch.from_numpy(w).cuda() for w in waves]
-    for precision, tol_single, tol_oracle in (("bf16x3", 2e-4, 1e-3), ("mixed", 1e-2, WAVE_TOL_FP16)):
+    for precision, tol_single, tol_oracle in (("bf16x3", 2e-4, 1e-3), ("mixed", 1e-2, 1e-2)):     # (mixed: the cap; the computed bound below is the test)
         sos_amd.set_precision(precision)
         try:
             outs, extra = pipeline.denoise_ragged(det, jm, clips, return_all=True)
