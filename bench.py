@@ -417,6 +417,23 @@ def main():
                 except Exception as e:        # a secondary line never takes the headline down
                     sec[key] = None
                     sec[key + "_error"] = repr(e)[:200]
+            # the headline workload with the denoiser's [stage 1 -> encoder_n] branch on a side stream beside encoder_x
+            # (JointModel.BRANCH_STREAMS, opt-in: +1.3-1.6 % here, but the dominant kernel then time-shares the chip and its
+            # HIP-event duration no longer measures the kernel alone -- DESIGN.md 5.0)
+            try:
+                from sos_amd.denoiser import networks as _jnet
+                _jnet.JointModel.BRANCH_STREAMS = True
+                try:
+                    w2 = Workload("train", "fp16", 64, rank)
+                    dt2, _, _ = run_timed(w2, 10, 3, barrier, profile=False)
+                    sec["train_fp16_branch_streams_utt_s"] = round(64 * 10 / dt2, 1)
+                    del w2
+                finally:
+                    _jnet.JointModel.BRANCH_STREAMS = False
+                torch.cuda.empty_cache()
+            except Exception as e:
+                sec["train_fp16_branch_streams_utt_s"] = None
+                sec["train_fp16_branch_streams_utt_s_error"] = repr(e)[:200]
             # the audio-visual variant's per-GPU share of BASELINE configs[4] (32 clips of 60 x 224 x 224 frames + audio): one
             # training step of the detector with its video branch
             try:
@@ -465,7 +482,8 @@ def main():
                            "train_fp16_16khz_2x256x251 = SURVEY.md 8-d's secondary (BASELINE-literal 16 kHz / STFT 512-128, Nyquist dropped) spectrogram "
                            "geometry, 1.41x the FLOPs per clip, throughput only; audiovisual_train = the detector with its video branch at BASELINE "
                            "configs[4]'s per-GPU share (32 clips of 60 x 224 x 224 frames) x 3 steps; train_fp16_forced_buckets = the headline "
-                           "workload with the data-parallel gradient path forced in a world of one (1-rank RCCL groups, one per model)")
+                           "workload with the data-parallel gradient path forced in a world of one (1-rank RCCL groups, one per model); "
+                           "train_fp16_branch_streams = the headline workload with SOS_BRANCH_STREAMS=1 (opt-in schedule)")
             line["secondary"] = sec
             sos_amd.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:
