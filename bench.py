@@ -300,6 +300,12 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         _self_launch(args.gpus)                       # does not return
+    # stdout carries exactly ONE line, the JSON record: RCCL prints a version banner through C stdio (flushed at exit, i.e.
+    # BEHIND the record) whenever a communicator is created.  File descriptor 1 is pointed at stderr for the whole run and
+    # the record is written to the saved descriptor at the very end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -488,7 +494,7 @@ def main():
             sos_amd.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
