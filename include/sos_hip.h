@@ -296,6 +296,15 @@ typedef struct sos_wgrad_desc {
 } sos_wgrad_desc;
 int64_t sos_wgrad_workspace_bytes(const sos_wgrad_desc* desc);
 int sos_conv2d_wgrad(const sos_wgrad_desc* desc, sos_stream_t stream);
+/* ABI 7: measured launch plans of sos_conv2d_wgrad (workgroup channel tile, pixel tile, pixel order, workgroups per CU), the
+ * counterpart of sos_conv2d_tune: times the candidate plans for the SHAPE of `desc` (`iters` launches each, the fastest few
+ * again over 8x as many; HIP events on `stream`, SYNCHRONISES, overwrites desc->dw / desc->partial: pass accumulate = 0 and
+ * scratch outputs) and caches the winner for every later sos_conv2d_wgrad of that shape.  *best_ms (optional) = the winning time,
+ * -1 if the shape already had a plan (or takes the GEMM path).  save / load: host text file; load returns the entries accepted
+ * (0: no file).  The package ships wgrad_table_gfx950.txt so that every process and rank runs the same plans. */
+int sos_wgrad_tune(const sos_wgrad_desc* desc, int iters, float* best_ms, sos_stream_t stream);
+int sos_wgrad_tune_save(const char* path);
+int sos_wgrad_tune_load(const char* path);
 
 /* ---- backward of the BatchNorm(+activation) / bias(+activation) tail of a conv block (autograd of
  * nn.BatchNorm2d + ReLU/PReLU in train mode).  dy: grad of the block output; x: raw conv output;

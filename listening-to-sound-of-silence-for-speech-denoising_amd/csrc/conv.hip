@@ -1522,16 +1522,53 @@ extern "C" int sos_conv2d_tune(const sos_conv_desc* d, int max_candidates, int i
     float best = 1e30f;
     int besti = 0;
     const int n = std::min<int>((int)cfgs.size(), max_candidates);
-    for (int i = 0; i < n; ++i) {
-        if ((rc = launch_cfg(d, cfgs[i], s))) break;           // warm-up
+    auto time_cfg = [&](const int i, const int reps, float* ms_out) {
+        int r = launch_cfg(d, cfgs[i], s);                      // warm-up
+        if (r) return r;
         (void)hipEventRecord(e0, s);
-        for (int k = 0; k < iters && !rc; ++k) rc = launch_cfg(d, cfgs[i], s);
+        for (int k = 0; k < reps && !r; ++k) r = launch_cfg(d, cfgs[i], s);
         (void)hipEventRecord(e1, s);
-        if (rc || hipEventSynchronize(e1) != hipSuccess) { if (!rc) rc = SOS_ELAUNCH; break; }
+        if (r || hipEventSynchronize(e1) != hipSuccess) return r ? r : (int)SOS_ELAUNCH;
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        ms /= iters;
+        *ms_out = ms / reps;
+        return (int)SOS_OK;
+    };
+    static const char* verbose = getenv("SOS_CONV_TUNE_VERBOSE");
+    std::vector<std::pair<float, int>> timed;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        if ((rc = time_cfg(i, iters, &ms))) break;
+        timed.push_back({ms, i});
         if (ms < best) { best = ms; besti = i; }
+    }
+    // Wide searches (round 4: more than 16 candidates, tools/make_tune_table.py --retune-wide) are decided in a second stage: a
+    // 3-launch timing of ~100 candidates picks a lucky sample as often as a better tiling (a 48-candidate table of single-stage
+    // timings measured no better than the 8-candidate one in round 3), so the five fastest are timed again over 8x the launches,
+    // ALTERNATING twice, and the cost model's first candidate is kept unless the winner beats it by more than 2 %.
+    if (!rc && n > 16) {
+        std::sort(timed.begin(), timed.end());
+        const int top = std::min<int>(5, (int)timed.size());
+        std::vector<int> cand;
+        for (int t = 0; t < top; ++t) cand.push_back(timed[t].second);
+        if (std::find(cand.begin(), cand.end(), 0) == cand.end()) cand.push_back(0);
+        std::vector<float> acc(cand.size(), 0.f);
+        for (int round = 0; round < 2 && !rc; ++round)
+            for (size_t t = 0; t < cand.size() && !rc; ++t) {
+                float ms = 0.f;
+                rc = time_cfg(cand[t], iters * 8, &ms);
+                acc[t] += ms * 0.5f;
+            }
+        if (!rc) {
+            size_t bt = 0, t0 = cand.size();
+            for (size_t t = 0; t < cand.size(); ++t) { if (acc[t] < acc[bt]) bt = t; if (cand[t] == 0) t0 = t; }
+            if (t0 < cand.size() && acc[bt] > 0.98f * acc[t0]) bt = t0;
+            best = acc[bt]; besti = cand[bt];
+            if (verbose)
+                fprintf(stderr, "tune k%dx%d d%dx%d s%d cin%d cout%d %dx%d B%d: %d candidates, pick #%d NC=%d TH=%d TW=%d ks=%d %.4f ms (model's first %.4f ms)\n",
+                        d->kh, d->kw, d->dil_h, d->dil_w, d->stride, d->cin, d->cout, d->Ho, d->Wo, d->B, n, besti, cfgs[besti].NC,
+                        tdim(cfgs[besti].lth), tdim(cfgs[besti].ltw), cfgs[besti].ks, best, t0 < cand.size() ? acc[t0] : -1.f);
+        }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

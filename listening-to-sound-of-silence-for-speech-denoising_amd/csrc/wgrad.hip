@@ -19,7 +19,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
+#include <algorithm>
 #include <map>
+#include <vector>
 #include <mutex>
 #include <type_traits>
 
@@ -959,6 +962,296 @@ static int wg_max_split(const sos_wgrad_desc* d) {
     return (int)(cap < 1 ? 1 : (cap > WG_MAXSPLIT ? WG_MAXSPLIT : cap));
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Host side of wgrad_kernel / wgrad16_kernel: a PLAN = the workgroup's channel tile (MT m-tiles x NTB n-tiles of 32), its pixel
+// tile (NC residue classes x 2^lth x 2^ltw = 256 pixels), the order of those pixels along the contraction and the number of
+// workgroups per CU.  Plans come from (1) the measured table (round 4: sos_wgrad_tune / sos_wgrad_tune_load, the shipped
+// wgrad_table_gfx950.txt -- every process and every rank then runs the same plans, hence the same summation order), else (2) the
+// calibrated cost model below.
+struct WgPlan { int mt, ntb, nc, lth, ltw, kord, occ, db, bufbytes, npixp, pw; double cost; };
+struct WgCtx {
+    bool temporal, is_flat, use16;
+    int khg, ntg, taps, taps_all, ntiles_m, ntiles_n, m16, n16, Hc, Wc;
+};
+struct WgKey {
+    int v[12];
+    bool operator<(const WgKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
+};
+static std::mutex& wg_mu() { static std::mutex m; return m; }
+static std::map<WgKey, WgPlan>& wg_table() { static std::map<WgKey, WgPlan> t; return t; }      // measured plans
+static std::map<WgKey, WgPlan>& wg_model_cache() { static std::map<WgKey, WgPlan> t; return t; } // the cost model's picks
+
+static WgCtx wg_ctx(const sos_wgrad_desc* d, bool temporal, bool is_flat) {
+    WgCtx c;
+    c.temporal = temporal; c.is_flat = is_flat;
+    // more taps than one workgroup's 32 (tap, n-tile) pairs (7x7): the tap ROWS are divided over ntg workgroups that read the
+    // same G tile at the same time on the same XCD (one launch, G fetched from HBM once instead of once per row)
+    // (the last group may own fewer real rows: its phantom taps are computed on the rows below and never stored)
+    int khg = d->kh;
+    if (khg * d->kw > WG_WAVES * WG_PAIRS) khg = WG_WAVES * WG_PAIRS / d->kw < 1 ? 1 : WG_WAVES * WG_PAIRS / d->kw;
+    c.khg = khg; c.ntg = (d->kh + khg - 1) / khg;
+    c.taps_all = d->kh * d->kw; c.taps = khg * d->kw;
+    c.ntiles_m = (d->M + 31) / 32; c.ntiles_n = (d->N + 31) / 32;
+    c.m16 = (d->M + 15) / 16; c.n16 = (d->N + 15) / 16;
+    // small channel counts: the 16x16x32 kernel owns all of dW in one workgroup (no padding to 32)
+    c.use16 = !temporal && c.ntg == 1 && c.m16 == 3 && c.n16 == 3 && (c.taps == 25 || c.taps == 9) && !getenv("SOS_WGRAD_NO16");
+    c.Hc = (d->Hg + d->dil_h - 1) / d->dil_h; c.Wc = (d->Wg + d->dil_w - 1) / d->dil_w;
+    return c;
+}
+static WgKey wg_key(const sos_wgrad_desc* d, const WgCtx& c) {
+    return WgKey{{d->Hg, d->Wg, d->kh, d->kw, d->stride, d->dil_h, d->dil_w, d->M, d->N, c.use16 ? 1 : 0, c.temporal ? d->t_taps : 0,
+                  c.is_flat ? 1 : 0}};
+}
+
+// Completes a plan (patch pitch, LDS bytes, double buffering) for the given channel / pixel tile and prices it with the cost
+// model; false: the tile is not legal for this shape (dilation classes, coordinate range, LDS).
+static bool wg_make_plan(const sos_wgrad_desc* d, const WgCtx& c, int mt, int ntb, int lnc, int lth, int kord, int occ, WgPlan* out) {
+    const size_t lds_max = 160 * 1024;
+    const int NC = 1 << lnc, ltw = 8 - lnc - lth;
+    if (ltw < 2 || lth < 0) return false;
+    if (NC > 1 && (d->stride > 1 || NC > d->dil_w || d->dil_w % NC)) return false;
+    const int TH = 1 << lth, TW = 1 << ltw;
+    const int PH = (TH - 1) * d->stride + c.khg, PW = (TW - 1) * d->stride + d->kw;
+    if ((TH - 1 + d->kh) * d->dil_h >= 0x7fff || (d->stride * NC + (PW - 1) * d->dil_w) >= 0x7fff) return false;
+    const int tiles_h = (c.Hc + TH - 1) / TH, tiles_w = (c.Wc + TW - 1) / TW, ngw = (d->dil_w + NC - 1) / NC;
+    const double ntiles = (double)d->dil_h * ngw * tiles_h * tiles_w;
+    // Column-major order: the pixels a transposed read gathers are consecutive ROWS of the patch, PWl pixel
+    // pitches apart; with an even PWl their 64-byte (32-byte) runs land on the same banks (PW = 12: 768 B = 0 mod
+    // 256 -- SQ_LDS_BANK_CONFLICT was 59 % of the LDS-active cycles of the 96 -> 96 gradient), with an odd one
+    // they tile the 64 banks.  One more (never multiplied) patch column buys that.
+    const int PWl = (kord == 1 && (PW & 1) == 0 && !getenv("SOS_WGRAD_EVEN_PITCH")) ? PW + 1 : PW;
+    const bool use16 = c.use16;
+    const int npixp = use16 ? (NC * PH * PWl + 31) / 32 * 32 : (NC * PH * PWl + 15) / 16 * 16;
+    const size_t one = use16 ? ((size_t)256 * 32 * c.m16 + (size_t)npixp * 32 * c.n16 + 1023) / 1024 * 1024
+                             : ((size_t)256 * 64 * mt + (size_t)npixp * 64 * ntb + 1023) / 1024 * 1024;
+    const size_t tabb = (size_t)(256 + npixp) * 8;
+    if (one + tabb > lds_max / occ) return false;
+    const int db = 2 * one + tabb <= lds_max / occ;
+    // Cost of one image in k-step units, calibrated on MI355X with tools/probe/wgrad_tile_sweep.py (round 3: every
+    // tile x order of the 96- and 48-channel layers timed; this model's pick is within 1.1 % of the best measured
+    // one on each).  A tile multiplies its k-steps that hold a pixel of the image (first pixel of the k-step
+    // inside); meanwhile the DMA of the NEXT tile runs, `kb` k-steps per KB of operand image whether its pixels
+    // are inside or not -- so a border tile that keeps 2 of its k-steps still takes its successor's fetch time
+    // (double buffered: the longer of the two; single buffered: a fraction of the fetch is exposed) -- plus a
+    // fixed barrier / drain cost per tile.  The 16x16x32 kernel's k-step is 32 pixels x 9 tiles per tap and
+    // fetches 48-channel operands: its DMA term weighs more (the former bank-conflict term of that kernel is
+    // subsumed: the sweep ranks its tiles correctly without it).
+    const double kb = use16 ? 0.15 : 0.04, sbf = use16 ? 0.3 : 0.5, fixed = use16 ? 1.5 : 1.0;
+    const double dma = (double)one / 1024.0 * kb;
+    const int kpix = use16 ? 32 : 16;              // tile pixels per k-step
+    double cost = 0.0;
+    const int nk = 256 / kpix;
+    int kh_rel[16], kw_rel[16];                       // first pixel of every k-step, relative to the tile origin
+    for (int ks = 0; ks < nk; ++ks) {
+        int cc, i, j;
+        wg_decode(ks * kpix, lth, ltw, kord, cc, i, j);
+        kh_rel[ks] = i * d->dil_h; kw_rel[ks] = cc + j * d->dil_w;
+    }
+    for (int rh = 0; rh < d->dil_h; ++rh)
+        for (int gw = 0; gw < ngw; ++gw)
+            for (int ti = 0; ti < tiles_h; ++ti)
+                for (int tj = 0; tj < tiles_w; ++tj) {
+                    const int gh0 = rh + ti * TH * d->dil_h, gw0 = gw * NC + tj * TW * d->dil_w;
+                    int nks = 0;
+                    for (int ks = 0; ks < nk; ++ks) nks += (gh0 + kh_rel[ks] < d->Hg) & (gw0 + kw_rel[ks] < d->Wg);
+                    cost += db ? (nks > dma ? nks : dma) : nks + sbf * dma;
+                }
+    cost += fixed * ntiles;
+    *out = WgPlan{mt, ntb, NC, lth, ltw, kord, occ, db, (int)one, npixp, PWl, cost};
+    return true;
+}
+
+// best pixel tile of the cost model for a channel tile (mt, ntb); false: no tile fits LDS
+static bool wg_best_tile(const sos_wgrad_desc* d, const WgCtx& c, int mt, int ntb, int occ, WgPlan* out) {
+    int fnc = -1, fth = -1, ftw = -1, fko = -1;
+    const char* force = getenv("SOS_WGRAD_TILE");  // experiments: "nc,lth,ltw,kord"
+    if (force) sscanf(force, "%d,%d,%d,%d", &fnc, &fth, &ftw, &fko);
+    bool any = false;
+    for (int lnc = 0; lnc <= 6; ++lnc)
+        for (int lth = 0; lth + lnc <= 8; ++lth)
+            for (int kord = 0; kord < 2; ++kord) {
+                if (force && fnc > 0 && ((1 << lnc) != fnc || lth != fth || 8 - lnc - lth != ftw)) continue;
+                if (force && fko >= 0 && kord != fko) continue;
+                WgPlan pl;
+                if (!wg_make_plan(d, c, mt, ntb, lnc, lth, kord, occ, &pl)) continue;
+                if (!any || pl.cost < out->cost) { *out = pl; any = true; }
+            }
+    return any;
+}
+
+// SIMD load of `pairs` (tap, n-tile) pairs dealt round robin to 8 waves, two waves per SIMD
+static int wg_simd_max(int pairs) {
+    int simd[4] = {0, 0, 0, 0};
+    for (int w = 0; w < WG_WAVES; ++w) simd[w & 3] += pairs / WG_WAVES + (w < pairs % WG_WAVES ? 1 : 0);
+    return std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3]));
+}
+
+// The cost model's plan.
+static int wg_model_plan(const sos_wgrad_desc* d, const WgCtx& c, WgPlan* out) {
+    int ntb = WG_WAVES * WG_PAIRS / c.taps;         // (tap, n-tile) pairs per workgroup <= 32
+    ntb = ntb >= 4 ? 4 : (ntb >= 2 ? 2 : 1);
+    if (ntb > c.ntiles_n) ntb = c.ntiles_n >= 4 ? 4 : (c.ntiles_n >= 2 ? 2 : 1);
+    int mgroups = (c.ntiles_m + 2) / 3;
+    int mt = (c.ntiles_m + mgroups - 1) / mgroups;              // 1..3 m-tiles per workgroup, balanced
+    bool forced_ntb = false;
+    {   // experiments (tools/probe/wgrad_cfg_sweep.py): force the workgroup's channel tile
+        const char* e = getenv("SOS_WGRAD_MT");
+        if (e && atoi(e) >= 1 && atoi(e) <= 3) { mt = std::min(atoi(e), c.ntiles_m); }
+        e = getenv("SOS_WGRAD_NTB");
+        if (e && atoi(e) >= 1 && atoi(e) <= 4 && atoi(e) * c.taps <= WG_WAVES * WG_PAIRS) { ntb = std::min(atoi(e), c.ntiles_n); forced_ntb = true; }
+    }
+    // workgroups per CU: one (its own double-buffered DMA pipeline covers the fetch of the next tile) unless a tile is so
+    // short that the fetch latency of a tile exceeds its MFMA time -- then several co-resident workgroups cover each other
+    // (measured: the 96 -> 8 / 48 -> 4 1x1 heads, two MFMAs per k-step and workgroup: 0.456 -> 0.338 / 0.239 -> 0.185 ms with
+    // two workgroups per CU; the thin 5x5 / 1x7 first layers, whose double buffers no longer fit then, get slower)
+    // (round 4: only when the M side is the thin one -- 96 -> 8: 0.42 -> 0.32 ms, 48 -> 4: 0.22 -> 0.18 with two; a thin N side with
+    // two m-tiles -- the first layers with their taps folded, 14 -> 48 -- is FASTER with one: 0.235 vs 0.285 ms)
+    int occ = c.is_flat && mt == 1 && ntb <= 2 ? 2 : 1;
+    { const char* e = getenv("SOS_WGRAD_OCC"); if (e && atoi(e) >= 1 && atoi(e) <= 4) occ = atoi(e); }
+    if (c.use16) { if (!wg_best_tile(d, c, mt, ntb, 1, out)) { sos_set_error("sos_conv2d_wgrad: patch does not fit LDS"); return SOS_ENOSPC; } return SOS_OK; }
+    // Few-tap kernels (3x3, 7x1; round 4): the (tap, n-tile) pairs of NTB n-tiles go round robin over 8 waves, two waves per
+    // SIMD, so NTB decides (a) how much of the last n-group is padding, (b) how evenly the pairs load the four SIMDs, (c) how
+    // many fragment reads an MFMA costs ((MT + pairs per wave) reads feed MT x pairs MFMAs) and (d) which pixel tiles still fit
+    // LDS, double buffered or not.  Time model: tile cost x n-groups x busiest SIMD's pairs x (1 + 0.8 reads per MFMA),
+    // fitted to tools/probe/wgrad_cfg_sweep.py on MI355X: 96 -> 96 7x1 takes NTB = 3 (21 pairs, one n-group: 0.73 -> 0.47 ms),
+    // 256 -> 256 3x3 NTB = 3 (0.292 -> 0.280), its dilation-16 sibling and 128 -> 256 / 64 -> 128 3x3 keep NTB = 2.
+    if (!forced_ntb && c.taps >= 5 && c.taps * 2 <= WG_WAVES * WG_PAIRS) {
+        double best = 1e300;
+        bool any = false;
+        for (int cn = 1; cn <= 4 && cn <= c.ntiles_n && cn * c.taps <= WG_WAVES * WG_PAIRS; ++cn) {
+            WgPlan pl;
+            if (!wg_best_tile(d, c, mt, cn, 1, &pl)) continue;
+            const int pairs = cn * c.taps, groups = (c.ntiles_n + cn - 1) / cn;
+            const double ppw = (double)pairs / WG_WAVES, reads = (mt + ppw) / (mt * ppw);
+            const double t = pl.cost * groups * wg_simd_max(pairs) * (1.0 + 0.8 * reads);
+            if (t < best) { best = t; *out = pl; any = true; }
+        }
+        if (any) return SOS_OK;
+    }
+    for (int ntb_try = ntb;;) {
+        int o = occ;
+        while (o >= 1 && !wg_best_tile(d, c, mt, ntb_try, o, out)) --o;     // (a second workgroup per CU only if the buffers allow it)
+        if (o >= 1) return SOS_OK;
+        if (ntb_try == 1) { sos_set_error("sos_conv2d_wgrad: patch does not fit LDS"); return SOS_ENOSPC; }
+        ntb_try = ntb_try == 3 ? 2 : ntb_try >> 1;
+    }
+}
+
+static int wg_choose_plan(const sos_wgrad_desc* d, const WgCtx& c, WgPlan* out) {
+    const WgKey key = wg_key(d, c);
+    const bool forced = getenv("SOS_WGRAD_TILE") || getenv("SOS_WGRAD_MT") || getenv("SOS_WGRAD_NTB") || getenv("SOS_WGRAD_OCC");
+    if (!forced) {
+        std::lock_guard<std::mutex> lk(wg_mu());
+        auto f = wg_table().find(key);
+        if (f != wg_table().end()) { *out = f->second; return SOS_OK; }
+        auto g = wg_model_cache().find(key);
+        if (g != wg_model_cache().end()) { *out = g->second; return SOS_OK; }
+    }
+    const int rc = wg_model_plan(d, c, out);
+    if (rc) return rc;
+    if (getenv("SOS_WGRAD_VERBOSE"))
+        fprintf(stderr, "sos_conv2d_wgrad: %dx%d k%dx%d s%d d%dx%d M%d N%d %s-> MT=%d NTB=%d NC=%d TH=%d TW=%d order=%d dbuf=%d occ=%d lds=%d pitch=%d\n",
+                d->Hg, d->Wg, d->kh, d->kw, d->stride, d->dil_h, d->dil_w, d->M, d->N, c.use16 ? "(16x16x32) " : "", out->mt, out->ntb,
+                out->nc, 1 << out->lth, 1 << out->ltw, out->kord, out->db, out->occ, out->bufbytes, out->pw);
+    if (!forced) {
+        std::lock_guard<std::mutex> lk(wg_mu());
+        wg_model_cache()[key] = *out;
+    }
+    return SOS_OK;
+}
+
+static int wg_launch(const sos_wgrad_desc* d, const WgCtx& c, const WgPlan& pl, hipStream_t s) {
+    WgParams p;
+    p.g = (const bf16_t*)d->g; p.x = (const bf16_t*)d->x; p.partial = d->partial;
+    p.B = d->B; p.Hg = d->Hg; p.Wg = d->Wg; p.g_cs = d->g_cs; p.g_off = d->g_off;
+    p.Hx = d->Hx; p.Wx = d->Wx; p.x_cs = d->x_cs; p.x_off = d->x_off;
+    p.M = d->M; p.N = d->N; p.Mp = (d->M + 31) / 32 * 32; p.Np = (d->N + 31) / 32 * 32;
+    p.kw = d->kw; p.stride = d->stride; p.dh = d->dil_h; p.dw = d->dil_w;
+    p.pad_t = d->pad_top; p.pad_l = d->pad_left; p.pad_mode = d->pad_mode;
+    p.tT = c.temporal ? d->t_frames : 0; p.tcin = c.temporal ? d->t_cin : 0; p.tpad = c.temporal ? d->t_pad : 0;
+    p.kh = c.khg; p.ntg = c.ntg; p.taps_all = c.taps_all;
+    const int taps = c.taps, taps_all = c.taps_all, mt = pl.mt, ntb = pl.ntb;
+    const bool use16 = c.use16;
+    const int mgroups = (c.ntiles_m + mt - 1) / mt;
+    p.NC = pl.nc; p.logTH = pl.lth; p.logTW = pl.ltw; p.dbuf = pl.db; p.kord = pl.kord; p.bufbytes = pl.bufbytes; p.npixp = pl.npixp;
+    {
+        const int TH = 1 << p.logTH, TW = 1 << p.logTW;
+        p.tiles_h = (c.Hc + TH - 1) / TH; p.tiles_w = (c.Wc + TW - 1) / TW; p.ngw = (d->dil_w + p.NC - 1) / p.NC;
+        p.PH = (TH - 1) * d->stride + c.khg; p.PW = pl.pw;        // patch pitch: (TW - 1) stride + kw, + 1 when that keeps it odd
+        p.npix = p.NC * p.PH * p.PW;
+    }
+    const int occ = pl.occ;
+    const size_t lds = (size_t)p.bufbytes * (p.dbuf ? 2 : 1) + (size_t)(256 + p.npixp) * 8;
+    { const char* e = getenv("SOS_WGRAD_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.nsteps = d->B * d->dil_h * p.ngw * p.tiles_h * p.tiles_w;
+    int ksplit = d->ksplit;
+    if (ksplit <= 0) {
+        const int groups = use16 ? 1 : mgroups * ((c.ntiles_n + ntb - 1) / ntb) * p.ntg;
+        ksplit = occ * WG_NCU / groups;
+        if (ksplit < 1) ksplit = 1;
+        const int cap = wg_max_split(d);
+        if (ksplit > cap) ksplit = cap;
+    }
+    if (ksplit > p.nsteps) ksplit = p.nsteps;                            // never an empty split
+    p.ksplit = ksplit;
+    p.steps_per_split = (p.nsteps + ksplit - 1) / ksplit;
+    p.ny = mgroups; p.nz = (c.ntiles_n + ntb - 1) / ntb * p.ntg;
+    p.xcdmap = 0;
+    if (!use16 && d->ksplit <= 0 && p.ny * p.nz > 1 && p.ny * p.nz <= 16 && !getenv("SOS_WGRAD_NOXCD")) {
+        // one workgroup per CU: an XCD (32 CUs) takes floor(32 / groups) splits, all groups of a split on one XCD
+        const int per_xcd = occ * 32 / (p.ny * p.nz);
+        int ks8 = 8 * per_xcd;
+        if (ks8 > p.nsteps) ks8 = p.nsteps / 8 * 8;
+        const int cap = wg_max_split(d) / 8 * 8;
+        if (ks8 > cap) ks8 = cap;
+        if (ks8 >= 8 && ks8 * 100 >= ksplit * 93) {        // only if (almost) as many workgroups as one per CU remain
+            ksplit = ks8;
+            p.ksplit = ksplit;
+            p.steps_per_split = (p.nsteps + ksplit - 1) / ksplit;
+            p.xcdmap = 1;
+        }
+    }
+    dim3 grid((unsigned)(ksplit * p.ny * p.nz), 1, 1);                       // see the id mapping in wgrad_kernel
+    static sos_device_once attr_once;
+    if (use16) grid = dim3((unsigned)ksplit, 1, 1);
+#define SOS_WG_ATTR(MTV, NTBV) \
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<MTV, NTBV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define SOS_WG_CASE(MTV, NTBV) \
+    if (mt == MTV && ntb == NTBV) hipLaunchKernelGGL((wgrad_kernel<MTV, NTBV>), grid, dim3(WG_THREADS), lds, s, p);
+    (void)sos_per_device_once(attr_once, [] {       // every instantiation may use the full 160 KB of LDS
+        SOS_WG_ATTR(1, 1) SOS_WG_ATTR(1, 2) SOS_WG_ATTR(1, 4) SOS_WG_ATTR(2, 1) SOS_WG_ATTR(2, 2) SOS_WG_ATTR(2, 4)
+        SOS_WG_ATTR(3, 1) SOS_WG_ATTR(3, 2) SOS_WG_ATTR(3, 4) SOS_WG_ATTR(1, 3) SOS_WG_ATTR(2, 3) SOS_WG_ATTR(3, 3)
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<3, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad16_kernel<3, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad16_kernel<3, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return (int)SOS_OK;
+    });
+    if (use16) {
+        if (taps == 25) hipLaunchKernelGGL((wgrad16_kernel<3, 3, 3>), grid, dim3(WG_THREADS), lds, s, p);
+        else hipLaunchKernelGGL((wgrad16_kernel<3, 3, 1>), grid, dim3(WG_THREADS), lds, s, p);
+    } else {
+        const bool bal = taps == 25 && ntb == 1 && mt >= 2 && !getenv("SOS_WGRAD_NOBAL");
+        if (bal && mt == 3) hipLaunchKernelGGL((wgrad_kernel<3, 1, true>), grid, dim3(WG_THREADS), lds, s, p);
+        else if (bal && mt == 2) hipLaunchKernelGGL((wgrad_kernel<2, 1, true>), grid, dim3(WG_THREADS), lds, s, p);
+        else {
+        SOS_WG_CASE(1, 1) SOS_WG_CASE(1, 2) SOS_WG_CASE(1, 4) SOS_WG_CASE(2, 1) SOS_WG_CASE(2, 2) SOS_WG_CASE(2, 4)
+        SOS_WG_CASE(3, 1) SOS_WG_CASE(3, 2) SOS_WG_CASE(3, 4) SOS_WG_CASE(1, 3) SOS_WG_CASE(2, 3) SOS_WG_CASE(3, 3)
+        }
+    }
+#undef SOS_WG_CASE
+#undef SOS_WG_ATTR
+    int rc = sos_check_launch("sos_conv2d_wgrad");
+    if (rc) return rc;
+    const long long total = (long long)d->M * d->N * taps_all;
+    long long gb = (total + 63) / 64;
+    if (gb > 8192) gb = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, d->partial, ksplit, taps_all, d->M, d->N,
+                       p.Mp, p.Np, d->dw, d->accumulate, d->scale, d->scale_dev);
+    return sos_check_launch("sos_conv2d_wgrad(reduce)");
+}
+
 extern "C" int64_t sos_wgrad_workspace_bytes(const sos_wgrad_desc* d) {
     if (!d) return -1;
     const int64_t Mp = (d->M + 31) / 32 * 32, Np = (d->N + 31) / 32 * 32;
@@ -1019,224 +1312,185 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
                            q.Mp, q.Np, d->dw, d->accumulate, d->scale, d->scale_dev);
         return sos_check_launch("sos_conv2d_wgrad(reduce)");
     }
-    WgParams p;
-    p.g = (const bf16_t*)d->g; p.x = (const bf16_t*)d->x; p.partial = d->partial;
-    p.B = d->B; p.Hg = d->Hg; p.Wg = d->Wg; p.g_cs = d->g_cs; p.g_off = d->g_off;
-    p.Hx = d->Hx; p.Wx = d->Wx; p.x_cs = d->x_cs; p.x_off = d->x_off;
-    p.M = d->M; p.N = d->N; p.Mp = (d->M + 31) / 32 * 32; p.Np = (d->N + 31) / 32 * 32;
-    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.dh = d->dil_h; p.dw = d->dil_w;
-    p.pad_t = d->pad_top; p.pad_l = d->pad_left; p.pad_mode = d->pad_mode;
-    p.tT = temporal ? d->t_frames : 0; p.tcin = temporal ? d->t_cin : 0; p.tpad = temporal ? d->t_pad : 0;
-    // more taps than one workgroup's 32 (tap, n-tile) pairs (7x7): the tap ROWS are divided over ntg workgroups that read the
-    // same G tile at the same time on the same XCD (one launch, G fetched from HBM once instead of once per row)
-    // (the last group may own fewer real rows: its phantom taps are computed on the rows below and never stored)
-    int khg = d->kh;
-    if (khg * d->kw > WG_WAVES * WG_PAIRS) khg = WG_WAVES * WG_PAIRS / d->kw < 1 ? 1 : WG_WAVES * WG_PAIRS / d->kw;
-    const int taps_all = d->kh * d->kw;
-    const int taps = khg * d->kw;
-    p.kh = khg; p.ntg = (d->kh + khg - 1) / khg; p.taps_all = taps_all;
-    if (taps > WG_WAVES * WG_PAIRS) { sos_set_error("sos_conv2d_wgrad: kernel with %d taps per row not supported", taps); return SOS_ENOSPC; }
-    int ntb = WG_WAVES * WG_PAIRS / taps;         // (tap, n-tile) pairs per workgroup <= 32
-    ntb = ntb >= 4 ? 4 : (ntb >= 2 ? 2 : 1);
-    const int ntiles_n = p.Np / 32, ntiles_m = p.Mp / 32;
-    if (ntb > ntiles_n) ntb = ntiles_n >= 4 ? 4 : (ntiles_n >= 2 ? 2 : 1);
-    const int mgroups = (ntiles_m + 2) / 3;
-    const int mt = (ntiles_m + mgroups - 1) / mgroups;          // 1..3 m-tiles per workgroup, balanced
-    const int Hc = (d->Hg + d->dil_h - 1) / d->dil_h, Wc = (d->Wg + d->dil_w - 1) / d->dil_w;
+    const WgCtx cx = wg_ctx(d, temporal, is_flat);
+    if (cx.taps > WG_WAVES * WG_PAIRS) { sos_set_error("sos_conv2d_wgrad: kernel with %d taps per row not supported", cx.taps); return SOS_ENOSPC; }
     if ((uint64_t)d->Hg * d->Wg * d->g_cs * 2 >= 0xffffff00ull || (uint64_t)d->Hx * d->Wx * d->x_cs * 2 >= 0xffffff00ull) {
         sos_set_error("sos_conv2d_wgrad: one image of an operand exceeds 4 GB");
         return SOS_ENOSPC;
     }
-    // small channel counts: the 16x16x32 kernel owns all of dW in one workgroup (no padding to 32)
-    const int m16 = (d->M + 15) / 16, n16 = (d->N + 15) / 16;
-    const bool use16 = !temporal && p.ntg == 1 && m16 == 3 && n16 == 3 && (taps == 25 || taps == 9) && !getenv("SOS_WGRAD_NO16");
-    // pixel tile (NC x TH x TW = 256) and the order of its pixels along the contraction: fewest k-steps THAT HOLD A PIXEL OF THE
-    // IMAGE (the kernels skip the others) among the shapes whose operands fit LDS (double buffered if possible); shrink the
-    // channel tile if none fits.  The choice depends on the shape only and is cached (the exact count walks every tile).
-    const size_t lds_max = 160 * 1024;
-    const int kpix = use16 ? 32 : 16;              // tile pixels per k-step
-    struct TileCfg { int nc, lth, ltw, db, kord, bufbytes, npixp, ntb, pw; };
-    struct TileKey {
-        int v[16];
-        bool operator<(const TileKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
-    };
-    static std::mutex tile_mu;
-    static std::map<TileKey, TileCfg> tile_cache;
-    const TileKey tkey = {{d->Hg, d->Wg, d->kh, d->kw, d->stride, d->dil_h, d->dil_w, mt, ntb, use16 ? 1 : 0, khg, m16, n16, 0, 0, 0}};
-    TileCfg tc;
-    bool cached = false;
-    {
-        std::lock_guard<std::mutex> lk(tile_mu);
-        auto f = tile_cache.find(tkey);
-        if (f != tile_cache.end()) { tc = f->second; cached = true; }
-    }
-    const char* force = getenv("SOS_WGRAD_TILE");  // experiments: "nc,lth,ltw,kord"
-    if (!cached || force) {
-        int fnc = -1, fth = -1, ftw = -1, fko = -1;
-        if (force) sscanf(force, "%d,%d,%d,%d", &fnc, &fth, &ftw, &fko);
-        int ntb_try = ntb;
-        for (;;) {
-            double best = 1e300;
-            tc.nc = 0;
-            for (int lnc = 0; lnc <= 6; ++lnc) {
-                const int NC = 1 << lnc;
-                if (NC > 1 && (d->stride > 1 || NC > d->dil_w || d->dil_w % NC)) break;
-                for (int lth = 0; lth + lnc <= 8; ++lth) {
-                    const int ltw = 8 - lnc - lth;
-                    if (ltw < 2) continue;
-                    if (force && fnc > 0 && (NC != fnc || lth != fth || ltw != ftw)) continue;
-                    const int TH = 1 << lth, TW = 1 << ltw;
-                    const int PH = (TH - 1) * d->stride + khg, PW = (TW - 1) * d->stride + d->kw;
-                    if ((TH - 1 + d->kh) * d->dil_h >= 0x7fff || (d->stride * NC + (PW - 1) * d->dil_w) >= 0x7fff) continue;
-                    const int tiles_h = (Hc + TH - 1) / TH, tiles_w = (Wc + TW - 1) / TW, ngw = (d->dil_w + NC - 1) / NC;
-                    const double ntiles = (double)d->dil_h * ngw * tiles_h * tiles_w;
-                    for (int kord = 0; kord < 2; ++kord) {
-                        if (force && fko >= 0 && kord != fko) continue;
-                        // Column-major order: the pixels a transposed read gathers are consecutive ROWS of the patch, PWl pixel
-                        // pitches apart; with an even PWl their 64-byte (32-byte) runs land on the same banks (PW = 12: 768 B = 0 mod
-                        // 256 -- SQ_LDS_BANK_CONFLICT was 59 % of the LDS-active cycles of the 96 -> 96 gradient), with an odd one
-                        // they tile the 64 banks.  One more (never multiplied) patch column buys that.
-                        const int PWl = (kord == 1 && (PW & 1) == 0 && !getenv("SOS_WGRAD_EVEN_PITCH")) ? PW + 1 : PW;
-                        const int npixp = use16 ? (NC * PH * PWl + 31) / 32 * 32 : (NC * PH * PWl + 15) / 16 * 16;
-                        const size_t one = use16 ? ((size_t)256 * 32 * m16 + (size_t)npixp * 32 * n16 + 1023) / 1024 * 1024
-                                                 : ((size_t)256 * 64 * mt + (size_t)npixp * 64 * ntb_try + 1023) / 1024 * 1024;
-                        const size_t tabb = (size_t)(256 + npixp) * 8;
-                        if (one + tabb > lds_max) continue;
-                        const int db = 2 * one + tabb <= lds_max;
-                        // Cost of one image in k-step units, calibrated on MI355X with tools/probe/wgrad_tile_sweep.py (round 3: every
-                        // tile x order of the 96- and 48-channel layers timed; this model's pick is within 1.1 % of the best measured
-                        // one on each).  A tile multiplies its k-steps that hold a pixel of the image (first pixel of the k-step
-                        // inside); meanwhile the DMA of the NEXT tile runs, `kb` k-steps per KB of operand image whether its pixels
-                        // are inside or not -- so a border tile that keeps 2 of its k-steps still takes its successor's fetch time
-                        // (double buffered: the longer of the two; single buffered: a fraction of the fetch is exposed) -- plus a
-                        // fixed barrier / drain cost per tile.  The 16x16x32 kernel's k-step is 32 pixels x 9 tiles per tap and
-                        // fetches 48-channel operands: its DMA term weighs more (the former bank-conflict term of that kernel is
-                        // subsumed: the sweep ranks its tiles correctly without it).
-                        const double kb = use16 ? 0.15 : 0.04, sbf = use16 ? 0.3 : 0.5, fixed = use16 ? 1.5 : 1.0;
-                        const double dma = (double)one / 1024.0 * kb;
-                        double cost = 0.0;
-                        const int nk = 256 / kpix;
-                        int kh_rel[16], kw_rel[16];                       // first pixel of every k-step, relative to the tile origin
-                        for (int ks = 0; ks < nk; ++ks) {
-                            int c, i, j;
-                            wg_decode(ks * kpix, lth, ltw, kord, c, i, j);
-                            kh_rel[ks] = i * d->dil_h; kw_rel[ks] = c + j * d->dil_w;
-                        }
-                        for (int rh = 0; rh < d->dil_h; ++rh)
-                            for (int gw = 0; gw < ngw; ++gw)
-                                for (int ti = 0; ti < tiles_h; ++ti)
-                                    for (int tj = 0; tj < tiles_w; ++tj) {
-                                        const int gh0 = rh + ti * TH * d->dil_h, gw0 = gw * NC + tj * TW * d->dil_w;
-                                        int nks = 0;
-                                        for (int ks = 0; ks < nk; ++ks) nks += (gh0 + kh_rel[ks] < d->Hg) & (gw0 + kw_rel[ks] < d->Wg);
-                                        cost += db ? (nks > dma ? nks : dma) : nks + sbf * dma;
-                                    }
-                        cost += fixed * ntiles;
-                        if (cost < best) { best = cost; tc = TileCfg{NC, lth, ltw, db, kord, (int)one, npixp, ntb_try, PWl}; }
-                    }
-                }
-            }
-            if (tc.nc) break;
-            if (ntb_try == 1 || use16) { sos_set_error("sos_conv2d_wgrad: patch does not fit LDS"); return SOS_ENOSPC; }
-            ntb_try >>= 1;
-        }
-        if (getenv("SOS_WGRAD_VERBOSE"))
-            fprintf(stderr, "sos_conv2d_wgrad: %dx%d k%dx%d s%d d%dx%d M%d N%d %s-> NC=%d TH=%d TW=%d order=%d dbuf=%d ntb=%d lds=%d pitch=%d\n", d->Hg, d->Wg,
-                    d->kh, d->kw, d->stride, d->dil_h, d->dil_w, d->M, d->N, use16 ? "(16x16x32) " : "", tc.nc, 1 << tc.lth, 1 << tc.ltw,
-                    tc.kord, tc.db, tc.ntb, tc.bufbytes, tc.pw);
-        if (!force) {
-            std::lock_guard<std::mutex> lk(tile_mu);
-            tile_cache[tkey] = tc;
-        }
-    }
-    ntb = tc.ntb;
-    p.NC = tc.nc; p.logTH = tc.lth; p.logTW = tc.ltw; p.dbuf = tc.db; p.kord = tc.kord; p.bufbytes = tc.bufbytes; p.npixp = tc.npixp;
-    {
-        const int TH = 1 << p.logTH, TW = 1 << p.logTW;
-        p.tiles_h = (Hc + TH - 1) / TH; p.tiles_w = (Wc + TW - 1) / TW; p.ngw = (d->dil_w + p.NC - 1) / p.NC;
-        p.PH = (TH - 1) * d->stride + khg; p.PW = tc.pw;        // patch pitch: (TW - 1) stride + kw, + 1 when that keeps it odd
-        p.npix = p.NC * p.PH * p.PW;
-    }
-    // workgroups per CU: one (its own double-buffered DMA pipeline covers the fetch of the next tile) unless a tile is so
-    // short that the fetch latency of a tile exceeds its MFMA time -- then several co-resident workgroups cover each other
-    // (measured: the 96 -> 8 / 48 -> 4 1x1 heads, two MFMAs per k-step and workgroup: 0.456 -> 0.338 / 0.239 -> 0.185 ms with
-    // two workgroups per CU; the thin 5x5 / 1x7 first layers, whose double buffers no longer fit then, get slower)
-    // (round 4: only when the M side is the thin one -- 96 -> 8: 0.42 -> 0.32 ms, 48 -> 4: 0.22 -> 0.18 with two; a thin N side with
-    // two m-tiles -- the first layers with their taps folded, 14 -> 48 -- is FASTER with one: 0.235 vs 0.285 ms)
-    int occ = is_flat && mt == 1 && ntb <= 2 ? 2 : 1;
-    { const char* e = getenv("SOS_WGRAD_OCC"); if (e && atoi(e) >= 1 && atoi(e) <= 4) occ = atoi(e); }
-    if (occ > 1) {
-        const size_t tabb = (size_t)(256 + p.npixp) * 8;
-        while (occ > 1 && (size_t)p.bufbytes + tabb > lds_max / occ) --occ;
-        if (occ > 1 && 2 * (size_t)p.bufbytes + tabb > lds_max / occ) p.dbuf = 0;
-    }
-    const size_t lds = (size_t)p.bufbytes * (p.dbuf ? 2 : 1) + (size_t)(256 + p.npixp) * 8;
-    { const char* e = getenv("SOS_WGRAD_DBG"); p.dbg = e ? atoi(e) : 0; }
-    p.nsteps = d->B * d->dil_h * p.ngw * p.tiles_h * p.tiles_w;
-    int ksplit = d->ksplit;
-    if (ksplit <= 0) {
-        const int groups = use16 ? 1 : mgroups * ((ntiles_n + ntb - 1) / ntb) * p.ntg;
-        ksplit = occ * WG_NCU / groups;
-        if (ksplit < 1) ksplit = 1;
-        const int cap = wg_max_split(d);
-        if (ksplit > cap) ksplit = cap;
-    }
-    if (ksplit > p.nsteps) ksplit = p.nsteps;                            // never an empty split
-    p.ksplit = ksplit;
-    p.steps_per_split = (p.nsteps + ksplit - 1) / ksplit;
-    p.ny = mgroups; p.nz = (ntiles_n + ntb - 1) / ntb * p.ntg;
-    p.xcdmap = 0;
-    if (!use16 && d->ksplit <= 0 && p.ny * p.nz > 1 && p.ny * p.nz <= 16 && !getenv("SOS_WGRAD_NOXCD")) {
-        // one workgroup per CU: an XCD (32 CUs) takes floor(32 / groups) splits, all groups of a split on one XCD
-        const int per_xcd = occ * 32 / (p.ny * p.nz);
-        int ks8 = 8 * per_xcd;
-        if (ks8 > p.nsteps) ks8 = p.nsteps / 8 * 8;
-        const int cap = wg_max_split(d) / 8 * 8;
-        if (ks8 > cap) ks8 = cap;
-        if (ks8 >= 8 && ks8 * 100 >= ksplit * 93) {        // only if (almost) as many workgroups as one per CU remain
-            ksplit = ks8;
-            p.ksplit = ksplit;
-            p.steps_per_split = (p.nsteps + ksplit - 1) / ksplit;
-            p.xcdmap = 1;
-        }
-    }
-    dim3 grid((unsigned)(ksplit * p.ny * p.nz), 1, 1);                       // see the id mapping in wgrad_kernel
-    hipStream_t s = (hipStream_t)stream;
-    static sos_device_once attr_once;
-    if (use16) grid = dim3((unsigned)ksplit, 1, 1);
-#define SOS_WG_ATTR(MTV, NTBV) \
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<MTV, NTBV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#define SOS_WG_CASE(MTV, NTBV) \
-    if (mt == MTV && ntb == NTBV) hipLaunchKernelGGL((wgrad_kernel<MTV, NTBV>), grid, dim3(WG_THREADS), lds, s, p);
-    (void)sos_per_device_once(attr_once, [] {       // every instantiation may use the full 160 KB of LDS
-        SOS_WG_ATTR(1, 1) SOS_WG_ATTR(1, 2) SOS_WG_ATTR(1, 4) SOS_WG_ATTR(2, 1) SOS_WG_ATTR(2, 2) SOS_WG_ATTR(2, 4)
-        SOS_WG_ATTR(3, 1) SOS_WG_ATTR(3, 2) SOS_WG_ATTR(3, 4)
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<3, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad16_kernel<3, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad16_kernel<3, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return (int)SOS_OK;
-    });
-    if (use16) {
-        if (taps == 25) hipLaunchKernelGGL((wgrad16_kernel<3, 3, 3>), grid, dim3(WG_THREADS), lds, s, p);
-        else hipLaunchKernelGGL((wgrad16_kernel<3, 3, 1>), grid, dim3(WG_THREADS), lds, s, p);
-    } else {
-        const bool bal = taps == 25 && ntb == 1 && mt >= 2 && !getenv("SOS_WGRAD_NOBAL");
-        if (bal && mt == 3) hipLaunchKernelGGL((wgrad_kernel<3, 1, true>), grid, dim3(WG_THREADS), lds, s, p);
-        else if (bal && mt == 2) hipLaunchKernelGGL((wgrad_kernel<2, 1, true>), grid, dim3(WG_THREADS), lds, s, p);
-        else {
-        SOS_WG_CASE(1, 1) SOS_WG_CASE(1, 2) SOS_WG_CASE(1, 4) SOS_WG_CASE(2, 1) SOS_WG_CASE(2, 2) SOS_WG_CASE(2, 4)
-        SOS_WG_CASE(3, 1) SOS_WG_CASE(3, 2) SOS_WG_CASE(3, 4)
-        }
-    }
-#undef SOS_WG_CASE
-#undef SOS_WG_ATTR
-    int rc = sos_check_launch("sos_conv2d_wgrad");
+    WgPlan plan;
+    int rc = wg_choose_plan(d, cx, &plan);
     if (rc) return rc;
-    const long long total = (long long)d->M * d->N * taps_all;
-    long long gb = (total + 63) / 64;
-    if (gb > 8192) gb = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, d->partial, ksplit, taps_all, d->M, d->N,
-                       p.Mp, p.Np, d->dw, d->accumulate, d->scale, d->scale_dev);
-    return sos_check_launch("sos_conv2d_wgrad(reduce)");
+    return wg_launch(d, cx, plan, (hipStream_t)stream);
+}
+
+// ---- measured plans (round 4).  sos_wgrad_tune times, for the SHAPE of `d`, every channel tile (MT x NTB, one or two workgroups
+// per CU) with the cost model's six cheapest pixel tiles each, in two stages like sos_conv2d_tune (all candidates over `iters`
+// launches; the five fastest and the cost model's pick again over 8x the launches, alternating twice; the model's pick is kept
+// unless the winner beats it by more than 2 %), and remembers the winner for later sos_conv2d_wgrad calls of that shape.
+// Synchronises; overwrites d->dw and d->partial (pass accumulate = 0 and scratch buffers).  Call outside timed regions / captures.
+extern "C" int sos_wgrad_tune(const sos_wgrad_desc* d, int iters, float* best_ms, sos_stream_t stream) {
+    if (!d || !d->g || !d->x || !d->partial || !d->dw) { sos_set_error("sos_wgrad_tune: null pointer"); return SOS_EINVAL; }
+    if (d->accumulate) { sos_set_error("sos_wgrad_tune: needs accumulate = 0 (the launches would pile up in dw)"); return SOS_EINVAL; }
+    const bool temporal = d->t_taps > 1;
+    sos_wgrad_desc flat = *d;
+    if (!temporal && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_top == 0 && d->pad_left == 0 && d->Hg == d->Hx && d->Wg == d->Wx) {
+        const uint64_t npx = (uint64_t)d->B * d->Hg * d->Wg;
+        if (npx * (uint64_t)d->g_cs * 2 < 0xfff00000ull && npx * (uint64_t)d->x_cs * 2 < 0xfff00000ull) {
+            flat.B = 1; flat.Hg = flat.Hx = 1; flat.Wg = flat.Wx = (int)npx;
+        }
+    }
+    const bool is_flat = !temporal && flat.B == 1 && flat.Hg == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_top == 0 &&
+                         d->pad_left == 0 && d->Hg == d->Hx && d->Wg == d->Wx;
+    d = &flat;
+    if (best_ms) *best_ms = -1.f;
+    if (is_flat && d->M >= 128 && d->N >= 128 && !getenv("SOS_WGRAD_NO_GEMM")) return SOS_OK;     // the GEMM path has no plan
+    const WgCtx cx = wg_ctx(d, temporal, is_flat);
+    if (cx.taps > WG_WAVES * WG_PAIRS) return SOS_OK;
+    const WgKey key = wg_key(d, cx);
+    {
+        std::lock_guard<std::mutex> lk(wg_mu());
+        if (wg_table().count(key)) return SOS_OK;
+    }
+    WgPlan model;
+    int rc = wg_model_plan(d, cx, &model);
+    if (rc) return rc;
+    std::vector<WgPlan> cands;
+    cands.push_back(model);
+    const int mt_hi = cx.use16 ? 1 : std::min(3, cx.ntiles_m), ntb_hi = cx.use16 ? 1 : std::min(4, cx.ntiles_n);
+    for (int mt = 1; mt <= mt_hi; ++mt)
+        for (int ntb = 1; ntb <= ntb_hi && ntb * cx.taps <= WG_WAVES * WG_PAIRS; ++ntb)
+            for (int occ = 1; occ <= (cx.use16 ? 1 : 2); ++occ) {
+                std::vector<WgPlan> tiles;
+                for (int lnc = 0; lnc <= 6; ++lnc)
+                    for (int lth = 0; lth + lnc <= 8; ++lth)
+                        for (int kord = 0; kord < 2; ++kord) {
+                            WgPlan pl;
+                            if (wg_make_plan(d, cx, cx.use16 ? model.mt : mt, cx.use16 ? model.ntb : ntb, lnc, lth, kord, occ, &pl)) tiles.push_back(pl);
+                        }
+                std::sort(tiles.begin(), tiles.end(), [](const WgPlan& a, const WgPlan& b) { return a.cost < b.cost; });
+                for (size_t t = 0; t < tiles.size() && t < (cx.use16 ? 12u : 6u); ++t) cands.push_back(tiles[t]);
+            }
+    if (iters < 1) iters = 1;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { sos_set_error("sos_wgrad_tune: hipEventCreate failed"); return SOS_ELAUNCH; }
+    auto time_plan = [&](const WgPlan& pl, const int reps, float* ms_out) {
+        int r = wg_launch(d, cx, pl, s);                         // warm-up
+        if (r) return r;
+        (void)hipEventRecord(e0, s);
+        for (int k = 0; k < reps && !r; ++k) r = wg_launch(d, cx, pl, s);
+        (void)hipEventRecord(e1, s);
+        if (r || hipEventSynchronize(e1) != hipSuccess) return r ? r : (int)SOS_ELAUNCH;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *ms_out = ms / reps;
+        return (int)SOS_OK;
+    };
+    std::vector<std::pair<float, int>> timed;
+    for (size_t i = 0; i < cands.size() && !rc; ++i) {
+        float ms = 0.f;
+        rc = time_plan(cands[i], iters, &ms);
+        timed.push_back({ms, (int)i});
+    }
+    int besti = 0;
+    float best = 0.f;
+    if (!rc) {
+        std::sort(timed.begin(), timed.end());
+        std::vector<int> fin;
+        for (size_t t = 0; t < timed.size() && t < 5; ++t) fin.push_back(timed[t].second);
+        if (std::find(fin.begin(), fin.end(), 0) == fin.end()) fin.push_back(0);
+        std::vector<float> acc(fin.size(), 0.f);
+        for (int round = 0; round < 2 && !rc; ++round)
+            for (size_t t = 0; t < fin.size() && !rc; ++t) {
+                float ms = 0.f;
+                rc = time_plan(cands[fin[t]], iters * 8, &ms);
+                acc[t] += 0.5f * ms;
+            }
+        if (!rc) {
+            size_t bt = 0, t0 = 0;
+            for (size_t t = 0; t < fin.size(); ++t) { if (acc[t] < acc[bt]) bt = t; if (fin[t] == 0) t0 = t; }
+            if (acc[bt] > 0.98f * acc[t0]) bt = t0;
+            besti = fin[bt]; best = acc[bt];
+            if (getenv("SOS_CONV_TUNE_VERBOSE")) {
+                const WgPlan& w = cands[besti];
+                fprintf(stderr, "wgrad tune %dx%d k%dx%d s%d d%dx%d M%d N%d B%d: %zu candidates, pick MT=%d NTB=%d NC=%d TH=%d TW=%d order=%d occ=%d dbuf=%d %.4f ms (model's MT=%d NTB=%d NC=%d TH=%d TW=%d order=%d occ=%d: %.4f ms)\n",
+                        d->Hg, d->Wg, d->kh, d->kw, d->stride, d->dil_h, d->dil_w, d->M, d->N, d->B, cands.size(), w.mt, w.ntb, w.nc, 1 << w.lth,
+                        1 << w.ltw, w.kord, w.occ, w.db, best, model.mt, model.ntb, model.nc, 1 << model.lth, 1 << model.ltw, model.kord, model.occ, acc[t0]);
+            }
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lk(wg_mu());
+        wg_table().emplace(key, cands[besti]);           // first writer wins
+    }
+    if (best_ms) *best_ms = best;
+    return SOS_OK;
+}
+
+// Text table: header `sos_wgrad_tune 1 nkey 12`, then 12 shape ints + (MT, NTB, log2 NC, log2 TH, order, workgroups per CU) per line.
+// An entry is accepted on load only if wg_make_plan() offers that plan for that shape with this build.
+#define SOS_WGTUNE_FORMAT 1
+extern "C" int sos_wgrad_tune_save(const char* path) {
+    if (!path) { sos_set_error("sos_wgrad_tune_save: null path"); return SOS_EINVAL; }
+    char tmp[4096];
+    snprintf(tmp, sizeof(tmp), "%s.tmp.%ld", path, (long)getpid());
+    FILE* f = fopen(tmp, "w");
+    if (!f) { sos_set_error("sos_wgrad_tune_save: cannot open %s", tmp); return SOS_EINVAL; }
+    fprintf(f, "sos_wgrad_tune %d nkey 12\n", SOS_WGTUNE_FORMAT);
+    {
+        std::lock_guard<std::mutex> lk(wg_mu());
+        for (const auto& kv : wg_table()) {
+            for (int i = 0; i < 12; ++i) fprintf(f, "%d ", kv.first.v[i]);
+            int lnc = 0;
+            while ((1 << lnc) < kv.second.nc) ++lnc;
+            fprintf(f, "%d %d %d %d %d %d\n", kv.second.mt, kv.second.ntb, lnc, kv.second.lth, kv.second.kord, kv.second.occ);
+        }
+    }
+    if (fclose(f) != 0 || rename(tmp, path) != 0) {
+        remove(tmp);
+        sos_set_error("sos_wgrad_tune_save: cannot write %s", path);
+        return SOS_EINVAL;
+    }
+    return SOS_OK;
+}
+
+extern "C" int sos_wgrad_tune_load(const char* path) {
+    if (!path) { sos_set_error("sos_wgrad_tune_load: null path"); return SOS_EINVAL; }
+    FILE* f = fopen(path, "r");
+    if (!f) return 0;
+    int fmt = -1, nkey = -1;
+    if (fscanf(f, " sos_wgrad_tune %d nkey %d", &fmt, &nkey) != 2 || fmt != SOS_WGTUNE_FORMAT || nkey != 12) {
+        fclose(f);
+        sos_set_error("sos_wgrad_tune_load: %s was written by another build (format %d)", path, fmt);
+        return SOS_EINVAL;
+    }
+    int n = 0;
+    for (;;) {
+        WgKey k;
+        bool ok = true;
+        for (int i = 0; i < 12 && ok; ++i) ok = fscanf(f, "%d", &k.v[i]) == 1;
+        int mt, ntb, lnc, lth, kord, occ;
+        if (!ok || fscanf(f, "%d %d %d %d %d %d", &mt, &ntb, &lnc, &lth, &kord, &occ) != 6) break;
+        sos_wgrad_desc d;
+        memset(&d, 0, sizeof(d));
+        d.Hg = k.v[0]; d.Wg = k.v[1]; d.kh = k.v[2]; d.kw = k.v[3]; d.stride = k.v[4]; d.dil_h = k.v[5]; d.dil_w = k.v[6];
+        d.M = k.v[7]; d.N = k.v[8]; d.t_taps = k.v[10];
+        if (d.Hg < 1 || d.Wg < 1 || d.kh < 1 || d.kw < 1 || d.stride < 1 || d.dil_h < 1 || d.dil_w < 1 || d.M < 1 || d.N < 1) continue;
+        const WgCtx cx = wg_ctx(&d, k.v[10] > 1, k.v[11] != 0);
+        if ((cx.use16 ? 1 : 0) != k.v[9] || cx.taps > WG_WAVES * WG_PAIRS) continue;
+        if (mt < 1 || mt > 3 || mt > cx.ntiles_m || ntb < 1 || ntb > 4 || ntb > cx.ntiles_n || ntb * cx.taps > WG_WAVES * WG_PAIRS ||
+            lnc < 0 || lnc > 6 || lth < 0 || kord < 0 || kord > 1 || occ < 1 || occ > 2)
+            continue;
+        WgPlan pl;
+        if (!wg_make_plan(&d, cx, mt, ntb, lnc, lth, kord, occ, &pl)) continue;
+        std::lock_guard<std::mutex> lk(wg_mu());
+        wg_table()[k] = pl;
+        ++n;
+    }
+    fclose(f);
+    return n;
 }

@@ -64,6 +64,8 @@ FLATTEN_1X1 = _os.environ.get("SOS_FLATTEN_1X1", "1") != "0"      # A/B switch o
 AUTOTUNE = _os.environ.get("SOS_CONV_TUNE", "0") == "1"
 TUNE_CANDIDATES = int(_os.environ.get("SOS_CONV_TUNE_CANDIDATES", "8"))     # best-ranked tilings of the cost model that get timed
 SHIPPED_TUNE_TABLE = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tune_table_gfx950.txt")
+SHIPPED_WGRAD_TABLE = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "wgrad_table_gfx950.txt")     # measured weight-gradient plans
+_WGRAD_CACHE = _os.environ.get("SOS_WGRAD_TUNE_CACHE")      # user table laid over the shipped one (written at exit when SOS_CONV_TUNE=1)
 _tuned = set()
 _tune_lock = _threading.Lock()
 _TUNE_CACHE = _os.environ.get("SOS_CONV_TUNE_CACHE")
@@ -92,6 +94,18 @@ def _load_tune_cache():
             import atexit
             h = L.lib()
             atexit.register(lambda: h.sos_conv2d_tune_save(user.encode()))
+        # the weight-gradient plans: same scheme (one table for both builds: the plans do not depend on the storage type)
+        if _os.environ.get("SOS_WGRAD_TUNE_TABLE", "1") != "0":
+            if L.lib().sos_wgrad_tune_load(SHIPPED_WGRAD_TABLE.encode()) < 0:
+                raise RuntimeError("sos_wgrad_tune_load: " + (L.lib().sos_last_error() or b"").decode())
+        if _WGRAD_CACHE and _os.path.exists(_WGRAD_CACHE):
+            if L.lib().sos_wgrad_tune_load(_WGRAD_CACHE.encode()) < 0:
+                import warnings
+                warnings.warn("SOS_WGRAD_TUNE_CACHE %s ignored: %s" % (_WGRAD_CACHE, (L.lib().sos_last_error() or b"").decode()))
+        if AUTOTUNE and _WGRAD_CACHE and int(_os.environ.get("RANK", "0")) == 0:
+            import atexit
+            hw = L.lib()
+            atexit.register(lambda: hw.sos_wgrad_tune_save(_WGRAD_CACHE.encode()))
         _cache_loaded.add(which)
 
 
@@ -708,6 +722,15 @@ def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0,
         d.accumulate = 1 if (accumulate or not first) else 0
         d.scale = scale
         d.scale_dev = gs.inv.data_ptr() if gs.inv is not None else None
+        _load_tune_cache()
+        if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+            tkey = ("wgrad", g.B, g.H, g.W, x.H, x.W, M, N, kh, kw, stride, dil, d.t_taps)
+            if tkey not in _tuned:
+                _tuned.add(tkey)
+                scratch = torch.empty_like(dw)             # the tuner launches the kernel many times: never into the real gradient
+                d.dw, d.accumulate = scratch.data_ptr(), 0
+                L.check(L.lib().sos_wgrad_tune(ctypes.byref(d), 3, None, L.stream_ptr()), "sos_wgrad_tune")
+                d.dw, d.accumulate = dw.data_ptr(), 1 if (accumulate or not first) else 0
         end = None
         if PROFILER is not None or _LAUNCH_LOG is not None:
             sig = ("wgrad", kh, kw, dil[0], dil[1], stride, M, N, g.B, g.H, g.W)

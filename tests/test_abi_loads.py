@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(precision, storage):
     for name in declared:
         assert hasattr(h, name), f"{name} declared in sos_hip.h but not exported"
     assert set(_lib.SIGNATURES) | {"sos_last_error"} == declared
-    assert h.sos_abi_version() == _lib.EXPECTED_ABI == 6
+    assert h.sos_abi_version() == _lib.EXPECTED_ABI == 7
     assert h.sos_storage_dtype() == storage
 
 
@@ -53,6 +53,29 @@ def test_tune_table_load_rejects_foreign_and_illegal_entries(tmp_path):
     if os.path.exists(engine.SHIPPED_TUNE_TABLE):
         lines = [ln for ln in open(engine.SHIPPED_TUNE_TABLE).read().splitlines()[1:] if ln.strip()]
         assert h.sos_conv2d_tune_load(engine.SHIPPED_TUNE_TABLE.encode()) == len(lines) > 0
+
+
+def test_wgrad_table_load_rejects_foreign_and_illegal_entries(tmp_path):
+    """sos_wgrad_tune_load (host only, no GPU; ABI 7): a table of another format is an error, a plan the build would not offer
+    for that shape is dropped, a legal one is accepted; the shipped table of measured weight-gradient plans loads completely."""
+    from sos_amd import _lib, engine
+    h = _lib.lib()
+    bad = tmp_path / "foreign.txt"
+    bad.write_text("sos_wgrad_tune 9 nkey 12\n")
+    assert h.sos_wgrad_tune_load(str(bad).encode()) < 0
+    shape = "256 178 5 5 1 4 4 96 96 0 0 0"          # Hg Wg kh kw stride dil_h dil_w M N 16x16x32-kernel temporal flat
+    mixed = tmp_path / "mixed.txt"
+    mixed.write_text("sos_wgrad_tune 1 nkey 12\n"
+                     f"{shape} 3 1 0 4 1 1\n"        # legal: 3 m-tiles x 1 n-tile, 16 x 16 pixels, column-major, one workgroup per CU
+                     f"{shape} 3 2 0 4 1 1\n"        # 2 n-tiles x 25 taps > 32 (tap, n-tile) pairs
+                     f"{shape} 3 1 3 4 1 1\n"        # 8 residue classes need dil_w % 8 == 0
+                     f"{shape} 4 1 0 4 1 1\n"        # 4 m-tiles
+                     f"{shape} 3 1 0 4 1 2\n"        # two workgroups per CU: 3 m-tiles + the 5x5 patch do not fit half the LDS
+                     "256 178 5 5 1 1 1 48 48 0 0 0 2 1 0 4 0 1\n")   # 48 x 48 x 25 taps is the 16x16x32 kernel's shape: flag mismatch
+    assert h.sos_wgrad_tune_load(str(mixed).encode()) == 1
+    assert h.sos_wgrad_tune_load(str(tmp_path / "missing.txt").encode()) == 0
+    lines = [ln for ln in open(engine.SHIPPED_WGRAD_TABLE).read().splitlines()[1:] if ln.strip()]
+    assert h.sos_wgrad_tune_load(engine.SHIPPED_WGRAD_TABLE.encode()) == len(lines)
 
 
 def test_state_dict_keys_match_reference_layout():

@@ -152,6 +152,49 @@ def test_conv_weight_grad_forced_tiles(tile, ch, monkeypatch):
     assert err < 2e-5 + 1e-3
 
 
+def test_wgrad_tune_measured_plan_gives_the_same_gradient(tmp_path):
+    """sos_wgrad_tune (ABI 7): timing the candidate plans of a shape and adopting the winner changes the launch, not the gradient
+    -- the tuned launch matches torch autograd like the cost model's launch did; the table survives a save / load round trip and
+    the second tune of the shape is a no-op (-1)."""
+    import ctypes
+    from sos_amd import engine as E, _lib as L
+    B, M, N, H, W, k, dil = 2, 64, 96, 40, 37, (3, 3), (2, 2)
+    pad = (2, 2)
+    x = torch.from_numpy(hashed(61, (B, N, H, W)).astype(np.float32))
+    xa, xheld = _act_from_nchw(x, False)
+    w = torch.zeros(M, N, 3, 3, requires_grad=True)
+    y = F.conv2d(xheld, w, None, 1, pad, dil)
+    g = torch.from_numpy(hashed(62, tuple(y.shape)).astype(np.float32))
+    ga, gheld = _act_from_nchw(g, False)
+    y.backward(gheld)
+    dw0 = torch.empty(M, N, 3, 3, dtype=torch.float32, device="cuda")
+    E.wgrad(ga, 0, M, xa, 0, N, 3, 3, dw0, dil=dil, pad=pad)
+    e0 = rel_err(dw0.cpu(), w.grad)
+    d = L.WgradDesc()
+    d.g, d.B, d.Hg, d.Wg, d.g_cs, d.g_off = ga.t.data_ptr(), B, H, W, ga.nseg * ga.cs, 0
+    d.x, d.Hx, d.Wx, d.x_cs, d.x_off = xa.t.data_ptr(), H, W, xa.nseg * xa.cs, 0
+    d.M, d.N, d.kh, d.kw, d.stride, d.dil_h, d.dil_w = M, N, 3, 3, 1, 2, 2
+    d.pad_top, d.pad_left, d.pad_mode, d.ksplit, d.scale = 2, 2, L.PAD_ZERO, 0, 1.0
+    ws = torch.empty(L.lib().sos_wgrad_workspace_bytes(ctypes.byref(d)) // 4 + 1, dtype=torch.float32, device="cuda")
+    scratch = torch.empty_like(dw0)
+    d.partial, d.dw, d.accumulate = ws.data_ptr(), scratch.data_ptr(), 0
+    best = ctypes.c_float(0.0)
+    L.check(L.lib().sos_wgrad_tune(ctypes.byref(d), 2, ctypes.byref(best), L.stream_ptr()), "sos_wgrad_tune")
+    assert best.value > 0.0
+    L.check(L.lib().sos_wgrad_tune(ctypes.byref(d), 2, ctypes.byref(best), L.stream_ptr()), "sos_wgrad_tune")
+    assert best.value == -1.0
+    dw1 = torch.empty_like(dw0)
+    E.wgrad(ga, 0, M, xa, 0, N, 3, 3, dw1, dil=dil, pad=pad)
+    e1 = rel_err(dw1.cpu(), w.grad)
+    print("wgrad vs autograd: model plan", e0, "measured plan", e1)
+    assert e0 < 2e-5 + 1e-3 and e1 < 2e-5 + 1e-3
+    path = str(tmp_path / "wg.txt").encode()
+    assert L.lib().sos_wgrad_tune_save(path) == 0
+    body = open(path).read().splitlines()
+    assert body[0] == "sos_wgrad_tune 1 nkey 12" and any(ln.startswith(f"{H} {W} 3 3 1 2 2 {M} {N} ") for ln in body[1:])
+    assert L.lib().sos_wgrad_tune_load(path) == len(body) - 1
+
+
 DOWN_CASES = [(64, 128, 5, 2, 1, 20, 27), (128, 128, 3, 1, 4, 16, 23), (64, 64, 5, 1, 1, 18, 21), (128, 64, 3, 2, 1, 17, 22),
               (64, 64, 3, 1, 16, 40, 37)]
 

@@ -25,8 +25,24 @@ RETUNE_X3 = "--retune-x3" in sys.argv        # keep the committed table, re-meas
 RETUNE_NPOT = "--retune-npot" in sys.argv    # keep the committed table, re-measure the shapes that gained non-power-of-two tile candidates
 RETUNE_16ROW = "--retune-16row" in sys.argv  # keep the committed table, re-measure the 16- / 48-channel-input shapes (round 4: the 16-row
                                              # kernel's 512-pixel workgroups; the first layers with their horizontal taps on the channel axis)
+RETUNE_WIDE = "--retune-wide" in sys.argv    # keep the committed table, re-measure the B = 64 single-segment shapes (the bench's training / fp16
+                                             # inference step) over up to 400 candidates with sos_conv2d_tune's two-stage decision (round 4)
+RETUNE_WIDE_ALL = "--retune-wide-all" in sys.argv   # every entry of the committed table re-measured that way (all batch sizes, the
+                                             # three-segment detector, the audio-visual variant)
+RETUNE_WGRAD = "--retune-wgrad" in sys.argv  # measure the weight-gradient plans of the B = 64 training step (sos_wgrad_tune, round 4) ->
+                                             # gpurun_out/wgrad_table_gfx950.txt; the conv table is loaded as shipped and left alone
+OUTW = os.path.join(ROOT, "gpurun_out", "wgrad_table_gfx950.txt")
+if RETUNE_WGRAD:
+    os.environ["SOS_CONV_TUNE_TABLE"] = "1"
+    os.environ.pop("SOS_CONV_TUNE_CACHE", None)
+    os.environ.pop("SOS_FOLD_FUSED", None)
+    os.environ["SOS_WGRAD_TUNE_TABLE"] = "0"
+    os.environ["SOS_WGRAD_TUNE_CACHE"] = OUTW
+    os.environ.setdefault("SOS_CONV_TUNE_VERBOSE", "1")
+    if os.path.exists(OUTW):
+        os.remove(OUTW)
 SHIPPED = os.path.join(ROOT, "listening-to-sound-of-silence-for-speech-denoising_amd", "tune_table_gfx950.txt")
-if os.path.exists(OUT):
+if os.path.exists(OUT) and not RETUNE_WGRAD:
     os.remove(OUT)
 if EXTEND_AV:
     import shutil
@@ -48,6 +64,19 @@ if RETUNE_16ROW:
     os.environ.setdefault("SOS_CONV_TUNE_CANDIDATES", "48")       # the 512-pixel candidates sit anywhere in the cost-ordered list
     lines = open(SHIPPED).read().splitlines()
     keep = [lines[0]] + [ln for ln in lines[1:] if ln.split()[4] not in ("16", "48")]      # column 4: cin (conv.hip, shape_key)
+    for path in (OUT, OUT + ".f16"):
+        open(path, "w").write("\n".join(keep) + "\n")
+    print("dropped", len(lines) - len(keep), "entries to re-measure")
+
+if RETUNE_WIDE_ALL:
+    os.environ.setdefault("SOS_CONV_TUNE_CANDIDATES", "400")
+    os.environ.setdefault("SOS_CONV_TUNE_VERBOSE", "1")
+
+if RETUNE_WIDE:
+    os.environ.setdefault("SOS_CONV_TUNE_CANDIDATES", "400")
+    os.environ.setdefault("SOS_CONV_TUNE_VERBOSE", "1")
+    lines = open(SHIPPED).read().splitlines()
+    keep = [lines[0]] + [ln for ln in lines[1:] if not (ln.split()[0] == "64" and ln.split()[5] == "1")]   # columns 0: B, 5: segments
     for path in (OUT, OUT + ".f16"):
         open(path, "w").write("\n".join(keep) + "\n")
     print("dropped", len(lines) - len(keep), "entries to re-measure")
@@ -146,7 +175,21 @@ def main():
         _lib.lib().sos_conv2d_tune_save(OUT.encode())
         print("wrote", OUT, sum(1 for _ in open(OUT)) - 1, "entries")
         return
-    if RETUNE_NPOT:
+    if RETUNE_WGRAD:
+        sos_amd.set_precision("bf16")
+        workloads(64)
+        from sos_amd import _lib
+        _lib.lib().sos_wgrad_tune_save(OUTW.encode())
+        print("wrote", OUTW, sum(1 for _ in open(OUTW)) - 1, "entries")
+        return
+    if RETUNE_WIDE:
+        sos_amd.set_precision("bf16")
+        workloads(64)
+        from sos_amd import _lib
+        _lib.lib().sos_conv2d_tune_save(OUT.encode())
+        print("wrote", OUT, sum(1 for _ in open(OUT)) - 1, "entries")
+        return
+    if RETUNE_NPOT or RETUNE_WIDE_ALL:
         for prec, batches in (("bf16", (64, 32, 16, 8, 4, 2, 1)), ("bf16x3", (64, 2, 1))):
             sos_amd.set_precision(prec)
             for B in batches:
