@@ -74,7 +74,25 @@ struct ConvParams {
     void* out2;
     int fP, fH, fW, fsy, foy, fsx, fox, frow;
     long long fthird;
+    // Divisions by tile / grid extents as multiplications (round 4): q = n / d == umulhi(n, mg) for mg = 2^32 / d + 1 whenever
+    // n * d < 2^32 (mg == 0 stands for d == 1).  A 32-bit division by a run-time value is ~40 VALU (or SALU + VALU) instructions;
+    // a tile's prologue / epilogue held ~15 of them per wave (slot -> (class, row, column) of the operand bases, the epilogue
+    // rows and the store table, the patch pixel table, the block id decode) -- per-TILE work, but the few-tap layers' tiles
+    // hold only 250-320 MFMAs per wave, and a wave's VALU issue competes with its SIMD partner's MFMA stream.
+    unsigned mgTW, mgTH, mgPW, mgPH, mg_tiles_w, mg_ngw, mg_tiles_h, mg_dh, mg_kw;
 };
+
+__host__ __device__ __forceinline__ unsigned mg_of(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
+__host__ __device__ __forceinline__ int mg_div(int n, unsigned mg) {
+    return mg ? (int)(((unsigned long long)(unsigned)n * mg) >> 32) : n;          // device: one v_mul_hi_u32 / s_mul_hi_u32
+}
+// slot m of a tile -> (class, row, column), as tile_decode() below, with the multiplications
+__host__ __device__ __forceinline__ void tile_decode_mg(int m, const ConvParams& p, int& cls, int& i, int& j) {
+    const int r = mg_div(m, p.mgTW);
+    j = m - r * p.TW;
+    cls = mg_div(r, p.mgTH);
+    i = r - cls * p.TH;
+}
 
 // pixel slot m (0..255) of a tile -> (residue class, row, column); slots with cls >= NC are dead (tiles of NC x TH x TW < 256
 // pixels: dilation 32 leaves 8 x 5.6 strided pixels per class -- 5 classes x 8 x 6 = 240 slots instead of 4 x 8 x 8 with a
@@ -98,9 +116,9 @@ __device__ __forceinline__ void build_pixel_table(const ConvParams& p, unsigned*
                                                   const int Wl, const int* __restrict__ wgather) {
     const bool reflect = p.pad_mode == SOS_PAD_REFLECT;
     for (int pix = tid; pix < p.npix; pix += 256) {
-        const int rr = pix / p.PW, c = pix - rr * p.PW;
+        const int rr = mg_div(pix, p.mgPW), c = pix - rr * p.PW;
         int r = rr, cls = 0;
-        if (p.NC > 1) { cls = rr / p.PH; r = rr - cls * p.PH; }
+        if (p.NC > 1) { cls = mg_div(rr, p.mgPH); r = rr - cls * p.PH; }
         int h = hin0 + r * p.dh;
         int w = win0 + cls * p.stride + c * p.dw;
         bool ok = (rw0 + cls) < p.dw || cls == 0;
@@ -171,7 +189,7 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
     int* otab = (int*)(smem + SLOTS * OROW * (x3 ? 2 : 1));
     for (int m = tid; m < SLOTS; m += 256) {
         int cls, i, j;
-        tile_decode(m, p.TH, p.TW, cls, i, j);
+        tile_decode_mg(m, p, cls, i, j);
         const int ho = ho_base + i * p.dh;
         const int wo = wo_base + cls + j * p.dw;
         const bool ok = cls < p.NC && ho < p.Ho && wo < Wo && (cls == 0 || rw0 + cls < p.dw);
@@ -324,11 +342,11 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
         const int xcd = bid % nx, loc = bid / nx;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    int t = bid;
-    const int tj = t % p.tiles_w; t /= p.tiles_w;
-    const int gw = t % p.ngw; t /= p.ngw;
-    const int ti = t % p.tiles_h; t /= p.tiles_h;
-    const int rh = t % p.dh; t /= p.dh;
+    int t = bid, tq;
+    tq = mg_div(t, p.mg_tiles_w); const int tj = t - tq * p.tiles_w; t = tq;
+    tq = mg_div(t, p.mg_ngw); const int gw = t - tq * p.ngw; t = tq;
+    tq = mg_div(t, p.mg_tiles_h); const int ti = t - tq * p.tiles_h; t = tq;
+    tq = mg_div(t, p.mg_dh); const int rh = t - tq * p.dh; t = tq;
     const int b = t;
     const int n0 = blockIdx.y * BROWS;
 
@@ -366,7 +384,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
     for (int mt = 0; mt < 2; ++mt) {
         const int m = wave * 64 + mt * 32 + lpix;
         int cls, i, j;
-        tile_decode(m, TH, TW, cls, i, j);
+        tile_decode_mg(m, p, cls, i, j);
         if (cls >= p.NC) cls = i = j = 0;          // dead slot: reads a valid patch pixel, its column is never stored
         abase[mt] = ((cls * p.PH + i * p.stride) * p.PW + j * p.stride) * PSTRIDE + lhi * 16;
     }
@@ -429,7 +447,8 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
     const int ntaps = p.kh * p.kw;
     // lane t: patch byte offset of tap t (<= 64 taps; validated on the host) -- one v_readlane per tap instead of
     // scalar row/column bookkeeping
-    const int tapoff = ((min(lane, ntaps - 1) / p.kw) * p.PW + (min(lane, ntaps - 1) % p.kw)) * PSTRIDE;
+    const int tl_ = min(lane, ntaps - 1), ta_ = mg_div(tl_, p.mg_kw);
+    const int tapoff = (ta_ * p.PW + (tl_ - ta_ * p.kw)) * PSTRIDE;
     // temporal taps: the buffer resource spans the image's whole CLIP (tT frames), a chunk of temporal tap dt reads frame
     // tfr + dt - tpad; frames before / behind the clip fall outside the resource's range and are read as zeros
     const int tfr = b % p.tT;
@@ -560,7 +579,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
     for (int mt = 0; mt < 2; ++mt) {
         const int m = wave * 64 + mt * 32 + lpix;
         int cls, i, j;
-        tile_decode(m, TH, TW, cls, i, j);
+        tile_decode_mg(m, p, cls, i, j);
         const int ho = ho_base + i * p.dh;
         const int wo = wo_base + cls + j * p.dw;
         mrow[mt] = m * OROW;
@@ -751,11 +770,11 @@ __global__ __launch_bounds__(256, (MODE == 1 && PT == 4) ? 3 : 2) void conv16_ke
         const int xcd = bid % nx, loc = bid / nx;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    int t = bid;
-    const int tj = t % p.tiles_w; t /= p.tiles_w;
-    const int gw = t % p.ngw; t /= p.ngw;
-    const int ti = t % p.tiles_h; t /= p.tiles_h;
-    const int rh = t % p.dh; t /= p.dh;
+    int t = bid, tq;
+    tq = mg_div(t, p.mg_tiles_w); const int tj = t - tq * p.tiles_w; t = tq;
+    tq = mg_div(t, p.mg_ngw); const int gw = t - tq * p.ngw; t = tq;
+    tq = mg_div(t, p.mg_tiles_h); const int ti = t - tq * p.tiles_h; t = tq;
+    tq = mg_div(t, p.mg_dh); const int rh = t - tq * p.dh; t = tq;
     const int b = t;
     const int TH = p.TH, TW = p.TW;
     const int rw0 = gw * p.NC;
@@ -774,7 +793,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && PT == 4) ? 3 : 2) void conv16_ke
     for (int pt = 0; pt < PT; ++pt) {
         const int m = wave * (16 * PT) + pt * 16 + l15;
         int cls, i, j;
-        tile_decode(m, TH, TW, cls, i, j);
+        tile_decode_mg(m, p, cls, i, j);
         if (cls >= p.NC) cls = i = j = 0;          // dead slot (see conv_mfma_kernel)
         pbase[pt] = ((cls * p.PH + i * p.stride) * p.PW + j * p.stride) * PSTRIDE;
     }
@@ -823,7 +842,8 @@ __global__ __launch_bounds__(256, (MODE == 1 && PT == 4) ? 3 : 2) void conv16_ke
         for (int nt = 0; nt < NT16; ++nt) acc[pt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ntaps = p.kh * p.kw, nwin = (ntaps + 1) >> 1;
-    const int tapoff16 = ((min(lane, ntaps - 1) / p.kw) * p.PW + (min(lane, ntaps - 1) % p.kw)) * PSTRIDE;   // lane t: tap t (<= 64 taps)
+    const int tl_ = min(lane, ntaps - 1), ta_ = mg_div(tl_, p.mg_kw);
+    const int tapoff16 = (ta_ * p.PW + (tl_ - ta_ * p.kw)) * PSTRIDE;   // lane t: tap t (<= 64 taps)
     const long long in_b = (long long)b * p.H * p.W;
     const __amdgpu_buffer_rsrc_t in_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + in_b * p.in_cs), 0, (unsigned)(p.H * p.W * p.in_cs) * 2u, 0x00020000);
@@ -1392,6 +1412,10 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     const long long nblk = (long long)d->B * d->dil_h * p.tiles_h * p.ngw * p.tiles_w;
     if (nblk > 0x7fffffffLL) { sos_set_error("sos_conv2d_fwd: grid too large"); return SOS_EINVAL; }
     p.nblk = (int)nblk;
+    // (n * d < 2^32 for every division the kernels make: block ids < 2^31 / (B dil_h) are divided by extents whose product is nblk / B)
+    if (nblk * std::max(std::max(p.tiles_w, p.ngw), std::max(p.tiles_h, (int)d->dil_h)) >= (1ll << 32)) { sos_set_error("sos_conv2d_fwd: grid too large"); return SOS_EINVAL; }
+    p.mgTW = mg_of(TW); p.mgTH = mg_of(TH); p.mgPW = mg_of(p.PW); p.mgPH = mg_of(p.PH);
+    p.mg_tiles_w = mg_of(p.tiles_w); p.mg_ngw = mg_of(p.ngw); p.mg_tiles_h = mg_of(p.tiles_h); p.mg_dh = mg_of(d->dil_h); p.mg_kw = mg_of(d->kw);
     { const char* e = getenv("SOS_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.lmap = 0;
     if (c.ks > 0) {

@@ -80,10 +80,15 @@ def main():
         if dgrad:
             pad = ((k[0] - 1) * dil[0], (k[1] - 1) * dil[1])
 
+        # SOS_BENCH_EPI: 'eval' (default: folded BatchNorm + ReLU epilogue), 'raw' (the training forward's / the data
+        # gradient's store of the bare accumulators), 'stats' (raw + the fused BatchNorm partial sums of the training forward)
+        epi = os.environ.get('SOS_BENCH_EPI', 'eval')
+        raw = dgrad or epi in ('raw', 'stats')
+
         def run():
-            E.conv_to_act(src, 0, cin, w, k[0], k[1], cout, None if dgrad else scale, None if dgrad else shift,
-                          L.ACT_NONE if dgrad else L.ACT_RELU, dst, cout_store=dst.cs,
-                          stride=stride, dil=dil, pad=pad, pad_mode=pm, Ho=Ho, Wo=Wo)
+            E.conv_to_act(src, 0, cin, w, k[0], k[1], cout, None if raw else scale, None if raw else shift,
+                          L.ACT_NONE if raw else L.ACT_RELU, dst, cout_store=dst.cs,
+                          stride=stride, dil=dil, pad=pad, pad_mode=pm, Ho=Ho, Wo=Wo, stats_c=cout if epi == 'stats' and not dgrad else 0)
         import time
         t_end = time.time() + a.warm
         run()
