@@ -140,14 +140,14 @@ __device__ __forceinline__ void build_pixel_table(const ConvParams& p, unsigned*
 // registers, no ds_write, and all of a wave's pieces are in flight at once.
 template <int CPR, bool PAD = true>
 __device__ __forceinline__ void stage_patch_dma(const ConvParams& p, char* patch, unsigned tab_addr, int lane, int wave,
-                                                __amdgpu_buffer_rsrc_t rsrc, unsigned cbytes) {
+                                                __amdgpu_buffer_rsrc_t rsrc, unsigned cbytes, const int first = 0) {
     constexpr int RP = CPR + (PAD ? 1 : 0);
     const int total = p.npix * RP;
     const int ninstr = (total + 63) >> 6;
     // Four DMA instructions per round: their four table entries are requested back to back and waited for ONCE (round 3: one
     // ds_read + s_waitcnt lgkmcnt(0) per instruction put ~11 serial LDS round trips per wave and chunk at the head of every
     // tile -- 20 % of a wave's life on the 3x3 / 7x1 layers, whose tiles hold 250-320 MFMAs per wave instead of 900).
-    for (int i0 = wave; i0 < ninstr; i0 += 16) {
+    for (int i0 = first + wave; i0 < ninstr; i0 += 16) {
         unsigned ent[4], ta[4];
         int qq[4];
 #pragma unroll
@@ -172,6 +172,80 @@ __device__ __forceinline__ void stage_patch_dma(const ConvParams& p, char* patch
             const unsigned voff = ok ? ent[u] + cbytes + (unsigned)qq[u] * 16u : 0xffffffffu;
             if (i < ninstr && L < total) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(patch + i * 1024), 16, voff, 0, 0, 0);
         }
+    }
+}
+
+// Round 4: the (pixel, piece) a lane moves in DMA instruction i -- hence its table entry, validity and source offset inside
+// the image -- is the same for EVERY channel chunk of a tile; only the chunk's channel offset differs.  stage_prepare() resolves
+// the first 16 * MAXR instructions of a workgroup's staging pass once per tile into per-lane offsets vb[r][u] (invalid lanes:
+// an offset that stays beyond the buffer resource's range after any chunk offset < 64 KB is added), stage_issue() then costs
+// one add per DMA instruction.  PMC per wave and tile before (ABLATE build, tools/probe/pmc_phases.sh): staging = 430 VALU +
+// 332 SALU for 24 DMA instructions on the 96 -> 96 layer (2 chunks), 1 140 VALU + 940 SALU on 256 -> 256 3x3 (4 chunks) --
+// a third of that layer's non-MFMA instructions.  Instructions past 16 * MAXR (patches > 64 KB) and temporal-tap layers
+// (their chunk offset moves by whole frames) keep the table path.
+#define SOS_STAGE_INVALID 0xfffe0000u
+// vb[r][u]: instruction wave + 16 r + 4 u (all but the LAST instruction of the pass, whose lanes past the patch's last piece must
+// not write -- the weight slab follows the patch: it gets its own offset register `vlast` and the only lane mask of the pass)
+template <int CPR, bool PAD, int MAXR>
+__device__ __forceinline__ void stage_prepare(const ConvParams& p, unsigned tab_addr, int lane, int wave, unsigned (&vb)[MAXR][4],
+                                              unsigned& vlast) {
+    constexpr int RP = CPR + (PAD ? 1 : 0);
+    const int total = p.npix * RP;
+    const int ninstr = (total + 63) >> 6;
+    auto resolve = [&](const int i) -> unsigned {           // (one instruction; used for the last one)
+        const int L = i * 64 + lane;
+        const int pix = L / RP, q = L - pix * RP;
+        unsigned ent;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ent) : "v"(tab_addr + (unsigned)min(pix, p.npix - 1) * 4u) : "memory");
+        return (q < CPR && ent != 0xffffffffu && L < total) ? ent + (unsigned)q * 16u : SOS_STAGE_INVALID;
+    };
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int i0 = wave + 16 * r;
+        unsigned ent[4], ta[4];
+        int qq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int L = (i0 + 4 * u) * 64 + lane;
+            const int pix = L / RP;
+            qq[u] = L - pix * RP;
+            ta[u] = tab_addr + (unsigned)min(pix, p.npix - 1) * 4u;
+        }
+        if (i0 < ninstr) {
+            asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(ent[0]), "=&v"(ent[1]), "=&v"(ent[2]), "=&v"(ent[3])
+                         : "v"(ta[0]), "v"(ta[1]), "v"(ta[2]), "v"(ta[3])
+                         : "memory");
+        } else {
+            ent[0] = ent[1] = ent[2] = ent[3] = 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = qq[u] < CPR && ent[u] != 0xffffffffu;
+            vb[r][u] = ok ? ent[u] + (unsigned)qq[u] * 16u : SOS_STAGE_INVALID;
+        }
+    }
+    vlast = SOS_STAGE_INVALID;
+    if (ninstr <= 16 * MAXR && ((ninstr - 1) & 3) == wave) vlast = resolve(ninstr - 1);
+}
+template <int CPR, bool PAD, int MAXR>
+__device__ __forceinline__ void stage_issue(const ConvParams& p, char* patch, unsigned tab_addr, int lane, int wave,
+                                            __amdgpu_buffer_rsrc_t rsrc, unsigned cbytes, const unsigned (&vb)[MAXR][4], const unsigned vlast) {
+    constexpr int RP = CPR + (PAD ? 1 : 0);
+    const int total = p.npix * RP;
+    const int ninstr = (total + 63) >> 6;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = wave + 16 * r + 4 * u;
+            if (i < ninstr - 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(patch + i * 1024), 16, vb[r][u] + cbytes, 0, 0, 0);
+        }
+    }
+    if (ninstr > 16 * MAXR) stage_patch_dma<CPR, PAD>(p, patch, tab_addr, lane, wave, rsrc, cbytes, 16 * MAXR);
+    else if (((ninstr - 1) & 3) == wave) {
+        if (lane < total - (ninstr - 1) * 64)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(patch + (ninstr - 1) * 1024), 16, vlast + cbytes, 0, 0, 0);
     }
 }
 
@@ -202,6 +276,64 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
         otab[m] = ok ? off : -1;
     }
     __syncthreads();
+    bf16_t* opm = (bf16_t*)p.out + (long long)b * p.sb + p.c_off + n0;
+    // fold mode: the padded scratch tensor (border cells), channels from 0
+    bf16_t* op2 = p.fP ? (bf16_t*)p.out2 + (long long)b * (p.fH + 2 * p.fP) * (p.fW + 2 * p.fP) * p.frow + n0 : nullptr;
+    if (!x3 && !p.accum && ((p.cout_store - n0) & 7) == 0) {
+        // ---- common case (whole 8-channel pieces, plain store), round 4: ONE walk over the staged tile does the cooperative
+        // store AND the fused BatchNorm statistics.  Thread = (16-byte piece cg of a pixel's channel run, pixel lane pl): its
+        // piece index and every address term but the pixel's are loop invariants, a pixel costs one table read, one LDS read,
+        // one add and the store (the former idx = m * PPX + q walk divided by PPX and rebuilt both addresses every iteration,
+        // and the statistics read the tile a second time: 626 / 1 156 VALU per wave and tile without / with statistics on the
+        // 96-channel layer, tools/probe/pmc_phases.sh).  Consecutive lanes still write consecutive 16-byte pieces.
+        constexpr int PL = 256 / PPX;
+        const int cg = tid % PPX, pl = tid / PPX;
+        const int npiece = min(PPX, (p.cout_store - n0) >> 3);
+        const bool st = p.stats != nullptr;
+        float s[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        if (pl < PL) {
+            const char* src = ost_hi + cg * 16;
+            const bool wr = cg < npiece;
+            typedef unsigned u32x4nt __attribute__((ext_vector_type(4)));
+#pragma unroll 4
+            for (int m = pl; m < SLOTS; m += PL) {
+                const int off = otab[m];
+                if (off == -1) continue;
+                const uint4 hv = *(const uint4*)(src + m * OROW);
+                if (st && off >= 0) {
+                    const unsigned hw[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v0 = sos_lo2f(hw[i]), v1 = sos_hi2f(hw[i]);
+                        s[2 * i] += v0; q[2 * i] = fmaf(v0, v0, q[2 * i]);
+                        s[2 * i + 1] += v1; q[2 * i + 1] = fmaf(v1, v1, q[2 * i + 1]);
+                    }
+                }
+                if (wr) {
+                    // streamed output (read back only after the whole tensor is written): non-temporal store, +0.9 % on inference
+                    bf16_t* dst = (off >= 0 ? opm + off : op2 + (-2 - off)) + cg * 8;
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4nt, hv), (u32x4nt*)dst);
+                }
+            }
+        }
+        if (st) {
+            // fixed-order sum over the pixel lanes (exactly the separate statistics pass's order of round 3: lanes, then tiles)
+            float* red = (float*)(smem + SLOTS * OROW + SLOTS * 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s[e]; red[tid * 16 + 8 + e] = q[e]; }
+            __syncthreads();
+            for (int o = tid; o < 2 * PPX * 8; o += 256) {
+                const int which = o / (PPX * 8), cc = o - which * (PPX * 8);
+                const int g8 = cc >> 3, e = cc & 7;
+                float acc = 0.f;
+                for (int l = 0; l < PL; ++l) acc += red[(l * PPX + g8) * 16 + which * 8 + e];
+                if (n0 + cc < p.stats_c) p.stats[((size_t)which * p.stats_c + n0 + cc) * p.nblk + blockIdx.x] = acc;   // [2][C][tiles]
+            }
+        }
+        return;
+    }
     if (p.stats) {
         // ---- fused BatchNorm statistics of this tile (of the bf16-rounded values, exactly what a separate pass over
         // the stored tensor would see): thread = (8-channel group, pixel lane), then a fixed-order sum over the lanes
@@ -238,26 +370,8 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
             if (n0 + cc < p.stats_c) p.stats[((size_t)which * p.stats_c + n0 + cc) * p.nblk + blockIdx.x] = acc;   // [2][C][tiles]
         }
     }
-    // ---- cooperative store: consecutive lanes write consecutive 16-byte pieces of a pixel's
-    // channel run (and consecutive pixels of a tile row are adjacent in memory when dil_w == 1).
-    bf16_t* opm = (bf16_t*)p.out + (long long)b * p.sb + p.c_off + n0;
-    // fold mode: the padded scratch tensor (border cells), channels from 0
-    bf16_t* op2 = p.fP ? (bf16_t*)p.out2 + (long long)b * (p.fH + 2 * p.fP) * (p.fW + 2 * p.fP) * p.frow + n0 : nullptr;
-    if (!x3 && !p.accum && ((p.cout_store - n0) & 7) == 0) {          // common case: whole 8-channel pieces, plain store
-        const int npiece = min(PPX, (p.cout_store - n0) >> 3);
-#pragma unroll 4
-        for (int idx = tid; idx < SLOTS * PPX; idx += 256) {
-            const int m = idx / PPX, q = idx - m * PPX;
-            const int off = otab[m];
-            if (q < npiece && off != -1) {
-                // streamed output (read back only after the whole tensor is written): non-temporal store, +0.9 % on inference
-                typedef unsigned u32x4nt __attribute__((ext_vector_type(4)));
-                bf16_t* dst = off >= 0 ? opm + off : op2 + (-2 - off);
-                __builtin_nontemporal_store(*(const u32x4nt*)(ost_hi + m * OROW + q * 16), (u32x4nt*)(dst + q * 8));
-            }
-        }
-        return;
-    }
+    // ---- general cooperative store (hi|hi|lo planes, gradient fan-in, ragged channel tails): consecutive lanes write consecutive
+    // 16-byte pieces of a pixel's channel run (and consecutive pixels of a tile row are adjacent in memory when dil_w == 1).
 #pragma unroll 4
     for (int idx = tid; idx < SLOTS * PPX; idx += 256) {
         const int m = idx / PPX, q = idx - m * PPX;
@@ -457,17 +571,28 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
     const __amdgpu_buffer_rsrc_t in_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + in_b * p.in_cs), 0, (unsigned)(p.tT * frame_elems) * 2u, 0x00020000);
     build_pixel_table(p, pixtab, tid, hin0, win0, rw0, Wl, wgather);
+    constexpr int STG_R = 4;                     // staging rounds resolved once per tile (64 DMA instructions = 64 KB of patch)
+    unsigned stg[STG_R][4], stg_last;
+    const bool stg_fast = p.tk == 1;             // (temporal taps move the chunk offset by whole frames: table path)
+    __syncthreads();                             // the pixel table is complete
+    if (stg_fast && !CDBG(1)) stage_prepare<CPR, true, STG_R>(p, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), stg, stg_last);
 
+    int seg = 0, cin_seg = 0;                    // chunk cc = cin_seg-th chunk of channel segment seg (no division per chunk)
     for (int cc = 0; cc < p.nchunks; ++cc) {
-        __syncthreads();   // everyone is done reading the previous chunk's patch / weight buffers
-        // ---- stage the input patch of this channel chunk (the first barrier above also publishes the pixel table)
+        if (cc) __syncthreads();   // everyone is done reading the previous chunk's patch / weight buffers
+        // ---- stage the input patch of this channel chunk
         if (!CDBG(1)) {
-            const int seg = cc / p.cps;            // (channel range, temporal tap)
-            const long long cbase = (long long)p.cin_off + (long long)(seg / p.tk) * p.seg_stride + (long long)(cc % p.cps) * KC +
-                                    (long long)(tfr + seg % p.tk - p.tpad) * frame_elems;
-            stage_patch_dma<CPR>(p, patch, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc,
-                                 (unsigned)(cbase * 2));
+            if (stg_fast) {
+                const unsigned cb = (unsigned)((p.cin_off + seg * p.seg_stride + cin_seg * KC) * 2);
+                stage_issue<CPR, true, STG_R>(p, patch, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc, cb, stg, stg_last);
+            } else {
+                const long long cbase = (long long)p.cin_off + (long long)(seg / p.tk) * p.seg_stride + (long long)cin_seg * KC +
+                                        (long long)(tfr + seg % p.tk - p.tpad) * frame_elems;
+                stage_patch_dma<CPR>(p, patch, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc,
+                                     (unsigned)(cbase * 2));
+            }
         }
+        if (++cin_seg == p.cps) { cin_seg = 0; ++seg; }
         // ---- weight slab of tap 0 straight into buffer 0
         if constexpr (!SB) dma_slab(0, (unsigned)(cc * KC * 2));
         else {
@@ -1321,6 +1446,10 @@ static int validate(const sos_conv_desc* d) {
     }
     if ((d->wl_tab == nullptr) != (d->wo_tab == nullptr) || (d->wl_tab && d->stats)) {
         sos_set_error("sos_conv2d_fwd: ragged batches need both wl_tab and wo_tab and no fused statistics");
+        return SOS_EINVAL;
+    }
+    if ((long long)d->in_cs * 2 > 0xffff) {        // (a chunk's byte offset inside a pixel is added to pre-resolved 32-bit offsets: stage_issue)
+        sos_set_error("sos_conv2d_fwd: pixel pitch of %d channels not supported (<= 32767)", d->in_cs);
         return SOS_EINVAL;
     }
     if ((uint64_t)d->H * d->W * d->in_cs * 2 >= 0xfff00000ull) {
