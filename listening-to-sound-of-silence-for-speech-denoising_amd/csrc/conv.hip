@@ -739,6 +739,8 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
         }
     } else if (staged && !x3 && p.act != SOS_ACT_SIGMOID && p.scale) {
         const float sn = p.act == SOS_ACT_RELU ? 0.f : (p.act == SOS_ACT_PRELU ? slope : 1.f);
+        const bool relu = p.act == SOS_ACT_RELU;               // (wave-uniform) fma + max instead of fma + min + max + fma: the inference
+                                                               // path's blocks are all BatchNorm + ReLU, two VALU per value less
         const bool partial = n0 + NT * 32 > p.cout;           // channels past cout are stored as zeros
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -754,10 +756,15 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     float v[4];
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(acc[mt][nt][g * 4 + e], scv[e], shv[e]), 0.f);
+                    } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float y = fmaf(acc[mt][nt][g * 4 + e], scv[e], shv[e]);
                         v[e] = fmaf(sn, fminf(y, 0.f), fmaxf(y, 0.f));
+                    }
                     }
                     if (partial) {
 #pragma unroll
@@ -976,6 +983,8 @@ __global__ __launch_bounds__(256, (MODE == 1 && PT == 4) ? 3 : 2) void conv16_ke
     for (int sg = 0; sg < p.nchunks; ++sg) {
     // (first segment: publishes the pixel table; later ones: every wave has passed the last window's barrier, i.e. is done
     // reading the patch and the slabs)
+    // (round 4: resolving the staging offsets once for the three segments of the hi|hi|lo mode, as conv_mfma_kernel does for its
+    // chunks, costs this kernel 15 VGPRs and 21 spilled SGPRs: inference in `mixed` 1 623 -> 1 591 utt/s -- not adopted)
     __syncthreads();
     segk = (unsigned)(sg * p.cin * 2);
     if (!CDBG(1)) stage_patch_dma<CPR, false>(p, patch, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc,
@@ -1100,6 +1109,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && PT == 4) ? 3 : 2) void conv16_ke
     const bool partial = ROWS > p.cout, sig = p.act == SOS_ACT_SIGMOID;
     const float sn = p.act == SOS_ACT_RELU ? 0.f : (p.act == SOS_ACT_PRELU ? slope : 1.f);   // max(y,0) + sn*min(y,0)
     const bool raw = !p.scale && p.act == SOS_ACT_NONE;          // training forward convs, data gradients
+    const bool relu16 = p.act == SOS_ACT_RELU;
     const bool x3out = p.out_dtype == SOS_DT_BF16X3;
 #pragma unroll
     for (int nt = 0; nt < NT16; ++nt) {
@@ -1114,12 +1124,17 @@ __global__ __launch_bounds__(256, (MODE == 1 && PT == 4) ? 3 : 2) void conv16_ke
             if (raw) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[pt][nt][e];
+            } else if (relu16) {                 // (wave-uniform branches: one code version per activation, no per-value selects)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(acc[pt][nt][e], scv[e], shv[e]), 0.f);
+            } else if (sig) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-fmaf(acc[pt][nt][e], scv[e], shv[e])));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float y = fmaf(acc[pt][nt][e], scv[e], shv[e]);
-                    if (sig) v[e] = 1.0f / (1.0f + expf(-y));
-                    else v[e] = fmaf(sn, fminf(y, 0.f), fmaxf(y, 0.f));
+                    v[e] = fmaf(sn, fminf(y, 0.f), fmaxf(y, 0.f));
                 }
             }
             if (partial) {
