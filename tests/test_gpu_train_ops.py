@@ -195,6 +195,33 @@ def test_wgrad_tune_measured_plan_gives_the_same_gradient(tmp_path):
     assert L.lib().sos_wgrad_tune_load(path) == len(body) - 1
 
 
+@pytest.mark.parametrize("geom", [(20, 27, 2, 64), (40, 37, 16, 64), (9, 11, 4, 24), (5, 6, 3, 16), (4, 7, 3, 16), (33, 18, 1, 128)],
+                         ids=lambda g: "%dx%d pad%d c%d" % g)
+def test_reflect_fold_border_adds_the_mirrored_cells(geom):
+    """sos_reflect_fold_border (the border kernel of round 4 enumerates only the pixels that have a mirrored cell; pad > min(H, W) - 2
+    keeps the all-pixel walk): out += every border cell of the padded tensor that mirrors onto the pixel, interior cells untouched
+    -- against the adjoint of torch's ReflectionPad2d.  Bands that meet (9 x 11, pad 4), pad = H - 2 and the fallback are covered."""
+    from sos_amd import train_ops as TO
+    H, W, pad, C = geom
+    B = 3
+    P = torch.from_numpy(hashed(71, (B, C, H + 2 * pad, W + 2 * pad)).astype(np.float32))
+    O = torch.from_numpy(hashed(72, (B, C, H, W)).astype(np.float32))
+    pa, pheld = _act_from_nchw(P, False)
+    oa, oheld = _act_from_nchw(O, False)
+    x = torch.zeros(B, C, H, W, requires_grad=True)
+    F.pad(x, (pad, pad, pad, pad), mode="reflect").backward(pheld)
+    want = oheld + x.grad - pheld[:, :, pad:pad + H, pad:pad + W]
+    TO.reflect_fold_border(pa, H, W, pad, oa, 0, C)
+    got = _act_to_nchw(oa, C)
+    # one rounding to the 16-bit storage type of a sum of <= 9 stored values
+    err = float((got - want).abs().max() / want.abs().max())
+    print(geom, "fold border rel err", err)
+    assert err < 6e-3
+    inner = (slice(None), slice(None), slice(pad + 1, H - 1 - pad), slice(pad + 1, W - 1 - pad))
+    if H - 2 - 2 * pad > 0 and W - 2 - 2 * pad > 0:
+        assert torch.equal(got[inner], oheld[inner]), "an interior pixel was rewritten"
+
+
 DOWN_CASES = [(64, 128, 5, 2, 1, 20, 27), (128, 128, 3, 1, 4, 16, 23), (64, 64, 5, 1, 1, 18, 21), (128, 64, 3, 2, 1, 17, 22),
               (64, 64, 3, 1, 16, 40, 37)]
 
