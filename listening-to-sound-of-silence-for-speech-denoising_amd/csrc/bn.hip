@@ -192,27 +192,30 @@ extern "C" int sos_bn_stats(const sos_view* x, float* partial, sos_stream_t stre
 // one workgroup per channel: 256 threads stride over the channel's row of per-workgroup partial sums ([2][C][blocks]:
 // contiguous, so the 12 288 tile sums of a conv epilogue are read coalesced; fixed order -> deterministic), double
 // accumulation, LDS tree.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+// NTH threads per channel: 256, or 1024 for the 12 288 tile sums of a full-resolution conv epilogue (round 4: a channel's row
+// is then two rounds of 8 loads per thread instead of six -- 20 -> ~6 us per launch of a kernel that runs with the chip to itself)
+template <int NTH>
+__global__ __launch_bounds__(NTH) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
                                    long long* __restrict__ nbt, float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-    __shared__ double rs[256], rq[256];
+    __shared__ double rs[NTH], rq[NTH];
     const int c = blockIdx.x, tid = threadIdx.x;
     double s = 0.0, q = 0.0;
     const float* ps = partial + ((size_t)0 * C + c) * nblk;
     const float* pq = partial + ((size_t)1 * C + c) * nblk;
     int b = tid;
-    for (; b + 768 < nblk; b += 1024) {          // 8 loads in flight per thread (12 288 conv tiles: 48 per thread); fixed order
-        const float a0 = ps[b], a1 = ps[b + 256], a2 = ps[b + 512], a3 = ps[b + 768];
-        const float c0 = pq[b], c1 = pq[b + 256], c2 = pq[b + 512], c3 = pq[b + 768];
+    for (; b + 3 * NTH < nblk; b += 4 * NTH) {   // 8 loads in flight per thread; fixed order
+        const float a0 = ps[b], a1 = ps[b + NTH], a2 = ps[b + 2 * NTH], a3 = ps[b + 3 * NTH];
+        const float c0 = pq[b], c1 = pq[b + NTH], c2 = pq[b + 2 * NTH], c3 = pq[b + 3 * NTH];
         s += (double)a0; s += (double)a1; s += (double)a2; s += (double)a3;
         q += (double)c0; q += (double)c1; q += (double)c2; q += (double)c3;
     }
-    for (; b < nblk; b += 256) { s += (double)ps[b]; q += (double)pq[b]; }
+    for (; b < nblk; b += NTH) { s += (double)ps[b]; q += (double)pq[b]; }
     rs[tid] = s; rq[tid] = q;
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
+    for (int st = NTH / 2; st > 0; st >>= 1) {
         if (tid < st) { rs[tid] += rs[tid + st]; rq[tid] += rq[tid + st]; }
         __syncthreads();
     }
@@ -238,9 +241,14 @@ extern "C" int sos_bn_finalize(const float* partial, int nblk, int C, int64_t co
                                int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
                                float* save_invstd, sos_stream_t stream) {
     if (!partial || !scale || !shift || nblk < 1 || C < 1 || count < 1) { sos_set_error("sos_bn_finalize: bad args"); return SOS_EINVAL; }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
-                       (double)count, gamma, beta, eps, momentum, running_mean, running_var,
-                       (long long*)num_batches_tracked, scale, shift, save_mean, save_invstd);
+    if (nblk >= 4096)
+        hipLaunchKernelGGL(bn_finalize_kernel<1024>, dim3(C), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C,
+                           (double)count, gamma, beta, eps, momentum, running_mean, running_var,
+                           (long long*)num_batches_tracked, scale, shift, save_mean, save_invstd);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
+                           (double)count, gamma, beta, eps, momentum, running_mean, running_var,
+                           (long long*)num_batches_tracked, scale, shift, save_mean, save_invstd);
     return sos_check_launch("sos_bn_finalize");
 }
 
@@ -619,6 +627,21 @@ __global__ __launch_bounds__(256) void pack_grad_kernel(const float* __restrict_
     }
 }
 
+// channel-contiguous rows (sc == 1: the LSTM gate gradients), round 4: a thread converts 8 consecutive channels of a row -- two
+// 16-byte loads, one 16-byte store, 32-bit index arithmetic (the element-wise kernel above pays three 64-bit divisions per VALUE)
+__global__ __launch_bounds__(256) void pack_grad_rows_kernel(const float* __restrict__ g, int inner, int CG, long long so, long long st,
+                                                             View out, const float* __restrict__ mul_p, int total) {
+    const float mul = mul_p ? mul_p[0] : 1.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int row = i / CG, cg = i - row * CG;
+        const int o = row / inner, t = row - o * inner;
+        const float4* src = (const float4*)(g + o * so + t * st + cg * 8);
+        const float4 a = src[0], b = src[1];
+        float f[8] = {a.x * mul, a.y * mul, a.z * mul, a.w * mul, b.x * mul, b.y * mul, b.z * mul, b.w * mul};
+        store8(out, row, cg * 8, f);
+    }
+}
+
 extern "C" int sos_pack_grad_f32(const float* g, const float* y, int act, int64_t outer, int64_t inner, int C,
                                  int64_t so, int64_t st, int64_t sc, const sos_view* out, const float* mul, sos_stream_t stream) {
     if (!g || !out || !out->ptr || outer < 1 || inner < 1 || C < 1 || (act == SOS_ACT_SIGMOID && !y)) {
@@ -626,6 +649,13 @@ extern "C" int sos_pack_grad_f32(const float* g, const float* y, int act, int64_
         return SOS_EINVAL;
     }
     const long long total = outer * inner * C;
+    if (sc == 1 && act != SOS_ACT_SIGMOID && C % 8 == 0 && total / 8 < 0x7fffffffLL && so % 4 == 0 && st % 4 == 0 &&
+        ((uintptr_t)g & 15) == 0 && out->c_off % 8 == 0 && out->row % 8 == 0 && out->C >= C) {
+        const int n8 = (int)(total / 8);
+        hipLaunchKernelGGL(pack_grad_rows_kernel, dim3(grid_for((long long)n8)), dim3(256), 0, (hipStream_t)stream, g, (int)inner, C / 8,
+                           (long long)so, (long long)st, to_view(out), mul, n8);
+        return sos_check_launch("sos_pack_grad_f32(rows)");
+    }
     hipLaunchKernelGGL(pack_grad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g, y, act, outer, inner, C,
                        so, st, sc, to_view(out), mul);
     return sos_check_launch("sos_pack_grad_f32");
@@ -642,6 +672,24 @@ __global__ __launch_bounds__(256) void feat_to_nhwc_kernel(View f, int H, int W,
         const long long b = r / W;
         const int i0 = lo ? lo[w] : w, i1 = hi ? hi[w] : w + 1;
         const long long pix = (b * H + h) * W + w;
+        if (out.C <= 8 && out.c_off % 8 == 0 && out.c_off + 8 <= out.row) {    // (the run's padding channels are written as zeros)
+            // (round 4) the heads feeding the BiLSTM have 8 / 4 channels: gather them and write the pixel's 16-byte run at once
+            // instead of one 2-byte store per channel at a 32-byte pitch across the wave
+            float acc[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                acc[c] = 0.f;
+                if (c < out.C) {
+                    for (int k = i0; k < i1; ++k) {
+                        const bf16_t* p = f.ptr + (b * Wo + k) * f.row + (long long)(f.c_off + c) * H + h;
+                        acc[c] += bf2f(p[0]);
+                        if (f.x3) acc[c] += bf2f(p[2 * f.third]);
+                    }
+                }
+            }
+            store8(out, pix, 0, acc);
+            continue;
+        }
         for (int c = 0; c < out.C; ++c) {
             float acc = 0.f;
             for (int k = i0; k < i1; ++k) {

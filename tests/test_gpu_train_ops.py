@@ -222,6 +222,29 @@ def test_reflect_fold_border_adds_the_mirrored_cells(geom):
         assert torch.equal(got[inner], oheld[inner]), "an interior pixel was rewritten"
 
 
+def test_pack_grad_rows_and_strided():
+    """sos_pack_grad_f32: f32 gradients -> 16-bit rows.  Channel-contiguous sources (the LSTM gate gradients) take the row kernel
+    of round 4 (8 channels per thread), anything else the element-wise kernel; both must equal a plain cast, and the sigmoid'
+    form (the denoiser's mask head, channel stride = T) the cast of g y (1 - y)."""
+    from sos_amd import engine as E, train_ops as TO, _lib as L
+    B, T, C = 3, 37, 1600
+    g = torch.from_numpy(hashed(81, (B, T, C)).astype(np.float32)).cuda()
+    dst = E.Act(B, 1, T, C, False, torch.device("cuda"))
+    dst.t.fill_(float("nan"))
+    TO.pack_grad(g, None, L.ACT_NONE, B, T, C, T * C, C, 1, dst)
+    got = dst.t.view(B, T, C).float().cpu()
+    assert torch.equal(got, g.cpu().to(E.act_dtype()).float())
+    # channel stride T (B, C, T source), with the sigmoid derivative
+    C2 = 48
+    g2 = torch.from_numpy(hashed(82, (B, C2, T)).astype(np.float32)).cuda()
+    y2 = torch.sigmoid(torch.from_numpy(hashed(83, (B, C2, T)).astype(np.float32))).cuda()
+    dst2 = E.Act(B, 1, T, C2, False, torch.device("cuda"))
+    TO.pack_grad(g2, y2, L.ACT_SIGMOID, B, T, C2, C2 * T, 1, T, dst2)
+    want2 = (g2 * y2 * (1 - y2)).permute(0, 2, 1).cpu()
+    got2 = dst2.t.view(B, T, C2).float().cpu()
+    assert float((got2 - want2).abs().max()) <= 2e-3 * float(want2.abs().max())
+
+
 DOWN_CASES = [(64, 128, 5, 2, 1, 20, 27), (128, 128, 3, 1, 4, 16, 23), (64, 64, 5, 1, 1, 18, 21), (128, 64, 3, 2, 1, 17, 22),
               (64, 64, 3, 1, 16, 40, 37)]
 
