@@ -18,6 +18,9 @@ from . import engine as E
 
 # SOS_FUSED_STATS=0: separate sos_bn_stats pass instead of the statistics fused into the conv epilogue (A/B timing)
 FUSED_STATS = __import__("os").environ.get("SOS_FUSED_STATS", "1") != "0"
+# SOS_FUSED_STATS_UNET=1: the U-Net's DownConvBlocks take their statistics from the conv epilogue too (14 statistics passes per step
+# less).  Measured +0.1 % on the step (531.9 -> 532.6, inside the noise): opt-in only
+FUSED_STATS_UNET = __import__("os").environ.get("SOS_FUSED_STATS_UNET", "0") == "1"
 
 
 def ones_zeros(n, device):
@@ -558,10 +561,10 @@ def down_forward_train(lp, src, cin_off, dst, c_off, Ho, Wo, x3):
     cs = E.pad_to(lp["cout"], 16)
     one, zero = ones_zeros(lp["w"].shape[1], dev)
     raw = E.Act(src.B, Ho, Wo, cs, x3, dev)
-    E.conv_to_act(src, cin_off, lp["cin_store"], lp["w"], lp["k"], lp["kw"], lp["cout"], one, zero, L.ACT_NONE, raw,
-                  cout_store=cs, stride=lp["stride"], dil=(lp["dil"], lp["dil"]), pad=(lp["pad"], lp["pad_w"]),
-                  pad_mode=L.PAD_REFLECT, Ho=Ho, Wo=Wo)
-    saved = E.bn_train(raw, 0, lp["cout"], lp["bn"], L.ACT_PRELU, lp["prelu"].weight, dst, c_off)
+    st = E.conv_to_act(src, cin_off, lp["cin_store"], lp["w"], lp["k"], lp["kw"], lp["cout"], one, zero, L.ACT_NONE, raw,
+                       cout_store=cs, stride=lp["stride"], dil=(lp["dil"], lp["dil"]), pad=(lp["pad"], lp["pad_w"]),
+                       pad_mode=L.PAD_REFLECT, Ho=Ho, Wo=Wo, stats_c=lp["cout"] if (FUSED_STATS and FUSED_STATS_UNET) else 0)
+    saved = E.bn_train(raw, 0, lp["cout"], lp["bn"], L.ACT_PRELU, lp["prelu"].weight, dst, c_off, stats=st)
     return dict(kind="down", lp=lp, src=src, cin_off=cin_off, dst=dst, c_off=c_off, raw=raw, saved=saved)
 
 
