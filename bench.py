@@ -426,28 +426,31 @@ def main():
             # the headline workload with the denoiser's [stage 1 -> encoder_n] branch on a side stream beside encoder_x
             # (JointModel.BRANCH_STREAMS, opt-in: +1.3-1.6 % here, but the dominant kernel then time-shares the chip and its
             # HIP-event duration no longer measures the kernel alone -- DESIGN.md 5.0)
-            def _headline_again(key):
-                # the box has been running for a minute by now and clocks drift: the lines below are compared with the headline
-                # workload timed AGAIN right before them (10 steps), not with the headline of the record
+            def _headline_again(key=None):
+                # the box has been running for a minute by now and its clocks drift (and sag while a workload is being built): the
+                # two lines below are compared with the headline workload timed AGAIN right before AND right after them (10 warm-up
+                # + 15 timed steps each: the clocks need about a second to come back after the idle time a workload's construction leaves), not with the headline of the record
                 w0 = Workload("train", "fp16", 64, rank)
-                dt0, _, _ = run_timed(w0, 10, 3, barrier, profile=False)
+                dt0, _, _ = run_timed(w0, 15, 10, barrier, profile=False)
                 del w0
                 torch.cuda.empty_cache()
-                sec[key] = round(64 * 10 / dt0, 1)
-                return 64 * 10 / dt0
+                if key:
+                    sec[key] = round(64 * 15 / dt0, 1)
+                return 64 * 15 / dt0
             try:
                 from sos_amd.denoiser import networks as _jnet
                 ref0 = _headline_again("train_fp16_before_branch_streams_utt_s")
                 _jnet.JointModel.BRANCH_STREAMS = True
                 try:
                     w2 = Workload("train", "fp16", 64, rank)
-                    dt2, _, _ = run_timed(w2, 10, 3, barrier, profile=False)
-                    sec["train_fp16_branch_streams_utt_s"] = round(64 * 10 / dt2, 1)
-                    sec["train_fp16_branch_streams_ratio"] = round(64 * 10 / dt2 / ref0, 4)
+                    dt2, _, _ = run_timed(w2, 15, 10, barrier, profile=False)
+                    sec["train_fp16_branch_streams_utt_s"] = round(64 * 15 / dt2, 1)
                     del w2
                 finally:
                     _jnet.JointModel.BRANCH_STREAMS = False
                 torch.cuda.empty_cache()
+                ref0 = 0.5 * (ref0 + _headline_again())
+                sec["train_fp16_branch_streams_ratio"] = round(64 * 15 / dt2 / ref0, 4)
             except Exception as e:
                 sec["train_fp16_branch_streams_utt_s"] = None
                 sec["train_fp16_branch_streams_utt_s_error"] = repr(e)[:200]
@@ -485,14 +488,15 @@ def main():
                 dist1.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
                 try:
                     w2 = Workload("train", "fp16", 64, rank)
-                    dt2, _, _ = run_timed(w2, 10, 3, barrier, profile=False)
-                    sec["train_fp16_forced_buckets_utt_s"] = round(64 * 10 / dt2, 1)
-                    sec["train_fp16_forced_buckets_ratio"] = round(64 * 10 / dt2 / ref1, 4)
+                    dt2, _, _ = run_timed(w2, 15, 10, barrier, profile=False)
+                    sec["train_fp16_forced_buckets_utt_s"] = round(64 * 15 / dt2, 1)
                     del w2
                 finally:
                     dist1.destroy_process_group()
                     os.environ.pop("SOS_FORCE_BUCKETS", None)
                 torch.cuda.empty_cache()
+                ref1 = 0.5 * (ref1 + _headline_again())
+                sec["train_fp16_forced_buckets_ratio"] = round(sec["train_fp16_forced_buckets_utt_s"] / ref1, 4)
             except Exception as e:
                 sec["train_fp16_forced_buckets_utt_s"] = None
                 sec["train_fp16_forced_buckets_utt_s_error"] = repr(e)[:200]
@@ -503,8 +507,8 @@ def main():
                            "configs[4]'s per-GPU share (32 clips of 60 x 224 x 224 frames) x 3 steps; train_fp16_forced_buckets = the headline "
                            "workload with the data-parallel gradient path forced in a world of one (1-rank RCCL groups, one per model); "
                            "train_fp16_branch_streams = the headline workload with SOS_BRANCH_STREAMS=1 (opt-in schedule); *_ratio = that line over the "
-                           "headline workload timed again right before it (train_fp16_before_*: the box's clocks drift over the minute the "
-                           "secondary lines take)")
+                           "mean of the headline workload timed again right before (train_fp16_before_*) and right after it, 10 + 15 steps each "
+                           "(the box's clocks drift over the minute the secondary lines take)")
             line["secondary"] = sec
             sos_amd.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:
