@@ -410,8 +410,7 @@ def main():
                                                  ("ragged_mixed_clips_s", "infer-ragged", "mixed", 256, 3, 1, None),
                                                  ("ragged_mixed_hipgraph_clips_s", "infer-ragged", "mixed", 256, 3, 1, "graph"),
                                                  ("train_bf16_utt_s", "train", "bf16", 64, 10, 3, None),
-                                                 ("train_mixed_utt_s", "train", "mixed", 64, 10, 3, None),
-                                                 ("train_fp16_16khz_2x256x251_utt_s", "train", "fp16", 64, 5, 2, 251)):
+                                                 ("train_mixed_utt_s", "train", "mixed", 64, 10, 3, None)):
                 try:
                     w2 = Workload(mode, prec, b, rank, frames=None if fr == "graph" else fr, graph=fr == "graph")
                     dt2, _, _ = run_timed(w2, k, w, barrier, profile=False)
@@ -439,6 +438,7 @@ def main():
                 return 64 * 15 / dt0
             try:
                 from sos_amd.denoiser import networks as _jnet
+                _headline_again()                # (thrown away: the first training run after the inference / mixed lines measures 3-5 % slow)
                 ref0 = _headline_again("train_fp16_before_branch_streams_utt_s")
                 _jnet.JointModel.BRANCH_STREAMS = True
                 try:
@@ -500,6 +500,17 @@ def main():
             except Exception as e:
                 sec["train_fp16_forced_buckets_utt_s"] = None
                 sec["train_fp16_forced_buckets_utt_s_error"] = repr(e)[:200]
+            # (the other-geometry line comes LAST: the first fp16 training run after it measured 4 % slow for dozens of steps -- cause
+            # not tracked down -- and it used to sit right in front of the bracketed comparisons above)
+            try:
+                w2 = Workload("train", "fp16", 64, rank, frames=251)
+                dt2, _, _ = run_timed(w2, 5, 2, barrier, profile=False)
+                sec["train_fp16_16khz_2x256x251_utt_s"] = round(64 * 5 / dt2, 1)
+                del w2
+                torch.cuda.empty_cache()
+            except Exception as e:
+                sec["train_fp16_16khz_2x256x251_utt_s"] = None
+                sec["train_fp16_16khz_2x256x251_utt_s_error"] = repr(e)[:200]
             sec["note"] = ("same box, after the headline loop: infer = B=64 2 s clips x 10 steps; ragged = BASELINE configs[3], B=256 "
                            "U(1 s,10 s) x 3 steps (eager launches / replayed hipGraphs); train_* = the headline workload in another precision x 10 steps; "
                            "train_fp16_16khz_2x256x251 = SURVEY.md 8-d's secondary (BASELINE-literal 16 kHz / STFT 512-128, Nyquist dropped) spectrogram "
