@@ -138,12 +138,47 @@ __device__ __forceinline__ void build_pixel_table(const ConvParams& p, unsigned*
 // a wave fills pieces [64 i, 64 i + 64).  A lane's source is table[pixel] + chunk offset; zero padding,
 // the pad piece and lanes past the image get an out-of-range offset (the hardware writes zeros).  No data
 // registers, no ds_write, and all of a wave's pieces are in flight at once.
+// Which pieces a DMA instruction moves.  Piece-linear (rounds 1-3): instruction i fills pieces [64 i, 64 i + 64), so a lane's
+// pixel is (64 i + lane) / RP -- a division and a remainder per (instruction, lane).  Pixel-aligned (round 4, when RP divides 64
+// to within 8 lanes: every kernel variant with <= 4 k-steps per chunk and the 16-row kernel): instruction i fills the PPI = 64 / RP
+// WHOLE pixels [PPI i, PPI i + PPI), so a lane's piece index and its pixel's offset inside the instruction are constants
+// (lane % RP, lane / RP) and the pixel is PPI i + const; the 64 - PPI RP lanes at the end are switched off for the whole pass
+// (their LDS slots belong to the next instruction's first pixel).  The patch image in LDS is the same [npix][RP] pieces.
+template <int RP> struct StageMap {
+    static constexpr int PPI = (64 / RP) * RP >= 56 ? 64 / RP : 0;          // 0: piece-linear
+    static constexpr int LDS_STEP = PPI ? PPI * RP * 16 : 1024;              // LDS bytes from one instruction to the next
+    int lp, lq;
+    bool on;
+    __device__ __forceinline__ StageMap(int lane) {
+        lp = PPI ? lane / RP : 0;
+        lq = PPI ? lane - lp * RP : 0;
+        on = PPI ? lane < PPI * RP : true;
+    }
+    static __device__ __forceinline__ int ninstr(int npix) { return PPI ? (npix + PPI - 1) / PPI : (npix * RP + 63) >> 6; }
+    __device__ __forceinline__ void at(int i, int lane, int& pix, int& q) const {
+        if constexpr (PPI != 0) { pix = i * PPI + lp; q = lq; }
+        else { const int L = i * 64 + lane; pix = L / RP; q = L - pix * RP; }
+    }
+    // may this lane write in instruction i?  (only the last instruction of a pass has lanes past the patch's last piece)
+    __device__ __forceinline__ bool writes(int i, int lane, int npix) const {
+        if constexpr (PPI != 0) return i * PPI + lp < npix;
+        else return i * 64 + lane < npix * RP;
+    }
+};
+
+// Stage the input patch of one channel chunk with LDS-DMA (buffer_load_dwordx4 ... lds): the patch image
+// is [npix][CPR + 1] 16-byte pieces (the last piece of a row is the bank-conflict pad).  A lane's source is
+// table[pixel] + chunk offset; zero padding,
+// the pad piece and lanes past the image get an out-of-range offset (the hardware writes zeros).  No data
+// registers, no ds_write, and all of a wave's pieces are in flight at once.
 template <int CPR, bool PAD = true>
 __device__ __forceinline__ void stage_patch_dma(const ConvParams& p, char* patch, unsigned tab_addr, int lane, int wave,
                                                 __amdgpu_buffer_rsrc_t rsrc, unsigned cbytes, const int first = 0) {
     constexpr int RP = CPR + (PAD ? 1 : 0);
-    const int total = p.npix * RP;
-    const int ninstr = (total + 63) >> 6;
+    typedef StageMap<RP> SM;
+    const SM sm(lane);
+    const int ninstr = SM::ninstr(p.npix);
+    if (!sm.on) return;
     // Four DMA instructions per round: their four table entries are requested back to back and waited for ONCE (round 3: one
     // ds_read + s_waitcnt lgkmcnt(0) per instruction put ~11 serial LDS round trips per wave and chunk at the head of every
     // tile -- 20 % of a wave's life on the 3x3 / 7x1 layers, whose tiles hold 250-320 MFMAs per wave instead of 900).
@@ -152,9 +187,8 @@ __device__ __forceinline__ void stage_patch_dma(const ConvParams& p, char* patch
         int qq[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int L = (i0 + 4 * u) * 64 + lane;
-            const int pix = L / RP;
-            qq[u] = L - pix * RP;
+            int pix;
+            sm.at(i0 + 4 * u, lane, pix, qq[u]);
             ta[u] = tab_addr + (unsigned)min(pix, p.npix - 1) * 4u;
         }
         // ONE asm statement: the four requests and their wait cannot be separated, and the early-clobber outputs cannot share a
@@ -167,10 +201,10 @@ __device__ __forceinline__ void stage_patch_dma(const ConvParams& p, char* patch
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + 4 * u;
-            const int L = i * 64 + lane;
             const bool ok = qq[u] < CPR && ent[u] != 0xffffffffu;
             const unsigned voff = ok ? ent[u] + cbytes + (unsigned)qq[u] * 16u : 0xffffffffu;
-            if (i < ninstr && L < total) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(patch + i * 1024), 16, voff, 0, 0, 0);
+            if (i < ninstr && sm.writes(i, lane, p.npix))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(patch + i * SM::LDS_STEP), 16, voff, 0, 0, 0);
         }
     }
 }
@@ -185,19 +219,20 @@ __device__ __forceinline__ void stage_patch_dma(const ConvParams& p, char* patch
 // (their chunk offset moves by whole frames) keep the table path.
 #define SOS_STAGE_INVALID 0xfffe0000u
 // vb[r][u]: instruction wave + 16 r + 4 u (all but the LAST instruction of the pass, whose lanes past the patch's last piece must
-// not write -- the weight slab follows the patch: it gets its own offset register `vlast` and the only lane mask of the pass)
+// not write -- the weight slab follows the patch: it gets its own offset register `vlast` and the only per-instruction lane mask)
 template <int CPR, bool PAD, int MAXR>
 __device__ __forceinline__ void stage_prepare(const ConvParams& p, unsigned tab_addr, int lane, int wave, unsigned (&vb)[MAXR][4],
                                               unsigned& vlast) {
     constexpr int RP = CPR + (PAD ? 1 : 0);
-    const int total = p.npix * RP;
-    const int ninstr = (total + 63) >> 6;
+    typedef StageMap<RP> SM;
+    const SM sm(lane);
+    const int ninstr = SM::ninstr(p.npix);
     auto resolve = [&](const int i) -> unsigned {           // (one instruction; used for the last one)
-        const int L = i * 64 + lane;
-        const int pix = L / RP, q = L - pix * RP;
+        int pix, q;
+        sm.at(i, lane, pix, q);
         unsigned ent;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ent) : "v"(tab_addr + (unsigned)min(pix, p.npix - 1) * 4u) : "memory");
-        return (q < CPR && ent != 0xffffffffu && L < total) ? ent + (unsigned)q * 16u : SOS_STAGE_INVALID;
+        return (q < CPR && ent != 0xffffffffu && sm.writes(i, lane, p.npix)) ? ent + (unsigned)q * 16u : SOS_STAGE_INVALID;
     };
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
@@ -206,9 +241,8 @@ __device__ __forceinline__ void stage_prepare(const ConvParams& p, unsigned tab_
         int qq[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int L = (i0 + 4 * u) * 64 + lane;
-            const int pix = L / RP;
-            qq[u] = L - pix * RP;
+            int pix;
+            sm.at(i0 + 4 * u, lane, pix, qq[u]);
             ta[u] = tab_addr + (unsigned)min(pix, p.npix - 1) * 4u;
         }
         if (i0 < ninstr) {
@@ -232,20 +266,23 @@ template <int CPR, bool PAD, int MAXR>
 __device__ __forceinline__ void stage_issue(const ConvParams& p, char* patch, unsigned tab_addr, int lane, int wave,
                                             __amdgpu_buffer_rsrc_t rsrc, unsigned cbytes, const unsigned (&vb)[MAXR][4], const unsigned vlast) {
     constexpr int RP = CPR + (PAD ? 1 : 0);
-    const int total = p.npix * RP;
-    const int ninstr = (total + 63) >> 6;
+    typedef StageMap<RP> SM;
+    const SM sm(lane);
+    const int ninstr = SM::ninstr(p.npix);
+    if (sm.on) {
 #pragma unroll
-    for (int r = 0; r < MAXR; ++r) {
+        for (int r = 0; r < MAXR; ++r) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = wave + 16 * r + 4 * u;
-            if (i < ninstr - 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(patch + i * 1024), 16, vb[r][u] + cbytes, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                const int i = wave + 16 * r + 4 * u;
+                if (i < ninstr - 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(patch + i * SM::LDS_STEP), 16, vb[r][u] + cbytes, 0, 0, 0);
+            }
         }
     }
     if (ninstr > 16 * MAXR) stage_patch_dma<CPR, PAD>(p, patch, tab_addr, lane, wave, rsrc, cbytes, 16 * MAXR);
     else if (((ninstr - 1) & 3) == wave) {
-        if (lane < total - (ninstr - 1) * 64)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(patch + (ninstr - 1) * 1024), 16, vlast + cbytes, 0, 0, 0);
+        if (sm.on && sm.writes(ninstr - 1, lane, p.npix))
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(patch + (ninstr - 1) * SM::LDS_STEP), 16, vlast + cbytes, 0, 0, 0);
     }
 }
 
