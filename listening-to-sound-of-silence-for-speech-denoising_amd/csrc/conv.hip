@@ -409,11 +409,14 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
     }
     // ---- general cooperative store (hi|hi|lo planes, gradient fan-in, ragged channel tails): consecutive lanes write consecutive
     // 16-byte pieces of a pixel's channel run (and consecutive pixels of a tile row are adjacent in memory when dil_w == 1).
-#pragma unroll 4
-    for (int idx = tid; idx < SLOTS * PPX; idx += 256) {
-        const int m = idx / PPX, q = idx - m * PPX;
-        const int co = n0 + q * 8;
-        if (co >= p.cout_store) continue;
+    // (round 4: the same thread = (piece, pixel lane) walk as the common case: no division per piece, the piece's channel test
+    // hoisted out of the loop)
+    constexpr int PLG = 256 / PPX;
+    const int q = tid % PPX, plg = tid / PPX;
+    const int co = n0 + q * 8;
+    if (plg >= PLG || co >= p.cout_store) return;
+#pragma unroll 2
+    for (int m = plg; m < SLOTS; m += PLG) {
         const int off = otab[m];
         if (off == -1) continue;
         const bool border = off < 0;                  // fold mode: a border cell of the padded scratch tensor (plain store)
