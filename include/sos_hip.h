@@ -296,6 +296,12 @@ typedef struct sos_wgrad_desc {
 } sos_wgrad_desc;
 int64_t sos_wgrad_workspace_bytes(const sos_wgrad_desc* desc);
 int sos_conv2d_wgrad(const sos_wgrad_desc* desc, sos_stream_t stream);
+/* ABI 8: the two halves of sos_conv2d_wgrad as separate entry points -- _partial launches the MFMA kernel (per-split partial sums
+ * into desc->partial), _reduce the deterministic reduction of those sums into desc->dw (scale, scale_dev, accumulate).  Both derive
+ * the same launch plan from the descriptor, so the reduce may run on ANOTHER stream behind an event (the gradient is needed only by
+ * the optimizer; engine.wgrad(defer=True) keeps a ring of workspaces and joins before the gradients are used). */
+int sos_conv2d_wgrad_partial(const sos_wgrad_desc* desc, sos_stream_t stream);
+int sos_conv2d_wgrad_reduce(const sos_wgrad_desc* desc, sos_stream_t stream);
 /* ABI 7: measured launch plans of sos_conv2d_wgrad (workgroup channel tile, pixel tile, pixel order, workgroups per CU), the
  * counterpart of sos_conv2d_tune: times the candidate plans for the SHAPE of `desc` (`iters` launches each, the fastest few
  * again over 8x as many; HIP events on `stream`, SYNCHRONISES, overwrites desc->dw / desc->partial: pass accumulate = 0 and

@@ -60,7 +60,7 @@ class WgradDesc(C.Structure):
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 ADAM_CHUNK = 16384          # SOS_ADAM_CHUNK of include/sos_hip.h
 GUARD_FLOATS = 5            # SOS_GUARD_FLOATS
-EXPECTED_ABI = 7            # sos_abi_version() of the library these argument lists were written for
+EXPECTED_ABI = 8            # sos_abi_version() of the library these argument lists were written for
 
 # name -> argtypes, exactly the prototypes of include/sos_hip.h
 SIGNATURES = {
@@ -113,6 +113,8 @@ SIGNATURES = {
     "sos_bn_act_apply": [C.POINTER(View), _P, _P, _I, _P, C.POINTER(View), _I, _I, _I, _P, _P],
     "sos_wgrad_workspace_bytes": [C.POINTER(WgradDesc)],
     "sos_conv2d_wgrad": [C.POINTER(WgradDesc), _P],
+    "sos_conv2d_wgrad_partial": [C.POINTER(WgradDesc), _P],
+    "sos_conv2d_wgrad_reduce": [C.POINTER(WgradDesc), _P],
     "sos_wgrad_tune": [C.POINTER(WgradDesc), _I, C.POINTER(C.c_float), _P],
     "sos_wgrad_tune_save": [C.c_char_p],
     "sos_wgrad_tune_load": [C.c_char_p],

@@ -1161,7 +1161,7 @@ static int wg_choose_plan(const sos_wgrad_desc* d, const WgCtx& c, WgPlan* out) 
     return SOS_OK;
 }
 
-static int wg_launch(const sos_wgrad_desc* d, const WgCtx& c, const WgPlan& pl, hipStream_t s) {
+static int wg_launch(const sos_wgrad_desc* d, const WgCtx& c, const WgPlan& pl, hipStream_t s, const int what = 3) {
     WgParams p;
     p.g = (const bf16_t*)d->g; p.x = (const bf16_t*)d->x; p.partial = d->partial;
     p.B = d->B; p.Hg = d->Hg; p.Wg = d->Wg; p.g_cs = d->g_cs; p.g_off = d->g_off;
@@ -1228,7 +1228,9 @@ static int wg_launch(const sos_wgrad_desc* d, const WgCtx& c, const WgPlan& pl, 
         (void)hipFuncSetAttribute((const void*)wgrad16_kernel<3, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return (int)SOS_OK;
     });
-    if (use16) {
+    if (!(what & 1)) {
+        // reduce only
+    } else if (use16) {
         if (taps == 25) hipLaunchKernelGGL((wgrad16_kernel<3, 3, 3>), grid, dim3(WG_THREADS), lds, s, p);
         else hipLaunchKernelGGL((wgrad16_kernel<3, 3, 1>), grid, dim3(WG_THREADS), lds, s, p);
     } else {
@@ -1244,6 +1246,7 @@ static int wg_launch(const sos_wgrad_desc* d, const WgCtx& c, const WgPlan& pl, 
 #undef SOS_WG_ATTR
     int rc = sos_check_launch("sos_conv2d_wgrad");
     if (rc) return rc;
+    if (!(what & 2)) return SOS_OK;
     const long long total = (long long)d->M * d->N * taps_all;
     long long gb = (total + 63) / 64;
     if (gb > 8192) gb = 8192;
@@ -1258,7 +1261,9 @@ extern "C" int64_t sos_wgrad_workspace_bytes(const sos_wgrad_desc* d) {
     return (int64_t)(d->ksplit > 0 ? d->ksplit : wg_max_split(d)) * d->kh * d->kw * Mp * Np * 4;
 }
 
-extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
+// what: 1 = the MFMA kernel (partial sums per pixel split), 2 = the deterministic reduce into dw, 3 = both (sos_conv2d_wgrad).
+// The two halves recompute the same launch plan from the descriptor, so they may run on different streams (ABI 8).
+static int wgrad_impl(const sos_wgrad_desc* d, sos_stream_t stream, const int what) {
     if (!d || !d->g || !d->x || !d->partial || !d->dw) { sos_set_error("sos_conv2d_wgrad: null pointer"); return SOS_EINVAL; }
     if (d->M < 1 || d->N < 1 || d->g_cs % 8 || d->x_cs % 8 || d->g_off % 8 || d->x_off % 8 || d->kh < 1 || d->kw < 1 ||
         d->stride < 1 || d->dil_h < 1 || d->dil_w < 1 || (d->stride > 1 && (d->dil_h > 1 || d->dil_w > 1)) ||
@@ -1302,9 +1307,12 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
             (void)hipFuncSetAttribute((const void*)wgrad_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WGG_BUF);
             return (int)SOS_OK;
         });
-        hipLaunchKernelGGL(wgrad_gemm_kernel, dim3((unsigned)(q.ntiles * q.ksplit)), dim3(256), 2 * WGG_BUF, s, q);
-        int rc = sos_check_launch("sos_conv2d_wgrad(gemm)");
-        if (rc) return rc;
+        if (what & 1) {
+            hipLaunchKernelGGL(wgrad_gemm_kernel, dim3((unsigned)(q.ntiles * q.ksplit)), dim3(256), 2 * WGG_BUF, s, q);
+            int rc = sos_check_launch("sos_conv2d_wgrad(gemm)");
+            if (rc) return rc;
+        }
+        if (!(what & 2)) return SOS_OK;
         const long long total = (long long)d->M * d->N;
         long long gb = (total + 63) / 64;
         if (gb > 8192) gb = 8192;
@@ -1321,8 +1329,11 @@ extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) {
     WgPlan plan;
     int rc = wg_choose_plan(d, cx, &plan);
     if (rc) return rc;
-    return wg_launch(d, cx, plan, (hipStream_t)stream);
+    return wg_launch(d, cx, plan, (hipStream_t)stream, what);
 }
+extern "C" int sos_conv2d_wgrad(const sos_wgrad_desc* d, sos_stream_t stream) { return wgrad_impl(d, stream, 3); }
+extern "C" int sos_conv2d_wgrad_partial(const sos_wgrad_desc* d, sos_stream_t stream) { return wgrad_impl(d, stream, 1); }
+extern "C" int sos_conv2d_wgrad_reduce(const sos_wgrad_desc* d, sos_stream_t stream) { return wgrad_impl(d, stream, 2); }
 
 // ---- measured plans (round 4).  sos_wgrad_tune times, for the SHAPE of `d`, every channel tile (MT x NTB, one or two workgroups
 // per CU) with the cost model's six cheapest pixel tiles each, in two stages like sos_conv2d_tune (all candidates over `iters`

@@ -258,7 +258,7 @@ class InpaintNet(nn.Module):
         # up2.1: conv + bias, no BN / activation
         grads[f"{prefix}.up2.1.block.1.bias"] = TO.colsum(d_out, 0, 2)
         dw = torch.empty((2, 64, 3, 3), dtype=torch.float32, device=dev)
-        E.wgrad(d_out, 0, 2, u64, 0, 64, 3, 3, dw, pad=(1, 1), pad_mode=L.PAD_REFLECT)
+        E.wgrad(d_out, 0, 2, u64, 0, 64, 3, 3, dw, pad=(1, 1), pad_mode=L.PAD_REFLECT, defer=type(grads) is dict)
         grads[f"{prefix}.up2.1.block.1.weight"] = dw
         last = dict(wd=plan["up2_1_wd"], pad=1, k=3, dil=1, stride=1, cin=64)
         TO._reflect_dgrad(last, d_out, u64, 0, gb, x3)
@@ -425,7 +425,8 @@ class _JointTrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_npred, g_out):
-        grads = ctx.net._backward(ctx.tape, g_npred, g_out)
+        with E.deferred_reductions():         # weight gradients reduce on a side stream; joined when the scope closes
+            grads = ctx.net._backward(ctx.tape, g_npred, g_out)
         ctx.tape = None
         if getattr(ctx.net, "grad_sink_factory", None) is not None:     # see detector/networks.py: the bucketer owns p.grad
             return (None, None, None) + (None,) * len(list(ctx.net.parameters()))

@@ -32,7 +32,8 @@ class _TrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        grads = ctx.net._backward(ctx.tape, g)
+        with E.deferred_reductions():         # weight gradients reduce on a side stream; joined when the scope closes
+            grads = ctx.net._backward(ctx.tape, g)
         ctx.tape = None
         if getattr(ctx.net, "grad_sink_factory", None) is not None:
             # data-parallel: the gradients sit in the all-reduce buckets, whose collectives are still running; the

@@ -690,10 +690,49 @@ def bn_apply(xv, scale, shift, act, slope, dst, dst_c_off, C, feat=None):
 
 
 _wg_ws = {}
+# Deferred reduction of the weight gradients (round 4, ABI 8).  A weight gradient is two launches: the MFMA kernel that leaves one
+# partial sum per pixel split, and a small HBM-bound reduce of those partials into dw -- which nobody needs before the optimizer.
+# With defer=True the reduce runs on a side stream behind an event (it then overlaps the next layers' MFMA kernels instead of
+# sitting between them: 72 launches, 1.8 ms of a 117 ms step), the partial sums live in a ring of workspaces (a slot is reused only
+# after the reduce that read it), and wgrad_join() makes the consuming stream wait before the gradients are handed on.
+# Same kernels, same summation order: bit-identical gradients (tests/test_gpu_agent.py).  MEASURED SLOWER: 539.9 -> 535.7 utt/s
+# (-0.8 %, same box, arms alternating) -- the trailing reduces take bandwidth and CUs from the kernels they run beside and the
+# two events per layer are not free; the launch gap they were meant to close is ~2 us.  Off by default (SOS_WGRAD_DEFER=1 opts in).
+WGRAD_DEFER = _os.environ.get("SOS_WGRAD_DEFER", "0") == "1"
+_WG_RING_SLOTS = 4
+_wg_ring = {}          # origin stream -> dict(slots=[[tensor, event], ...], nxt=0, side=reduce stream)
+_wg_pending = {}       # reduce stream -> event of its last reduce not yet joined (one host thread enqueues everything)
+
+
+_wg_scope = [0]        # > 0: inside deferred_reductions(): only there a call site's defer=True is honoured
+
+
+class deferred_reductions:
+    """`with deferred_reductions():` around a model's whole backward pass: weight gradients marked defer=True reduce on the side
+    stream, and leaving the scope joins them.  Outside the scope every wgrad is complete on the calling stream when it returns
+    (what a caller that reads a gradient right after one backward function -- the tests do -- relies on)."""
+
+    def __enter__(self):
+        _wg_scope[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _wg_scope[0] -= 1
+        if _wg_scope[0] == 0:
+            wgrad_join()
+
+
+def wgrad_join():
+    """The current stream waits for every deferred weight-gradient reduce launched so far (call before the gradients are used)."""
+    if _wg_pending:
+        cur = torch.cuda.current_stream()
+        for ev in _wg_pending.values():
+            cur.wait_event(ev)
+        _wg_pending.clear()
 
 
 def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0, 0), pad_mode=L.PAD_ZERO,
-          accumulate=False, scale=1.0, gs=None, temporal=None):
+          accumulate=False, scale=1.0, gs=None, temporal=None, defer=False):
     """dw[m][n][a][b] (+)= scale * sum_p G[p][m] X[p*stride + (a,b)*dil - pad][n] (sos_conv2d_wgrad).
     g, x: Act.  In bf16x3 mode the product (g_hi+g_lo)(x_hi+x_lo) is taken as hi*hi + hi*lo + lo*hi
     with three accumulating passes over the thirds.  temporal = (frames per clip, kt, channels per frame): column
@@ -714,10 +753,26 @@ def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0,
         npix = g.B * g.H * g.W
         d.ksplit = 0                               # automatic pixel-range split (one workgroup per CU)
         need = L.lib().sos_wgrad_workspace_bytes(ctypes.byref(d))
-        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)     # one workspace per stream: agents may run concurrently
-        if key not in _wg_ws or _wg_ws[key].numel() * 4 < need:
-            _wg_ws[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
-        d.partial = _wg_ws[key].data_ptr()
+        cur_stream = torch.cuda.current_stream(dev)
+        key = (str(dev), cur_stream.cuda_stream)     # one workspace per stream: agents may run concurrently
+        deferred = defer and WGRAD_DEFER and _wg_scope[0] > 0 and not torch.cuda.is_current_stream_capturing()
+        slot = None
+        if deferred:
+            ring = _wg_ring.get(key)
+            if ring is None:
+                ring = _wg_ring[key] = dict(slots=[[None, None] for _ in range(_WG_RING_SLOTS)], nxt=0,
+                                            side=torch.cuda.Stream(device=dev))
+            slot = ring["slots"][ring["nxt"]]
+            ring["nxt"] = (ring["nxt"] + 1) % _WG_RING_SLOTS
+            if slot[1] is not None:
+                cur_stream.wait_event(slot[1])         # the reduce that last read this workspace
+            if slot[0] is None or slot[0].numel() * 4 < need:
+                slot[0] = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+            d.partial = slot[0].data_ptr()
+        else:
+            if key not in _wg_ws or _wg_ws[key].numel() * 4 < need:
+                _wg_ws[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+            d.partial = _wg_ws[key].data_ptr()
         d.dw = dw.data_ptr()
         d.accumulate = 1 if (accumulate or not first) else 0
         d.scale = scale
@@ -738,7 +793,22 @@ def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0,
                 _log_launch("wgrad", sig, 2.0 * g.B * g.H * g.W * M * N * kh * kw)
             if PROFILER is not None:
                 end = PROFILER.bracket(sig, 2.0 * g.B * g.H * g.W * M * N * kh * kw)
-        L.check(L.lib().sos_conv2d_wgrad(ctypes.byref(d), L.stream_ptr()), "sos_conv2d_wgrad")
-        if end is not None:
-            end.record()
+        if deferred:
+            side = ring["side"]
+            L.check(L.lib().sos_conv2d_wgrad_partial(ctypes.byref(d), L.stream_ptr()), "sos_conv2d_wgrad_partial")
+            if end is not None:
+                end.record()
+            done = torch.cuda.Event()
+            done.record(cur_stream)
+            side.wait_event(done)
+            L.check(L.lib().sos_conv2d_wgrad_reduce(ctypes.byref(d), ctypes.c_void_p(side.cuda_stream)), "sos_conv2d_wgrad_reduce")
+            red = torch.cuda.Event()
+            red.record(side)
+            slot[1] = red
+            _wg_pending[side.cuda_stream] = red
+            dw.record_stream(side)
+        else:
+            L.check(L.lib().sos_conv2d_wgrad(ctypes.byref(d), L.stream_ptr()), "sos_conv2d_wgrad")
+            if end is not None:
+                end.record()
         first = False

@@ -180,7 +180,9 @@ def _encoder_backward(plan, tape, dy, grads, prefix, x3, need_input_grad, dev, c
             dw.record_stream(cur)
         else:
             dw = torch.empty(dw_shape, dtype=torch.float32, device=dev)
-            E.wgrad(d_raw, 0, lp["cout"], tp["inp"], 0, lp["cin"], lp["kh"], lp["kw"], dw, dil=lp["dil"], pad=lp["pad"])
+            # (the reduce of the partial sums may trail on a side stream when nothing touches dw before the optimizer: engine.wgrad)
+            E.wgrad(d_raw, 0, lp["cout"], tp["inp"], 0, lp["cin"], lp["kh"], lp["kw"], dw, dil=lp["dil"], pad=lp["pad"],
+                    defer="unfold" not in lp and type(grads) is dict)
         grads[f"{prefix}.{i}.block.0.weight"] = lp["unfold"](dw) if "unfold" in lp else dw
         if i == 0 and not need_input_grad:
             break
@@ -478,7 +480,7 @@ def linear_train_plan(lin, cin_store, x3):
 def linear_backward(lp, a_in, dz, grads, prefix, x3, dev):
     """dz: Act grad of the pre-activation output (rows [B,1,T,*]).  Returns Act grad of the input."""
     dw = torch.empty((lp["cout"], lp["cin"]), dtype=torch.float32, device=dev)
-    E.wgrad(dz, 0, lp["cout"], a_in, 0, lp["cin"], 1, 1, dw)
+    E.wgrad(dz, 0, lp["cout"], a_in, 0, lp["cin"], 1, 1, dw, defer=type(grads) is dict)
     grads[f"{prefix}.weight"] = dw
     grads[f"{prefix}.bias"] = colsum(dz, 0, lp["cout"])
     d_in = E.Act(a_in.B, 1, a_in.W, a_in.cs, x3, dev)
@@ -708,7 +710,8 @@ def down_backward(t, gb, grads, name, x3, need_src_grad=True):
     grads[f"{name}.block.2.weight"], grads[f"{name}.block.2.bias"], grads[f"{name}.block.3.weight"] = dgamma, dbeta, dslope
     dw = torch.empty((lp["cout"], lp["cin"], lp["k"], lp["kw"]), dtype=torch.float32, device=dev)
     E.wgrad(d_raw, 0, lp["cout"], t["src"], t["cin_off"], lp["cin"], lp["k"], lp["kw"], dw, stride=lp["stride"],
-            dil=(lp["dil"], lp["dil"]), pad=(lp["pad"], lp["pad_w"]), pad_mode=L.PAD_REFLECT)
+            dil=(lp["dil"], lp["dil"]), pad=(lp["pad"], lp["pad_w"]), pad_mode=L.PAD_REFLECT,
+            defer="unfold" not in lp and lp["in_perm"] is None and type(grads) is dict)
     if "unfold" in lp:                      # first block with its horizontal taps on the channel axis: back to (O, I, kh, kw)
         dw = lp["unfold"](dw)
     if lp["in_perm"] is not None:           # dw is in the stored channel order; undo the concat permutation
@@ -743,7 +746,7 @@ def up_backward(t, gb, grads, name, x3):
                                    lp["prelu"].weight, d_raw)
     grads[f"{name}.block.1.weight"], grads[f"{name}.block.1.bias"], grads[f"{name}.block.2.weight"] = dgamma, dbeta, dslope
     dw = torch.empty_like(lp["ct"].weight, dtype=torch.float32)                      # (Cin, Cout, 3, 3)
-    E.wgrad(src, 0, lp["cin"], d_raw, 0, lp["cout"], 3, 3, dw, stride=2, pad=(1, 1))
+    E.wgrad(src, 0, lp["cin"], d_raw, 0, lp["cout"], 3, 3, dw, stride=2, pad=(1, 1), defer=type(grads) is dict)
     grads[f"{name}.block.0.weight"] = dw
     gsrc = gb.of(src)
     one, zero = ones_zeros(lp["wd"].shape[1], dev)

@@ -135,6 +135,46 @@ def test_train_concurrent_matches_serial(branch, monkeypatch):
             assert torch.equal(p, q), k
 
 
+def test_deferred_weight_gradient_reductions_are_bit_identical(monkeypatch):
+    """engine.wgrad(defer=True) inside engine.deferred_reductions() (SOS_WGRAD_DEFER=1, ABI 8: sos_conv2d_wgrad_partial on the
+    model's stream, sos_conv2d_wgrad_reduce on a side stream behind an event, a ring of workspaces, a join before the gradients
+    reach autograd): three training steps of both models under train_concurrent end bit-identical to the same steps with every
+    reduce on the launching stream -- the same kernels in the same order, only the stream of the small one differs."""
+    import sos_amd
+    from sos_amd import agent, engine
+    from sos_amd.common import MyConfig
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+    sos_amd.set_precision("fp16")
+    try:
+        B, T = 2, 89
+        x = spec_input(100 + B, B, T).cuda()
+        clean = (spec_input(300, B, T) * 0.5).cuda()
+        bj = {"mixed": x, "noise": silent_gate(x.cpu()).cuda(), "clean": clean, "full_noise": x - clean}
+        bd = {"label": (torch.from_numpy(hashed(301, (B, 60))) > 0).float().cuda(), "audio": x}
+
+        def make():
+            det = dnet.get_network(); det.load_state_dict(onet.closed_form_state(onet.detector_spec(), seed=1))
+            jm = jnet.get_network(MyConfig()); jm.load_state_dict(onet.closed_form_state(onet.joint_spec(), seed=2))
+            return agent.DetectorAgent(det, lr=1e-3), agent.DenoiserAgent(jm, lr=1e-3)
+
+        d1, j1 = make()
+        d2, j2 = make()
+        for _ in range(3):
+            monkeypatch.setattr(engine, "WGRAD_DEFER", False)
+            agent.train_concurrent([(j1, bj), (d1, bd)])
+            monkeypatch.setattr(engine, "WGRAD_DEFER", True)
+            agent.train_concurrent([(j2, bj), (d2, bd)])
+        torch.cuda.synchronize()
+        assert engine._wg_ring, "no reduce was deferred"
+        assert not engine._wg_pending, "a deferred reduce was never joined"
+        for a, b in ((d1, d2), (j1, j2)):
+            for (k, p), (_, q) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
+                assert torch.equal(p, q), k
+    finally:
+        sos_amd.set_precision("bf16")
+
+
 _RCCL_CHILD = r"""
 import os, sys
 sys.path.insert(0, os.environ["SOS_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SOS_ROOT"], "tests"))
