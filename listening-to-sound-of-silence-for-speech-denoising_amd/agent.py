@@ -113,6 +113,14 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_scale = 1.0
         self.guard = None          # engine.guard_state(net): device-side overflow guard, the step is skipped when a gradient is Inf / NaN
         self._tables = {}
+        # Skipped steps are counted ONCE for the whole model (guard[3]) while `step` is per parameter.  A parameter whose state is
+        # created in a later step() call than the first (it joined the group late, or had no gradient before) must not be
+        # charged the steps skipped before it existed: its baseline -- guard[3] at the moment its state is created, a
+        # device scalar, no host sync -- is kept here and subtracted in its (per-tensor) launches and in save_ckpt.  Parameters
+        # born in the first call have baseline 0 by construction: the guard is created (or restored from the same checkpoint)
+        # together with the optimizer state (BaseAgent.__init__ / load_ckpt).
+        self._calls = 0
+        self._skip_base = {}       # late-born parameter -> device f32 [1]
 
     def _table(self, gi, ps):
         key = tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in ps)
@@ -136,6 +144,7 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         work = []
+        self._calls += 1
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
@@ -147,6 +156,8 @@ class FusedAdam(torch.optim.Optimizer):
                     st["step"] = torch.zeros((), dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    if self.guard is not None and self._calls > 1:
+                        self._skip_base[p] = self.guard[3:4].clone()
                 st["step"] += 1
             ent = self._table(gi, ps)
             torch._foreach_copy_(ent["views"], [p.grad.reshape(-1) for p in ps])        # batched gather of the gradients
@@ -166,7 +177,7 @@ class FusedAdam(torch.optim.Optimizer):
         for group, ps, ent in work:
             b1, b2 = group["betas"]
             steps = {int(self.state[p]["step"]) for p in ps}
-            if len(steps) == 1:
+            if len(steps) == 1 and not any(p in self._skip_base for p in ps):
                 L.check(L.lib().sos_adam_multi_step(L.ptr(ent["tab"]), ent["n"], L.ptr(ent["chunks"]), ent["nchunks"],
                                                     float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                     float(group["weight_decay"]), steps.pop(), float(self.grad_scale),
@@ -174,10 +185,14 @@ class FusedAdam(torch.optim.Optimizer):
             else:       # parameters that joined the group at different times: per-tensor launches
                 for p, g in zip(ps, ent["views"]):
                     st = self.state[p]
+                    sk = skip
+                    if skip is not None and p in self._skip_base:
+                        sk = skip.clone()                       # this parameter's view of the guard: steps skipped since it was born
+                        sk[3:4].sub_(self._skip_base[p])
                     L.check(L.lib().sos_adam_step(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
                                                   float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                   float(group["weight_decay"]), int(st["step"]), float(self.grad_scale),
-                                                  L.ptr(skip), L.stream_ptr()), "sos_adam_step")
+                                                  L.ptr(sk), L.stream_ptr()), "sos_adam_step")
             for p in ps:
                 bump_version(p)     # raw-pointer write: invalidate the packed-weight caches keyed on _version
         return None
@@ -323,7 +338,11 @@ class BaseAgent(object):
         skipped = float(guard[3])
         osd = self.optimizer.state_dict()
         if skipped:
-            osd = dict(osd, state={k: (dict(v, step=v["step"] - skipped) if "step" in v else v) for k, v in osd["state"].items()})
+            # per state entry: the steps skipped since THAT parameter's state was created (FusedAdam._skip_base)
+            order = [p for g_ in self.optimizer.param_groups for p in g_["params"]]
+            base = {i: float(self.optimizer._skip_base[p]) for i, p in enumerate(order) if p in self.optimizer._skip_base}
+            osd = dict(osd, state={k: (dict(v, step=v["step"] - (skipped - base.get(k, 0.0))) if "step" in v else v)
+                                   for k, v in osd["state"].items()})
         guard[3] = 0.0
         guard[0] = 0.0
         torch.save({"clock": self.clock.make_checkpoint(),
@@ -341,6 +360,8 @@ class BaseAgent(object):
         ck = torch.load(path, map_location=self.device)
         self.net.load_state_dict(ck["model_state_dict"])
         self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        self.optimizer._skip_base.clear()            # the checkpoint holds applied steps and a zero skipped count: every baseline is 0
+        self.optimizer._calls = 1 if self.optimizer.state else 0
         for st in self.optimizer.state.values():     # map_location moved the step counters to the GPU: int(step) would
             if torch.is_tensor(st.get("step")):      # then synchronise once per parameter and step
                 st["step"] = st["step"].detach().cpu()

@@ -454,10 +454,12 @@ class JointModel(nn.Module):
         x3 = E.is_x3()
         return dict(x3=x3, s1=self.stage1.build_train_plan(x3), s2=self.stage2.build_train_plan(x3))
 
-    # SOS_BRANCH_STREAMS=1: the branch [stage 1 -> encoder_n] (forward) / [encoder_n -> stage 1] (backward) on a side stream
-    # beside encoder_x (HBM-bound BatchNorm passes and the low-efficiency U-Net launches of one branch under
-    # the MFMA-bound 96-channel convolutions of the other).  Same kernels, same order per branch: bit-identical results.
-    BRANCH_STREAMS = __import__("os").environ.get("SOS_BRANCH_STREAMS", "0") == "1"
+    # The branch [stage 1 -> encoder_n] (forward) / [encoder_n -> stage 1] (backward) runs on a side stream beside encoder_x
+    # (HBM-bound BatchNorm passes and the low-efficiency U-Net launches of one branch under the MFMA-bound 96-channel
+    # convolutions of the other).  Same kernels, same order per branch: bit-identical results.  Default since round 5 (the
+    # driver's round-4 record: 552.0 vs ~530 utt/s, +4.2 %); SOS_BRANCH_STREAMS=0 is the one-stream schedule (A/B, and
+    # bench.py's serial pre-pass that times the dominant kernel alone on the chip).
+    BRANCH_STREAMS = __import__("os").environ.get("SOS_BRANCH_STREAMS", "1") != "0"
 
     def _side_stream(self, dev):
         if not self.BRANCH_STREAMS or torch.cuda.is_current_stream_capturing():

@@ -62,6 +62,12 @@ def _log_launch(kind, sig, flops):
 
 FLATTEN_1X1 = _os.environ.get("SOS_FLATTEN_1X1", "1") != "0"      # A/B switch of the batch-flattened 1x1 layers (conv())
 AUTOTUNE = _os.environ.get("SOS_CONV_TUNE", "0") == "1"
+if AUTOTUNE and int(_os.environ.get("WORLD_SIZE", "1")) > 1:
+    # timing-based tuning is a single-process activity: ranks tuning on their own would pick different tilings -- different
+    # summation orders -- during that run.  Tune once with one process, then ship / point every rank at the table.
+    import warnings as _warnings
+    _warnings.warn("SOS_CONV_TUNE=1 ignored in a multi-process job (WORLD_SIZE > 1): tune with one process and reuse the table")
+    AUTOTUNE = False
 TUNE_CANDIDATES = int(_os.environ.get("SOS_CONV_TUNE_CANDIDATES", "8"))     # best-ranked tilings of the cost model that get timed
 SHIPPED_TUNE_TABLE = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tune_table_gfx950.txt")
 SHIPPED_WGRAD_TABLE = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "wgrad_table_gfx950.txt")     # measured weight-gradient plans
@@ -98,14 +104,17 @@ def _load_tune_cache():
         if _os.environ.get("SOS_WGRAD_TUNE_TABLE", "1") != "0":
             if L.lib().sos_wgrad_tune_load(SHIPPED_WGRAD_TABLE.encode()) < 0:
                 raise RuntimeError("sos_wgrad_tune_load: " + (L.lib().sos_last_error() or b"").decode())
-        if _WGRAD_CACHE and _os.path.exists(_WGRAD_CACHE):
-            if L.lib().sos_wgrad_tune_load(_WGRAD_CACHE.encode()) < 0:
+        # each build keeps its own plan table and saves it at exit: the bf16 build to X, the fp16 build to X.f16 (one path for
+        # both made the second save overwrite the first); a build reads X and then its own file over it
+        wuser = None if not _WGRAD_CACHE else _WGRAD_CACHE + ("" if which == "bf16" else ".f16")
+        for wpath in ([_WGRAD_CACHE] if _WGRAD_CACHE else []) + ([wuser] if wuser and wuser != _WGRAD_CACHE else []):
+            if _os.path.exists(wpath) and L.lib().sos_wgrad_tune_load(wpath.encode()) < 0:
                 import warnings
-                warnings.warn("SOS_WGRAD_TUNE_CACHE %s ignored: %s" % (_WGRAD_CACHE, (L.lib().sos_last_error() or b"").decode()))
-        if AUTOTUNE and _WGRAD_CACHE and int(_os.environ.get("RANK", "0")) == 0:
+                warnings.warn("SOS_WGRAD_TUNE_CACHE %s ignored: %s" % (wpath, (L.lib().sos_last_error() or b"").decode()))
+        if AUTOTUNE and wuser and int(_os.environ.get("RANK", "0")) == 0:
             import atexit
             hw = L.lib()
-            atexit.register(lambda: hw.sos_wgrad_tune_save(_WGRAD_CACHE.encode()))
+            atexit.register(lambda: hw.sos_wgrad_tune_save(wuser.encode()))
         _cache_loaded.add(which)
 
 
@@ -700,11 +709,18 @@ _wg_ws = {}
 # two events per layer are not free; the launch gap they were meant to close is ~2 us.  Off by default (SOS_WGRAD_DEFER=1 opts in).
 WGRAD_DEFER = _os.environ.get("SOS_WGRAD_DEFER", "0") == "1"
 _WG_RING_SLOTS = 4
-_wg_ring = {}          # origin stream -> dict(slots=[[tensor, event], ...], nxt=0, side=reduce stream)
-_wg_pending = {}       # reduce stream -> event of its last reduce not yet joined (one host thread enqueues everything)
 
 
-_wg_scope = [0]        # > 0: inside deferred_reductions(): only there a call site's defer=True is honoured
+class _WgState(_threading.local):
+    """Per HOST THREAD (DataParallel-style callers run one backward per thread; an inner scope exit on one thread must
+    not skip the join another thread's gradients need): ring = origin stream -> dict(slots=[[tensor, event], ...], nxt, side),
+    pending = reduce stream -> event of its last reduce not yet joined, scope > 0 inside deferred_reductions()."""
+
+    def __init__(self):
+        self.ring, self.pending, self.scope = {}, {}, 0
+
+
+_wg = _WgState()
 
 
 class deferred_reductions:
@@ -713,22 +729,22 @@ class deferred_reductions:
     (what a caller that reads a gradient right after one backward function -- the tests do -- relies on)."""
 
     def __enter__(self):
-        _wg_scope[0] += 1
+        _wg.scope += 1
         return self
 
     def __exit__(self, *exc):
-        _wg_scope[0] -= 1
-        if _wg_scope[0] == 0:
+        _wg.scope -= 1
+        if _wg.scope == 0:
             wgrad_join()
 
 
 def wgrad_join():
     """The current stream waits for every deferred weight-gradient reduce launched so far (call before the gradients are used)."""
-    if _wg_pending:
+    if _wg.pending:
         cur = torch.cuda.current_stream()
-        for ev in _wg_pending.values():
+        for ev in _wg.pending.values():
             cur.wait_event(ev)
-        _wg_pending.clear()
+        _wg.pending.clear()
 
 
 def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0, 0), pad_mode=L.PAD_ZERO,
@@ -755,12 +771,14 @@ def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0,
         need = L.lib().sos_wgrad_workspace_bytes(ctypes.byref(d))
         cur_stream = torch.cuda.current_stream(dev)
         key = (str(dev), cur_stream.cuda_stream)     # one workspace per stream: agents may run concurrently
-        deferred = defer and WGRAD_DEFER and _wg_scope[0] > 0 and not torch.cuda.is_current_stream_capturing()
+        # (never with autotuning on: _partial and _reduce each derive the launch plan from the plan table, which a tune between
+        # the two calls could change -- ADVICE r4; the shipped table is loaded once, before the first launch)
+        deferred = defer and WGRAD_DEFER and not AUTOTUNE and _wg.scope > 0 and not torch.cuda.is_current_stream_capturing()
         slot = None
         if deferred:
-            ring = _wg_ring.get(key)
+            ring = _wg.ring.get(key)
             if ring is None:
-                ring = _wg_ring[key] = dict(slots=[[None, None] for _ in range(_WG_RING_SLOTS)], nxt=0,
+                ring = _wg.ring[key] = dict(slots=[[None, None] for _ in range(_WG_RING_SLOTS)], nxt=0,
                                             side=torch.cuda.Stream(device=dev))
             slot = ring["slots"][ring["nxt"]]
             ring["nxt"] = (ring["nxt"] + 1) % _WG_RING_SLOTS
@@ -805,7 +823,7 @@ def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0,
             red = torch.cuda.Event()
             red.record(side)
             slot[1] = red
-            _wg_pending[side.cuda_stream] = red
+            _wg.pending[side.cuda_stream] = red
             dw.record_stream(side)
         else:
             L.check(L.lib().sos_conv2d_wgrad(ctypes.byref(d), L.stream_ptr()), "sos_conv2d_wgrad")

@@ -169,9 +169,10 @@ def _encoder_backward(plan, tape, dy, grads, prefix, x3, need_input_grad, dev, c
         grads[f"{prefix}.{i}.block.1.weight"] = dgamma
         grads[f"{prefix}.{i}.block.1.bias"] = dbeta
         dw_shape = (lp["cout"], lp["cin"], lp["kh"], lp["kw"])       # (the folded first block: (O, kw * I, kh, 1), un-folded below)
-        if side is not None:
+        if side is not None and "unfold" not in lp:
             # the weight gradient (MFMA bound, one workgroup per CU) depends only on d_raw and the block's input: it runs on
-            # a side stream under the data gradient + the BatchNorm backward passes of the block below (HBM bound)
+            # a side stream under the data gradient + the BatchNorm backward passes of the block below (HBM bound).  A folded
+            # first block stays on the main stream: its un-fold copy below reads dw right away (stream race)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 dw = torch.empty(dw_shape, dtype=torch.float32, device=dev)

@@ -92,6 +92,18 @@ def up_block(x, sd, prefix, training, stats_out=None):
     return Q(onet.prelu(y, sd[prefix + ".block.2.weight"]))
 
 
+def conv3d_block(x, sd, prefix, stride, training=False, stats_out=None):
+    """Conv3dBlock of the audio-visual variant: stored input frames, stored packed weight, stored (raw and) block output."""
+    w = _wq(sd, prefix + ".block.0.weight")
+    pad = tuple((k - 1) // 2 for k in w.shape[2:])
+    y = F.conv3d(Q(x), w, None, stride, pad)
+    if training:
+        y = Q(y)
+    shp = y.shape
+    y = onet.batch_norm(y.reshape(shp[0], shp[1], shp[2] * shp[3], shp[4]), sd, prefix + ".block.1", training, stats_out)
+    return Q(torch.relu(y.reshape(shp)))
+
+
 def lstm_bidir(x, sd, prefix):
     T, B, _ = x.shape
     outs = []
@@ -120,7 +132,8 @@ def linear(x, sd, prefix):
     return Q(x) @ _wq(sd, prefix + ".weight").t() + sd[prefix + ".bias"]
 
 
-_PATCH = dict(conv_block=conv_block, down_block=down_block, up_block=up_block, lstm_bidir=lstm_bidir, linear=linear)
+_PATCH = dict(conv_block=conv_block, down_block=down_block, up_block=up_block, lstm_bidir=lstm_bidir, linear=linear,
+              conv3d_block=conv3d_block)
 
 
 @contextlib.contextmanager

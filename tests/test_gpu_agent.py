@@ -166,8 +166,8 @@ def test_deferred_weight_gradient_reductions_are_bit_identical(monkeypatch):
             monkeypatch.setattr(engine, "WGRAD_DEFER", True)
             agent.train_concurrent([(j2, bj), (d2, bd)])
         torch.cuda.synchronize()
-        assert engine._wg_ring, "no reduce was deferred"
-        assert not engine._wg_pending, "a deferred reduce was never joined"
+        assert engine._wg.ring, "no reduce was deferred"
+        assert not engine._wg.pending, "a deferred reduce was never joined"
         for a, b in ((d1, d2), (j1, j2)):
             for (k, p), (_, q) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
                 assert torch.equal(p, q), k

@@ -22,6 +22,12 @@ DET_TOL_FP16, JM_TOL_FP16 = 0.1, 0.15
 # eps of the terms moves it by ~eps * scale.  Observed: bf16x3 3e-4, fp16 1.7e-3, bf16 5e-3 of the scale.
 SLOPE_TOL = {"bf16x3": 1e-3, "fp16": 5e-3, "bf16": 2e-2}
 
+# ABSOLUTE ceilings of the 16-bit train-mode forward (VERDICT r4 #2b / ADVICE r4): the computed bound "2 x the storage model's own
+# deviation" follows the model, so a regression that also moved tests/storage_model.py would pass; these do not follow anything.
+# The model's deviations are themselves pinned on the CPU (tests/test_storage_model.py: fp16 9.5e-3 / 1.0e-3 / 7.3e-3, bf16
+# 7.8e-2 / 7.1e-3 / 5.1e-2 for logits / n_pred / mask), the ceilings sit ~1.3x above twice those.
+CEIL = {"fp16": dict(logits=2.5e-2, n_pred=3e-3, mask=2e-2), "bf16": dict(logits=2e-1, n_pred=2e-2, mask=1.3e-1)}
+
 
 def _model_deviation(which, precision, x, n, nfr, g):
     """Deviation from the reference goldens of the storage model (tests/storage_model.py: the f32 oracle with round trips
@@ -97,6 +103,7 @@ def test_detector_train_step_matches_reference_autograd(golden, precision):
             e_model = _model_deviation("det", precision, x.cpu(), None, nfr, g)
             print(precision, "  storage-model logits deviation", e_model, " HIP / model", e_lo / e_model)
             assert e_lo < 2.0 * e_model + 1e-4
+            assert e_lo < CEIL[precision]["logits"]
         worst, med = _check_grads(list(det.named_parameters()), g["train_det_gradnorm"], g["train_det_gradhead"], tol, precision)
         print(precision, "worst grad err", worst, "median", med)
         assert med < {"bf16x3": 2e-3, "fp16": 2e-2, "bf16": 8e-2}[precision]
@@ -140,6 +147,7 @@ def test_denoiser_train_step_matches_reference_autograd(golden, precision):
             m1, m2 = _model_deviation("jm", precision, x.cpu(), n.cpu(), None, g)
             print(precision, "  storage-model n_pred / mask deviation", m1, m2, " HIP / model", e1 / m1, e2 / m2)
             assert e1 < 2.0 * m1 + 1e-4 and e2 < 2.0 * m2 + 1e-4
+            assert e1 < CEIL[precision]["n_pred"] and e2 < CEIL[precision]["mask"]
         ltol = {"bf16x3": 1e-3, "fp16": 5e-3, "bf16": 5e-2}[precision]
         assert abs(float(l1) / float(g["train_l1"]) - 1) < ltol
         assert abs(float(l2) / float(g["train_l2"]) - 1) < ltol

@@ -20,7 +20,7 @@ ref.load_state_dict(enc.state_dict())
 enc = enc.cuda().train()
 x = torch.from_numpy(hashed(5, (B, 2, H, W)).astype(np.float32))
 plan = TO.encoder_train_plan(enc, x3)
-a = E.pack_input(x.cuda(), x3)
+a = CN.pack_encoder_input(plan, x.cuda(), x3)       # (block 0 of a training plan may be folded: engine.wfold_spec)
 nseg = 3
 nfeat = 8 * H
 feat = torch.empty((B, W, nseg * nfeat), dtype=torch.bfloat16, device="cuda")

@@ -14,7 +14,7 @@ enc = CN.make_encoder([(5, 5), (5, 5)], [(2, 1), (1, 1)], nf=48, outf=8).cuda().
 x = torch.from_numpy(hashed(5, (B, 2, H, W)).astype(np.float32))
 plan = TO.encoder_train_plan(enc, x3)
 for i, lp in enumerate(plan): print("plan", i, "w nan", bool(torch.isnan(lp["w"].float()).any()), "wd nan", bool(torch.isnan(lp["wd"].float()).any()))
-a = E.pack_input(x.cuda(), x3)
+a = CN.pack_encoder_input(plan, x.cuda(), x3)       # (block 0 of a training plan may be folded: engine.wfold_spec)
 print("pack nan", bool(torch.isnan(a.t.float()).any()))
 dev = a.t.device
 cur = a
