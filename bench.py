@@ -149,7 +149,7 @@ def _self_launch(n):
 class Workload:
     """One (mode, precision) line: builds the resident inputs and models, exposes step()."""
 
-    def __init__(self, mode, precision, B, rank, serial=False, graph=False, frames=None):
+    def __init__(self, mode, precision, B, rank, serial=False, graph=False, frames=None, train_detector=0):
         import sos_amd
         from sos_amd import agent, pipeline, tools, transform
         from sos_amd.common import MyConfig
@@ -162,6 +162,18 @@ class Workload:
         torch.manual_seed(0)
         det = dnet.get_network().cuda().eval()
         jm = jnet.get_network(MyConfig()).cuda().eval()
+        if train_detector:
+            # trained-like detector weights: `train_detector` Adam steps on fresh synthetic batches (fp16), so that
+            # its logits have the confident / transition structure of a trained model instead of random-init noise around 0 --
+            # what the two-pass detector's re-run fraction depends on
+            from sos_amd.dataset import make_batch
+            sos_amd.set_precision("fp16")
+            ag0 = agent.DetectorAgent(det.train(), lr=1e-3)
+            for it in range(train_detector):
+                ag0.train_func(make_batch("detector", 5000 + 16 * it, 16))
+            det = ag0.net.eval()
+            del ag0
+            sos_amd.set_precision(precision)
         self.det, self.jm = det, jm
         # B DISTINCT synthetic clips (rounds 1-4 tiled 8 clips 8x: the dominant kernel is power- and data-dependent,
         # profiles/r02_power_evidence.txt, so the batch must not repeat itself)
@@ -457,6 +469,7 @@ def main():
                         "frac": ach2 / PEAK_BF16_TFLOPS, "timed_in": prof2.get("timed_in", "timed region")}
 
             for key, mode, prec, b, k, w, fr in (("infer_mixed_utt_s", "infer", "mixed", 64, 10, 3, "roofline"),
+                                                 ("infer_mixed_trained_detector_utt_s", "infer", "mixed", 64, 10, 3, "trained"),
                                                  ("infer_fp16_utt_s", "infer", "fp16", 64, 10, 3, None),
                                                  ("ragged_mixed_clips_s", "infer-ragged", "mixed", 256, 3, 1, None),
                                                  ("ragged_mixed_hipgraph_clips_s", "infer-ragged", "mixed", 256, 3, 1, "graph"),
@@ -466,9 +479,16 @@ def main():
                                                  ("train_bf16x3_utt_s", "train", "bf16x3", 64, 3, 1, None),
                                                  ("infer_bf16x3_utt_s", "infer", "bf16x3", 64, 3, 1, None)):
                 try:
-                    w2 = Workload(mode, prec, b, rank, graph=fr == "graph")
+                    w2 = Workload(mode, prec, b, rank, graph=fr == "graph", train_detector=60 if fr == "trained" else 0)
+                    if prec == "mixed" and mode == "infer":
+                        w2.pipeline.two_pass_stats(reset=True)
                     dt2, dom2, prof2 = run_timed(w2, k, w, barrier, profile=fr == "roofline")
                     sec[key] = round(b * k / dt2, 1)
+                    if prec == "mixed" and mode == "infer":
+                        # two-pass detector (pipeline.detect): clips whose fp16 logits came within the error band of the
+                        # threshold and were re-run in the parity precision, over all clips of the run
+                        mk, seen = w2.pipeline.two_pass_stats(reset=True)
+                        sec[key.replace("_utt_s", "_rerun_fraction")] = round(mk / max(1, seen), 4)
                     if fr == "roofline":
                         sec[key.replace("_utt_s", "_roofline")] = _roof(dom2, prof2)
                     if mode == "infer-ragged":
@@ -581,7 +601,10 @@ def main():
                 sec["train_fp16_16khz_2x256x251_utt_s"] = None
                 sec["train_fp16_16khz_2x256x251_utt_s_error"] = repr(e)[:200]
             sec["note"] = ("same box, after the headline loop: infer = B=64 2 s clips x 10 steps (infer_mixed_roofline: its dominant launch "
-                           "signature bracketed with HIP events in that run); ragged = BASELINE configs[3], B=256 "
+                           "signature bracketed with HIP events in that run; 'mixed' = two-pass detector: fp16 for every clip, bf16x3 again "
+                           "for the clips with a logit inside the fp16 error band of the threshold -- *_rerun_fraction; "
+                           "infer_mixed_trained_detector = the same with a detector trained for 60 Adam steps on synthetic batches first, "
+                           "random-init logits all sit near the threshold); ragged = BASELINE configs[3], B=256 "
                            "U(1 s,10 s) x 3 steps (eager launches / replayed hipGraphs); train_* = the headline workload in another precision x 10 steps "
                            "(bf16x3 = the three-pass parity mode, 3x the MACs, the one mode within 1e-3 of the reference on every tensor: 3 steps, "
                            "also as infer_bf16x3); "

@@ -242,6 +242,7 @@ def nearest_index_ragged(rag, n_max, device):
     """(B, n_max) int32: row b = nearest_index(rag.T[b], rag.n_vframes[b]) padded with zeros (never read: the conv's
     per-clip logical width stops at n_vframes[b]); cached on the Ragged object."""
     key = ("nearest", n_max)
+    rag = getattr(rag, "base", rag)             # (engine.MaskedRagged: the gather rows are its base geometry's, built once)
     t = rag._tabs.get(key)
     if t is None:
         rows = np.zeros((len(rag.T), n_max), dtype=np.int32)

@@ -295,6 +295,60 @@ extern "C" int sos_threshold_bits(const float* logits, int64_t n, float threshol
     return sos_check_launch("sos_threshold_bits");
 }
 
+// ---- two-pass detector of the 'mixed' pipeline (round 5): which clips have a frame whose 16-bit logit lies within `band_rel`
+// x max(1, max_t |logit|) of the threshold (logit 0 <=> sigmoid 0.5)?  One workgroup per clip; fixed-order LDS tree for the
+// maximum.  Marked clips keep their rows of the geometry tables (tabs_out = tabs_in), unmarked clips get width 0 in every table:
+// the second (parity-precision) detector pass then runs through the ragged per-clip geometry of the kernels and every tile of an
+// unmarked clip exits at once -- the selection never reaches the host.  count[0] += marked clips, count[1] += clips.
+__global__ void logit_band_mark_kernel(const float* __restrict__ logits, int64_t n, const int32_t* __restrict__ n_valid,
+                                       float band_rel, const int32_t* __restrict__ tabs_in, int32_t* __restrict__ tabs_out,
+                                       int ntab, int64_t B, int32_t* __restrict__ mark, int32_t* __restrict__ count) {
+    __shared__ float red[64];
+    const int64_t b = blockIdx.x;
+    const int nv = n_valid ? min((int)n, n_valid[b]) : (int)n;
+    const float* lp = logits + b * n;
+    float m = 0.f;
+    for (int t = threadIdx.x; t < nv; t += 64) m = fmaxf(m, fabsf(lp[t]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    const float band = band_rel * fmaxf(1.f, red[0]);
+    __syncthreads();
+    float hit = 0.f;
+    for (int t = threadIdx.x; t < nv; t += 64) {
+        const float v = fabsf(lp[t]);
+        if (!(v >= band)) hit = 1.f;              // (NaN counts as a hit: the parity pass decides)
+    }
+    red[threadIdx.x] = hit;
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    const int mk = red[0] != 0.f ? 1 : 0;
+    if (threadIdx.x == 0) {
+        mark[b] = mk;
+        if (count) { atomicAdd(count, mk); atomicAdd(count + 1, 1); }
+    }
+    for (int k = threadIdx.x; k < ntab; k += 64) tabs_out[(int64_t)k * B + b] = mk ? tabs_in[(int64_t)k * B + b] : 0;
+}
+
+extern "C" int sos_logit_band_mark(const float* logits, int64_t batch, int64_t n, const int32_t* n_valid, float band_rel,
+                                   const int32_t* tabs_in, int32_t* tabs_out, int ntab, int32_t* mark, int32_t* count,
+                                   sos_stream_t stream) {
+    if (!logits || !mark || batch < 1 || batch > 0x7fffffff || n < 1 || !(band_rel >= 0.f) || ntab < 0 ||
+        (ntab > 0 && (!tabs_in || !tabs_out))) {
+        sos_set_error("sos_logit_band_mark: bad args");
+        return SOS_EINVAL;
+    }
+    hipLaunchKernelGGL(logit_band_mark_kernel, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, logits, n, n_valid,
+                       band_rel, tabs_in, tabs_out, ntab, batch, mark, count);
+    return sos_check_launch("sos_logit_band_mark");
+}
+
 // ----------------------------------------------------------------- NCHW f32 -> NHWC bf16 pack
 __global__ void pack_kernel(const float* __restrict__ in, int C, int64_t HW, int64_t total, bf16_t* __restrict__ out,
                             int cs, int x3, const float* __restrict__ mul_p) {

@@ -57,8 +57,19 @@ class AudioVisualNet(nn.Module):
         if video:       # registered after fc1, like assigning it to the reference module after construction
             self.encoder_video = CN.make_video_branch(CN.VIDEO_KERNEL_SIZES, CN.VIDEO_STRIDES, nf=128, outf=256)
         self.freq_bins = freq_bins
-        self._cache = E.PlanCache()
+        self._caches = {}            # inference plans, one per precision mode (see _cache)
         self._tcache = E.PlanCache(record=True)
+
+    @property
+    def _cache(self):
+        """The inference plan cache of the CURRENT precision mode.  One per mode: the two-pass detector of the 'mixed' pipeline
+        (pipeline.detect_two_pass) runs this network in fp16 and, for the clips it marks, in bf16x3 within the same call -- with a
+        single cache every pass would re-pack all the weights."""
+        from .. import get_precision
+        c = self._caches.get(get_precision())
+        if c is None:
+            c = self._caches[get_precision()] = E.PlanCache()
+        return c
 
     def _build_plan(self):
         x3 = E.is_x3()

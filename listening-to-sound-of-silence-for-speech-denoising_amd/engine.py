@@ -580,6 +580,55 @@ class Ragged:
         return dict(wl_tab=self.level(lin), wo_tab=self.level(lout), valid_cols=sum(self.widths(lout)))
 
 
+class MaskedRagged(Ragged):
+    """A ragged geometry restricted ON THE DEVICE to the clips a 16-bit detector pass marked (sos_logit_band_mark): the host-side
+    lists are the base geometry's, every device width table is the base table where mark[b] = 1 and 0 elsewhere, so a launch
+    sequence over this geometry computes the marked clips only (tiles of a zero-width clip exit at once; the BiLSTM idles on a
+    zero-length clip) and no selection ever reaches the host.  Built by mask_ragged()."""
+
+    def __init__(self, base, mark, tabs):
+        super().__init__(base.T, base.device, n_vframes=base.n_vframes, n_samples=base.n_samples)
+        self.base, self.mark = base, mark
+        self._tabs.update(tabs)
+        for k, v in base._tabs.items():           # tables that are not widths (the nearest-resize gather rows) are shared
+            if isinstance(k, tuple) and k and isinstance(k[0], str):
+                self._tabs.setdefault(k, v)
+
+    def tab(self, widths):
+        key = tuple(int(x) for x in widths)
+        t = self._tabs.get(key)
+        if t is None:                             # a table the mark kernel was not handed: masked by one tiny elementwise launch
+            t = self._tabs[key] = self.base.tab(widths) * self.mark
+        return t
+
+
+_band_count = {}
+
+
+def band_count(device):
+    """int32 [2] on `device`: {clips the two-pass detector re-ran in the parity precision, clips it saw} since the process started
+    (sos_logit_band_mark accumulates; reading it synchronises -- bench.py does so outside its timed regions)."""
+    key = str(device)
+    if key not in _band_count:
+        _band_count[key] = torch.zeros(2, dtype=torch.int32, device=device)
+    return _band_count[key]
+
+
+def mask_ragged(base, logits, band_rel, width_lists):
+    """logits f32 (B, n) of a 16-bit detector pass over the geometry `base` -> (MaskedRagged, mark int32 (B,)).  width_lists:
+    the per-clip width lists whose device tables the second pass will ask for (masked by the same launch)."""
+    B, n = logits.shape
+    tabs_in = torch.stack([base.tab(w) for w in width_lists]).contiguous()
+    tabs_out = torch.empty_like(tabs_in)
+    mark = torch.empty(B, dtype=torch.int32, device=logits.device)
+    nv = base.tab(base.n_vframes) if base.n_vframes is not None else None
+    L.check(L.lib().sos_logit_band_mark(L.ptr(logits), B, n, L.ptr(nv), float(band_rel), L.ptr(tabs_in), L.ptr(tabs_out),
+                                        len(width_lists), L.ptr(mark), L.ptr(band_count(logits.device)), L.stream_ptr()),
+            "sos_logit_band_mark")
+    tabs = {tuple(int(x) for x in w): tabs_out[k] for k, w in enumerate(width_lists)}
+    return MaskedRagged(base, mark, tabs), mark
+
+
 class PlanCache:
     """Packed weights keyed by the parameters' in-place version counters (optimizer steps and
     load_state_dict bump them), the device, the precision mode and the parameters' storage.  When only the VALUES changed

@@ -4,8 +4,11 @@ STFT -> JointModel -> mask apply -> ISTFT, with no host round trip.
 Restates M1/predict.py:38-233 (detector pass) + M2/predict.py:255-326,377-447 (denoiser pass);
 the reference hands results over through JSON/WAV files on disk, here the hand-off is the
 `bits` tensor in HBM."""
+import os
+
 import torch
 
+from . import get_mode, precision_scope
 from . import tools
 from . import transform
 
@@ -19,15 +22,63 @@ def n_video_frames(n_samples, sr=SR, fps=FPS):
     return int(round(n_samples / sr * fps))
 
 
+# ---- the detector of the 'mixed' mode in two passes (round 5).  The only thing the pipeline takes from the detector is the SIGN
+# of every frame's logit (M1/predict.py:117-119: sigmoid(logit) >= 0.5), and a 16-bit pass gets the sign wrong only where the
+# logit lies inside its own error band around 0.  So: (1) the whole batch through the detector in fp16 (1x the MACs); (2) a device
+# kernel marks the clips with ANY frame at |logit| < TWO_PASS_BAND x max(1, max_t |logit|) -- three times the fp16 logit tolerance
+# the parity tests assert (tests/test_gpu_nets.py: 3e-3 of max |logit|; observed 1.5-1.8e-3); (3) ONLY the marked clips run again
+# in the parity precision (bf16x3, 3x the MACs) through the kernels' ragged per-clip geometry -- unmarked clips get width 0 in
+# every device table, their tiles exit at once, nothing is read back by the host (hipGraph-capturable); (4) marked clips take the
+# parity logits, the others keep the fp16 ones.  Frame decisions equal the parity detector's: by recomputation inside the band,
+# and outside it because an fp16 logit further than three tolerances from 0 has the reference's sign.  SOS_MIXED_TWO_PASS=0: every
+# clip through the parity-precision detector (rounds 3-4).  The audio-visual variant and plain modes are untouched.
+TWO_PASS = os.environ.get("SOS_MIXED_TWO_PASS", "1") != "0"
+TWO_PASS_BAND = 3 * 3e-3
+_fixed_rag = {}
+
+
+def detect(detector, S_mixed, n_frames, rag=None, return_mark=False):
+    """Detector logits (B, n_frames) for the pipeline: the two-pass scheme above under set_precision('mixed'), one plain call
+    otherwise.  rag: engine.Ragged of a variable-length batch."""
+    from . import engine as E
+    if get_mode() != "mixed" or not TWO_PASS or getattr(detector, "video_feat", 0):
+        lo = detector(s=S_mixed, v_num_frames=n_frames, rag=rag)
+        return (lo, None) if return_mark else lo
+    with precision_scope("fp16"):
+        lo16 = detector(s=S_mixed, v_num_frames=n_frames, rag=rag)
+    base = rag
+    if base is None:                                  # fixed-length batch: every clip has the same geometry (cached tables)
+        B, T = S_mixed.shape[0], S_mixed.shape[3]
+        key = (B, T, n_frames, str(S_mixed.device))
+        base = _fixed_rag.get(key)
+        if base is None:
+            base = _fixed_rag[key] = E.Ragged([T] * B, S_mixed.device, n_vframes=[n_frames] * B)
+            base.level(0), base.tab(base.n_vframes)
+    mrag, mark = E.mask_ragged(base, lo16, TWO_PASS_BAND, [base.widths(0), base.n_vframes])
+    lo3 = detector(s=S_mixed, v_num_frames=n_frames, rag=mrag)
+    lo = torch.where(mark[:, None] != 0, lo3, lo16)
+    return (lo, mark) if return_mark else lo
+
+
+def two_pass_stats(device=None, reset=False):
+    """(clips re-run in the parity precision, clips seen) by detect() on `device` so far; synchronises."""
+    from . import engine as E
+    c = E.band_count(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
+    out = tuple(int(v) for v in c.tolist())
+    if reset:
+        c.zero_()
+    return out
+
+
 @torch.no_grad()
 def denoise(detector, denoiser, mixed, sr=SR, fps=FPS, bits=None, return_all=False):
     """mixed f32 (B, N) on the GPU -> denoised f32 (B, hop*(T-1)).  `bits` (uint8 (B, n_frames),
     1 = non-silent) overrides the detector (M2/predict.py's `recovered_prediction` input)."""
     B, N = mixed.shape
     S_mixed = transform.stft_batch(mixed)
-    logits = None
+    logits = mark = None
     if bits is None:
-        logits = detector(s=S_mixed, v_num_frames=n_video_frames(N, sr, fps))
+        logits, mark = detect(detector, S_mixed, n_video_frames(N, sr, fps), return_mark=True)
         bits, _ = tools.threshold_bits(logits, SIGMOID_THRESHOLD)
     mask, noise_sig = tools.bits_to_mask_batch(bits, float(sr) / fps, N, mixed)
     S_noise = transform.stft_batch(noise_sig)
@@ -35,8 +86,9 @@ def denoise(detector, denoiser, mixed, sr=SR, fps=FPS, bits=None, return_all=Fal
     S_out = transform.batch_fast_icRM_sigmoid(S_mixed, crm)
     out = transform.istft_batch(S_out)
     if return_all:
+        # mark (two-pass detector of the 'mixed' mode only): int32 (B,), 1 = the clip's logits are the parity-precision pass's
         return dict(out=out, logits=logits, bits=bits, mask=mask, n_pred=n_pred, crm=crm, S_mixed=S_mixed,
-                    S_noise=S_noise, S_out=S_out)
+                    S_noise=S_noise, S_out=S_out, mark=mark)
     return out
 
 
@@ -60,7 +112,7 @@ def _denoise_group_padded(detector, denoiser, wave, rag, sr, fps):
     ns, nv = rag.n_samples, rag.n_vframes
     t_ns, t_nv = rag.tab(ns), rag.tab(nv)
     S_mixed = transform.stft_batch(wave, clip_samples=t_ns)
-    logits = detector(s=S_mixed, v_num_frames=max(nv), rag=rag)
+    logits = detect(detector, S_mixed, max(nv), rag=rag)
     bits, _ = tools.threshold_bits(logits, SIGMOID_THRESHOLD)
     mask, noise_sig = tools.bits_to_mask_batch(bits, float(sr) / fps, wave.shape[1], wave, clip_frames=t_nv, clip_samples=t_ns)
     S_noise = transform.stft_batch(noise_sig, clip_samples=t_ns)

@@ -383,3 +383,75 @@ def test_si_sdr_parity_with_briefly_trained_weights():
             assert abs(s_hip - s_ref) <= tol, (precision, s_hip, s_ref)
         gains.append(s_or - s_in)
     assert np.mean(gains) > 1.0, gains                      # the briefly trained chain really denoises
+
+
+@pytest.mark.parametrize("shift", [0.0, 0.6, 50.0], ids=["centred", "some-marked", "none-marked"])
+def test_two_pass_detector_of_the_mixed_mode_equals_the_parity_detector(shift, monkeypatch):
+    """'mixed' runs the silent-interval detector in two passes (pipeline.detect): every clip in fp16, then ONLY the clips with a
+    logit inside the fp16 error band around the threshold again in bf16x3, selected on the device (sos_logit_band_mark +
+    zero-width rows of the ragged geometry tables).  Against the one-pass parity detector (SOS_MIXED_TWO_PASS=0) on the same
+    batch: identical frame decisions for EVERY clip; marked clips carry the parity logits (same kernels through the ragged
+    geometry: 1e-4), unmarked clips the fp16 ones (3e-3 of the logit range) with every logit outside the band.  `shift` moves
+    the logits off the threshold (fc1.2.bias) so that all / some / none of the clips are marked; the counter of re-run clips
+    follows.  The same through the variable-length path (denoise_ragged)."""
+    from sos_amd import engine as E, pipeline
+    from sos_amd.common import MyConfig
+    from sos_amd.dataset import synth_batch
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+    sd1 = onet.closed_form_state(onet.detector_spec(), seed=1)
+    sd2 = onet.closed_form_state(onet.joint_spec(), seed=2)
+    raw = synth_batch(60, 6)
+    n_frames = pipeline.n_video_frames(raw["mixed"].shape[1])
+    S0 = torch.from_numpy(np.stack([ofe.fast_stft(w).transpose(2, 0, 1) for w in raw["mixed"]]).astype(np.float32))
+    with torch.no_grad():
+        lo_all = torch.sort(onet.detector_forward(sd1, S0, n_frames).reshape(-1)).values
+        mid = lo_all[len(lo_all) // 2 - 10:len(lo_all) // 2 + 10]
+        k = int(torch.argmax(mid[1:] - mid[:-1]))
+        span = float(lo_all[-1] - lo_all[0])
+        sd1["fc1.2.bias"] = sd1["fc1.2.bias"] - 0.5 * (mid[k] + mid[k + 1]) + shift * span
+        lo_ref = onet.detector_forward(sd1, S0, n_frames).numpy()
+    det = dnet.get_network(); det.load_state_dict(sd1)
+    jm = jnet.get_network(MyConfig()); jm.load_state_dict(sd2)
+    det, jm = det.cuda().eval(), jm.cuda().eval()
+    x = torch.from_numpy(raw["mixed"]).cuda()
+    sos_amd.set_precision("mixed")
+    try:
+        monkeypatch.setattr(pipeline, "TWO_PASS", False)
+        one = pipeline.denoise(det, jm, x, return_all=True)
+        assert one["mark"] is None
+        monkeypatch.setattr(pipeline, "TWO_PASS", True)
+        pipeline.two_pass_stats(reset=True)
+        two = pipeline.denoise(det, jm, x, return_all=True)
+        marked, seen = pipeline.two_pass_stats()
+        clips = [x[i, :n].contiguous() for i, n in enumerate((28000, 21000, 28000, 16000, 28000, 25000))]
+        monkeypatch.setattr(pipeline, "TWO_PASS", False)
+        _, ex1 = pipeline.denoise_ragged(det, jm, clips, return_all=True)
+        monkeypatch.setattr(pipeline, "TWO_PASS", True)
+        ys2, ex2 = pipeline.denoise_ragged(det, jm, clips, return_all=True)
+    finally:
+        sos_amd.set_precision("bf16")
+    mark = two["mark"].cpu().numpy()
+    print("shift", shift, "marked clips", mark.tolist(), "counter", marked, seen)
+    assert seen == len(mark) and marked == int(mark.sum())
+    if shift == 0.0:
+        assert mark.all()
+    if shift == 50.0:
+        assert not mark.any()
+    assert torch.equal(one["bits"], two["bits"])
+    lo1, lo2 = one["logits"].cpu().numpy(), two["logits"].cpu().numpy()
+    rng = np.abs(lo_ref).max()
+    for b in range(len(mark)):
+        if mark[b]:
+            assert np.abs(lo2[b] - lo1[b]).max() < 1e-4 * rng, b
+        else:
+            assert np.abs(lo2[b] - lo_ref[b]).max() < 3e-3 * rng, b
+            assert np.abs(lo2[b]).min() >= pipeline.TWO_PASS_BAND * max(1.0, np.abs(lo2[b]).max()), b
+    # frame decisions equal the f32 oracle's wherever the oracle's own logit is not within rounding of the threshold
+    sure = np.abs(lo_ref) > 1e-4 * rng
+    assert np.array_equal(two["bits"].cpu().numpy()[sure], (lo_ref >= 0).astype(np.uint8)[sure])
+    if not mark.any():
+        assert torch.equal(one["out"], two["out"])          # identical bits -> the denoiser saw identical inputs
+    for a, b in zip(ex1, ex2):
+        assert torch.equal(a["bits"], b["bits"])
+    assert all(bool(torch.isfinite(y).all()) for y in ys2)
