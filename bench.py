@@ -178,6 +178,8 @@ class Workload:
         # B DISTINCT synthetic clips (rounds 1-4 tiled 8 clips 8x: the dominant kernel is power- and data-dependent,
         # profiles/r02_power_evidence.txt, so the batch must not repeat itself)
         raw = synth_batch(1000 * rank, B)
+        if os.environ.get("SOS_BENCH_TILE8") == "1":      # diagnostic: the 8-clips-tiled-8x batch of rounds 1-4
+            raw = {k: (np.tile(v[:8], (B // 8,) + (1,) * (np.ndim(v) - 1)) if isinstance(v, np.ndarray) else v) for k, v in raw.items()}
         mixed = torch.from_numpy(raw["mixed"]).cuda().contiguous()
         self.mixed = mixed
         self.audio_seconds = B * N_SAMPLES / 14000.0
@@ -500,20 +502,24 @@ def main():
                     sec[key + "_error"] = repr(e)[:200]
 
             def _alternate(make_a, make_b, rounds=3, steps=12, warm=6):
-                """Two variants of the headline workload built once and timed ALTERNATELY (A B A B A B, `warm` untimed + `steps`
-                timed steps each): the box's clocks drift over the minute the secondary lines take, so a ratio is the mean of B
-                over the mean of A of interleaved runs, not a comparison with the headline of the record."""
-                wa, wb = make_a(), make_b()
+                """Two variants of the headline workload timed ALTERNATELY (A B A B A B; each run builds its workload afresh, `warm`
+                untimed + `steps` timed steps, then frees it): the box's clocks drift over the minute the secondary lines take, so
+                a ratio is the mean of B over the mean of A of interleaved runs, not a comparison with the headline of the record.
+                (Round 5 first kept both workloads alive and alternated between them: that measured the branch streams 2.8 %
+                SLOWER while separate processes on the same box had them 2.2 % faster -- tools/probe/ab_env.sh, 542.7 vs 554.6 --;
+                two live workloads hold two sets of per-stream allocator pools.  One workload at a time, like a real job.)"""
                 ta, tb = [], []
-                try:
-                    run_timed(wa, 3, 8, barrier, profile=False)       # (thrown away: the first training run after the inference lines measures slow)
-                    for _ in range(rounds):
-                        for wx, acc in ((wa, ta), (wb, tb)):
-                            dtx, _, _ = run_timed(wx, steps, warm, barrier, profile=False)
-                            acc.append(64 * steps / dtx)
-                finally:
-                    del wa, wb
-                    torch.cuda.empty_cache()
+                w0 = make_a()
+                run_timed(w0, 3, 8, barrier, profile=False)       # (thrown away: the first training run after the inference lines measures slow)
+                del w0
+                torch.cuda.empty_cache()
+                for _ in range(rounds):
+                    for mk, acc in ((make_a, ta), (make_b, tb)):
+                        wx = mk()
+                        dtx, _, _ = run_timed(wx, steps, warm, barrier, profile=False)
+                        acc.append(64 * steps / dtx)
+                        del wx
+                        torch.cuda.empty_cache()
                 return sum(ta) / len(ta), sum(tb) / len(tb), ta, tb
 
             # the headline schedule (branch streams, the default since round 5) against the one-stream-per-model schedule of rounds 2-4
@@ -613,8 +619,8 @@ def main():
                            "configs[4]'s per-GPU share (32 clips of 60 x 224 x 224 frames) x 3 steps; train_fp16_forced_buckets = the headline "
                            "workload with the data-parallel gradient path forced in a world of one (1-rank RCCL groups, one per model); "
                            "train_fp16_branch_streams = the headline schedule, train_fp16_no_branch_streams = SOS_BRANCH_STREAMS=0 (the "
-                           "schedule of rounds 2-4); *_ratio = mean of three runs with over mean of three runs without, the two workloads "
-                           "built once and timed alternately (6 warm-up + 12 timed steps per run; *_runs lists them)")
+                           "schedule of rounds 2-4); *_ratio = mean of three runs with over mean of three runs without, timed alternately, "
+                           "every run on a freshly built workload (6 warm-up + 12 timed steps per run; *_runs lists them)")
             line["secondary"] = sec
             sos_amd.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:

@@ -770,6 +770,7 @@ class _WgState(_threading.local):
 
 
 _wg = _WgState()
+WG_STATS = {"deferred": 0, "joined": 0}      # process-wide counters (diagnostics / tests: the autograd engine runs backward on its own thread)
 
 
 class deferred_reductions:
@@ -793,6 +794,7 @@ def wgrad_join():
         cur = torch.cuda.current_stream()
         for ev in _wg.pending.values():
             cur.wait_event(ev)
+        WG_STATS["joined"] += len(_wg.pending)
         _wg.pending.clear()
 
 
@@ -873,6 +875,7 @@ def wgrad(g, g_off, M, x, x_off, N, kh, kw, dw, *, stride=1, dil=(1, 1), pad=(0,
             red.record(side)
             slot[1] = red
             _wg.pending[side.cuda_stream] = red
+            WG_STATS["deferred"] += 1
             dw.record_stream(side)
         else:
             L.check(L.lib().sos_conv2d_wgrad(ctypes.byref(d), L.stream_ptr()), "sos_conv2d_wgrad")

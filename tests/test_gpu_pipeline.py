@@ -17,7 +17,13 @@ pytestmark = pytest.mark.gpu
 # of stage 2 alone gives 3e-3 on the reconstructed spectrogram, the BiLSTM input projection 1.8e-3, the FC head 6e-4 --
 # tools/probe/precision_study.py jm; no single stage carries it, so no cheap parity-precision tail exists); the HIP waveform must
 # lie within WAVE_MODEL_FACTOR x m of the oracle: the kernels add nothing beyond the format.  WAVE_TOL_FP16 caps it from above.
-WAVE_TOL_FP16 = 6e-3
+# Absolute ceilings next to the computed bound (VERDICT r4 #2b; a bug in storage_model.py must not loosen the product's bound
+# silently -- the model itself is pinned in tests/test_storage_model.py).  Observed on MI355X, round 5 (HIP / model 0.78-1.44):
+# 2 s clips 1.4e-3, 1.8e-3 and 4.6e-3 -- the last on the clip whose reference output sits at -40 dB SI-SDR, where the FORMAT alone
+# (the model) costs 4.2e-3, so the 3e-3 the verdict asked for is below what IEEE-half storage can deliver there; the 10 s clip of
+# the ragged test 7.2e-3 against a model deviation of 5.0e-3.
+WAVE_TOL_FP16 = 5.5e-3
+WAVE_TOL_FP16_RAGGED = 9e-3
 WAVE_MODEL_FACTOR = 2.0
 
 
@@ -233,7 +239,7 @@ def test_ragged_one_launch_1s_and_10s_vs_oracle():
                 if precision == "mixed":            # computed bound (see _model_wave_deviation)
                     m = _model_wave_deviation(sd2, waves[i], bits, y)
                     print("   storage-model waveform deviation", m, " HIP / model", err / m)
-                    assert err < WAVE_MODEL_FACTOR * m + 1e-4
+                    assert err < WAVE_MODEL_FACTOR * m + 1e-4 and err < WAVE_TOL_FP16_RAGGED
         finally:
             sos_amd.set_precision("bf16")
 
@@ -385,14 +391,15 @@ def test_si_sdr_parity_with_briefly_trained_weights():
     assert np.mean(gains) > 1.0, gains                      # the briefly trained chain really denoises
 
 
-@pytest.mark.parametrize("shift", [0.0, 0.6, 50.0], ids=["centred", "some-marked", "none-marked"])
+@pytest.mark.parametrize("shift", [0.0, -1.0, 50.0], ids=["centred", "some-marked", "none-marked"])
 def test_two_pass_detector_of_the_mixed_mode_equals_the_parity_detector(shift, monkeypatch):
     """'mixed' runs the silent-interval detector in two passes (pipeline.detect): every clip in fp16, then ONLY the clips with a
     logit inside the fp16 error band around the threshold again in bf16x3, selected on the device (sos_logit_band_mark +
     zero-width rows of the ragged geometry tables).  Against the one-pass parity detector (SOS_MIXED_TWO_PASS=0) on the same
     batch: identical frame decisions for EVERY clip; marked clips carry the parity logits (same kernels through the ragged
-    geometry: 1e-4), unmarked clips the fp16 ones (3e-3 of the logit range) with every logit outside the band.  `shift` moves
-    the logits off the threshold (fc1.2.bias) so that all / some / none of the clips are marked; the counter of re-run clips
+    geometry: 1e-4), unmarked clips the fp16 ones (3e-3 of the logit range) with every logit outside the band.  `shift` places
+    the threshold (fc1.2.bias): 0 = in the middle of the logits (every clip marked), -1 = between the two lowest logits of the
+    batch (only the clips that own them come near it), 50 = fifty logit ranges away (none marked); the counter of re-run clips
     follows.  The same through the variable-length path (denoise_ragged)."""
     from sos_amd import engine as E, pipeline
     from sos_amd.common import MyConfig
@@ -409,7 +416,12 @@ def test_two_pass_detector_of_the_mixed_mode_equals_the_parity_detector(shift, m
         mid = lo_all[len(lo_all) // 2 - 10:len(lo_all) // 2 + 10]
         k = int(torch.argmax(mid[1:] - mid[:-1]))
         span = float(lo_all[-1] - lo_all[0])
-        sd1["fc1.2.bias"] = sd1["fc1.2.bias"] - 0.5 * (mid[k] + mid[k + 1]) + shift * span
+        if shift < 0:       # threshold in the widest gap among the 12 lowest logits: only the clips owning those frames come near it
+            low = lo_all[:12]
+            k2 = int(torch.argmax(low[1:] - low[:-1]))
+            sd1["fc1.2.bias"] = sd1["fc1.2.bias"] - 0.5 * (low[k2] + low[k2 + 1])
+        else:
+            sd1["fc1.2.bias"] = sd1["fc1.2.bias"] - 0.5 * (mid[k] + mid[k + 1]) + shift * span
         lo_ref = onet.detector_forward(sd1, S0, n_frames).numpy()
     det = dnet.get_network(); det.load_state_dict(sd1)
     jm = jnet.get_network(MyConfig()); jm.load_state_dict(sd2)
@@ -438,6 +450,8 @@ def test_two_pass_detector_of_the_mixed_mode_equals_the_parity_detector(shift, m
         assert mark.all()
     if shift == 50.0:
         assert not mark.any()
+    if shift < 0:
+        assert mark.any(), "the threshold sits between two logits of the batch: their clips must be marked"
     assert torch.equal(one["bits"], two["bits"])
     lo1, lo2 = one["logits"].cpu().numpy(), two["logits"].cpu().numpy()
     rng = np.abs(lo_ref).max()
