@@ -898,6 +898,62 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SOS_C16_XPF 0       // 1: the next window's first pixel fragments requested before the barrier that closes a window (experiment: inside the noise)
 #endif
 
+#if __HIP_DEVICE_COMPILE__
+// ---- epilogue of the 16-row kernels: D[m = cout][n = pixel]: lane = pixel + 16 * (cout / 4), register = cout % 4
+template <int NT16, int PT>
+__device__ __forceinline__ void conv16_epilogue(const ConvParams& p, f32x4 (&acc)[PT][NT16], char* smem, const int tid, const int wave,
+                                                const int l15, const int g, const int b, const int ho_base, const int wo_base,
+                                                const int rw0, const int Wo) {
+    constexpr int ROWS = NT16 * 16, OROW = NT16 * 32 + 16, SLOTS = 64 * PT;
+    const float slope = (p.act == SOS_ACT_PRELU && p.slope) ? p.slope[0] : 0.f;
+    const bool partial = ROWS > p.cout, sig = p.act == SOS_ACT_SIGMOID;
+    const float sn = p.act == SOS_ACT_RELU ? 0.f : (p.act == SOS_ACT_PRELU ? slope : 1.f);   // max(y,0) + sn*min(y,0)
+    const bool raw = !p.scale && p.act == SOS_ACT_NONE;          // training forward convs, data gradients
+    const bool relu16 = p.act == SOS_ACT_RELU;
+    const bool x3out = p.out_dtype == SOS_DT_BF16X3;
+#pragma unroll
+    for (int nt = 0; nt < NT16; ++nt) {
+        const int co = nt * 16 + 4 * g;                   // 4 consecutive channels co..co+3
+        if (co >= p.cout_store) continue;
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) { sc4 = *(const float4*)(p.scale + co); sh4 = *(const float4*)(p.shift + co); }
+        const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            float v[4];
+            if (raw) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[pt][nt][e];
+            } else if (relu16) {                 // (wave-uniform branches: one code version per activation, no per-value selects)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(acc[pt][nt][e], scv[e], shv[e]), 0.f);
+            } else if (sig) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-fmaf(acc[pt][nt][e], scv[e], shv[e])));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = fmaf(acc[pt][nt][e], scv[e], shv[e]);
+                    v[e] = fmaf(sn, fminf(y, 0.f), fmaxf(y, 0.f));
+                }
+            }
+            if (partial) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (co + e < p.cout) ? v[e] : 0.f;
+            }
+            const int m = wave * (16 * PT) + pt * 16 + l15;
+            const unsigned h01 = pack2bf(v[0], v[1]), h23 = pack2bf(v[2], v[3]);
+            *(uint2*)(smem + m * OROW + co * 2) = make_uint2(h01, h23);
+            if (x3out) {              // hi|hi|lo output: the low parts go to the second staging plane
+                *(uint2*)(smem + SLOTS * OROW + m * OROW + co * 2) =
+                    make_uint2(pack2bf(v[0] - sos_lo2f(h01), v[1] - sos_hi2f(h01)), pack2bf(v[2] - sos_lo2f(h23), v[3] - sos_hi2f(h23)));
+            }
+        }
+    }
+    store_staged_tile<NT16 * 2, OROW, SLOTS>(p, smem, tid, b, 0, ho_base, wo_base, rw0, x3out, Wo);
+}
+#endif
+
 // MODE 0: two window-slab buffers, the next window's DMA issued at the start of a window (lands in ~600 cycles of MFMAs or
 // is waited for); 1: ONE buffer refilled behind a barrier (three workgroups per CU cover each other's refill latency);
 // 2 (round 3, an A/B switch only: SOS_CONV16_MODE=2): a RING OF THREE buffers, the DMA of window w + 2 issued at the start of
@@ -1144,53 +1200,155 @@ __global__ __launch_bounds__(256, (MODE == 1 && PT == 4) ? 3 : 2) void conv16_ke
     }
 
     if (CDBG(4)) return;
-    // ---- epilogue: D[m = cout][n = pixel]: lane = pixel + 16 * (cout / 4), register = cout % 4
-    const float slope = (p.act == SOS_ACT_PRELU && p.slope) ? p.slope[0] : 0.f;
-    const bool partial = ROWS > p.cout, sig = p.act == SOS_ACT_SIGMOID;
-    const float sn = p.act == SOS_ACT_RELU ? 0.f : (p.act == SOS_ACT_PRELU ? slope : 1.f);   // max(y,0) + sn*min(y,0)
-    const bool raw = !p.scale && p.act == SOS_ACT_NONE;          // training forward convs, data gradients
-    const bool relu16 = p.act == SOS_ACT_RELU;
-    const bool x3out = p.out_dtype == SOS_DT_BF16X3;
+    conv16_epilogue<NT16, PT>(p, acc, smem, tid, wave, l15, g, b, ho_base, wo_base, rw0, Wo);
+#endif
+}
+
+// ---- 16-row kernel, CHUNK-RESIDENT weights (round 5; ConvCfg.ks == -3, SOS_CONV16_MODE=3).  conv16_kernel keeps the patch of ALL
+// cin channels in LDS and streams the weights two taps at a time: 13 slab refills and 26 barriers per 5x5 tile, three K-blocks
+// (36 MFMAs) between barriers.  Here the contraction is cut the other way round: the channels go in chunks of 16, and for one chunk
+// the patch (npix x 32 B) AND the weights of EVERY tap ([window][2 taps][rows][16 ch], taps x rows x 32 B) are resident at once --
+// the same LDS (48 -> 48 5x5: 12.8 + 39.9 KB against 38.4 + 9.2 KB: three workgroups per CU either way) and the same bytes per
+// tile, but ONE refill and two barriers per chunk (6 instead of 26 barriers per tile), and 13 barrier-free K-blocks (156 MFMAs)
+// between them.  K = 32 of an MFMA is the two taps of a window x 16 channels: exactly conv16_kernel's KS = 1 fragment layout.
+template <int NT16>
+__global__ __launch_bounds__(256, 3) void conv16c_kernel(ConvParams p) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int PT = 4, PSTRIDE = 32, BSTRIDE = 32, CPR = 2;
+    constexpr int ROWS = NT16 * 16, TAPBYTES = ROWS * BSTRIDE, TPIECES = ROWS * CPR;
+    constexpr int WBYTES = 2 * TAPBYTES;              // one window (two taps): 3 072 B (48 rows) / 1 024 B (16 rows)
+    constexpr int WI = WBYTES / 1024;                 // DMA instructions per window
+    static_assert(WBYTES % 1024 == 0, "a window is whole 1 KB DMA instructions");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch = smem;
+    const int ntaps = p.kh * p.kw, nwin = (ntaps + 1) >> 1;
+    const int boff0 = p.npix * PSTRIDE;
+    unsigned* pixtab = (unsigned*)(smem + boff0 + nwin * WBYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    int bid = blockIdx.x;
+    {
+        const int nx = 8, q = p.nblk / nx, r = p.nblk % nx;
+        const int xcd = bid % nx, loc = bid / nx;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    int t = bid, tq;
+    tq = mg_div(t, p.mg_tiles_w); const int tj = t - tq * p.tiles_w; t = tq;
+    tq = mg_div(t, p.mg_ngw); const int gw = t - tq * p.ngw; t = tq;
+    tq = mg_div(t, p.mg_tiles_h); const int ti = t - tq * p.tiles_h; t = tq;
+    tq = mg_div(t, p.mg_dh); const int rh = t - tq * p.dh; t = tq;
+    const int b = t;
+    const int TH = p.TH, TW = p.TW;
+    const int rw0 = gw * p.NC;
+    const int ho_base = rh + ti * TH * p.dh, wo_base = rw0 + tj * TW * p.dw;
+    const int hin0 = ho_base * p.stride - p.pad_t, win0 = wo_base * p.stride - p.pad_l;
+    int Wl = p.Wl, Wo = p.Wo;                     // ragged batch: per-image widths (see conv_mfma_kernel)
+    if (p.wl_tab) {
+        Wl = p.wl_tab[b]; Wo = p.wo_tab[b];
+        if (wo_base >= Wo) return;
+    }
+    const int* wgather = p.wgather ? p.wgather + (long long)b * p.wg_stride : nullptr;
+
+    int pbase[PT];
 #pragma unroll
-    for (int nt = 0; nt < NT16; ++nt) {
-        const int co = nt * 16 + 4 * g;                   // 4 consecutive channels co..co+3
-        if (co >= p.cout_store) continue;
-        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.scale) { sc4 = *(const float4*)(p.scale + co); sh4 = *(const float4*)(p.shift + co); }
-        const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+    for (int pt = 0; pt < PT; ++pt) {
+        const int m = wave * (16 * PT) + pt * 16 + l15;
+        int cls, i, j;
+        tile_decode_mg(m, p, cls, i, j);
+        if (cls >= p.NC) cls = i = j = 0;          // dead slot (see conv_mfma_kernel)
+        pbase[pt] = ((cls * p.PH + i * p.stride) * p.PW + j * p.stride) * PSTRIDE;
+    }
+    // lane group g of a window's K-block: tap g >> 1 of the window, channels 8 (g & 1) of the chunk
+    const bool tap1 = g >= 2;
+    const int c8 = (g & 1) * 16;
+    const int aoff = (g >> 1) * TAPBYTES + l15 * BSTRIDE + c8;
+    const long long tap_stride = (long long)p.cout_pad * p.ktot;
+    // LDS-DMA source offsets of the WI instructions of a window (piece = (tap of the window, row, 8-channel half)); window w adds
+    // 2 w taps, the chunk its channel offset.  A tap past the last one lies beyond the buffer resource: zeros (the odd window).
+    unsigned wvoff[WI];
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            float v[4];
-            if (raw) {
+    for (int u = 0; u < WI; ++u) {
+        const int idx = u * 64 + lane;
+        const int tl = idx / TPIECES, rem = idx - tl * TPIECES;
+        const int row = rem / CPR, c = rem - row * CPR;
+        wvoff[u] = (unsigned)((tl * tap_stride + (long long)row * p.ktot + c * 8) * 2);
+    }
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.wgt, 0, (unsigned)((long long)p.kh * p.kw * tap_stride * 2), 0x00020000);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+
+    f32x4 acc[PT][NT16];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[pt][nt][e];
-            } else if (relu16) {                 // (wave-uniform branches: one code version per activation, no per-value selects)
+    for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(acc[pt][nt][e], scv[e], shv[e]), 0.f);
-            } else if (sig) {
+        for (int nt = 0; nt < NT16; ++nt) acc[pt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int tl_ = min(lane, ntaps - 1), ta_ = mg_div(tl_, p.mg_kw);
+    const int tapoff16 = (ta_ * p.PW + (tl_ - ta_ * p.kw)) * PSTRIDE;   // lane t: patch byte offset of tap t (<= 64 taps)
+    const long long in_b = (long long)b * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + in_b * p.in_cs), 0, (unsigned)(p.H * p.W * p.in_cs) * 2u, 0x00020000);
+    build_pixel_table(p, pixtab, tid, hin0, win0, rw0, Wl, wgather);
+    const int ninstr_w = nwin * WI;
+    int seg = 0, ch = 0;                          // chunk cc = 16-channel chunk `ch` of channel segment `seg` (hi|hi|lo thirds)
+    for (int cc = 0; cc < p.nchunks; ++cc) {
+        // (first chunk: publishes the pixel table; later ones: every wave is done reading the previous chunk's patch and weights)
+        __syncthreads();
+        if (!CDBG(1)) stage_patch_dma<CPR, false>(p, patch, (unsigned)(uintptr_t)pixtab, lane, wv, in_rsrc,
+                                                  (unsigned)((p.cin_off + seg * p.seg_stride + ch * 16) * 2));
+        if (!CDBG(8)) {
+            const unsigned segk = (unsigned)((seg * p.cin + ch * 16) * 2);
+            for (int i = wv; i < ninstr_w; i += 4) {
+                const int w = i / WI, u = i - w * WI;
+                unsigned vo = wvoff[0];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-fmaf(acc[pt][nt][e], scv[e], shv[e])));
-            } else {
+                for (int k = 1; k < WI; ++k) vo = (u == k) ? wvoff[k] : vo;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(smem + boff0 + i * 1024), 16,
+                                                         vo + (unsigned)((long long)w * 2 * tap_stride * 2) + segk, 0, 0, 0);
+            }
+        }
+        if (++ch == p.cps) { ch = 0; ++seg; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's patch and weight pieces have landed
+        __syncthreads();
+
+        bf16x8 fa[2][NT16], fb[2][PT];
+        auto read_win = [&](const int w, const int buf) {
+            const int toff0 = __builtin_amdgcn_readlane(tapoff16, 2 * w);
+            const int toff1 = __builtin_amdgcn_readlane(tapoff16, min(2 * w + 1, ntaps - 1));
+            const int toff = tap1 ? toff1 : toff0;
+            const char* slab = smem + boff0 + w * WBYTES + aoff;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float y = fmaf(acc[pt][nt][e], scv[e], shv[e]);
-                    v[e] = fmaf(sn, fminf(y, 0.f), fmaxf(y, 0.f));
+            for (int nt = 0; nt < NT16; ++nt) fa[buf][nt] = lds_frag(slab + nt * 16 * BSTRIDE);
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) fb[buf][pt] = lds_frag(patch + pbase[pt] + toff + c8);
+        };
+        auto mfma_win = [&](const int buf) {
+#pragma unroll
+            for (int nt = 0; nt < NT16; ++nt)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    acc[pt][nt] = SOS_MFMA_16x16x32(fa[buf][nt], fb[buf][pt], acc[pt][nt], 0, 0, 0);
+        };
+        if (!CDBG(2)) {
+            read_win(0, 0);
+            for (int w = 0; w < nwin; w += 2) {
+                if (w + 1 < nwin) read_win(w + 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_win(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (w + 1 < nwin) {
+                    if (w + 2 < nwin) read_win(w + 2, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_win(1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
-            if (partial) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (co + e < p.cout) ? v[e] : 0.f;
-            }
-            const int m = wave * (16 * PT) + pt * 16 + l15;
-            const unsigned h01 = pack2bf(v[0], v[1]), h23 = pack2bf(v[2], v[3]);
-            *(uint2*)(smem + m * OROW + co * 2) = make_uint2(h01, h23);
-            if (x3out) {              // hi|hi|lo output: the low parts go to the second staging plane
-                *(uint2*)(smem + SLOTS * OROW + m * OROW + co * 2) =
-                    make_uint2(pack2bf(v[0] - sos_lo2f(h01), v[1] - sos_hi2f(h01)), pack2bf(v[2] - sos_lo2f(h23), v[3] - sos_hi2f(h23)));
             }
         }
     }
-    store_staged_tile<NT16 * 2, OROW, SLOTS>(p, smem, tid, b, 0, ho_base, wo_base, rw0, x3out, Wo);
+    if (CDBG(4)) return;
+    __syncthreads();                              // the staged output tile overlays the patch and the weights
+    conv16_epilogue<NT16, PT>(p, acc, smem, tid, wave, l15, g, b, ho_base, wo_base, rw0, Wo);
 #endif
 }
 
@@ -1261,7 +1419,8 @@ static int nt16_for(const sos_conv_desc* d) {
     if (d->cout > 32 && d->cout <= 48) return 3;
     return 0;
 }
-static size_t lds_bytes16(int npix, int nt16, int ks, int mode) {     // mode 0: two slab buffers, 1: one, 2: ring of three
+static size_t lds_bytes16(int npix, int nt16, int ks, int mode, int taps = 0) {     // mode 0: two slab buffers, 1: one, 2: ring of three, 3: chunk-resident (conv16c_kernel)
+    if (mode == 3) return (size_t)npix * 32 + (size_t)((taps + 1) / 2) * 2 * nt16 * 16 * 32 + (size_t)npix * 4;
     const size_t row = (size_t)ks * 32;            // unpadded pitches
     const size_t slab = mode == 1 ? (size_t)2 * nt16 * 16 * row : ((size_t)2 * nt16 * 16 * 2 * ks + 63) / 64 * 1024;   // WBYTES
     return (size_t)npix * row + (mode == 1 ? 1 : (mode == 2 ? 3 : 2)) * slab + (size_t)npix * 4;
@@ -1331,6 +1490,15 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
                 if (lds > LDS_LIMIT / 2) per_block *= 1.3;
                 else if (lds <= LDS_LIMIT / 3) per_block *= 0.95;
                 out.push_back({NC, tenc(TH), tenc(TW), -mode, blocks * per_block});
+            }
+            // chunk-resident weights (conv16c_kernel, ks -3): the same bytes and MFMAs per tile, one refill per 16-channel chunk
+            static const char* no_c = getenv("SOS_CONV16_NO_CRAT");
+            const size_t ldsc = std::max(lds_bytes16(npix, nt16, k16, 3, taps), (size_t)256 * (nt16 * 32 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + 1024 + 16384);
+            if (!no_c && ldsc <= LDS_LIMIT) {
+                double per_block = 0.75 * nseg_eff(d) * (256.0 * taps * k16 + 3.0 * npix * k16 + 40.0 * (6 + 3 * k16));
+                if (ldsc > LDS_LIMIT / 2) per_block *= 1.3;
+                else if (ldsc <= LDS_LIMIT / 3) per_block *= 0.95;
+                out.push_back({NC, tenc(TH), tenc(TW), -3, blocks * per_block * 1.02});
             }
         }
         for (int ks : kscand) {
@@ -1612,8 +1780,9 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
         const int nt16 = nt16_for(d), ks16 = d->cin / 16;
         if (!nt16) { sos_set_error("sos_conv2d_fwd: internal: 16-row tiling for an ineligible shape"); return SOS_EINVAL; }
         p.cps = 1; p.nchunks = nseg_eff(d);              // channel segments (3 in the hi|hi|lo mode), whole cin per segment
-        if (mode < 0 || mode > (pt8 ? 1 : 2) || lds_bytes16(p.npix, nt16, ks16, mode) > LDS_LIMIT) mode = pt8 ? -c.ks - 4 : -c.ks;
-        size_t lds16 = lds_bytes16(p.npix, nt16, ks16, mode);
+        if (mode < 0 || mode > (pt8 ? 1 : 3) || lds_bytes16(p.npix, nt16, ks16, mode, d->kh * d->kw) > LDS_LIMIT) mode = pt8 ? -c.ks - 4 : -c.ks;
+        if (mode == 3) { p.cps = ks16; p.nchunks = nseg_eff(d) * ks16; }      // conv16c_kernel: 16-channel chunks of every segment
+        size_t lds16 = lds_bytes16(p.npix, nt16, ks16, mode, d->kh * d->kw);
         const size_t slots = pt8 ? 512 : 256;
         const size_t stage16 = slots * (nt16 * 32 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + slots * 4 + (d->stats ? 16384 : 0);
         if (stage16 > lds16) lds16 = stage16;
@@ -1624,6 +1793,7 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
                                                 : (mode == 1 ? conv16_kernel<NTV, KSV, 1> : (mode == 2 ? conv16_kernel<NTV, KSV, 2> : conv16_kernel<NTV, KSV, 0>));
         SOS_C16(1, 1) SOS_C16(1, 3) SOS_C16(3, 1) SOS_C16(3, 3)
 #undef SOS_C16
+        if (mode == 3) k = nt16 == 1 ? conv16c_kernel<1> : conv16c_kernel<3>;
         static sos_device_once attr16;
         (void)sos_per_device_once(attr16, [] {
 #define SOS_C16A(NTV, KSV)                                                                                                        \
@@ -1634,6 +1804,8 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
             SOS_C16A(1, 1) SOS_C16A(1, 3) SOS_C16A(3, 1) SOS_C16A(3, 3)
 #undef SOS_C16A
+            (void)hipFuncSetAttribute((const void*)conv16c_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+            (void)hipFuncSetAttribute((const void*)conv16c_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
             return (int)SOS_OK;
         });
         hipLaunchKernelGGL(k, dim3((unsigned)nblk, 1), dim3(256), lds16, s, p);

@@ -398,8 +398,8 @@ def test_two_pass_detector_of_the_mixed_mode_equals_the_parity_detector(shift, m
     zero-width rows of the ragged geometry tables).  Against the one-pass parity detector (SOS_MIXED_TWO_PASS=0) on the same
     batch: identical frame decisions for EVERY clip; marked clips carry the parity logits (same kernels through the ragged
     geometry: 1e-4), unmarked clips the fp16 ones (3e-3 of the logit range) with every logit outside the band.  `shift` places
-    the threshold (fc1.2.bias): 0 = in the middle of the logits (every clip marked), -1 = between the two lowest logits of the
-    batch (only the clips that own them come near it), 50 = fifty logit ranges away (none marked); the counter of re-run clips
+    the threshold (fc1.2.bias): 0 = in the middle of the logits (every clip marked), -1 = just above the 6th-lowest logit of the
+    batch (only the clips with a frame that low come near it), 50 = fifty logit ranges away (none marked); the counter of re-run clips
     follows.  The same through the variable-length path (denoise_ragged)."""
     from sos_amd import engine as E, pipeline
     from sos_amd.common import MyConfig
@@ -416,10 +416,9 @@ def test_two_pass_detector_of_the_mixed_mode_equals_the_parity_detector(shift, m
         mid = lo_all[len(lo_all) // 2 - 10:len(lo_all) // 2 + 10]
         k = int(torch.argmax(mid[1:] - mid[:-1]))
         span = float(lo_all[-1] - lo_all[0])
-        if shift < 0:       # threshold in the widest gap among the 12 lowest logits: only the clips owning those frames come near it
-            low = lo_all[:12]
-            k2 = int(torch.argmax(low[1:] - low[:-1]))
-            sd1["fc1.2.bias"] = sd1["fc1.2.bias"] - 0.5 * (low[k2] + low[k2 + 1])
+        if shift < 0:       # threshold 2e-3 logit ranges above the 6th-lowest logit of the batch: inside the band for the clip that
+            # owns it (and whoever else has a frame that low), far away for clips whose logits all sit higher
+            sd1["fc1.2.bias"] = sd1["fc1.2.bias"] - (lo_all[5] + 2e-3 * max(1.0, span))
         else:
             sd1["fc1.2.bias"] = sd1["fc1.2.bias"] - 0.5 * (mid[k] + mid[k + 1]) + shift * span
         lo_ref = onet.detector_forward(sd1, S0, n_frames).numpy()
