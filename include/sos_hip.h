@@ -206,6 +206,14 @@ typedef struct sos_conv_desc {
     void* fold_pad_out;
     int32_t fold_pad, fold_H, fold_W, fold_sy, fold_oy, fold_sx, fold_ox, fold_row;
     int64_t fold_third;
+    /* optional FUSED INPUT BatchNorm + ReLU (round 5; Conv2dBlock, M2/networks.py:28-51, training mode): `in` holds the RAW conv
+     * output of the producing block and in_scale / in_shift (f32 [cin], channel c of the contraction = input channel cin_off + c)
+     * its batch-statistics scale / shift: every value read becomes max(x * in_scale[c] + in_shift[c], 0), rounded to the storage
+     * type exactly as sos_bn_act_apply would have stored it, while the patch is staged; zero padding stays zero.  The separate
+     * apply pass and the activated tensor are then not needed by this consumer.  One 16-bit channel segment, no temporal taps;
+     * built for the 96-channel context layers' tilings (EINVAL otherwise: the caller falls back to the materialised tensor). */
+    const float* in_scale;
+    const float* in_shift;
 } sos_conv_desc;
 
 int sos_conv2d_fwd(const sos_conv_desc* desc /* host pointer */, sos_stream_t stream);

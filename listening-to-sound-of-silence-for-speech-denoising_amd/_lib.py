@@ -37,6 +37,7 @@ class ConvDesc(C.Structure):
         ("fold_pad_out", C.c_void_p),
         ("fold_pad", C.c_int32), ("fold_H", C.c_int32), ("fold_W", C.c_int32), ("fold_sy", C.c_int32), ("fold_oy", C.c_int32),
         ("fold_sx", C.c_int32), ("fold_ox", C.c_int32), ("fold_row", C.c_int32), ("fold_third", C.c_int64),
+        ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
     ]
 
 

@@ -54,6 +54,10 @@ struct ConvParams {
     int out_dtype, c_off, act, accum;
     float* stats;           // optional fused BatchNorm partial sums [tile][2][stats_c]
     int stats_c;
+    // fused INPUT BatchNorm + ReLU (sos_conv_desc.in_scale / in_shift): every value read from the input image becomes
+    // max(x * in_scale[c] + in_shift[c], 0) on its way into LDS (c counted from cin_off); padding stays zero
+    const float* in_scale;
+    const float* in_shift;
     // ragged batches (variable-length clips stored in buffers of the batch's maximum width): per-image logical input
     // width / valid output width, and the per-image stride of the column-gather table
     const int* wl_tab;
@@ -286,6 +290,65 @@ __device__ __forceinline__ void stage_issue(const ConvParams& p, char* patch, un
     }
 }
 
+// Round 5 (VERDICT r4 #1c): patch staging THROUGH REGISTERS with the producer's training-mode BatchNorm + ReLU applied on the
+// way -- the consumer reads the producer's RAW conv output and the separate bn_apply pass (read raw, write y: two tensor passes
+// per block) disappears from the forward, the activated tensor from the tape.  Same (instruction, lane) -> (pixel, piece) map as
+// stage_issue(): a lane's 16-byte piece always holds the same 8 channels of a chunk (StageMap: lq = lane % RP), so its 8 scale /
+// shift values are loaded once per chunk; all of a wave's loads are issued before the first is used.  The arithmetic is
+// bn_apply_kernel's (f32 fma, max, round to nearest even): the LDS image is bit-identical to staging the stored y.  Lanes whose
+// source is padding / out of range (offset SOS_STAGE_INVALID) and the pad piece store zeros, like the DMA path's out-of-range lanes.
+typedef unsigned sos_u32x4 __attribute__((ext_vector_type(4)));
+template <int CPR, int MAXR>
+__device__ __forceinline__ void stage_issue_bn(const ConvParams& p, char* patch, int lane, int wave, __amdgpu_buffer_rsrc_t rsrc,
+                                               unsigned cbytes, const unsigned (&vb)[MAXR][4], const unsigned vlast, const int chan0) {
+    constexpr int RP = CPR + 1;
+    typedef StageMap<RP> SM;
+    static_assert(SM::PPI != 0, "fused input BatchNorm needs the pixel-aligned staging map");
+    const SM sm(lane);
+    const int ninstr = SM::ninstr(p.npix);
+    if (!sm.on) return;
+    float sc[8], sh[8];
+    {
+        const int c0 = chan0 + min(sm.lq, CPR - 1) * 8;
+        const float4 a0 = *(const float4*)(p.in_scale + c0), a1 = *(const float4*)(p.in_scale + c0 + 4);
+        const float4 b0 = *(const float4*)(p.in_shift + c0), b1 = *(const float4*)(p.in_shift + c0 + 4);
+        sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
+        sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
+    }
+    auto xform = [&](const sos_u32x4 v, const bool valid) -> uint4 {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        unsigned o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float y0 = fmaxf(fmaf(sos_lo2f(w[e]), sc[2 * e], sh[2 * e]), 0.f);
+            const float y1 = fmaxf(fmaf(sos_hi2f(w[e]), sc[2 * e + 1], sh[2 * e + 1]), 0.f);
+            o[e] = valid ? pack2bf(y0, y1) : 0u;
+        }
+        return make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    sos_u32x4 v[MAXR][4];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = wave + 16 * r + 4 * u;
+            v[r][u] = sos_u32x4{0u, 0u, 0u, 0u};
+            if (i < ninstr - 1) v[r][u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(vb[r][u] + cbytes), 0, 0);
+        }
+    sos_u32x4 vl = sos_u32x4{0u, 0u, 0u, 0u};
+    const bool last_mine = ((ninstr - 1) & 3) == wave && sm.writes(ninstr - 1, lane, p.npix);
+    if (last_mine) vl = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(vlast + cbytes), 0, 0);
+    char* dst = patch + lane * 16;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = wave + 16 * r + 4 * u;
+            if (i < ninstr - 1) *(uint4*)(dst + i * SM::LDS_STEP) = xform(v[r][u], vb[r][u] != SOS_STAGE_INVALID && sm.lq < CPR);
+        }
+    if (last_mine) *(uint4*)(dst + (ninstr - 1) * SM::LDS_STEP) = xform(vl, vlast != SOS_STAGE_INVALID && sm.lq < CPR);
+}
+
 #if __HIP_DEVICE_COMPILE__
 // ---- cooperative store of the staged bf16 output tile ([256 pixels][OROW bytes] in LDS at smem, the lo
 // plane of the hi|hi|lo mode behind it): consecutive lanes write consecutive 16-byte pieces of a pixel's channel
@@ -467,7 +530,8 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
 #endif
 
 // SB: single weight-slab buffer (an extra barrier per tap, but a third workgroup fits a CU's LDS)
-template <int NT, int KS, bool SB>
+// INBN: the input is a producer's RAW conv output and its BatchNorm + ReLU is applied while the patch is staged (stage_issue_bn)
+template <int NT, int KS, bool SB, bool INBN = false>
 __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p) {
 #if __HIP_DEVICE_COMPILE__     // buffer-resource builtins exist in the device pass only; the host pass needs just the stub
     constexpr int KC = 16 * KS;                 // channels per chunk
@@ -624,7 +688,8 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
         if (!CDBG(1)) {
             if (stg_fast) {
                 const unsigned cb = (unsigned)((p.cin_off + seg * p.seg_stride + cin_seg * KC) * 2);
-                stage_issue<CPR, true, STG_R>(p, patch, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc, cb, stg, stg_last);
+                if constexpr (INBN) stage_issue_bn<CPR, STG_R>(p, patch, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc, cb, stg, stg_last, cin_seg * KC);
+                else stage_issue<CPR, true, STG_R>(p, patch, (unsigned)(uintptr_t)pixtab, lane, __builtin_amdgcn_readfirstlane(wave), in_rsrc, cb, stg, stg_last);
             } else {
                 const long long cbase = (long long)p.cin_off + (long long)(seg / p.tk) * p.seg_stride + (long long)cin_seg * KC +
                                         (long long)(tfr + seg % p.tk - p.tpad) * frame_elems;
@@ -1204,163 +1269,20 @@ __global__ __launch_bounds__(256, (MODE == 1 && PT == 4) ? 3 : 2) void conv16_ke
 #endif
 }
 
-// ---- 16-row kernel, CHUNK-RESIDENT weights (round 5; ConvCfg.ks == -3, SOS_CONV16_MODE=3).  conv16_kernel keeps the patch of ALL
-// cin channels in LDS and streams the weights two taps at a time: 13 slab refills and 26 barriers per 5x5 tile, three K-blocks
-// (36 MFMAs) between barriers.  Here the contraction is cut the other way round: the channels go in chunks of 16, and for one chunk
-// the patch (npix x 32 B) AND the weights of EVERY tap ([window][2 taps][rows][16 ch], taps x rows x 32 B) are resident at once --
-// the same LDS (48 -> 48 5x5: 12.8 + 39.9 KB against 38.4 + 9.2 KB: three workgroups per CU either way) and the same bytes per
-// tile, but ONE refill and two barriers per chunk (6 instead of 26 barriers per tile), and 13 barrier-free K-blocks (156 MFMAs)
-// between them.  K = 32 of an MFMA is the two taps of a window x 16 channels: exactly conv16_kernel's KS = 1 fragment layout.
-template <int NT16>
-__global__ __launch_bounds__(256, 3) void conv16c_kernel(ConvParams p) {
-#if __HIP_DEVICE_COMPILE__
-    constexpr int PT = 4, PSTRIDE = 32, BSTRIDE = 32, CPR = 2;
-    constexpr int ROWS = NT16 * 16, TAPBYTES = ROWS * BSTRIDE, TPIECES = ROWS * CPR;
-    constexpr int WBYTES = 2 * TAPBYTES;              // one window (two taps): 3 072 B (48 rows) / 1 024 B (16 rows)
-    constexpr int WI = WBYTES / 1024;                 // DMA instructions per window
-    static_assert(WBYTES % 1024 == 0, "a window is whole 1 KB DMA instructions");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* patch = smem;
-    const int ntaps = p.kh * p.kw, nwin = (ntaps + 1) >> 1;
-    const int boff0 = p.npix * PSTRIDE;
-    unsigned* pixtab = (unsigned*)(smem + boff0 + nwin * WBYTES);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-
-    int bid = blockIdx.x;
-    {
-        const int nx = 8, q = p.nblk / nx, r = p.nblk % nx;
-        const int xcd = bid % nx, loc = bid / nx;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    int t = bid, tq;
-    tq = mg_div(t, p.mg_tiles_w); const int tj = t - tq * p.tiles_w; t = tq;
-    tq = mg_div(t, p.mg_ngw); const int gw = t - tq * p.ngw; t = tq;
-    tq = mg_div(t, p.mg_tiles_h); const int ti = t - tq * p.tiles_h; t = tq;
-    tq = mg_div(t, p.mg_dh); const int rh = t - tq * p.dh; t = tq;
-    const int b = t;
-    const int TH = p.TH, TW = p.TW;
-    const int rw0 = gw * p.NC;
-    const int ho_base = rh + ti * TH * p.dh, wo_base = rw0 + tj * TW * p.dw;
-    const int hin0 = ho_base * p.stride - p.pad_t, win0 = wo_base * p.stride - p.pad_l;
-    int Wl = p.Wl, Wo = p.Wo;                     // ragged batch: per-image widths (see conv_mfma_kernel)
-    if (p.wl_tab) {
-        Wl = p.wl_tab[b]; Wo = p.wo_tab[b];
-        if (wo_base >= Wo) return;
-    }
-    const int* wgather = p.wgather ? p.wgather + (long long)b * p.wg_stride : nullptr;
-
-    int pbase[PT];
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        const int m = wave * (16 * PT) + pt * 16 + l15;
-        int cls, i, j;
-        tile_decode_mg(m, p, cls, i, j);
-        if (cls >= p.NC) cls = i = j = 0;          // dead slot (see conv_mfma_kernel)
-        pbase[pt] = ((cls * p.PH + i * p.stride) * p.PW + j * p.stride) * PSTRIDE;
-    }
-    // lane group g of a window's K-block: tap g >> 1 of the window, channels 8 (g & 1) of the chunk
-    const bool tap1 = g >= 2;
-    const int c8 = (g & 1) * 16;
-    const int aoff = (g >> 1) * TAPBYTES + l15 * BSTRIDE + c8;
-    const long long tap_stride = (long long)p.cout_pad * p.ktot;
-    // LDS-DMA source offsets of the WI instructions of a window (piece = (tap of the window, row, 8-channel half)); window w adds
-    // 2 w taps, the chunk its channel offset.  A tap past the last one lies beyond the buffer resource: zeros (the odd window).
-    unsigned wvoff[WI];
-#pragma unroll
-    for (int u = 0; u < WI; ++u) {
-        const int idx = u * 64 + lane;
-        const int tl = idx / TPIECES, rem = idx - tl * TPIECES;
-        const int row = rem / CPR, c = rem - row * CPR;
-        wvoff[u] = (unsigned)((tl * tap_stride + (long long)row * p.ktot + c * 8) * 2);
-    }
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.wgt, 0, (unsigned)((long long)p.kh * p.kw * tap_stride * 2), 0x00020000);
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-
-    f32x4 acc[PT][NT16];
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-        for (int nt = 0; nt < NT16; ++nt) acc[pt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int tl_ = min(lane, ntaps - 1), ta_ = mg_div(tl_, p.mg_kw);
-    const int tapoff16 = (ta_ * p.PW + (tl_ - ta_ * p.kw)) * PSTRIDE;   // lane t: patch byte offset of tap t (<= 64 taps)
-    const long long in_b = (long long)b * p.H * p.W;
-    const __amdgpu_buffer_rsrc_t in_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + in_b * p.in_cs), 0, (unsigned)(p.H * p.W * p.in_cs) * 2u, 0x00020000);
-    build_pixel_table(p, pixtab, tid, hin0, win0, rw0, Wl, wgather);
-    const int ninstr_w = nwin * WI;
-    int seg = 0, ch = 0;                          // chunk cc = 16-channel chunk `ch` of channel segment `seg` (hi|hi|lo thirds)
-    for (int cc = 0; cc < p.nchunks; ++cc) {
-        // (first chunk: publishes the pixel table; later ones: every wave is done reading the previous chunk's patch and weights)
-        __syncthreads();
-        if (!CDBG(1)) stage_patch_dma<CPR, false>(p, patch, (unsigned)(uintptr_t)pixtab, lane, wv, in_rsrc,
-                                                  (unsigned)((p.cin_off + seg * p.seg_stride + ch * 16) * 2));
-        if (!CDBG(8)) {
-            const unsigned segk = (unsigned)((seg * p.cin + ch * 16) * 2);
-            for (int i = wv; i < ninstr_w; i += 4) {
-                const int w = i / WI, u = i - w * WI;
-                unsigned vo = wvoff[0];
-#pragma unroll
-                for (int k = 1; k < WI; ++k) vo = (u == k) ? wvoff[k] : vo;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(smem + boff0 + i * 1024), 16,
-                                                         vo + (unsigned)((long long)w * 2 * tap_stride * 2) + segk, 0, 0, 0);
-            }
-        }
-        if (++ch == p.cps) { ch = 0; ++seg; }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's patch and weight pieces have landed
-        __syncthreads();
-
-        bf16x8 fa[2][NT16], fb[2][PT];
-        auto read_win = [&](const int w, const int buf) {
-            const int toff0 = __builtin_amdgcn_readlane(tapoff16, 2 * w);
-            const int toff1 = __builtin_amdgcn_readlane(tapoff16, min(2 * w + 1, ntaps - 1));
-            const int toff = tap1 ? toff1 : toff0;
-            const char* slab = smem + boff0 + w * WBYTES + aoff;
-#pragma unroll
-            for (int nt = 0; nt < NT16; ++nt) fa[buf][nt] = lds_frag(slab + nt * 16 * BSTRIDE);
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) fb[buf][pt] = lds_frag(patch + pbase[pt] + toff + c8);
-        };
-        auto mfma_win = [&](const int buf) {
-#pragma unroll
-            for (int nt = 0; nt < NT16; ++nt)
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt)
-                    acc[pt][nt] = SOS_MFMA_16x16x32(fa[buf][nt], fb[buf][pt], acc[pt][nt], 0, 0, 0);
-        };
-        if (!CDBG(2)) {
-            read_win(0, 0);
-            for (int w = 0; w < nwin; w += 2) {
-                if (w + 1 < nwin) read_win(w + 1, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_win(0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (w + 1 < nwin) {
-                    if (w + 2 < nwin) read_win(w + 2, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mfma_win(1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-    }
-    if (CDBG(4)) return;
-    __syncthreads();                              // the staged output tile overlays the patch and the weights
-    conv16_epilogue<NT16, PT>(p, acc, smem, tid, wave, l15, g, b, ho_base, wo_base, rw0, Wo);
-#endif
-}
+// (Round 5, built and removed -- profiles/r05_conv16_chunk_resident.txt: a 16-row kernel with CHUNK-RESIDENT weights, i.e. per
+// 16-channel chunk the patch and the weights of ALL taps in LDS at once: same LDS, bytes and MFMAs per tile as conv16_kernel, 6
+// instead of 26 barriers per tile.  48 -> 48 5x5 at B = 64: 0.400 ms against 0.318 ms; the one 52 KB refill per chunk behind a
+// barrier is exposed where thirteen 9 KB refills interleave with the other two workgroups' MFMAs.)
 
 // ------------------------------------------------------------------------------ host side
 static const size_t LDS_LIMIT = 160 * 1024;
 
 typedef void (*conv_kernel_t)(ConvParams);
 
-template <int NT, int KS, bool SB>
+template <int NT, int KS, bool SB, bool INBN = false>
 static int launch_one(const ConvParams& p, dim3 grid, size_t lds, hipStream_t stream) {
     static sos_device_once attr_once;           // one per instantiation
-    conv_kernel_t k = conv_mfma_kernel<NT, KS, SB>;
+    conv_kernel_t k = conv_mfma_kernel<NT, KS, SB, INBN>;
     const int arc = sos_per_device_once(attr_once, [k] {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         if (e != hipSuccess) {
@@ -1377,6 +1299,15 @@ static int launch_one(const ConvParams& p, dim3 grid, size_t lds, hipStream_t st
 // ks: k-steps per channel chunk; + 100: single weight-slab buffer (NT <= 3, ks <= 4 only)
 template <int NT>
 static int launch_ks(int ks, const ConvParams& p, dim3 grid, size_t lds, hipStream_t stream) {
+    if (p.in_scale) {
+        // fused input BatchNorm: the 96-channel context layers' tilings only (three n-tiles, 2 or 3 k-steps per chunk, double slab)
+        if constexpr (NT == 3) {
+            if (ks == 3) return launch_one<3, 3, false, true>(p, grid, lds, stream);
+            if (ks == 2) return launch_one<3, 2, false, true>(p, grid, lds, stream);
+        }
+        sos_set_error("sos_conv2d_fwd: fused input BatchNorm (in_scale) is not built for this tiling (nt=%d ks=%d)", NT, ks);
+        return SOS_EINVAL;
+    }
     if constexpr (NT <= 3) {
         switch (ks) {
             case 101: return launch_one<NT, 1, true>(p, grid, lds, stream);
@@ -1419,8 +1350,7 @@ static int nt16_for(const sos_conv_desc* d) {
     if (d->cout > 32 && d->cout <= 48) return 3;
     return 0;
 }
-static size_t lds_bytes16(int npix, int nt16, int ks, int mode, int taps = 0) {     // mode 0: two slab buffers, 1: one, 2: ring of three, 3: chunk-resident (conv16c_kernel)
-    if (mode == 3) return (size_t)npix * 32 + (size_t)((taps + 1) / 2) * 2 * nt16 * 16 * 32 + (size_t)npix * 4;
+static size_t lds_bytes16(int npix, int nt16, int ks, int mode) {     // mode 0: two slab buffers, 1: one, 2: ring of three
     const size_t row = (size_t)ks * 32;            // unpadded pitches
     const size_t slab = mode == 1 ? (size_t)2 * nt16 * 16 * row : ((size_t)2 * nt16 * 16 * 2 * ks + 63) / 64 * 1024;   // WBYTES
     return (size_t)npix * row + (mode == 1 ? 1 : (mode == 2 ? 3 : 2)) * slab + (size_t)npix * 4;
@@ -1490,15 +1420,6 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
                 if (lds > LDS_LIMIT / 2) per_block *= 1.3;
                 else if (lds <= LDS_LIMIT / 3) per_block *= 0.95;
                 out.push_back({NC, tenc(TH), tenc(TW), -mode, blocks * per_block});
-            }
-            // chunk-resident weights (conv16c_kernel, ks -3): the same bytes and MFMAs per tile, one refill per 16-channel chunk
-            static const char* no_c = getenv("SOS_CONV16_NO_CRAT");
-            const size_t ldsc = std::max(lds_bytes16(npix, nt16, k16, 3, taps), (size_t)256 * (nt16 * 32 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + 1024 + 16384);
-            if (!no_c && ldsc <= LDS_LIMIT) {
-                double per_block = 0.75 * nseg_eff(d) * (256.0 * taps * k16 + 3.0 * npix * k16 + 40.0 * (6 + 3 * k16));
-                if (ldsc > LDS_LIMIT / 2) per_block *= 1.3;
-                else if (ldsc <= LDS_LIMIT / 3) per_block *= 0.95;
-                out.push_back({NC, tenc(TH), tenc(TW), -3, blocks * per_block * 1.02});
             }
         }
         for (int ks : kscand) {
@@ -1671,6 +1592,11 @@ static int validate(const sos_conv_desc* d) {
         sos_set_error("sos_conv2d_fwd: ragged batches need both wl_tab and wo_tab and no fused statistics");
         return SOS_EINVAL;
     }
+    if ((d->in_scale == nullptr) != (d->in_shift == nullptr) ||
+        (d->in_scale && (d->in_nseg != 1 || d->t_taps > 1 || d->cin % 8 || d->out_dtype == SOS_DT_BF16X3))) {
+        sos_set_error("sos_conv2d_fwd: fused input BatchNorm needs in_scale AND in_shift, one 16-bit channel segment, no temporal taps");
+        return SOS_EINVAL;
+    }
     if ((long long)d->in_cs * 2 > 0xffff) {        // (a chunk's byte offset inside a pixel is added to pre-resolved 32-bit offsets: stage_issue)
         sos_set_error("sos_conv2d_fwd: pixel pitch of %d channels not supported (<= 32767)", d->in_cs);
         return SOS_EINVAL;
@@ -1740,6 +1666,7 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     p.stride = d->stride; p.dh = d->dil_h; p.dw = d->dil_w; p.pad_t = d->pad_top; p.pad_l = d->pad_left;
     p.pad_mode = d->pad_mode; p.Ho = d->Ho; p.Wo = d->Wo; p.out_dtype = d->out_dtype; p.c_off = d->out_c_off;
     p.stats = d->stats; p.stats_c = d->stats_c;
+    p.in_scale = d->in_scale; p.in_shift = d->in_shift;
     p.wl_tab = d->wl_tab; p.wo_tab = d->wo_tab; p.wg_stride = d->w_gather_stride;
     p.act = d->act; p.accum = d->accumulate; p.sb = d->out_sb; p.sh = d->out_sh; p.sw = d->out_sw; p.sc = d->out_sc; p.third = d->out_third;
     p.out2 = d->fold_pad_out; p.fP = d->fold_pad; p.fH = d->fold_H; p.fW = d->fold_W; p.fsy = d->fold_sy; p.foy = d->fold_oy;
@@ -1780,9 +1707,8 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
         const int nt16 = nt16_for(d), ks16 = d->cin / 16;
         if (!nt16) { sos_set_error("sos_conv2d_fwd: internal: 16-row tiling for an ineligible shape"); return SOS_EINVAL; }
         p.cps = 1; p.nchunks = nseg_eff(d);              // channel segments (3 in the hi|hi|lo mode), whole cin per segment
-        if (mode < 0 || mode > (pt8 ? 1 : 3) || lds_bytes16(p.npix, nt16, ks16, mode, d->kh * d->kw) > LDS_LIMIT) mode = pt8 ? -c.ks - 4 : -c.ks;
-        if (mode == 3) { p.cps = ks16; p.nchunks = nseg_eff(d) * ks16; }      // conv16c_kernel: 16-channel chunks of every segment
-        size_t lds16 = lds_bytes16(p.npix, nt16, ks16, mode, d->kh * d->kw);
+        if (mode < 0 || mode > (pt8 ? 1 : 2) || lds_bytes16(p.npix, nt16, ks16, mode) > LDS_LIMIT) mode = pt8 ? -c.ks - 4 : -c.ks;
+        size_t lds16 = lds_bytes16(p.npix, nt16, ks16, mode);
         const size_t slots = pt8 ? 512 : 256;
         const size_t stage16 = slots * (nt16 * 32 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + slots * 4 + (d->stats ? 16384 : 0);
         if (stage16 > lds16) lds16 = stage16;
@@ -1793,7 +1719,6 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
                                                 : (mode == 1 ? conv16_kernel<NTV, KSV, 1> : (mode == 2 ? conv16_kernel<NTV, KSV, 2> : conv16_kernel<NTV, KSV, 0>));
         SOS_C16(1, 1) SOS_C16(1, 3) SOS_C16(3, 1) SOS_C16(3, 3)
 #undef SOS_C16
-        if (mode == 3) k = nt16 == 1 ? conv16c_kernel<1> : conv16c_kernel<3>;
         static sos_device_once attr16;
         (void)sos_per_device_once(attr16, [] {
 #define SOS_C16A(NTV, KSV)                                                                                                        \
@@ -1804,8 +1729,6 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)conv16_kernel<NTV, KSV, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
             SOS_C16A(1, 1) SOS_C16A(1, 3) SOS_C16A(3, 1) SOS_C16A(3, 3)
 #undef SOS_C16A
-            (void)hipFuncSetAttribute((const void*)conv16c_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
-            (void)hipFuncSetAttribute((const void*)conv16c_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
             return (int)SOS_OK;
         });
         hipLaunchKernelGGL(k, dim3((unsigned)nblk, 1), dim3(256), lds16, s, p);

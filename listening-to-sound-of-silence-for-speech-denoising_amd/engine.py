@@ -393,7 +393,7 @@ def fold_bn(bn, cout_pad):
 def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dtype, sb, sh, sw, sc,
          Ho, Wo, c_off=0, cout_store=None, third=0, stride=1, dil=(1, 1), pad=(0, 0), pad_mode=L.PAD_ZERO,
          slope=None, w_gather=None, out_elem_offset=0, in_dims=None, accumulate=False, stats_c=0, wl_tab=None,
-         wo_tab=None, wg_stride=0, valid_cols=None, temporal=None, fold=None):
+         wo_tab=None, wg_stride=0, valid_cols=None, temporal=None, fold=None, in_bn=None):
     """Fill a sos_conv_desc and enqueue sos_conv2d_fwd.  `src` is an Act (or a (tensor,B,H,W,cs,nseg)
     view described by in_dims).  stats_c > 0: also return the fused BatchNorm partial sums of the first stats_c
     output channels as (partial [2][stats_c][tiles], tiles) for sos_bn_finalize.  temporal = (frames per clip, kt): the
@@ -443,6 +443,8 @@ def conv(src, cin_off, cin, wgt, kh, kw, cout, scale, shift, act, *, out, out_dt
         d.t_frames, d.t_taps, d.t_pad = temporal[0], temporal[1], (temporal[1] - 1) // 2
     if wl_tab is not None:                # ragged batch: per-image logical input width / valid output width (sos_hip.h)
         d.wl_tab, d.wo_tab, d.w_gather_stride = wl_tab.data_ptr(), wo_tab.data_ptr(), wg_stride
+    if in_bn is not None:                 # (scale, shift) f32 [cin] of the producer's BatchNorm: `src` is its RAW output (sos_conv_desc.in_scale)
+        d.in_scale, d.in_shift = in_bn[0].data_ptr(), in_bn[1].data_ptr()
     if fold is not None:
         fa, fp, fH, fW, fsy, foy, fsx, fox = fold
         d.fold_pad_out, d.fold_pad, d.fold_H, d.fold_W = fa.t.data_ptr(), fp, fH, fW

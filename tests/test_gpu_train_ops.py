@@ -538,3 +538,35 @@ def test_flattened_1x1_layers_are_bit_identical(T, cin, cout, monkeypatch):
         assert float(outs[0].float().abs().max()) > 0
     finally:
         sos_amd.set_precision("bf16")
+
+
+@pytest.mark.parametrize("dil", [(1, 1), (4, 1), (16, 16)], ids=["d1", "d4x1", "d16"])
+def test_fused_input_batchnorm_equals_the_materialised_apply(dil):
+    """sos_conv_desc.in_scale / in_shift (round 5): the consumer conv of a training-mode Conv2dBlock reads the producer's RAW conv
+    output and applies the producer's BatchNorm + ReLU while it stages the patch.  The staged values are computed with
+    sos_bn_act_apply's arithmetic and rounding, so the result must equal -- bit for bit -- the same conv over the tensor
+    sos_bn_act_apply materialises, zero padding included (a padded pixel must stay 0, not relu(shift))."""
+    import sos_amd
+    from sos_amd import engine as E, _lib as L
+    sos_amd.set_precision("fp16")
+    try:
+        dev = torch.device("cuda")
+        B, H, W, Cc = 2, 40, 37, 96
+        torch.manual_seed(5)
+        raw = E.Act(B, H, W, Cc, False, dev)
+        raw.t.normal_()
+        scale = (torch.rand(Cc, device=dev) + 0.5).float()
+        shift = (torch.randn(Cc, device=dev) * 0.3 + 0.2).float()        # mostly positive: relu(shift) != 0 would show at the borders
+        y = E.Act(B, H, W, Cc, False, dev)
+        E.bn_apply(E.view(raw, 0, Cc), scale, shift, L.ACT_RELU, None, y, 0, Cc)
+        w = E.pack_weight(torch.randn(Cc, Cc, 5, 5, device=dev) * 0.05, Cc, False)
+        pad = (2 * dil[0], 2 * dil[1])
+        outs = []
+        for src, in_bn in ((y, None), (raw, (scale, shift))):
+            dst = E.Act(B, H, W, Cc, False, dev, zero=True)
+            E.conv_to_act(src, 0, Cc, w, 5, 5, Cc, None, None, L.ACT_NONE, dst, cout_store=Cc, dil=dil, pad=pad, Ho=H, Wo=W, in_bn=in_bn)
+            outs.append(dst.t.clone())
+        assert bool(torch.isfinite(outs[0].float()).all()) and float(outs[0].float().abs().max()) > 0.1
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        sos_amd.set_precision("bf16")

@@ -85,10 +85,16 @@ def main():
         epi = os.environ.get('SOS_BENCH_EPI', 'eval')
         raw = dgrad or epi in ('raw', 'stats')
 
+        # SOS_BENCH_INBN=1: the producer's BatchNorm + ReLU fused into the patch staging (sos_conv_desc.in_scale, round 5)
+        in_bn = None
+        if os.environ.get('SOS_BENCH_INBN') == '1':
+            in_bn = (torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1)
+
         def run():
             E.conv_to_act(src, 0, cin, w, k[0], k[1], cout, None if raw else scale, None if raw else shift,
                           L.ACT_NONE if raw else L.ACT_RELU, dst, cout_store=dst.cs,
-                          stride=stride, dil=dil, pad=pad, pad_mode=pm, Ho=Ho, Wo=Wo, stats_c=cout if epi == 'stats' and not dgrad else 0)
+                          stride=stride, dil=dil, pad=pad, pad_mode=pm, Ho=Ho, Wo=Wo, stats_c=cout if epi == 'stats' and not dgrad else 0,
+                          in_bn=in_bn)
         import time
         t_end = time.time() + a.warm
         run()
