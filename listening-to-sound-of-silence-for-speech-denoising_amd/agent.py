@@ -213,40 +213,100 @@ class GradBucketer:
         self.shapes = {n: p.shape for n, p in named_params}
         self.params = dict(named_params)
         self.bucket_bytes = bucket_bytes
+        self._comm = None
+        self._flush_stream = None
+        self._inline_streams = set()
         self.reset()
 
     def reset(self):
         self.buckets, self.cur, self.cur_fill, self.handles, self.views = [], None, 0, [], {}
         self.pending, self.pending_streams = ([], []), []
 
+    # Where the bucket copies and the collectives are enqueued (SOS_DDP_COMM; GPU gradients only):
+    #   "inline" (default)  no communication stream: a bucket is closed whenever the producing stream changes, and its copy and its
+    #                       collective (async_op=False: ProcessGroupNCCL then enqueues on the caller's stream, no internal stream,
+    #                       no extra events) go onto the stream that produced it.  No cross-stream wait anywhere; the collective
+    #                       sits in that stream's order and overlaps the OTHER streams' compute (the step runs three).
+    #   "shared"            ONE communication stream for every model's buckets, synchronous collectives on it
+    #   "own"               a communication stream per bucketer + async collectives on ProcessGroupNCCL's internal stream
+    # Why: HIP multiplexes streams onto 4 hardware queues and the host enqueues ~100 ms ahead of the GPU, so a stream that waits for
+    # "bucket k of the backward pass is full" blocks the hardware queue it shares with whatever the host enqueues later.  With a
+    # communicator stream per model (rounds 3-4; fine with round 4's stream creation order: 0.998) round 5's first refresh had the
+    # detector's WHOLE step start only when the denoiser's had ended (tools/probe/stream_timeline.py: its stream shared a queue with
+    # a waiting communicator stream): forced-bucket path 0.944-0.952 of the plain step; GPU_MAX_HW_QUEUES=8 / 16 made it worse
+    # (0.82 / 0.80: blocked queues still occupy the command processor).  Same box, `bench.py --force-buckets`, plain step 542.4
+    # utt/s: "own" 512.8, "shared" 514.9, "inline" 541.4 (0.998); "inline" on ONE process group for both models
+    # (SOS_SHARED_GROUP=1) 515.5 -- one communicator serialises the two models' collectives.
+    COMM_MODE = os.environ.get("SOS_DDP_COMM", "inline")
+    _shared_comm = {}
+
+    def _comm_stream(self):
+        if self.COMM_MODE == "own":
+            if self._comm is None:
+                self._comm = torch.cuda.Stream()
+            return self._comm
+        dev = torch.cuda.current_device()
+        st = GradBucketer._shared_comm.get(dev)
+        if st is None:
+            st = GradBucketer._shared_comm[dev] = torch.cuda.Stream()
+        self._comm = st
+        return st
+
     def _flush_pending(self):
-        """ONE batched copy of the pending gradients into their bucket views, on the current stream.  Gradients produced on
-        another stream (the denoiser's branch streams, denoiser/networks.py) are waited for, and their memory is kept from
-        the caching allocator until this stream's copy has run."""
+        """ONE batched copy of the pending gradients into their bucket views.  GPU: on the communication stream, behind an
+        event of every producing stream ("inline": on the producing stream itself); the gradients' and the bucket's memory is
+        kept from the caching allocator until that stream's copy (and collective) has run.  CPU (gloo tests): in place."""
         if not self.pending[0]:
             return
-        if any(st is not None for st in self.pending_streams):          # (gloo CPU tests: no streams)
-            cur = torch.cuda.current_stream()
-            for st in {s_ for s_ in self.pending_streams if s_ is not None and s_ != cur}:
-                cur.wait_stream(st)
-            for g, st in zip(self.pending[1], self.pending_streams):
-                if st is not None and st != cur:
-                    g.record_stream(cur)
-        torch._foreach_copy_(self.pending[0], self.pending[1])
+        streams = {s_ for s_ in self.pending_streams if s_ is not None}
+        if streams and self.COMM_MODE == "inline":
+            (st,) = streams                    # ready() closes a bucket when the producing stream changes
+            with torch.cuda.stream(st):
+                torch._foreach_copy_(self.pending[0], self.pending[1])
+        elif streams:
+            comm = self._comm_stream()
+            for st in streams:
+                comm.wait_event(st.record_event())
+            for g in self.pending[1]:
+                g.record_stream(comm)
+            with torch.cuda.stream(comm):
+                torch._foreach_copy_(self.pending[0], self.pending[1])
+        else:
+            torch._foreach_copy_(self.pending[0], self.pending[1])
+        self._flush_stream = next(iter(streams)) if streams else None
         self.pending, self.pending_streams = ([], []), []
 
     def _launch(self, flat, fill):
         # the bucket's gradients are gathered with ONE batched copy (a copy per tensor was 322 launches per step), then
         # its all-reduce starts while the backward pass goes on
         self._flush_pending()
+        if not flat.is_cuda:
+            if self.collective:
+                self.handles.append(dist.all_reduce(flat[:fill], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        inline = self.COMM_MODE == "inline"
+        st = self._flush_stream if inline else self._comm_stream()
+        if not inline:
+            flat.record_stream(st)
+        elif self._flush_stream is not None:
+            self._inline_streams.add(self._flush_stream)
         if self.collective:
-            self.handles.append(dist.all_reduce(flat[:fill], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            with torch.cuda.stream(st):
+                if self.COMM_MODE == "own":
+                    self.handles.append(dist.all_reduce(flat[:fill], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                else:       # synchronous: enqueued on `st` itself
+                    dist.all_reduce(flat[:fill], op=dist.ReduceOp.SUM, group=self.group, async_op=False)
 
     def ready(self, name, g):
         """Called by the backward pass when a parameter gradient is final; returns the bucket view that
         will hold it (filled when the bucket is flushed)."""
         n = g.numel()
         cap = max(self.bucket_bytes // 4, n)
+        here = torch.cuda.current_stream() if g.is_cuda else None
+        if (self.COMM_MODE == "inline" and self.cur is not None and self.pending_streams and here is not None
+                and self.pending_streams[-1] != here):
+            self._launch(self.cur, self.cur_fill)         # the producing stream changed: this bucket ends here
+            self.cur = None
         if self.cur is None or self.cur_fill + n > self.cur.numel():
             if self.cur is not None:
                 self._launch(self.cur, self.cur_fill)
@@ -256,7 +316,7 @@ class GradBucketer:
         v = self.cur[self.cur_fill:self.cur_fill + n]
         self.pending[0].append(v)
         self.pending[1].append(g.reshape(-1))
-        self.pending_streams.append(torch.cuda.current_stream() if g.is_cuda else None)
+        self.pending_streams.append(here)
         self.cur_fill += n
         self.views[name] = v.view(self.shapes[name])
         return self.views[name]
@@ -270,6 +330,12 @@ class GradBucketer:
             self._flush_pending()
         for h in self.handles:
             h.wait()
+        if self._comm is not None:          # the consumer (the optimizer on the caller's stream) follows the copies and collectives
+            torch.cuda.current_stream().wait_stream(self._comm)
+        for st in self._inline_streams:     # "inline": they ran on the producing streams
+            if st != torch.cuda.current_stream():
+                torch.cuda.current_stream().wait_stream(st)
+        self._inline_streams = set()
         for name, v in self.views.items():
             self.params[name].grad = v
         self.reset_keep_views()
@@ -402,6 +468,21 @@ class BaseAgent(object):
             return self.forward(data)
 
 
+_job_streams = {}
+
+
+def _job_stream(device, k, prio=0):
+    """The HIP stream of job k of train_concurrent on `device`: ONE per (device, k) for the life of the process, shared by every
+    agent that is ever job k.  HIP multiplexes streams onto 4 hardware queues; every further stream that sits in a long wait
+    (the second model waits tens of milliseconds for the first one's gates) is one more way for two streams to collide on a queue
+    -- two sets of agents alive in one process (bench.py's alternating A/B) measured 2.8 % slower than either alone."""
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), k, prio)
+    st = _job_streams.get(key)
+    if st is None:
+        st = _job_streams[key] = torch.cuda.Stream(device=device, priority=prio)
+    return st
+
+
 def train_concurrent(jobs):
     """One training step of several independent agents (the reference trains its two models in two separate
     processes), each on its own HIP stream: [(agent, batch), ...] -> [(outputs, losses), ...].
@@ -420,9 +501,8 @@ def train_concurrent(jobs):
     gate = gate_f = None
     mode = os.environ.get("SOS_STREAM_OVERLAP", "split")
     for k, (ag, data) in enumerate(jobs):
-        if getattr(ag, "stream", None) is None:
-            prio = -1 if (k == 0 and os.environ.get("SOS_STREAM_PRIO") == "1") else 0     # A/B: big model on a high-priority stream
-            ag.stream = torch.cuda.Stream(device=ag.device, priority=prio)
+        prio = -1 if (k == 0 and os.environ.get("SOS_STREAM_PRIO") == "1") else 0     # A/B: big model on a high-priority stream
+        ag.stream = _job_stream(ag.device, k, prio)
         ag.stream.wait_stream(cur)
         net = getattr(ag, "net", None)
         ag.backward_gate = None

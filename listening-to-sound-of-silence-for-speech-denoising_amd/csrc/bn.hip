@@ -146,7 +146,7 @@ extern "C" int sos_bn_stats_blocks(int64_t npix) {
 // thread = (pixel lane, 8-channel group); per-thread sums, then an LDS tree over the pixel lanes.
 __global__ __launch_bounds__(256) void bn_stats_kernel(View x, float* __restrict__ partial) {
     constexpr int BN_U = 4;
-    __shared__ float red[256 * 16];
+    __shared__ float red[256 * 8];          // (8 KB: the two sums go through it one after the other, see bn_bwd_reduce_kernel)
     const int CG = (x.C + 7) / 8;           // <= 256 (C <= 2048)
     const int PL = bn_pl(CG, x.row);
     const int tid = threadIdx.x;
@@ -167,16 +167,19 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(View x, float* __restrict
             }
         }
     }
+    // one thread per channel: add over the pixel lanes in a fixed order (sum, then sum of squares)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { red[tid * 16 + i] = s[i]; red[tid * 16 + 8 + i] = q[i]; }
-    __syncthreads();
-    // one thread per (channel, sum|sq): add over the pixel lanes in a fixed order
-    for (int o = tid; o < 2 * x.C; o += 256) {
-        const int which = o / x.C, c = o - which * x.C;
-        const int g = c >> 3, e = c & 7;
-        float acc = 0.f;
-        for (int l = 0; l < PL; ++l) acc += red[(l * CG + g) * 16 + which * 8 + e];
-        partial[((size_t)which * x.C + c) * gridDim.x + blockIdx.x] = acc;       // [2][C][blocks]
+    for (int which = 0; which < 2; ++which) {
+        if (which) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[tid * 8 + i] = which ? q[i] : s[i];
+        __syncthreads();
+        for (int c = tid; c < x.C; c += 256) {
+            const int g = c >> 3, e = c & 7;
+            float acc = 0.f;
+            for (int l = 0; l < PL; ++l) acc += red[(l * CG + g) * 8 + e];
+            partial[((size_t)which * x.C + c) * gridDim.x + blockIdx.x] = acc;       // [2][C][blocks]
+        }
     }
 }
 
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(View dy, View x, con
                                                             const float* __restrict__ slope_p,
                                                             float* __restrict__ partial) {
     constexpr int BN_U = SOS_BN_RED_U;
-    __shared__ float red[256 * 24];
+    __shared__ float red[256 * 8];
     const int CG = (x.C + 7) / 8;
     const int PL = SOS_BN_BWD_ALIGNED ? bn_pl(CG, x.row) : 256 / CG;      // pixel lanes spanning whole 128-byte lines (see bn_pl)
     const int tid = threadIdx.x;
@@ -421,15 +424,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(View dy, View x, con
             }
         }
     }
+    // Fixed-order sum over the pixel lanes, ONE of the three sums at a time through an 8 KB buffer (round 5; rounds 1-4 held all
+    // three at once in 24 KB).  Same order of additions, bit-identical partials -- but a workgroup now fits beside two resident
+    // workgroups of the 96-channel conv kernel (2 x 72.6 KB of a CU's 160 KB leave 18 KB): under the concurrent training schedule
+    // this pass sat at 32.7 ms of kernel time per step against 12.3 ms alone, waiting for LDS that the other streams' MFMA
+    // workgroups held (profiles/r05_steady_families.md of the first refresh); bn_stats (16 KB) and the apply passes (0) always fitted.
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { red[tid * 24 + i] = s1[i]; red[tid * 24 + 8 + i] = s2[i]; red[tid * 24 + 16 + i] = s3[i]; }
-    __syncthreads();
-    for (int o = tid; o < 3 * x.C; o += 256) {
-        const int which = o / x.C, c = o - which * x.C;
-        const int g = c >> 3, e = c & 7;
-        float acc = 0.f;
-        for (int l = 0; l < PL; ++l) acc += red[(l * CG + g) * 24 + which * 8 + e];
-        partial[((size_t)which * x.C + c) * gridDim.x + blockIdx.x] = acc;      // [3][C][blocks]: the finalize reads a channel's row contiguously
+    for (int which = 0; which < 3; ++which) {
+        if (which) __syncthreads();
+        if (RELU_ONLY && which == 2) {
+            for (int c = tid; c < x.C; c += 256) partial[((size_t)2 * x.C + c) * gridDim.x + blockIdx.x] = 0.f;
+            break;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[tid * 8 + i] = which == 0 ? s1[i] : (which == 1 ? s2[i] : s3[i]);
+        __syncthreads();
+        for (int c = tid; c < x.C; c += 256) {
+            const int g = c >> 3, e = c & 7;
+            float acc = 0.f;
+            for (int l = 0; l < PL; ++l) acc += red[(l * CG + g) * 8 + e];
+            partial[((size_t)which * x.C + c) * gridDim.x + blockIdx.x] = acc;      // [3][C][blocks]: the finalize reads a channel's row contiguously
+        }
     }
 }
 

@@ -461,14 +461,18 @@ class JointModel(nn.Module):
     # bench.py's serial pre-pass that times the dominant kernel alone on the chip).
     BRANCH_STREAMS = __import__("os").environ.get("SOS_BRANCH_STREAMS", "1") != "0"
 
+    _SIDE_STREAMS = {}      # (device, calling stream) -> its branch stream: one per calling stream for the life of the process, shared
+                            # by every JointModel (HIP has 4 hardware queues: streams are not free, see agent._job_stream)
+
     def _side_stream(self, dev):
         if not self.BRANCH_STREAMS or torch.cuda.is_current_stream_capturing():
             return None
         cur = torch.cuda.current_stream(dev)
         key = (dev.index, cur.cuda_stream)
-        ss = self.__dict__.setdefault("_side_streams", {})
+        ss = JointModel._SIDE_STREAMS
         if key not in ss:
             ss[key] = torch.cuda.Stream(device=dev)
+        self.__dict__["_used_side_stream"] = True
         return ss[key]
 
     def _forward_train(self, x, n):

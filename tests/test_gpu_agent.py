@@ -129,7 +129,7 @@ def test_train_concurrent_matches_serial(branch, monkeypatch):
         monkeypatch.setattr(jnet.JointModel, "BRANCH_STREAMS", branch)
         agent.train_concurrent([(j2, bj), (d2, bd)])
     torch.cuda.synchronize()
-    assert bool(j2.net.__dict__.get("_side_streams")) == branch
+    assert bool(j2.net.__dict__.get("_used_side_stream")) == branch
     for a, b in ((d1, d2), (j1, j2)):
         for (k, p), (_, q) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
             assert torch.equal(p, q), k

@@ -5,7 +5,7 @@
 #   rocprofv3 --kernel-trace --stats summaries of the train / infer / ragged benches,
 #   the HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs) of the dominant conv kernel,
 #   the micro-benchmarks.  Every process loads the shipped tiling table: nothing is tuned here.
-R=${1:-r04}
+R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/refresh; mkdir -p $O
 python tools/conv_bench.py > $O/conv_bench.txt 2>&1
@@ -14,7 +14,9 @@ python tools/lstm_bench.py > $O/lstm_bench.txt 2>&1
 python tools/bn_bench.py > $O/bn_bench.txt 2>&1
 python tools/frontend_bench.py > $O/frontend_bench.txt 2>&1
 rm -f $O/launch_train.log
-SOS_LAUNCH_LOG=$O/launch_train.log rocprofv3 --kernel-trace --stats -d $O/prof_train -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $O/prof_train.log 2>&1
+# (--serial: every kernel alone on the chip, like the serial pre-pass bench.py takes roofline.avg_ms in -- the per-signature averages of
+# this trace are the ones to compare with the bench line; the concurrent schedule is profiled by steady_families.sh below)
+SOS_LAUNCH_LOG=$O/launch_train.log rocprofv3 --kernel-trace --stats -d $O/prof_train -o t -- python bench.py --serial --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $O/prof_train.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_infer -o t -- python bench.py --mode infer --steps 5 --warmup 1 --no-cpu-baseline --no-secondary > $O/prof_infer.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_ragged -o t -- python bench.py --mode infer-ragged --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $O/prof_ragged.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
