@@ -92,6 +92,129 @@ __global__ __launch_bounds__(WAVES * 64) void probe(const char* __restrict__ wgt
     if (sum == 12345.678f) out[blockIdx.x * blockDim.x + tid] = sum;
 }
 
+// RING: three slab buffers packed tightly (96 rows x 7 pieces = 10 752 B each), the DMA of tap t + 2 issued at the start of tap t, and NO
+// workgroup-wide barrier inside the tap loop: every wave publishes two monotonic counters in LDS -- landed[w] = taps whose share of the
+// slab DMA wave w has seen land, done[w] = taps wave w has finished reading -- and checks the minimum over the four waves before it
+// reads a slab (all shares landed) and before it overwrites one (everybody is done with the tap that used it).  A wave may run one
+// whole tap ahead of the slowest one; with a barrier it may not run ahead at all.
+constexpr int SLABT = 96 * 7 * 16;                  // 10 752 B
+template <int DMA>
+__global__ __launch_bounds__(256) void probe_ring(const char* __restrict__ wgt, const char* __restrict__ act, unsigned act_bytes,
+                                                  const uint4* __restrict__ fill, float* out, int tiles_per_wg) {
+    constexpr int TW = 16, PW = 20, NPIX = 400, PATCH = NPIX * PSTRIDE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < (PATCH + 3 * SLABT) / 16; i += 256) ((uint4*)smem)[i] = fill[(i + blockIdx.x * 7) % 4096];
+    volatile int* flags = (volatile int*)(smem + PATCH + 3 * SLABT);      // landed[4], done[4]
+    if (tid < 8) flags[tid] = 0;
+    __syncthreads();
+    const char* patch = smem;
+    char* slab = smem + PATCH;
+    int abase[2];
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = wave * 64 + mt * 32 + l31, i = m / TW, j = m % TW;
+        abase[mt] = (i * PW + j) * PSTRIDE + lhi * 16;
+    }
+    const int boff = l31 * PSTRIDE + lhi * 16;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wgt, 0, (unsigned)(CHUNKS * TAPS * SLAB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)act, 0, act_bytes, 0x00020000);
+    // 11 DMA instructions per slab (the last one half full): wave w issues instructions w, w + 4, w + 8
+    const int nshare = wave < 3 ? 3 : 2;
+    auto dma_slab = [&](const int buf, const int ct) {
+        for (int i = wave; i < WINSTR; i += 4)
+            if (i * 1024 + lane * 16 < SLABT)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(slab + buf * SLABT + i * 1024), 16, (unsigned)(lane * 16),
+                                                         (unsigned)(ct * SLAB + i * 1024), 0, 0);
+    };
+    auto wait_min = [&](const int base, const int want) {          // spin until min(flags[base .. base + 3]) >= want
+        for (;;) {
+            const int f0 = flags[base], f1 = flags[base + 1], f2 = flags[base + 2], f3 = flags[base + 3];
+            if (min(min(f0, f1), min(f2, f3)) >= want) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    float sum = 0.f;
+    int g0 = 0;                                         // global tap counter of this workgroup (monotonic over chunks and tiles)
+    for (int t = 0; t < tiles_per_wg; ++t) {
+        f16v acc[2][3];
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        const unsigned tile_off = (unsigned)(((blockIdx.x * tiles_per_wg + t) * 2) % 4000) * 65536u;
+        for (int cc = 0; cc < CHUNKS; ++cc, g0 += TAPS) {
+            __syncthreads();                            // everybody is done with the previous chunk's patch and slabs
+            if constexpr (DMA >= 2) {
+                constexpr int PINSTR = (PATCH + 1023) / 1024;
+                for (int i = wave; i < PINSTR; i += 4)
+                    if (i * 1024 + lane * 16 < PATCH)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(smem + i * 1024), 16, (unsigned)(lane * 16),
+                                                                 tile_off + (unsigned)(cc * 65536 / 2 + i * 1024), 0, 0);
+            }
+            if constexpr (DMA >= 1) { dma_slab(g0 % 3, cc * TAPS); dma_slab((g0 + 1) % 3, cc * TAPS + 1); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) { flags[wave] = g0 + 2; flags[4 + wave] = g0; }
+            __syncthreads();
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int g = g0 + tap;
+                if constexpr (DMA >= 1) {
+                    if (tap >= 2) {
+                        // my share of slab g (issued during tap g - 2) has landed when at most the share of slab g + 1 is outstanding
+                        if (tap + 1 < TAPS) { if (nshare == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) flags[wave] = g + 1;
+                        wait_min(0, g + 1);             // every wave's share of slab g has landed
+                    }
+                    if (tap + 2 < TAPS) {
+                        if (tap >= 1) wait_min(4, g);   // every wave has finished tap g - 1: its buffer may be overwritten
+                        dma_slab((g + 2) % 3, cc * TAPS + tap + 2);
+                    }
+                }
+                const int toff = ((tap / 5) * PW + tap % 5) * PSTRIDE;
+                const char* bp = slab + (g % 3) * SLABT + boff;
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    h8 w[3], x[2];
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) w[nt] = lds_frag(bp + nt * 32 * PSTRIDE + kk * 32);
+                    x[0] = lds_frag(patch + abase[0] + toff + kk * 32);
+                    x[1] = lds_frag(patch + abase[1] + toff + kk * 32);
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) {
+                        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[nt], x[0], acc[0][nt], 0, 0, 0);
+                        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[nt], x[1], acc[1][nt], 0, 0, 0);
+                    }
+                }
+                if constexpr (DMA >= 1) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my fragment reads of this tap are done
+                    if (lane == 0) flags[4 + wave] = g + 1;
+                }
+            }
+        }
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) sum += acc[a][b][0] + acc[a][b][7];
+    }
+    if (sum == 12345.678f) out[blockIdx.x * blockDim.x + tid] = sum;
+}
+
+template <int DMA>
+static void run_ring(const char* name, const char* w, const char* act, unsigned act_bytes, const uint4* fill, float* out) {
+    const int lds = 400 * PSTRIDE + 3 * SLABT + 64;
+    hipFuncSetAttribute((const void*)probe_ring<DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int nwg = 512, tiles = 12288 / nwg;
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((probe_ring<DMA>), dim3(nwg), dim3(256), lds, 0, w, act, act_bytes, fill, out, tiles);
+    hipDeviceSynchronize();
+    hipEvent_t s, e;
+    hipEventCreate(&s); hipEventCreate(&e);
+    const int iters = 10;
+    hipEventRecord(s);
+    for (int rep = 0; rep < iters; ++rep) hipLaunchKernelGGL((probe_ring<DMA>), dim3(nwg), dim3(256), lds, 0, w, act, act_bytes, fill, out, tiles);
+    hipEventRecord(e);
+    hipEventSynchronize(e);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, s, e);
+    ms /= iters;
+    const double flops = 2.0 * 12288.0 * 256 * 96 * 96 * 25;
+    printf("%-58s 2 WG/CU LDS %3d KB  %7.3f ms  %.3f of 2.5 PF\n", name, lds / 1024, ms, flops / ms / 1e9 / 2500.0);
+}
+
 template <int WAVES, int DMA>
 static void run(const char* name, const char* w, const char* act, unsigned act_bytes, const uint4* fill, float* out, int wgs_per_cu) {
     constexpr int TW = WAVES == 4 ? 16 : 32, NPIX = 20 * (TW + 4);
@@ -131,6 +254,8 @@ int main() {
     run<4, 0>("4 waves / 256 px, static slabs (barrier only)", dw, da, (unsigned)abytes, dfill, dout, 2);
     run<4, 1>("4 waves / 256 px, + weight-slab DMA", dw, da, (unsigned)abytes, dfill, dout, 2);
     run<4, 2>("4 waves / 256 px, + weight-slab and patch DMA", dw, da, (unsigned)abytes, dfill, dout, 2);
+    run_ring<1>("4 waves / 256 px, RING of 3 slabs, flag sync, slab DMA", dw, da, (unsigned)abytes, dfill, dout);
+    run_ring<2>("4 waves / 256 px, RING of 3 slabs, flag sync, slab+patch DMA", dw, da, (unsigned)abytes, dfill, dout);
     run<8, 0>("8 waves / 512 px, static slabs (barrier only)", dw, da, (unsigned)abytes, dfill, dout, 1);
     run<8, 1>("8 waves / 512 px, + weight-slab DMA", dw, da, (unsigned)abytes, dfill, dout, 1);
     run<8, 2>("8 waves / 512 px, + weight-slab and patch DMA", dw, da, (unsigned)abytes, dfill, dout, 1);
