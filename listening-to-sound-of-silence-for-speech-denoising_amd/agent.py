@@ -502,8 +502,6 @@ def train_concurrent(jobs):
     mode = os.environ.get("SOS_STREAM_OVERLAP", "split")
     for k, (ag, data) in enumerate(jobs):
         prio = -1 if (k == 0 and os.environ.get("SOS_STREAM_PRIO") == "1") else 0     # A/B: big model on a high-priority stream
-        if k > 0 and os.environ.get("SOS_DET_PRIO") == "1":                           # A/B: the small model(s) on high-priority streams
-            prio = -1
         ag.stream = _job_stream(ag.device, k, prio)
         ag.stream.wait_stream(cur)
         net = getattr(ag, "net", None)

@@ -471,7 +471,7 @@ class JointModel(nn.Module):
         key = (dev.index, cur.cuda_stream)
         ss = JointModel._SIDE_STREAMS
         if key not in ss:
-            ss[key] = torch.cuda.Stream(device=dev, priority=-1 if __import__("os").environ.get("SOS_SIDE_PRIO") == "1" else 0)      # (A/B switch)
+            ss[key] = torch.cuda.Stream(device=dev)
         self.__dict__["_used_side_stream"] = True
         return ss[key]
 

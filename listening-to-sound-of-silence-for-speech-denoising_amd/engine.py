@@ -696,46 +696,11 @@ def view(act, c_off=0, C=None, third_index=None):
     return v
 
 
-# ---- high-priority companion stream for the HBM-bound BatchNorm passes (round 5 experiment, SOS_BW_PRIO=1, default off).
-# profiles/r05_stream_timeline.txt: under the three-stream schedule the side branch's bn_bwd_reduce launches take ~10x their
-# stand-alone time -- the other stream's MFMA kernel always has workgroups pending and wins the dispatch.  With SOS_BW_PRIO=1 every
-# chain enqueues its BatchNorm passes on a HIGH-PRIORITY companion stream, ordered against the chain by events (same execution order
-# per chain, bit-identical results), so that their workgroups are dispatched ahead of pending MFMA workgroups.
-BW_PRIO = _os.environ.get("SOS_BW_PRIO", "0") == "1"
-_bw_streams = {}
-
-
-class bw_scope:
-    def __enter__(self):
-        self.ctx = None
-        if BW_PRIO and not torch.cuda.is_current_stream_capturing():
-            self.cur = torch.cuda.current_stream()
-            key = (self.cur.device.index, self.cur.cuda_stream)
-            self.bw = _bw_streams.get(key)
-            if self.bw is None:
-                self.bw = _bw_streams[key] = torch.cuda.Stream(device=self.cur.device, priority=-1)
-            self.bw.wait_stream(self.cur)
-            self.ctx = torch.cuda.stream(self.bw)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-            self.cur.wait_stream(self.bw)
-        return False
-
-
 def bn_train(raw, c_off, Cn, bn, act, slope, dst, dst_c_off=0, feat=None, stats=None):
     """Training-mode BatchNorm (+activation) of the raw conv output `raw[:, c_off:c_off+C]`:
     stats -> finalize (updates bn.running_* in place like torch) -> apply into `dst`.
     `stats` = (partial, tiles) from the producing conv's fused statistics (engine.conv(stats_c=...)) skips the
     separate statistics pass.  Returns the saved tensors for backward."""
-    with bw_scope():
-        return _bn_train(raw, c_off, Cn, bn, act, slope, dst, dst_c_off, feat, stats)
-
-
-def _bn_train(raw, c_off, Cn, bn, act, slope, dst, dst_c_off, feat, stats):
     dev = raw.t.device
     xv = view(raw, c_off, Cn)
     if stats is not None:

@@ -55,11 +55,6 @@ def pack_grad(g, y, act, outer, inner, C, so, st, sc, dst, c_off=0, scaled=False
 def bn_bwd(dy, dy_off, raw, raw_off, C, saved, gamma, act, slope, dx, dx_off=0):
     """Backward of BatchNorm(train)+activation (or bias+activation when saved has no mean).
     Returns (dgamma, dbeta, dslope)."""
-    with E.bw_scope():          # (SOS_BW_PRIO: the two HBM-bound passes on the chain's high-priority companion stream)
-        return _bn_bwd(dy, dy_off, raw, raw_off, C, saved, gamma, act, slope, dx, dx_off)
-
-
-def _bn_bwd(dy, dy_off, raw, raw_off, C, saved, gamma, act, slope, dx, dx_off):
     dev = raw.t.device
     dyv, xv, dxv = E.view(dy, dy_off, C), E.view(raw, raw_off, C), E.view(dx, dx_off, C)
     nblk = L.lib().sos_bn_stats_blocks(xv.npix)
