@@ -1,13 +1,7 @@
 #!/bin/bash
 # The ONE metered-GPU batch script (rewritten per call; replaces round 4's tools/gpu/g*.sh):  gpurun -- bash tools/gpu_job.sh
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/j25; mkdir -p $O
-run() { env $1 python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-secondary $2 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.readline()); print(round(d['value'], 1), 'utt/s', '[$1] [$2]')"; }
-for i in 1 2 3; do
-run "SOS_DUMMY=0" "" >> $O/q.txt
-run "SOS_BW_PRIO=1" "" >> $O/q.txt
-run "SOS_SIDE_PRIO=1" "" >> $O/q.txt
-run "SOS_DET_PRIO=1" "" >> $O/q.txt
-run "SOS_SIDE_PRIO=1 SOS_DET_PRIO=1" "" >> $O/q.txt
-done
-cat $O/q.txt
+O=gpurun_out/j26; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_train_ops.py tests/test_gpu_train_nets.py tests/test_gpu_agent.py tests/test_gpu_determinism.py tests/test_audiovisual.py -m gpu -q -x > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+python tools/bn_bench.py 2>&1 | grep -v amdgpu > $O/bn.txt; BN_C=48 python tools/bn_bench.py 2>&1 | grep -v amdgpu >> $O/bn.txt; cat $O/bn.txt
+bash tools/probe/ab_bench.sh 3 > $O/ab.txt 2>&1; tail -7 $O/ab.txt
