@@ -335,6 +335,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="infer / infer-ragged: replay hipGraph-captured launch sequences (pipeline.GraphedDenoiser) instead "
                          "of eager launches")
+    ap.add_argument("--train-detector", type=int, default=0,
+                    help="inference modes: train the detector for this many Adam steps on synthetic batches first (trained-like logits: "
+                         "what the two-pass detector's re-run fraction depends on)")
     ap.add_argument("--force-buckets", action="store_true",
                     help="world of one: run the data-parallel gradient path anyway (bucket copies + RCCL all-reduce of every "
                          "bucket on a 1-rank group) to measure its overhead on a single GPU")
@@ -391,7 +394,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    wl = Workload(args.mode, args.precision, B, rank, serial=args.serial, graph=args.graph)
+    wl = Workload(args.mode, args.precision, B, rank, serial=args.serial, graph=args.graph, train_detector=args.train_detector)
     dt, dom, prof = run_timed(wl, args.steps, args.warmup, barrier)
     if dist is not None:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)

@@ -292,18 +292,37 @@ class ContextAggNet(nn.Module):
                     fc0=CN.linear_plan(self.fc[0], 400, x3), fc2=CN.linear_plan(self.fc[2], E.pad_to(600, 16), x3),
                     fc4=CN.linear_plan(self.fc[4], E.pad_to(600, 16), x3))
 
-    def run(self, plan, x, n, x3, rag=None):
+    def start_x(self, plan, x, x3, rag, side):
+        """encoder_x of forward(x, n) -- the half of stage 2 that does not depend on n (M2/networks.py:84) -- enqueued on `side`
+        ahead of the rest; returns the handle run(..., started=) takes."""
+        B, _, F, T = x.shape
+        nseg = 3 if x3 else 1
+        nfeat = 12 * F
+        feat = (torch.empty if rag is None else torch.zeros)((B, T, nseg * nfeat), dtype=E.act_dtype(), device=x.device)
+        cur = torch.cuda.current_stream(x.device)
+        side.wait_stream(cur)                     # the input, the packed weights and `feat` exist
+        with torch.cuda.stream(side):
+            CN.run_encoder(plan["enc_x"], CN.pack_encoder_input(plan["enc_x"], x, x3, rag), feat, nseg * nfeat, nfeat, 0, x3, rag=rag)
+        return dict(feat=feat, side=side, x=x, x3=x3)
+
+    def run(self, plan, x, n, x3, rag=None, started=None):
         """forward(x, n) of M2/networks.py:82-94 -> sigmoid mask f32 (B,2,F,T).  rag: engine.Ragged of a variable-length
-        batch."""
+        batch.  started: handle of start_x() for this very x (encoder_x is already running on a side stream: joined before the
+        BiLSTM)."""
         dev = x.device
         B, _, F, T = x.shape
         nseg = 3 if x3 else 1
         nfeat = 12 * F
-        # ragged: rows of frames past a clip's end stay zero (finite) -- the FC head runs over all rows
-        feat = (torch.empty if rag is None else torch.zeros)((B, T, nseg * nfeat), dtype=E.act_dtype(), device=dev)
         lengths = rag.level(0) if rag is not None else None
-        CN.run_encoder(plan["enc_x"], CN.pack_encoder_input(plan["enc_x"], x, x3, rag), feat, nseg * nfeat, nfeat, 0, x3, rag=rag)
+        if started is not None:
+            feat = started["feat"]
+        else:
+            # ragged: rows of frames past a clip's end stay zero (finite) -- the FC head runs over all rows
+            feat = (torch.empty if rag is None else torch.zeros)((B, T, nseg * nfeat), dtype=E.act_dtype(), device=dev)
+            CN.run_encoder(plan["enc_x"], CN.pack_encoder_input(plan["enc_x"], x, x3, rag), feat, nseg * nfeat, nfeat, 0, x3, rag=rag)
         CN.run_encoder(plan["enc_n"], CN.pack_encoder_input(plan["enc_n"], n, x3, rag), feat, nseg * nfeat, nfeat, 8, x3, rag=rag)
+        if started is not None:
+            torch.cuda.current_stream(dev).wait_stream(started["side"])      # join: the feature matrix is complete
         h = CN.run_lstm(plan["lstm"], (feat, B, 1, T, nfeat, nseg), B, T, x3, dev, lengths=lengths)
         f0, f2, f4 = plan["fc0"], plan["fc2"], plan["fc4"]
         a0 = E.Act(B, 1, T, E.pad_to(600, 16), x3, dev)
@@ -518,7 +537,22 @@ class JointModel(nn.Module):
             self.stage2.backward(plan["s2"], tape["t2"], g_out, grads, x3, side=side, tail=stage1_tail, before_join=hook)
         return grads
 
-    def forward(self, x, n, rag=None):
+    @torch.no_grad()
+    def begin_x(self, x, rag=None):
+        """Eval only: start encoder_x(x) -- the part of forward(x, n) that does not need n -- on this model's branch stream and
+        return a handle for forward(x, n, started=handle).  The pipeline calls it between the two passes of the `mixed` detector
+        so that the parity pass over a handful of marked clips (a batch too small to fill the chip) runs under encoder_x's
+        chip-filling convolutions.  Returns None when it cannot (training mode, inside a stream capture, branch streams off)."""
+        if self.training or x.dim() != 4:
+            return None
+        side = self._side_stream(x.device)
+        if side is None:
+            return None
+        plan = self._cache.get(self, self._build_plan)
+        x = x.contiguous().float()
+        return self.stage2.start_x(plan["s2"], x, plan["x3"], rag, side)
+
+    def forward(self, x, n, rag=None, started=None):
         """rag (eval only): engine.Ragged with the clips' own frame counts of a variable-length batch; x, n are then
         (B,2,F,max T) and only the first rag.T[b] columns of clip b's outputs are valid -- each clip computed exactly as
         if it were run alone at its own length (M2/predict.py:405-412 runs one file at a time)."""
@@ -533,6 +567,8 @@ class JointModel(nn.Module):
         x3 = plan["x3"]
         x = x.contiguous().float()
         n = n.contiguous().float()
+        if started is not None and (started["x"].data_ptr() != x.data_ptr() or started["x3"] != x3):
+            raise ValueError("forward(started=): the handle belongs to another input or precision mode")
         n_pred = self.stage1.run(plan["s1"], n, x, x3, rag)
-        out = self.stage2.run(plan["s2"], x, n_pred, x3, rag)
+        out = self.stage2.run(plan["s2"], x, n_pred, x3, rag, started=started)
         return n_pred, out

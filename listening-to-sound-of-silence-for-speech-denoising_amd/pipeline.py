@@ -37,15 +37,18 @@ TWO_PASS_BAND = 3 * 3e-3
 _fixed_rag = {}
 
 
-def detect(detector, S_mixed, n_frames, rag=None, return_mark=False):
+def detect(detector, S_mixed, n_frames, rag=None, return_mark=False, between=None):
     """Detector logits (B, n_frames) for the pipeline: the two-pass scheme above under set_precision('mixed'), one plain call
-    otherwise.  rag: engine.Ragged of a variable-length batch."""
+    otherwise.  rag: engine.Ragged of a variable-length batch.  between: optional callable run between the two passes (the
+    pipeline starts the denoiser's encoder_x there: the second pass -- a few clips, or none -- cannot fill the chip)."""
     from . import engine as E
     if get_mode() != "mixed" or not TWO_PASS or getattr(detector, "video_feat", 0):
         lo = detector(s=S_mixed, v_num_frames=n_frames, rag=rag)
         return (lo, None) if return_mark else lo
     with precision_scope("fp16"):
         lo16 = detector(s=S_mixed, v_num_frames=n_frames, rag=rag)
+    if between is not None:
+        between()
     base = rag
     if base is None:                                  # fixed-length batch: every clip has the same geometry (cached tables)
         B, T = S_mixed.shape[0], S_mixed.shape[3]
@@ -58,6 +61,16 @@ def detect(detector, S_mixed, n_frames, rag=None, return_mark=False):
     lo3 = detector(s=S_mixed, v_num_frames=n_frames, rag=mrag)
     lo = torch.where(mark[:, None] != 0, lo3, lo16)
     return (lo, mark) if return_mark else lo
+
+
+OVERLAP_X = os.environ.get("SOS_MIXED_OVERLAP_X", "1") != "0"      # A/B: encoder_x of the denoiser under the detector's second pass
+
+
+def _begin_x(denoiser, S_mixed, rag=None):
+    """Start the denoiser's encoder_x on its branch stream if the model offers it (denoiser.networks.JointModel.begin_x)."""
+    if not OVERLAP_X or not hasattr(denoiser, "begin_x"):
+        return None
+    return denoiser.begin_x(S_mixed, rag)
 
 
 def two_pass_stats(device=None, reset=False):
@@ -77,12 +90,14 @@ def denoise(detector, denoiser, mixed, sr=SR, fps=FPS, bits=None, return_all=Fal
     B, N = mixed.shape
     S_mixed = transform.stft_batch(mixed)
     logits = mark = None
+    started = []
     if bits is None:
-        logits, mark = detect(detector, S_mixed, n_video_frames(N, sr, fps), return_mark=True)
+        logits, mark = detect(detector, S_mixed, n_video_frames(N, sr, fps), return_mark=True,
+                              between=lambda: started.append(_begin_x(denoiser, S_mixed)))
         bits, _ = tools.threshold_bits(logits, SIGMOID_THRESHOLD)
     mask, noise_sig = tools.bits_to_mask_batch(bits, float(sr) / fps, N, mixed)
     S_noise = transform.stft_batch(noise_sig)
-    n_pred, crm = denoiser(S_mixed, S_noise)
+    n_pred, crm = denoiser(S_mixed, S_noise, **({"started": started[0]} if started and started[0] is not None else {}))
     S_out = transform.batch_fast_icRM_sigmoid(S_mixed, crm)
     out = transform.istft_batch(S_out)
     if return_all:
@@ -112,11 +127,12 @@ def _denoise_group_padded(detector, denoiser, wave, rag, sr, fps):
     ns, nv = rag.n_samples, rag.n_vframes
     t_ns, t_nv = rag.tab(ns), rag.tab(nv)
     S_mixed = transform.stft_batch(wave, clip_samples=t_ns)
-    logits = detect(detector, S_mixed, max(nv), rag=rag)
+    started = []
+    logits = detect(detector, S_mixed, max(nv), rag=rag, between=lambda: started.append(_begin_x(denoiser, S_mixed, rag)))
     bits, _ = tools.threshold_bits(logits, SIGMOID_THRESHOLD)
     mask, noise_sig = tools.bits_to_mask_batch(bits, float(sr) / fps, wave.shape[1], wave, clip_frames=t_nv, clip_samples=t_ns)
     S_noise = transform.stft_batch(noise_sig, clip_samples=t_ns)
-    n_pred, crm = denoiser(S_mixed, S_noise, rag=rag)
+    n_pred, crm = denoiser(S_mixed, S_noise, rag=rag, **({"started": started[0]} if started and started[0] is not None else {}))
     S_out = transform.batch_fast_icRM_sigmoid(S_mixed, crm)
     return transform.istft_batch(S_out, clip_frames=rag.level(0)), logits, bits
 
