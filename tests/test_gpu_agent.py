@@ -478,3 +478,35 @@ def test_backward_after_an_optimizer_step_is_refused():
     ag.train_func(batch)                       # forward + backward + Adam: the weights move on
     with pytest.raises(RuntimeError, match="parameters changed"):
         sum(stale.values()).backward()
+
+
+def test_bucketer_keeps_every_bucket_on_its_producing_stream():
+    """GradBucketer, SOS_DDP_COMM=inline (round 5): gradients produced on two streams (the denoiser's branch streams) never share a
+    bucket -- a bucket is closed when the producing stream changes, and its gather copy is enqueued on the stream that produced it,
+    so no stream ever waits for another one before finalize().  After finalize() every parameter's .grad is the bucket view holding
+    exactly the gradient that was handed in, whatever the stream it came from."""
+    from sos_amd import agent
+    assert agent.GradBucketer.COMM_MODE == "inline"
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    params = [(f"p{i}", torch.nn.Parameter(torch.zeros(1000 + 37 * i, device=dev))) for i in range(12)]
+    b = agent.GradBucketer(params, bucket_bytes=16 * 1024)          # ~4 gradients per bucket
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    grads, order = {}, []
+    cur = torch.cuda.current_stream()
+    for i, (name, p) in enumerate(params):
+        st = s1 if (i // 3) % 2 == 0 else s2                          # the producing stream changes every three gradients
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            g = torch.randn(p.numel(), device=dev) * (i + 1)
+            # keep the producing stream busy behind the gradient: a copy enqueued on ANOTHER stream without a wait would race
+            torch.cuda._sleep(200000)
+            grads[name] = g.clone()
+            b.ready(name, g)
+            order.append(st)
+    # buckets never mix streams: with the stream changing every 3 gradients and ~4 fitting a bucket, there are >= 4 buckets
+    assert len(b.buckets) >= 4
+    b.finalize()
+    torch.cuda.synchronize()
+    for name, p in params:
+        assert p.grad is not None and torch.equal(p.grad.reshape(-1), grads[name]), name
