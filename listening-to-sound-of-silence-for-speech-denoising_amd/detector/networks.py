@@ -145,7 +145,7 @@ class AudioVisualNet(nn.Module):
             TO.video_backward(plan["vid"], tape["vid"], dfeat, nseg * nfeat, nfeat, 8 * F, grads, "encoder_video", B, n, x3)
         return grads
 
-    def forward(self, s, v_num_frames=60, v=None, rag=None):
+    def forward(self, s, v_num_frames=60, v=None, rag=None, before_lstm=None):
         """s (B,2,F,T) -> logits (B, v_num_frames).  Audio-visual variant: v (B,3,Tv,H,W) video frames; the audio
         features are resized to Tv frames (M1/networks.py:138) and v_num_frames is ignored.
         rag (eval only): engine.Ragged with the clips' own STFT frame counts (rag.T) and video-frame counts
@@ -165,10 +165,12 @@ class AudioVisualNet(nn.Module):
         if self.training:
             return _TrainFn.apply(self, s.contiguous().float(), int(v_num_frames),
                                   v.contiguous().float() if v is not None else None, *self.parameters())
+        # before_lstm (eval only): called once the encoder's convolutions are enqueued -- what follows (the recurrence over the
+        # frames on 8 workgroups, the FC head) leaves the chip mostly idle, the pipeline starts the denoiser's encoder_x there
         with precision_scope(detector_precision()):
-            return self._forward_eval(s, int(v_num_frames), v, rag)
+            return self._forward_eval(s, int(v_num_frames), v, rag, before_lstm)
 
-    def _forward_eval(self, s, n, v, rag):
+    def _forward_eval(self, s, n, v, rag, before_lstm=None):
         plan = self._cache.get(self, self._build_plan)
         x3 = plan["x3"]
         dev = s.device
@@ -193,6 +195,8 @@ class AudioVisualNet(nn.Module):
             # frames as a batch of B*Tv images; the video features land next to the audio ones (channel concat)
             frames = E.pack_input(v.float().permute(0, 2, 1, 3, 4).reshape(B * n, 3, v.shape[3], v.shape[4]), x3)
             CN.run_video_branch(plan["vid"], frames, B, n, feat, nseg * nfeat, nfeat, 8 * F, x3)
+        if before_lstm is not None:
+            before_lstm()
         h = CN.run_lstm(plan["lstm"], (feat, B, 1, n, nfeat, nseg), B, n, x3, dev, lengths=lengths)
         f0, f2 = plan["fc0"], plan["fc2"]
         m = E.Act(B, 1, n, E.pad_to(f0["cout"], 16), x3, dev)

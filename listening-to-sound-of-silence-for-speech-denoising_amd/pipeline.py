@@ -42,11 +42,17 @@ def detect(detector, S_mixed, n_frames, rag=None, return_mark=False, between=Non
     otherwise.  rag: engine.Ragged of a variable-length batch.  between: optional callable run between the two passes (the
     pipeline starts the denoiser's encoder_x there: the second pass -- a few clips, or none -- cannot fill the chip)."""
     from . import engine as E
+    # `between` fires where the chip starts to idle: before the (first) pass's BiLSTM if the detector offers the hook
+    # (detector.networks.AudioVisualNet.forward(before_lstm=)), else after the pass
+    hook = {}
+    if between is not None and EARLY_X and "before_lstm" in getattr(getattr(detector.forward, "__code__", None), "co_varnames", ()):
+        hook = dict(before_lstm=between)
+        between = None
     if get_mode() != "mixed" or not TWO_PASS or getattr(detector, "video_feat", 0):
-        lo = detector(s=S_mixed, v_num_frames=n_frames, rag=rag)
+        lo = detector(s=S_mixed, v_num_frames=n_frames, rag=rag, **hook)
         return (lo, None) if return_mark else lo
     with precision_scope("fp16"):
-        lo16 = detector(s=S_mixed, v_num_frames=n_frames, rag=rag)
+        lo16 = detector(s=S_mixed, v_num_frames=n_frames, rag=rag, **hook)
     if between is not None:
         between()
     base = rag
@@ -63,14 +69,19 @@ def detect(detector, S_mixed, n_frames, rag=None, return_mark=False, between=Non
     return (lo, mark) if return_mark else lo
 
 
-OVERLAP_X = os.environ.get("SOS_MIXED_OVERLAP_X", "1") != "0"      # A/B: encoder_x of the denoiser under the detector's second pass
+OVERLAP_X = os.environ.get("SOS_MIXED_OVERLAP_X", "1") != "0"      # A/B: encoder_x of the denoiser under the detector's low-occupancy tail
+EARLY_X = os.environ.get("SOS_EARLY_X", "1") != "0"                # A/B: ... from the detector's BiLSTM on (every mode), not only between the two passes
 
 
 def _begin_x(denoiser, S_mixed, rag=None):
     """Start the denoiser's encoder_x on its branch stream if the model offers it (denoiser.networks.JointModel.begin_x)."""
     if not OVERLAP_X or not hasattr(denoiser, "begin_x"):
         return None
-    return denoiser.begin_x(S_mixed, rag)
+    # (the hook may fire inside the detector's precision scope -- bf16x3 for the one-pass parity detector of 'mixed': the denoiser
+    # runs in the pipeline's own mode)
+    mode = get_mode()
+    with precision_scope("fp16" if mode == "mixed" else mode):
+        return denoiser.begin_x(S_mixed, rag)
 
 
 def two_pass_stats(device=None, reset=False):

@@ -1,5 +1,6 @@
 #!/bin/bash
 # The ONE metered-GPU batch script (rewritten per call; replaces round 4's tools/gpu/g*.sh):  gpurun -- bash tools/gpu_job.sh
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/j28; mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_agent.py -m gpu -q -x -k "bucketer" > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+O=gpurun_out/j30; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
