@@ -149,7 +149,7 @@ def _self_launch(n):
 class Workload:
     """One (mode, precision) line: builds the resident inputs and models, exposes step()."""
 
-    def __init__(self, mode, precision, B, rank, serial=False, graph=False, frames=None, train_detector=0):
+    def __init__(self, mode, precision, B, rank, serial=False, graph=False, frames=None, train_detector=0, pipelined=False):
         import sos_amd
         from sos_amd import agent, pipeline, tools, transform
         from sos_amd.common import MyConfig
@@ -235,6 +235,9 @@ class Workload:
             graphed = pipeline.GraphedDenoiser(det, jm) if graph else None
             self.eager = lambda: pipeline.denoise(det, jm, mixed)
             step = (lambda: graphed(mixed, clone=False)) if graph else self.eager
+            if pipelined and not graph:       # consecutive batches on two alternating streams (pipeline.PipelinedDenoiser)
+                piped = pipeline.PipelinedDenoiser(det, jm)
+                step = lambda: piped(mixed)   # noqa: E731  (the timed region ends with torch.cuda.synchronize(): both streams drained)
         self.step = step
 
     def gflop_per_utt(self):
@@ -335,6 +338,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="infer / infer-ragged: replay hipGraph-captured launch sequences (pipeline.GraphedDenoiser) instead "
                          "of eager launches")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="infer: consecutive batches alternate between two HIP streams (pipeline.PipelinedDenoiser): the latency-bound "
+                         "tail of one batch runs under the head of the next")
     ap.add_argument("--train-detector", type=int, default=0,
                     help="inference modes: train the detector for this many Adam steps on synthetic batches first (trained-like logits: "
                          "what the two-pass detector's re-run fraction depends on)")
@@ -394,7 +400,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    wl = Workload(args.mode, args.precision, B, rank, serial=args.serial, graph=args.graph, train_detector=args.train_detector)
+    wl = Workload(args.mode, args.precision, B, rank, serial=args.serial, graph=args.graph, train_detector=args.train_detector,
+                  pipelined=args.pipelined)
     dt, dom, prof = run_timed(wl, args.steps, args.warmup, barrier)
     if dist is not None:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -476,6 +483,9 @@ def main():
             for key, mode, prec, b, k, w, fr in (("infer_mixed_utt_s", "infer", "mixed", 64, 10, 3, "roofline"),
                                                  ("infer_mixed_trained_detector_utt_s", "infer", "mixed", 64, 10, 3, "trained"),
                                                  ("infer_fp16_utt_s", "infer", "fp16", 64, 10, 3, None),
+                                                 # consecutive batches on two alternating streams (pipeline.PipelinedDenoiser)
+                                                 ("infer_fp16_pipelined_utt_s", "infer", "fp16", 64, 10, 3, "pipelined"),
+                                                 ("infer_mixed_pipelined_utt_s", "infer", "mixed", 64, 10, 3, "pipelined"),
                                                  ("ragged_mixed_clips_s", "infer-ragged", "mixed", 256, 3, 1, None),
                                                  ("ragged_mixed_hipgraph_clips_s", "infer-ragged", "mixed", 256, 3, 1, "graph"),
                                                  ("train_bf16_utt_s", "train", "bf16", 64, 10, 3, None),
@@ -484,7 +494,8 @@ def main():
                                                  ("train_bf16x3_utt_s", "train", "bf16x3", 64, 3, 1, None),
                                                  ("infer_bf16x3_utt_s", "infer", "bf16x3", 64, 3, 1, None)):
                 try:
-                    w2 = Workload(mode, prec, b, rank, graph=fr == "graph", train_detector=60 if fr == "trained" else 0)
+                    w2 = Workload(mode, prec, b, rank, graph=fr == "graph", train_detector=60 if fr == "trained" else 0,
+                                  pipelined=fr == "pipelined")
                     if prec == "mixed" and mode == "infer":
                         w2.pipeline.two_pass_stats(reset=True)
                     dt2, dom2, prof2 = run_timed(w2, k, w, barrier, profile=fr == "roofline")
@@ -613,7 +624,8 @@ def main():
                            "signature bracketed with HIP events in that run; 'mixed' = two-pass detector: fp16 for every clip, bf16x3 again "
                            "for the clips with a logit inside the fp16 error band of the threshold -- *_rerun_fraction; "
                            "infer_mixed_trained_detector = the same with a detector trained for 60 Adam steps on synthetic batches first, "
-                           "random-init logits all sit near the threshold); ragged = BASELINE configs[3], B=256 "
+                           "random-init logits all sit on one side of the threshold: no clip is marked; infer_*_pipelined = consecutive batches alternating between two "
+                           "HIP streams, pipeline.PipelinedDenoiser: one batch's BiLSTM / FC / ISTFT tail under the next one's head); ragged = BASELINE configs[3], B=256 "
                            "U(1 s,10 s) x 3 steps (eager launches / replayed hipGraphs); train_* = the headline workload in another precision x 10 steps "
                            "(bf16x3 = the three-pass parity mode, 3x the MACs, the one mode within 1e-3 of the reference on every tensor: 3 steps, "
                            "also as infer_bf16x3); "

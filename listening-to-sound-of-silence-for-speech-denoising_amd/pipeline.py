@@ -203,6 +203,36 @@ def denoise_ragged(detector, denoiser, clips, sr=SR, fps=FPS, max_batch=256, max
     return (outs, extra) if return_all else outs
 
 
+class PipelinedDenoiser:
+    """Serving loop over CONSECUTIVE batches (M2/predict.py:405-447 denoises file after file): batch i and batch i + 1 alternate
+    between two HIP streams, so that the latency-bound tail of batch i -- the denoiser's BiLSTM on 8 workgroups, the FC head, the mask
+    apply, the ISTFT -- runs under the chip-filling head of batch i + 1 (STFT, the detector's convolutions).  Each call returns
+    (output, event): the output is complete once `event` has been waited for (event.synchronize() on the host, or
+    stream.wait_event(event) on a consumer stream); synchronize() drains both streams.  The batches themselves are computed exactly
+    as by denoise() (same kernels, same order per batch: bit-identical outputs)."""
+
+    def __init__(self, detector, denoiser, sr=SR, fps=FPS):
+        self.detector, self.denoiser, self.sr, self.fps = detector, denoiser, sr, fps
+        self.streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        self.k = 0
+
+    @torch.no_grad()
+    def __call__(self, mixed):
+        st = self.streams[self.k & 1]
+        self.k += 1
+        st.wait_stream(torch.cuda.current_stream())          # the input exists
+        with torch.cuda.stream(st):
+            out = denoise(self.detector, self.denoiser, mixed, self.sr, self.fps)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        mixed.record_stream(st)
+        return out, ev
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+
 class GraphedDenoiser:
     """hipGraph-captured inference chain (BASELINE configs[3]): the whole `denoise` launch sequence (~190 kernels
     for one (batch, length)) is captured once per shape and replayed, so a request costs one graph launch instead

@@ -468,3 +468,29 @@ def test_two_pass_detector_of_the_mixed_mode_equals_the_parity_detector(shift, m
     for a, b in zip(ex1, ex2):
         assert torch.equal(a["bits"], b["bits"])
     assert all(bool(torch.isfinite(y).all()) for y in ys2)
+
+
+def test_pipelined_denoiser_equals_sequential_calls():
+    """pipeline.PipelinedDenoiser: consecutive batches alternate between two HIP streams (the tail of batch i under the head of batch
+    i + 1); every batch's output must equal the plain denoise() call bit for bit, and be complete once its event has been waited for."""
+    from sos_amd import pipeline
+    from sos_amd.common import MyConfig
+    from sos_amd.dataset import synth_batch
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+    det = dnet.get_network(); det.load_state_dict(onet.closed_form_state(onet.detector_spec(), seed=1))
+    jm = jnet.get_network(MyConfig()); jm.load_state_dict(onet.closed_form_state(onet.joint_spec(), seed=2))
+    det, jm = det.cuda().eval(), jm.cuda().eval()
+    batches = [torch.from_numpy(synth_batch(300 + 4 * i, 4, n_samples=14000 + 1580 * i)["mixed"]).cuda() for i in range(5)]
+    sos_amd.set_precision("mixed")
+    try:
+        want = [pipeline.denoise(det, jm, b) for b in batches]
+        torch.cuda.synchronize()
+        piped = pipeline.PipelinedDenoiser(det, jm)
+        got = [piped(b) for b in batches]
+        for (out, ev), ref in zip(got, want):
+            ev.synchronize()
+            assert torch.equal(out, ref)
+        piped.synchronize()
+    finally:
+        sos_amd.set_precision("bf16")
