@@ -758,6 +758,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_kernel(WgParams p) {
 #pragma unroll
     for (int f = 0; f < FT; ++f) {
         const int tap = wave + WG_WAVES * f;
+        if (tap >= taps) continue;                 // (7-tap kernels: the eighth wave multiplied rows below the patch)
 #pragma unroll
         for (int a = 0; a < M16; ++a)
 #pragma unroll
@@ -951,6 +952,118 @@ static int wg_gemm_split(int ntiles, int K, int64_t plane_bytes, int cap) {
     return best;
 }
 
+// ---- 1x1 gradients with FEW channels on one side (the first / last layers of the encoders: 14 -> 48 / 96 with the horizontal
+// taps folded into the channel axis, 48 / 96 -> 4 / 8): no FLOPs to speak of (<= 6 MFMAs per 32 pixels), two tensors to stream.
+// The tiled kernel walks them at 1.6 TB/s (one 256-pixel tile in flight per CU behind a workgroup barrier).  Here every WAVE
+// is its own stream: it owns a contiguous run of pixels, fetches 32 of them at a time -- M16 + N16 sub-images of 16 channels,
+// one 1 KB LDS-DMA instruction each -- into a private ring of NBUF slots (NBUF - 1 stages in flight per wave: four waves x
+// 3 x 7 KB = 84 KB per CU for 96 + 16 channels) and multiplies the slot that has landed with v_mfma_f32_16x16x32 through the
+// same transposing reads as wgrad16_kernel.  No barrier until the four waves' sums are added (fixed order, through LDS) into
+// the workgroup's plane of the [ksplit][1][Mp][Np] buffer that wgrad_reduce_kernel folds.  Pixels past a wave's run lie
+// beyond its buffer resources' range (zeros); channels past M / N read neighbouring channels into rows / columns that are
+// never stored.
+struct WgThinParams {
+    const bf16_t* g; const bf16_t* x; float* partial;
+    int K, g_cs, x_cs, Mp, Np, kper;
+};
+#define WGT_NBUF 4
+
+template <int M16, int N16>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(WgThinParams p) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SUBS = M16 + N16, STAGE = SUBS * 1024;
+    const unsigned sbase = (unsigned)(uintptr_t)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long kbeg = (long long)(blockIdx.x * 4 + wave) * p.kper;
+    const long long kend = kbeg + p.kper < (long long)p.K ? kbeg + p.kper : (long long)p.K;
+    const long long klim = kend > kbeg ? kend : 0;                 // an empty run reads nothing but zeros
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, (unsigned)(klim * p.g_cs * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)(klim * p.x_cs * 2), 0x00020000);
+    // a DMA instruction fills 1 KB = 32 pixels x 32 B: lane l = pixel l >> 1, channels 8 (l & 1) .. + 7 of the sub-image
+    const unsigned lane_g = (unsigned)(((lane >> 1) * p.g_cs + (lane & 1) * 8) * 2);
+    const unsigned lane_x = (unsigned)(((lane >> 1) * p.x_cs + (lane & 1) * 8) * 2);
+    const unsigned wbase = (unsigned)(wave * WGT_NBUF * STAGE);
+    auto issue = [&](const long long k0, const int slot) {
+        const unsigned dst = wbase + (unsigned)(slot * STAGE);
+        const unsigned og = (unsigned)(k0 * p.g_cs * 2), ox = (unsigned)(k0 * p.x_cs * 2);
+#pragma unroll
+        for (int a = 0; a < M16; ++a)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr_t)(smem + dst + a * 1024), 16, lane_g + og + a * 32, 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < N16; ++n)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + dst + (M16 + n) * 1024), 16, lane_x + ox + n * 32, 0, 0, 0);
+    };
+    const int g4 = lane >> 4, s16 = lane & 15;
+    const unsigned rlane = (unsigned)((4 * g4 + (s16 >> 2)) * 32 + (s16 & 3) * 8);     // see wgrad16_kernel: pixel 4 g + e / 16 + 4 g + e
+
+    f32x4 acc[M16][N16];
+#pragma unroll
+    for (int a = 0; a < M16; ++a)
+#pragma unroll
+        for (int n = 0; n < N16; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nst = kend > kbeg ? (int)((kend - kbeg + 31) / 32) : 0;
+#pragma unroll
+    for (int s = 0; s < WGT_NBUF - 1; ++s) issue(kbeg + 32ll * s, s);             // (stages past the run: zeros, never multiplied)
+    int slot = 0;
+    for (int s = 0; s < nst; ++s) {
+        // stage s has landed when only the (NBUF - 2) younger stages' instructions are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WGT_NBUF - 2) * SUBS) : "memory");
+        const unsigned b = sbase + wbase + (unsigned)(slot * STAGE) + rlane;
+        uint2 lo[SUBS], hi[SUBS];
+#pragma unroll
+        for (int i = 0; i < SUBS; ++i) { lo[i] = lds_tr(b + i * 1024); hi[i] = lds_tr(b + i * 1024 + 512); }
+        // every half is named by a wait before anything reads it (the compiler does not know these reads are asynchronous)
+#pragma unroll
+        for (int i = 0; i < SUBS; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[i]), "+v"(hi[i]));
+        u32x4 av[M16], bv[N16];
+#pragma unroll
+        for (int a = 0; a < M16; ++a) av[a] = u32x4{lo[a].x, lo[a].y, hi[a].x, hi[a].y};
+#pragma unroll
+        for (int n = 0; n < N16; ++n) bv[n] = u32x4{lo[M16 + n].x, lo[M16 + n].y, hi[M16 + n].x, hi[M16 + n].y};
+        // the slot that stage s - 1 used is free (its reads were waited for before its MFMAs): stage s + NBUF - 1 goes there
+        issue(kbeg + 32ll * (s + WGT_NBUF - 1), slot == 0 ? WGT_NBUF - 1 : slot - 1);
+#pragma unroll
+        for (int a = 0; a < M16; ++a)
+#pragma unroll
+            for (int n = 0; n < N16; ++n)
+                acc[a][n] = SOS_MFMA_16x16x32(__builtin_bit_cast(bf16x8, av[a]), __builtin_bit_cast(bf16x8, bv[n]), acc[a][n], 0, 0, 0);
+        slot = slot + 1 == WGT_NBUF ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // every wave's ring is idle: the sums go through the same LDS
+    float* red = (float*)smem;                     // [wave][M16 * N16 * 4][64]
+#pragma unroll
+    for (int a = 0; a < M16; ++a)
+#pragma unroll
+        for (int n = 0; n < N16; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * (M16 * N16 * 4) + (a * N16 + n) * 4 + r) * 64 + lane] = acc[a][n][r];
+    __syncthreads();
+    float* out = p.partial + (size_t)blockIdx.x * p.Mp * p.Np;
+    for (int idx = tid; idx < M16 * N16 * 4 * 64; idx += 256) {
+        const int l = idx & 63, q = idx >> 6, r = q & 3, an = q >> 2, a = an / N16, n = an - a * N16;
+        const float v = ((red[(0 * (M16 * N16 * 4) + q) * 64 + l] + red[(1 * (M16 * N16 * 4) + q) * 64 + l]) +
+                         red[(2 * (M16 * N16 * 4) + q) * 64 + l]) + red[(3 * (M16 * N16 * 4) + q) * 64 + l];
+        // D[m][n] of v_mfma_f32_16x16x32: n = lane & 15, m = 4 (lane >> 4) + reg
+        const int m = a * 16 + 4 * (l >> 4) + r, nn = n * 16 + (l & 15);
+        if (m < p.Mp && nn < p.Np) out[(size_t)m * p.Np + nn] = v;
+    }
+#endif
+}
+
+// which 1x1 gradients take the streaming kernel, and with how many workgroups (= partial planes)
+static bool wg_thin_shape(const sos_wgrad_desc* d, bool is_flat, int* m16, int* n16) {
+    if (!is_flat || getenv("SOS_WGRAD_NO_THIN")) return false;
+    const int a = (d->M + 15) / 16, b = (d->N + 15) / 16;
+    if (!((a == 1 && b >= 1 && b <= 6) || (b == 1 && a >= 1 && a <= 6))) return false;
+    if (a == 5 || b == 5) return false;                       // (no instance)
+    *m16 = a; *n16 = b;
+    return true;
+}
+
 // ksplit <= 0 in the descriptor = automatic: one workgroup per CU (MI355X: 256) over (pixel split, m-group, n-group),
 // bounded by 256 MB of partial sums.
 static const int WG_NCU = 256;
@@ -960,6 +1073,17 @@ static int wg_max_split(const sos_wgrad_desc* d) {
     const int64_t per = (int64_t)d->kh * d->kw * Mp * Np * 4;
     const int64_t cap = ((int64_t)256 << 20) / per;
     return (int)(cap < 1 ? 1 : (cap > WG_MAXSPLIT ? WG_MAXSPLIT : cap));
+}
+// workgroups (= partial planes) of wgrad_thin_kernel: one per CU, at least 16 stages per wave
+static int wg_thin_split(const sos_wgrad_desc* d, int subs) {
+    int occ = 1;                                   // measured (48 + 16 channels, 2.9 M pixels): 1 -> 73 us, 2 -> 81, 3 -> 90
+    { const char* e = getenv("SOS_WGT_OCC"); if (e && atoi(e) >= 1 && atoi(e) <= 8) occ = atoi(e); }
+    int n = WG_NCU * occ;
+    const int cap = d->ksplit > 0 ? d->ksplit : wg_max_split(d);
+    if (n > cap) n = cap;
+    const int by_work = d->Wg / (4 * 32 * 16);
+    if (n > by_work) n = by_work;
+    return n < 1 ? 1 : n;
 }
 
 
@@ -995,7 +1119,8 @@ static WgCtx wg_ctx(const sos_wgrad_desc* d, bool temporal, bool is_flat) {
     c.ntiles_m = (d->M + 31) / 32; c.ntiles_n = (d->N + 31) / 32;
     c.m16 = (d->M + 15) / 16; c.n16 = (d->N + 15) / 16;
     // small channel counts: the 16x16x32 kernel owns all of dW in one workgroup (no padding to 32)
-    c.use16 = !temporal && c.ntg == 1 && c.m16 == 3 && c.n16 == 3 && (c.taps == 25 || c.taps == 9) && !getenv("SOS_WGRAD_NO16");
+    c.use16 = !temporal && c.ntg == 1 && c.m16 == 3 && c.n16 == 3 && (c.taps == 25 || c.taps == 9 || (c.taps == 7 && !getenv("SOS_WGRAD_NO16_7"))) &&
+              !getenv("SOS_WGRAD_NO16");      // (7 taps: one per wave, the eighth wave only stages)
     c.Hc = (d->Hg + d->dil_h - 1) / d->dil_h; c.Wc = (d->Wg + d->dil_w - 1) / d->dil_w;
     return c;
 }
@@ -1320,6 +1445,37 @@ static int wgrad_impl(const sos_wgrad_desc* d, sos_stream_t stream, const int wh
                            q.Mp, q.Np, d->dw, d->accumulate, d->scale, d->scale_dev);
         return sos_check_launch("sos_conv2d_wgrad(reduce)");
     }
+    int m16 = 0, n16 = 0;
+    if (wg_thin_shape(d, is_flat, &m16, &n16)) {
+        WgThinParams q;
+        q.g = (const bf16_t*)d->g + d->g_off; q.x = (const bf16_t*)d->x + d->x_off; q.partial = d->partial;
+        q.K = d->Wg; q.g_cs = d->g_cs; q.x_cs = d->x_cs;
+        q.Mp = (d->M + 31) / 32 * 32; q.Np = (d->N + 31) / 32 * 32;
+        const int ksplit = wg_thin_split(d, m16 + n16);
+        q.kper = ((q.K + ksplit * 4 - 1) / (ksplit * 4) + 31) / 32 * 32;
+        const size_t lds = (size_t)4 * WGT_NBUF * (m16 + n16) * 1024;
+        hipStream_t s = (hipStream_t)stream;
+        static sos_device_once thin_once;
+#define SOS_WGT_ALL(F) F(1, 1) F(2, 1) F(3, 1) F(4, 1) F(6, 1) F(1, 2) F(1, 3) F(1, 4) F(1, 6)
+#define SOS_WGT_ATTR(A, B) (void)hipFuncSetAttribute((const void*)wgrad_thin_kernel<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define SOS_WGT_CASE(A, B) if (m16 == A && n16 == B) hipLaunchKernelGGL((wgrad_thin_kernel<A, B>), dim3((unsigned)ksplit), dim3(256), lds, s, q);
+        (void)sos_per_device_once(thin_once, [] { SOS_WGT_ALL(SOS_WGT_ATTR) return (int)SOS_OK; });
+        if (what & 1) {
+            SOS_WGT_ALL(SOS_WGT_CASE)
+            int rc = sos_check_launch("sos_conv2d_wgrad(thin)");
+            if (rc) return rc;
+        }
+#undef SOS_WGT_CASE
+#undef SOS_WGT_ATTR
+#undef SOS_WGT_ALL
+        if (!(what & 2)) return SOS_OK;
+        const long long total = (long long)d->M * d->N;
+        long long gb = (total + 63) / 64;
+        if (gb > 8192) gb = 8192;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, d->partial, ksplit, 1, d->M, d->N,
+                           q.Mp, q.Np, d->dw, d->accumulate, d->scale, d->scale_dev);
+        return sos_check_launch("sos_conv2d_wgrad(reduce)");
+    }
     const WgCtx cx = wg_ctx(d, temporal, is_flat);
     if (cx.taps > WG_WAVES * WG_PAIRS) { sos_set_error("sos_conv2d_wgrad: kernel with %d taps per row not supported", cx.taps); return SOS_ENOSPC; }
     if ((uint64_t)d->Hg * d->Wg * d->g_cs * 2 >= 0xffffff00ull || (uint64_t)d->Hx * d->Wx * d->x_cs * 2 >= 0xffffff00ull) {
@@ -1356,6 +1512,7 @@ extern "C" int sos_wgrad_tune(const sos_wgrad_desc* d, int iters, float* best_ms
     d = &flat;
     if (best_ms) *best_ms = -1.f;
     if (is_flat && d->M >= 128 && d->N >= 128 && !getenv("SOS_WGRAD_NO_GEMM")) return SOS_OK;     // the GEMM path has no plan
+    { int a, b; if (wg_thin_shape(d, is_flat, &a, &b)) return SOS_OK; }                          // nor has the streaming path
     const WgCtx cx = wg_ctx(d, temporal, is_flat);
     if (cx.taps > WG_WAVES * WG_PAIRS) return SOS_OK;
     const WgKey key = wg_key(d, cx);

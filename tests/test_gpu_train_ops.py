@@ -103,6 +103,13 @@ CASES = [
     ("5x5 dil(16,1) 96x64", 96, 64, (5, 5), 1, (16, 1), (32, 2), "zeros", 40, 51),
     ("16: 5x5 dil(16,16) 48x48", 48, 48, (5, 5), 1, (16, 16), (32, 32), "zeros", 64, 45),
     ("16: 5x5 dil(32,32) 48x48", 48, 48, (5, 5), 1, (32, 32), (64, 64), "zeros", 70, 81),
+    # round 5: the streaming kernel of the thin 1x1 gradients (one side <= 16 channels): pixel counts that are not multiples of
+    # the 32-pixel stage, waves with an empty run, several workgroups
+    ("thin 1x1 48x14", 48, 14, (1, 1), 1, (1, 1), (0, 0), "zeros", 37, 50),
+    ("thin 1x1 96x14 long", 96, 14, (1, 1), 1, (1, 1), (0, 0), "zeros", 64, 201),
+    ("thin 1x1 8x96", 8, 96, (1, 1), 1, (1, 1), (0, 0), "zeros", 33, 47),
+    ("thin 1x1 4x48 short", 4, 48, (1, 1), 1, (1, 1), (0, 0), "zeros", 1, 20),
+    ("thin 1x1 64x10", 64, 10, (1, 1), 1, (1, 1), (0, 0), "zeros", 19, 23),
 ]
 
 
