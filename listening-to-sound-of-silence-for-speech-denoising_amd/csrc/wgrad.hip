@@ -1054,6 +1054,105 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(WgThinParams p) {
 #endif
 }
 
+// ---- the same for a THIN INPUT under a kh x 1 kernel (the U-Net's first block with its horizontal taps folded into the channel
+// axis: 10 of 16 stored channels, 5 vertical taps, reflection padding): tap a of pixel (b, h, w) multiplies X at row
+// reflect(h + a dil - pad) of the same column -- one more 1 KB DMA instruction per tap and stage (X is the thin side: 32 B per
+// pixel) whose per-lane source offset follows the lane's row; G is fetched once.  M16 x KH accumulator tiles per wave.
+struct WgThinTapParams {
+    const bf16_t* g; const bf16_t* x; float* partial;
+    int K, H, W, g_cs, x_cs, Mp, Np, kper, dil, pad, reflect;
+};
+
+template <int M16, int KH>
+__global__ __launch_bounds__(256) void wgrad_thin_taps_kernel(WgThinTapParams p) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SUBS = M16 + KH, STAGE = SUBS * 1024;
+    const unsigned sbase = (unsigned)(uintptr_t)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long kbeg = (long long)(blockIdx.x * 4 + wave) * p.kper;
+    const long long kend = kbeg + p.kper < (long long)p.K ? kbeg + p.kper : (long long)p.K;
+    const long long klim = kend > kbeg ? kend : 0;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, (unsigned)(klim * p.g_cs * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)((long long)p.K * p.x_cs * 2), 0x00020000);
+    const unsigned lane_g = (unsigned)(((lane >> 1) * p.g_cs + (lane & 1) * 8) * 2);
+    const unsigned xhalf = (unsigned)((lane & 1) * 16);
+    const unsigned wbase = (unsigned)(wave * WGT_NBUF * STAGE);
+    // this lane's pixel of the NEXT stage to be issued: flat index, row, column (advanced by 32 pixels per stage)
+    long long lk = kbeg + (lane >> 1);
+    int lw = (int)(lk % p.W), lh = (int)((lk / p.W) % p.H);
+    auto issue = [&](const long long k0, const int slot) {
+        const unsigned dst = wbase + (unsigned)(slot * STAGE);
+        const unsigned og = (unsigned)(k0 * p.g_cs * 2);
+#pragma unroll
+        for (int a = 0; a < M16; ++a)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr_t)(smem + dst + a * 1024), 16, lane_g + og + a * 32, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < KH; ++t) {
+            int hh = lh + t * p.dil - p.pad;
+            if (p.reflect) hh = reflect_index(hh, p.H);
+            const bool ok = (unsigned)hh < (unsigned)p.H && lk < kend;
+            const unsigned vo = ok ? (unsigned)((lk + (long long)(hh - lh) * p.W) * p.x_cs * 2) + xhalf : 0xffffffffu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + dst + (M16 + t) * 1024), 16, vo, 0, 0, 0);
+        }
+        lk += 32; lw += 32;
+        while (lw >= p.W) { lw -= p.W; if (++lh == p.H) lh = 0; }
+    };
+    const int g4 = lane >> 4, s16 = lane & 15;
+    const unsigned rlane = (unsigned)((4 * g4 + (s16 >> 2)) * 32 + (s16 & 3) * 8);
+
+    f32x4 acc[KH][M16];
+#pragma unroll
+    for (int t = 0; t < KH; ++t)
+#pragma unroll
+        for (int a = 0; a < M16; ++a) acc[t][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nst = kend > kbeg ? (int)((kend - kbeg + 31) / 32) : 0;
+#pragma unroll
+    for (int s = 0; s < WGT_NBUF - 1; ++s) issue(kbeg + 32ll * s, s);
+    int slot = 0;
+    for (int s = 0; s < nst; ++s) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WGT_NBUF - 2) * SUBS) : "memory");
+        const unsigned b = sbase + wbase + (unsigned)(slot * STAGE) + rlane;
+        uint2 lo[SUBS], hi[SUBS];
+#pragma unroll
+        for (int i = 0; i < SUBS; ++i) { lo[i] = lds_tr(b + i * 1024); hi[i] = lds_tr(b + i * 1024 + 512); }
+#pragma unroll
+        for (int i = 0; i < SUBS; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[i]), "+v"(hi[i]));
+        issue(kbeg + 32ll * (s + WGT_NBUF - 1), slot == 0 ? WGT_NBUF - 1 : slot - 1);
+#pragma unroll
+        for (int t = 0; t < KH; ++t) {
+            const u32x4 bv = u32x4{lo[M16 + t].x, lo[M16 + t].y, hi[M16 + t].x, hi[M16 + t].y};
+#pragma unroll
+            for (int a = 0; a < M16; ++a) {
+                const u32x4 av = u32x4{lo[a].x, lo[a].y, hi[a].x, hi[a].y};
+                acc[t][a] = SOS_MFMA_16x16x32(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[t][a], 0, 0, 0);
+            }
+        }
+        slot = slot + 1 == WGT_NBUF ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* red = (float*)smem;                     // [wave][KH * M16 * 4][64]
+    constexpr int NQ = KH * M16 * 4;
+#pragma unroll
+    for (int t = 0; t < KH; ++t)
+#pragma unroll
+        for (int a = 0; a < M16; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * NQ + (t * M16 + a) * 4 + r) * 64 + lane] = acc[t][a][r];
+    __syncthreads();
+    float* out = p.partial + (size_t)blockIdx.x * KH * p.Mp * p.Np;
+    for (int idx = tid; idx < NQ * 64; idx += 256) {
+        const int l = idx & 63, q = idx >> 6, r = q & 3, ta = q >> 2, t = ta / M16, a = ta - t * M16;
+        const float v = ((red[(0 * NQ + q) * 64 + l] + red[(1 * NQ + q) * 64 + l]) + red[(2 * NQ + q) * 64 + l]) + red[(3 * NQ + q) * 64 + l];
+        const int m = a * 16 + 4 * (l >> 4) + r, nn = l & 15;
+        if (m < p.Mp && nn < p.Np) out[((size_t)t * p.Mp + m) * p.Np + nn] = v;
+    }
+#endif
+}
+
 // which 1x1 gradients take the streaming kernel, and with how many workgroups (= partial planes)
 static bool wg_thin_shape(const sos_wgrad_desc* d, bool is_flat, int* m16, int* n16) {
     if (!is_flat || getenv("SOS_WGRAD_NO_THIN")) return false;
@@ -1073,6 +1172,14 @@ static int wg_max_split(const sos_wgrad_desc* d) {
     const int64_t per = (int64_t)d->kh * d->kw * Mp * Np * 4;
     const int64_t cap = ((int64_t)256 << 20) / per;
     return (int)(cap < 1 ? 1 : (cap > WG_MAXSPLIT ? WG_MAXSPLIT : cap));
+}
+// the kh x 1 gradients of a thin input that take wgrad_thin_taps_kernel (instance: 49..64 output channels, 5 taps)
+static bool wg_thin_taps_shape(const sos_wgrad_desc* d, bool temporal) {
+    if (temporal || getenv("SOS_WGRAD_NO_THIN") || d->kw != 1 || d->kh != 5 || d->stride != 1 || d->N > 16 || (d->M + 15) / 16 != 4) return false;
+    if (d->Hg != d->Hx || d->Wg != d->Wx || d->pad_left != 0 || d->Wg < 32) return false;
+    if (d->pad_mode == SOS_PAD_REFLECT && d->pad_top >= d->Hg) return false;
+    const uint64_t npx = (uint64_t)d->B * d->Hg * d->Wg;
+    return npx * (uint64_t)d->g_cs * 2 < 0xfff00000ull && npx * (uint64_t)d->x_cs * 2 < 0xfff00000ull;
 }
 // workgroups (= partial planes) of wgrad_thin_kernel: one per CU, at least 16 stages per wave
 static int wg_thin_split(const sos_wgrad_desc* d, int subs) {
@@ -1476,6 +1583,36 @@ static int wgrad_impl(const sos_wgrad_desc* d, sos_stream_t stream, const int wh
                            q.Mp, q.Np, d->dw, d->accumulate, d->scale, d->scale_dev);
         return sos_check_launch("sos_conv2d_wgrad(reduce)");
     }
+    if (wg_thin_taps_shape(d, temporal)) {
+        WgThinTapParams q;
+        q.g = (const bf16_t*)d->g + d->g_off; q.x = (const bf16_t*)d->x + d->x_off; q.partial = d->partial;
+        q.K = d->B * d->Hg * d->Wg; q.H = d->Hg; q.W = d->Wg; q.g_cs = d->g_cs; q.x_cs = d->x_cs;
+        q.Mp = (d->M + 31) / 32 * 32; q.Np = (d->N + 31) / 32 * 32;
+        q.dil = d->dil_h; q.pad = d->pad_top; q.reflect = d->pad_mode == SOS_PAD_REFLECT;
+        sos_wgrad_desc one = *d;
+        one.Wg = q.K;                                   // (wg_thin_split looks at the pixel count only)
+        const int ksplit = wg_thin_split(&one, 4 + 5);
+        q.kper = ((q.K + ksplit * 4 - 1) / (ksplit * 4) + 31) / 32 * 32;
+        const size_t lds = (size_t)4 * WGT_NBUF * (4 + 5) * 1024;
+        hipStream_t s = (hipStream_t)stream;
+        static sos_device_once taps_once;
+        (void)sos_per_device_once(taps_once, [] {
+            (void)hipFuncSetAttribute((const void*)wgrad_thin_taps_kernel<4, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            return (int)SOS_OK;
+        });
+        if (what & 1) {
+            hipLaunchKernelGGL((wgrad_thin_taps_kernel<4, 5>), dim3((unsigned)ksplit), dim3(256), lds, s, q);
+            int rc = sos_check_launch("sos_conv2d_wgrad(thin taps)");
+            if (rc) return rc;
+        }
+        if (!(what & 2)) return SOS_OK;
+        const long long total = (long long)d->M * d->N * d->kh;
+        long long gb = (total + 63) / 64;
+        if (gb > 8192) gb = 8192;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, d->partial, ksplit, d->kh, d->M, d->N,
+                           q.Mp, q.Np, d->dw, d->accumulate, d->scale, d->scale_dev);
+        return sos_check_launch("sos_conv2d_wgrad(reduce)");
+    }
     const WgCtx cx = wg_ctx(d, temporal, is_flat);
     if (cx.taps > WG_WAVES * WG_PAIRS) { sos_set_error("sos_conv2d_wgrad: kernel with %d taps per row not supported", cx.taps); return SOS_ENOSPC; }
     if ((uint64_t)d->Hg * d->Wg * d->g_cs * 2 >= 0xffffff00ull || (uint64_t)d->Hx * d->Wx * d->x_cs * 2 >= 0xffffff00ull) {
@@ -1512,7 +1649,7 @@ extern "C" int sos_wgrad_tune(const sos_wgrad_desc* d, int iters, float* best_ms
     d = &flat;
     if (best_ms) *best_ms = -1.f;
     if (is_flat && d->M >= 128 && d->N >= 128 && !getenv("SOS_WGRAD_NO_GEMM")) return SOS_OK;     // the GEMM path has no plan
-    { int a, b; if (wg_thin_shape(d, is_flat, &a, &b)) return SOS_OK; }                          // nor has the streaming path
+    { int a, b; if (wg_thin_shape(d, is_flat, &a, &b) || wg_thin_taps_shape(d, temporal)) return SOS_OK; }   // nor have the streaming paths
     const WgCtx cx = wg_ctx(d, temporal, is_flat);
     if (cx.taps > WG_WAVES * WG_PAIRS) return SOS_OK;
     const WgKey key = wg_key(d, cx);

@@ -110,6 +110,10 @@ CASES = [
     ("thin 1x1 8x96", 8, 96, (1, 1), 1, (1, 1), (0, 0), "zeros", 33, 47),
     ("thin 1x1 4x48 short", 4, 48, (1, 1), 1, (1, 1), (0, 0), "zeros", 1, 20),
     ("thin 1x1 64x10", 64, 10, (1, 1), 1, (1, 1), (0, 0), "zeros", 19, 23),
+    # ... and of the thin input under 5 vertical taps (the U-Net's folded first block): reflection and zero padding, dilation
+    ("thin 5x1 64x10 reflect", 64, 10, (5, 1), 1, (1, 1), (2, 0), "reflect", 37, 50),
+    ("thin 5x1 56x10 zero", 56, 10, (5, 1), 1, (1, 1), (2, 0), "zeros", 20, 33),
+    ("thin 5x1 64x16 dil2", 64, 16, (5, 1), 1, (2, 1), (4, 0), "zeros", 23, 40),
 ]
 
 
