@@ -1,12 +1,10 @@
 #!/bin/bash
 # The ONE metered-GPU batch script (rewritten per call; replaces round 4's tools/gpu/g*.sh):  gpurun -- bash tools/gpu_job.sh
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/j35; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_train_ops.py -m gpu -q -x -k "conv_weight_grad" > $O/pytest.log 2>&1; tail -5 $O/pytest.log
-for sw in "SOS_NOP=1" "SOS_WGRAD_NO_THIN=1"; do
-  echo "== fp16 $sw" >> $O/wgrad.txt
-  for only in "fold 10->64"; do
-    env SOS_PRECISION=fp16 $sw timeout 300 python tools/wgrad_bench.py --only "$only" 2>&1 | grep -v amdgpu >> $O/wgrad.txt
-  done
-done
-cat $O/wgrad.txt
+O=gpurun_out/j36; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; python -c "
+import json; d=json.loads(open('$O/bench.json').read()); s=d['secondary']
+print(round(d['value'],1), d['roofline']['frac'])
+print({k:v for k,v in s.items() if k!='note' and 'roofline' not in k and 'runs' not in k})"
