@@ -502,6 +502,110 @@ __global__ __launch_bounds__(256) void slope_sum_kernel(const float* __restrict_
     if (threadIdx.x == 0) dslope[0] = (float)r[0];
 }
 
+// ---- round 5: the ReLU reduce as per-wave streams.  bn_bwd_reduce_kernel above reads its two tensors at 4.6-4.9 TB/s where the
+// one-tensor bn_stats reaches 6.1 and the two-tensor thin weight-gradient kernel (wgrad.hip) 6.0: its 2 048 workgroups walk the
+// tensor block-interleaved and every thread issues its next 4 loads only after the sums of the previous 4 are done.  Here a WAVE
+// owns a contiguous run of pixels (lane = (pixel lane, 8-channel group) as above, 64 / CG pixels per instruction) and keeps TWO
+// register sets of U loads per tensor: the loads of iteration k + 1 are in flight while iteration k is summed.  Same per-element
+// arithmetic; the partial sums are added in a different (fixed) order.  partial: [3][C][gridDim.x] like the kernel above.
+template <int U, bool RELU_ONLY>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_stream_kernel(View dy, View x, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, int act,
+                                                                   const float* __restrict__ slope_p,
+                                                                   float* __restrict__ partial) {
+    __shared__ float red[256 * 8];
+    const int CG = (x.C + 7) / 8;
+    const int PLW = 64 / CG;                            // pixels per wave instruction (launcher: CG <= 64)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = lane % CG, pw = lane / CG;
+    const bool live = pw < PLW;
+    const float slope = slope_p ? slope_p[0] : 0.f;
+    float s1[8], s2[8], s3[8], sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s1[i] = s2[i] = s3[i] = 0.f;
+        const int c = min(cg * 8 + i, x.C - 1);
+        sc[i] = scale[c]; sh[i] = shift[c];
+        mu[i] = mean ? mean[c] : 0.f; is[i] = invstd ? invstd[c] : 1.f;
+    }
+    const long long nw = (long long)gridDim.x * 4, wid = (long long)blockIdx.x * 4 + wave;
+    const int IT = U * PLW;                             // pixels per wave iteration
+    long long per = (x.npix + nw - 1) / nw;
+    per = (per + IT - 1) / IT * IT;
+    const long long p0 = wid * per, p1 = p0 + per < x.npix ? p0 + per : x.npix;
+    // addresses relative to the wave's first pixel (32-bit); a pixel past the tensor's end is clamped to the last one and skipped
+    // by the sums.  The fetches are UNCONDITIONAL so that the compiler's wait-count model of the two register sets is exact
+    // (a fetch under a branch made it drain every load at the top of the loop).
+    const bf16_t* xb = x.ptr + x.c_off + cg * 8 + p0 * x.row;
+    const bf16_t* gb = dy.ptr + dy.c_off + cg * 8 + p0 * dy.row;
+    const int rmax = (int)(x.npix - 1 - p0), rend = (int)(p1 - p0);
+    auto fetch = [&](int r0, uint4 (&hx)[U], uint4 (&hg)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = min(r0 + u * PLW + pw, rmax);
+            hx[u] = ld16(xb + (size_t)((unsigned)r * (unsigned)x.row));
+            hg[u] = ld16(gb + (size_t)((unsigned)r * (unsigned)dy.row));
+        }
+    };
+    auto sum = [&](int r0, const uint4 (&hx)[U], const uint4 (&hg)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = r0 + u * PLW + pw < rend;
+            const unsigned xw[4] = {hx[u].x, hx[u].y, hx[u].z, hx[u].w}, gw[4] = {hg[u].x, hg[u].y, hg[u].z, hg[u].w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xv = (i & 1) ? sos_hi2f(xw[i >> 1]) : sos_lo2f(xw[i >> 1]);
+                const float gv = (i & 1) ? sos_hi2f(gw[i >> 1]) : sos_lo2f(gw[i >> 1]);
+                const float z = fmaf(xv, sc[i], sh[i]);
+                if constexpr (RELU_ONLY) {
+                    const float dz = (ok && z > 0.f) ? gv : 0.f;
+                    s1[i] += dz;
+                    s2[i] = fmaf(dz, (xv - mu[i]) * is[i], s2[i]);
+                } else {
+                    const float g0 = ok ? gv : 0.f;
+                    const float dz = g0 * act_grad(z, act, slope);
+                    s1[i] += dz;
+                    s2[i] = fmaf(dz, (xv - mu[i]) * is[i], s2[i]);
+                    if (z < 0.f) s3[i] = fmaf(g0, z, s3[i]);
+                }
+            }
+        }
+    };
+    if (live && p0 < p1) {
+        uint4 ax[U], ag[U], bx[U], bg[U];
+        fetch(0, ax, ag);
+        for (int r = 0; r < rend; r += 2 * IT) {
+            fetch(r + IT, bx, bg);
+            sum(r, ax, ag);
+            fetch(r + 2 * IT, ax, ag);
+            sum(r + IT, bx, bg);
+        }
+    }
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        if (which) __syncthreads();
+        if (RELU_ONLY && which == 2) {
+            for (int c = tid; c < x.C; c += 256) partial[((size_t)2 * x.C + c) * gridDim.x + blockIdx.x] = 0.f;
+            break;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[tid * 8 + i] = which == 0 ? s1[i] : (which == 1 ? s2[i] : s3[i]);
+        __syncthreads();
+        for (int c = tid; c < x.C; c += 256) {
+            const int g = c >> 3, e = c & 7;
+            float acc = 0.f;
+            for (int w = 0; w < 4; ++w)
+                for (int l = 0; l < PLW; ++l) acc += red[(w * 64 + l * CG + g) * 8 + e];
+            partial[((size_t)which * x.C + c) * gridDim.x + blockIdx.x] = acc;
+        }
+    }
+}
+
+// (The apply pass -- 2 reads + 1 write per element -- was written the same way and measured: 315-330 us against 316 us for the
+// block-interleaved kernel below at 96 channels, 157-167 against 162 at 48: it is bound by the read / write mix, not by the loads in
+// flight.  Removed.)
 template <bool RELU_ONLY>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View x, const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
@@ -559,9 +663,25 @@ extern "C" int sos_bn_bwd(const sos_view* dy, const sos_view* x, const float* sc
         return SOS_EINVAL;
     }
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = sos_bn_stats_blocks(x->npix);
+    int nblk = sos_bn_stats_blocks(x->npix);
     const int C = x->C;
-    if (act == SOS_ACT_RELU)
+    // SOS_BN_STREAM=<workgroups> (e.g. 512): the per-wave streaming reduce.  OFF by default: alone on the chip it is 17-33 % faster
+    // (96 channels 219 -> 184 us = 6.1 TB/s, 48: 120 -> 92, 128 channels at 128 x 89: 98 -> 66), but the three-stream training
+    // step did not move (555.0 -> 553.8 utt/s over three alternations; 256 / 1024 workgroups and U = 2 likewise 0.99-1.00): beside the
+    // other streams' MFMA workgroups the pass is not limited by its own loads in flight, and its 168 VGPRs co-reside less well than
+    // the 56 of the block-interleaved kernel.  The thin weight gradients (wgrad.hip) gained because they were LATENCY-bound.
+    static const int stream_wgs = [] { const char* e = getenv("SOS_BN_STREAM"); return e ? atoi(e) : 0; }();
+    const bool use_stream = stream_wgs > 0 && !x->x3 && !dy->x3 && (C + 7) / 8 <= 64 && x->npix >= 1 << 16;
+    if (use_stream) {
+        // (the partial buffer is sized for sos_bn_stats_blocks workgroups: fewer rows are used, with their own pitch)
+        if (nblk > stream_wgs) nblk = stream_wgs;
+        if (act == SOS_ACT_RELU)
+            hipLaunchKernelGGL((bn_bwd_reduce_stream_kernel<4, true>), dim3(nblk), dim3(256), 0, s, to_view(dy), to_view(x), scale, shift,
+                               mean, invstd, act, slope, partial);
+        else
+            hipLaunchKernelGGL((bn_bwd_reduce_stream_kernel<4, false>), dim3(nblk), dim3(256), 0, s, to_view(dy), to_view(x), scale, shift,
+                               mean, invstd, act, slope, partial);
+    } else if (act == SOS_ACT_RELU)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, s, to_view(dy), to_view(x), scale, shift, mean,
                            invstd, act, slope, partial);
     else
@@ -681,10 +801,19 @@ extern "C" int sos_pack_grad_f32(const float* g, const float* y, int act, int64_
 __global__ __launch_bounds__(256) void feat_to_nhwc_kernel(View f, int H, int W, int Wo, const int* __restrict__ lo,
                                                            const int* __restrict__ hi, View out, long long total) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int h = (int)(i % H);
-        const long long r = i / H;
-        const int w = (int)(r % W);
-        const long long b = r / W;
+        int h, w;
+        long long b;
+        if (total < 0x7fffffffll) {
+            const unsigned iu = (unsigned)i, ru = iu / (unsigned)H;
+            h = (int)(iu - ru * (unsigned)H);
+            b = ru / (unsigned)W;
+            w = (int)(ru - (unsigned)b * (unsigned)W);
+        } else {
+            h = (int)(i % H);
+            const long long r = i / H;
+            w = (int)(r % W);
+            b = r / W;
+        }
         const int i0 = lo ? lo[w] : w, i1 = hi ? hi[w] : w + 1;
         const long long pix = (b * H + h) * W + w;
         if (out.C <= 8 && out.c_off % 8 == 0 && out.c_off + 8 <= out.row) {    // (the run's padding channels are written as zeros)
@@ -720,6 +849,37 @@ __global__ __launch_bounds__(256) void feat_to_nhwc_kernel(View f, int H, int W,
     }
 }
 
+// the plain case of the above (no pooling ranges, <= 8 channels, 16-bit single storage, W == Wo) through an LDS tile: the
+// kernel above reads along h (coalesced) and writes one 16-byte pixel run per thread at a pitch of W pixels -- 0.9 TB/s.  Here a
+// workgroup owns (clip, 64 rows, 8 columns): it reads the 8 x 8 (column, channel) runs of 64 h-contiguous values (128 B each),
+// transposes through LDS and writes 8 neighbouring pixels' runs per row.
+__global__ __launch_bounds__(256) void feat_to_nhwc_tile_kernel(View f, int H, int W, View out, int tiles_h, int tiles_w) {
+    __shared__ unsigned short tile[8][64][8 + 2];          // [w][h][c] (+2: the transposing writes spread over the banks)
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tw = t % tiles_w; t /= tiles_w;
+    const int th = t % tiles_h;
+    const long long b = t / tiles_h;
+    const int h0 = th * 64, w0 = tw * 8;
+    // read: run q = (w, c) of 64 values; 4 runs per pass of 256 threads
+    for (int q = tid >> 6; q < 64; q += 4) {
+        const int w = q >> 3, c = q & 7, h = h0 + (tid & 63);
+        unsigned short v = 0;
+        if (c < out.C && w0 + w < W && h < H) v = f.ptr[(b * W + w0 + w) * f.row + (long long)(f.c_off + c) * H + h];
+        tile[w][tid & 63][c] = v;
+    }
+    __syncthreads();
+    // write: 512 pixels, 2 per thread, w fastest
+    for (int p = tid; p < 512; p += 256) {
+        const int w = p & 7, hh = p >> 3;
+        if (w0 + w >= W || h0 + hh >= H) continue;
+        const unsigned short* r = tile[w][hh];
+        const uint4 v = make_uint4(r[0] | ((unsigned)r[1] << 16), r[2] | ((unsigned)r[3] << 16), r[4] | ((unsigned)r[5] << 16),
+                                   r[6] | ((unsigned)r[7] << 16));
+        *(uint4*)(out.ptr + ((b * H + h0 + hh) * W + w0 + w) * out.row + out.c_off) = v;
+    }
+}
+
 extern "C" int sos_feat_to_nhwc(const sos_view* feat, int B, int H, int W, int Wo, const int32_t* lo, const int32_t* hi,
                                 const sos_view* out, sos_stream_t stream) {
     if (!feat || !feat->ptr || !out || !out->ptr || B < 1 || H < 1 || W < 1 || Wo < 1 || (lo == nullptr) != (hi == nullptr)) {
@@ -727,6 +887,13 @@ extern "C" int sos_feat_to_nhwc(const sos_view* feat, int B, int H, int W, int W
         return SOS_EINVAL;
     }
     const long long total = (long long)B * W * H;
+    const int tiles_h = (H + 63) / 64, tiles_w = (W + 7) / 8;
+    if (!lo && W == Wo && !feat->x3 && !out->x3 && out->C <= 8 && out->c_off % 8 == 0 && out->c_off + 8 <= out->row &&
+        (long long)B * tiles_h * tiles_w < 0x7fffffffll && !getenv("SOS_FEAT_NO_TILE")) {
+        hipLaunchKernelGGL(feat_to_nhwc_tile_kernel, dim3((unsigned)(B * tiles_h * tiles_w)), dim3(256), 0, (hipStream_t)stream,
+                           to_view(feat), H, W, to_view(out), tiles_h, tiles_w);
+        return sos_check_launch("sos_feat_to_nhwc");
+    }
     hipLaunchKernelGGL(feat_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, to_view(feat), H, W, Wo,
                        lo, hi, to_view(out), total);
     return sos_check_launch("sos_feat_to_nhwc");
@@ -893,11 +1060,21 @@ extern "C" int sos_reflect_fold_border(const sos_view* padded, int H, int W, int
 __global__ __launch_bounds__(256) void copy_crop_kernel(View src, int Hs, int Ws, View dst, int Hd, int Wd, long long total) {
     const int CG = (dst.C + 7) / 8;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cg = (int)(i % CG);
-        long long r = i / CG;
-        const int w = (int)(r % Wd); r /= Wd;
-        const int h = (int)(r % Hd);
-        const long long b = r / Hd;
+        int cg, w, h;
+        long long b;
+        if (total < 0x7fffffffll) {        // 32-bit divisions (the 64-bit ones cost more than the 16-byte copy they index)
+            unsigned r = (unsigned)i;
+            cg = (int)(r % (unsigned)CG); r /= (unsigned)CG;
+            w = (int)(r % (unsigned)Wd); r /= (unsigned)Wd;
+            h = (int)(r % (unsigned)Hd);
+            b = r / (unsigned)Hd;
+        } else {
+            cg = (int)(i % CG);
+            long long r = i / CG;
+            w = (int)(r % Wd); r /= Wd;
+            h = (int)(r % Hd);
+            b = r / Hd;
+        }
         float f[8];
         if (h < Hs && w < Ws) {
             load8(src, (b * Hs + h) * Ws + w, cg * 8, f);

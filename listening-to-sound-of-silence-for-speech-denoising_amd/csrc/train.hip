@@ -259,12 +259,23 @@ __global__ __launch_bounds__(256) void gather_pack_kernel(const PackEntry* __res
     const PackEntry e = tab[c.x];
     const long long lo = (long long)c.y * SOS_ADAM_CHUNK;
     const long long hi = lo + SOS_ADAM_CHUNK < e.n ? lo + SOS_ADAM_CHUNK : e.n;
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-        const long long a = e.idx[i];
-        bf16_t r = 0;
-        if (a > 0) r = f2bf(*(const float*)a);
-        else if (a < 0) { const float v = *(const float*)(-a); r = f2bf(v - bf2f(f2bf(v))); }
-        e.out[i] = r;
+    // four elements per thread and step: the four index loads, then the four dependent value loads, are in flight together (one
+    // element at a time ran at 0.76 TB/s: two dependent memory latencies per 14 bytes)
+    for (long long i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * 256) {
+        long long a[4];
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = i0 + u * 256 < hi ? e.idx[i0 + u * 256] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = a[u] ? *(const float*)(a[u] > 0 ? a[u] : -a[u]) : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * 256 >= hi) continue;
+            bf16_t r = 0;
+            if (a[u] > 0) r = f2bf(v[u]);
+            else if (a[u] < 0) r = f2bf(v[u] - bf2f(f2bf(v[u])));
+            e.out[i0 + u * 256] = r;
+        }
     }
 }
 extern "C" int sos_gather_pack_multi(const sos_pack_entry* entries, int n_entries, const int32_t* chunks, int64_t n_chunks,
