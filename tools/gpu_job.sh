@@ -1,7 +1,5 @@
 #!/bin/bash
 # The ONE metered-GPU batch script (rewritten per call; replaces round 4's tools/gpu/g*.sh):  gpurun -- bash tools/gpu_job.sh
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/j45; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; tail -3 $O/pytest.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
-bash tools/refresh_profiles.sh r05 > $O/refresh.log 2>&1; tail -14 $O/refresh.log | cut -c1-200
+O=gpurun_out/j46; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_forced_tilings.py -m gpu -q -x -k alternative > $O/pytest.log 2>&1; tail -3 $O/pytest.log
