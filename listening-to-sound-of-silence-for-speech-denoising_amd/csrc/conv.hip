@@ -1561,6 +1561,157 @@ static void tuned_store(const ShapeKey& k, const ConvCfg& c, bool overwrite) {
     else tuned_cache().emplace(k, c);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Thin-input convolutions as per-wave streams (round 5): the layers whose input is the 16-channel packed module input (horizontal
+// taps on the channel axis, §3.1c) -- 14 -> 96 1x1 and 10 -> 64 5x1 -- and the 1x1 data gradients of the 8-channel heads contract
+// K = 16 channels per tap: one MFMA per tap and 32 pixels, and 6 (4) KB to WRITE per 1 (5) KB read.  On the tiled kernels a
+// workgroup lives ~15 us for a 56 KB tile (pixel table, patch DMA, slab DMA, barrier, one tap, staged epilogue): 2.4-2.9 TB/s.
+// Here a wave owns a contiguous run of pixels: the pixel operand of a 32-pixel stage is ONE 16-byte global load per lane (pixel =
+// lane & 31, channels 8 (lane >> 5) ..: the MFMA fragment as it lies in memory), the weights of all taps stay in registers, the
+// result goes through a wave-private LDS tile (no barrier) to 16-byte stores that cover the stage's contiguous output bytes.
+// The pixel operands of the next D stages are in flight while a stage is multiplied.  Epilogue y = act(acc * scale + shift) as sos_conv_desc says.
+struct ThinParams {
+    const bf16_t* in; const bf16_t* wgt; bf16_t* out;
+    const float* scale; const float* shift; const float* slope;
+    long long K;                // pixels (B * H * W)
+    int H, W, cout, cout_pad, dil, pad, reflect, act, per;
+};
+
+template <int NT, int KH, int D>
+__global__ __launch_bounds__(256) void conv_thin_kernel(ThinParams p) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWB = NT * 64, PITCH = ROWB + 16;            // bytes of an output pixel row / of its LDS image
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* tile = smem + wave * (32 * PITCH);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const long long k0 = ((long long)blockIdx.x * 4 + wave) * p.per;
+    const long long k1 = k0 + p.per < p.K ? k0 + p.per : p.K;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (unsigned)(p.K * 32), 0x00020000);
+    // weights: fragment (tap, tile) = rows tile*32 + l31, channels 8 lhi ..
+    bf16x8 wf[KH][NT];
+#pragma unroll
+    for (int t = 0; t < KH; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            wf[t][n] = *(const bf16x8*)(p.wgt + ((size_t)(t * p.cout_pad + n * 32 + l31) * 16 + lhi * 8));
+    // epilogue coefficients: [scale | shift] of all rows behind the waves' tiles in LDS (a lane's four consecutive rows of a
+    // register quad are one broadcast 16-byte read each; 96 + 96 registers per lane otherwise)
+    const bool affine = p.scale != nullptr;
+    const float slope = (p.act == SOS_ACT_PRELU && p.slope) ? p.slope[0] : 0.f;
+    const float sn = p.act == SOS_ACT_RELU ? 0.f : (p.act == SOS_ACT_PRELU ? slope : 1.f);
+    float* coef = (float*)(smem + 4 * 32 * PITCH);
+    if (affine) {
+        for (int c = tid; c < NT * 32; c += 256) { coef[c] = p.scale[c]; coef[NT * 32 + c] = p.shift[c]; }
+    }
+    __syncthreads();                               // (the only barrier; before any wave can leave)
+    if (k0 >= k1) return;
+    // this lane's pixel of the next stage to fetch: flat index, row (for the vertical taps)
+    long long lk = k0 + l31;
+    int lw = (int)(lk % p.W), lh = (int)((lk / p.W) % p.H);
+    auto fetch = [&](sos_u32x4 (&b)[KH]) {
+#pragma unroll
+        for (int t = 0; t < KH; ++t) {
+            int hh = lh + t * p.dil - p.pad;
+            if (p.reflect) hh = reflect_index(hh, p.H);
+            const bool ok = (unsigned)hh < (unsigned)p.H && lk < k1;
+            const unsigned off = ok ? (unsigned)((lk + (long long)(hh - lh) * p.W) * 32) + (unsigned)(lhi * 16) : 0xffffffffu;
+            b[t] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)off, 0, 0);
+        }
+        lk += 32; lw += 32;
+        while (lw >= p.W) { lw -= p.W; if (++lh == p.H) lh = 0; }
+    };
+    auto stage = [&](const long long kb, const sos_u32x4 (&b)[KH]) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < KH; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = SOS_MFMA_32x32x16(wf[t][n], __builtin_bit_cast(bf16x8, b[t]), acc[n], 0, 0, 0);
+        // D[row][pixel l31]: four consecutive rows per register quad -> one 8-byte LDS write
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float y[4];
+                float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), h4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (affine) {
+                    s4 = *(const float4*)(coef + n * 32 + 8 * q + 4 * lhi);
+                    h4 = *(const float4*)(coef + NT * 32 + n * 32 + 8 * q + 4 * lhi);
+                }
+                const float sq[4] = {s4.x, s4.y, s4.z, s4.w}, hq[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * q + e;
+                    float v = affine ? fmaf(acc[n][r], sq[e], hq[e]) : acc[n][r];
+                    if (p.act == SOS_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                    else if (p.act != SOS_ACT_NONE) v = fmaxf(v, 0.f) + sn * fminf(v, 0.f);
+                    y[e] = (n * 32 + 8 * q + 4 * lhi + e < p.cout) ? v : 0.f;
+                }
+                *(uint2*)(tile + l31 * PITCH + (n * 32 + 8 * q + 4 * lhi) * 2) = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+            }
+        // the stage's 32 x ROWB output bytes are contiguous in memory: 16-byte pieces, lane-contiguous
+        const int npx = (int)(k1 - kb < 32 ? k1 - kb : 32);
+        char* ob = (char*)p.out + kb * ROWB;
+#pragma unroll
+        for (int i = 0; i < (32 * ROWB) / 1024; ++i) {
+            const int j = i * 64 + lane, px = j / (ROWB / 16), pc = j - px * (ROWB / 16);
+            const uint4 v = *(const uint4*)(tile + px * PITCH + pc * 16);
+            if (px < npx) *(uint4*)(ob + (size_t)j * 16) = v;
+        }
+    };
+    // D stages of pixel operands in flight per wave; slot d is refilled for stage + D right after its stage is done.  D = 2 is
+    // enough: these layers WRITE 6 (4) KB per KB read and sit on the chip's write rate (14 -> 96: 560 MB out in 181 us; D = 8
+    // measured 213 us, 256 instead of 512 workgroups 274 us, 1 024 the same 181)
+    sos_u32x4 b[D][KH];
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(b[d]);
+    for (long long kb = k0; kb < k1; kb += 32 * D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (kb + 32 * d < k1) stage(kb + 32 * d, b[d]);
+            fetch(b[d]);
+        }
+    }
+#endif
+}
+
+// which descriptors take it (everything else of sos_conv_desc must be off), and with how many workgroups
+static bool thin_conv_shape(const sos_conv_desc* d) {
+    if (getenv("SOS_CONV_NO_THIN")) return false;            // (read per call: the equality test flips it)
+    if (d->cin != 16 || d->in_cs != 16 || d->cin_off != 0 || d->in_nseg != 1 || d->w_gather || d->wl_tab || d->t_taps > 1 ||
+        d->fold_pad || d->in_scale || d->accumulate || d->stats || d->out_dtype != SOS_DT_BF16)
+        return false;
+    if (d->kw != 1 || (d->kh != 1 && d->kh != 5) || d->stride != 1 || d->pad_left != 0 || d->Ho != d->H || d->Wo != d->W || d->W < 32)
+        return false;
+    if (d->kh == 5 ? d->cout_pad != 64 : d->cout_pad != 96) return false;             // (the two instances)
+    if (d->pad_top != (d->kh - 1) / 2 * d->dil_h || (d->pad_mode == SOS_PAD_REFLECT && d->pad_top >= d->H)) return false;
+    if (d->cout_store != d->cout_pad || d->out_c_off != 0 || d->out_sc != 1 || d->out_sw != d->cout_store ||
+        d->out_sh != (int64_t)d->Wo * d->out_sw || d->out_sb != (int64_t)d->Ho * d->out_sh)
+        return false;
+    const long long K = (long long)d->B * d->H * d->W;
+    return K >= 2048 && K * 32 < 0xfff00000ll;
+}
+static int thin_conv_launch(const sos_conv_desc* d, hipStream_t s) {
+    ThinParams q;
+    q.in = (const bf16_t*)d->in; q.wgt = (const bf16_t*)d->wgt; q.out = (bf16_t*)d->out;
+    q.scale = d->scale; q.shift = d->shift; q.slope = d->act_param;
+    q.K = (long long)d->B * d->H * d->W; q.H = d->H; q.W = d->W; q.cout = d->cout; q.cout_pad = d->cout_pad;
+    q.dil = d->dil_h; q.pad = d->pad_top; q.reflect = d->pad_mode == SOS_PAD_REFLECT; q.act = d->act;
+    static const int wgs = [] { const char* e = getenv("SOS_CONV_THIN_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    long long per = (q.K + wgs * 4 - 1) / (wgs * 4);
+    per = (per + 31) / 32 * 32;
+    q.per = (int)per;
+    const unsigned grid = (unsigned)((q.K + per * 4 - 1) / (per * 4));
+    if (d->kh == 5) hipLaunchKernelGGL((conv_thin_kernel<2, 5, 2>), dim3(grid), dim3(256), 4 * 32 * (2 * 64 + 16) + 2 * 64 * 4, s, q);
+    else hipLaunchKernelGGL((conv_thin_kernel<3, 1, 2>), dim3(grid), dim3(256), 4 * 32 * (3 * 64 + 16) + 2 * 96 * 4, s, q);
+    return sos_check_launch("sos_conv2d_fwd(thin)");
+}
+
 static int validate(const sos_conv_desc* d) {
     if (!d || !d->in || !d->wgt || !d->out || ((d->scale == nullptr) != (d->shift == nullptr))) {
         sos_set_error("sos_conv2d_fwd: null pointer");
@@ -1783,6 +1934,7 @@ extern "C" int64_t sos_conv2d_tile_count(const sos_conv_desc* d) {
 extern "C" int sos_conv2d_fwd(const sos_conv_desc* d, sos_stream_t stream) {
     int rc = validate(d);
     if (rc) return rc;
+    if (thin_conv_shape(d)) return thin_conv_launch(d, (hipStream_t)stream);
     { ConvCfg c5; if (forced_512(d, &c5)) return launch_cfg(d, c5, (hipStream_t)stream); }
     // SOS_CONV_FORCE_CFG=k (testing): use the k-th candidate tiling (mod count) instead of the tuned one
     static const char* force = getenv("SOS_CONV_FORCE_CFG");

@@ -30,13 +30,13 @@ lines = [f"total kernel time {tot:.2f} ms over {sum(r[6] for r in rows)} dispatc
 for r in rows[:60]:
     lines.append(f"| {r[0][:90]} | {r[1]} | {r[2]} | {r[3]} | {r[4]} | {r[5]} | {r[6]} | {r[7]:.2f} | {100*r[7]/tot:.1f} | {r[8]:.1f} | {r[9]:.1f} |")
 # ---- one row per (kernel, layer signature): join with the engine's launch log (SOS_LAUNCH_LOG, one line per conv / wgrad launch
-# in enqueue order): the k-th dispatch of the conv family (conv_mfma_kernel / conv16_kernel) is the k-th "conv" line, the k-th
+# in enqueue order): the k-th dispatch of the conv family (conv_mfma_kernel / conv16_kernel / conv_thin_kernel) is the k-th "conv" line, the k-th
 # dispatch of the weight-gradient family (wgrad_kernel / wgrad16_kernel / wgrad_gemm_kernel / wgrad_thin*_kernel; not the reduce) the k-th "wgrad" line
 if len(sys.argv) > 3:
     log = [ln.rstrip("\n").split("|") for ln in open(sys.argv[3]) if "|" in ln]
     cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
     order = "dispatch_id" if "dispatch_id" in cols else "start"
-    for kind, pat in (("conv", r"conv_mfma_kernel|conv16_kernel"), ("wgrad", r"wgrad_kernel|wgrad16_kernel|wgrad_gemm_kernel|wgrad_thin_kernel|wgrad_thin_taps_kernel")):
+    for kind, pat in (("conv", r"conv_mfma_kernel|conv16_kernel|conv_thin_kernel"), ("wgrad", r"wgrad_kernel|wgrad16_kernel|wgrad_gemm_kernel|wgrad_thin_kernel|wgrad_thin_taps_kernel")):
         disp = [r for r in c.execute(f"select name, end-start from kernels order by {order}").fetchall() if re.search(pat, r[0])]
         ents = [e for e in log if e[0] == kind]
         lines += ["", f"### {kind} launches by layer signature ({len(disp)} dispatches, {len(ents)} logged launches)"]
@@ -45,7 +45,7 @@ if len(sys.argv) > 3:
             continue
         agg = {}
         for (name, ns), (_, sig, flops) in zip(disp, ents):
-            m = re.search(r"(conv_mfma_kernel|conv16_kernel|wgrad16_kernel|wgrad_gemm_kernel|wgrad_thin_taps_kernel|wgrad_thin_kernel|wgrad_kernel)(<[^>]*>)?", name)
+            m = re.search(r"(conv_mfma_kernel|conv16_kernel|conv_thin_kernel|wgrad16_kernel|wgrad_gemm_kernel|wgrad_thin_taps_kernel|wgrad_thin_kernel|wgrad_kernel)(<[^>]*>)?", name)
             a = agg.setdefault((m.group(0) if m else name[:40], sig), [0, 0.0, 1e30, float(flops)])
             a[0] += 1
             a[1] += ns

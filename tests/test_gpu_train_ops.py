@@ -581,3 +581,60 @@ def test_fused_input_batchnorm_equals_the_materialised_apply(dil):
         assert torch.equal(outs[0], outs[1])
     finally:
         sos_amd.set_precision("bf16")
+
+
+@pytest.mark.parametrize("case", [("1x1 raw", 1, 96, 96, "zeros", 1, None), ("1x1 affine relu", 1, 96, 96, "zeros", 1, "relu"),
+                                  ("1x1 cout 90", 1, 90, 96, "zeros", 1, "relu"), ("5x1 reflect prelu", 5, 64, 64, "reflect", 1, "prelu"),
+                                  ("5x1 zero raw", 5, 64, 64, "zeros", 1, None), ("5x1 dil2 zero relu", 5, 60, 64, "zeros", 2, "relu")],
+                         ids=lambda c: c[0])
+def test_thin_input_streaming_conv_equals_the_tiled_kernel(case, monkeypatch):
+    """conv_thin_kernel (round 5): the convs over the 16-channel packed module input (14 -> 96 1x1, 10 -> 64 5x1) and the 1x1 data
+    gradients of the 8-channel heads as per-wave streams.  Same MFMA per tap, same epilogue arithmetic: the output must equal the
+    tiled kernel's bit for bit (SOS_CONV_NO_THIN=1 selects it), borders, partial last stage and padded output channels included;
+    and both match torch on the storage-rounded operands."""
+    import sos_amd
+    from sos_amd import engine as E, _lib as L
+    _, kh, cout, cs, pmode, dil, act = case
+    sos_amd.set_precision("fp16")
+    try:
+        dev = torch.device("cuda")
+        B, H, W = 2, 41, 37                                     # 3 034 pixels: not a multiple of the 32-pixel stage
+        torch.manual_seed(11)
+        x = E.Act(B, H, W, 16, False, dev)
+        x.t.normal_()
+        wt = torch.randn(cout, 16, kh, 1, device=dev) * 0.2
+        w = E.pack_weight(wt, 16, False)
+        scale = shift = None
+        actc, slope = L.ACT_NONE, None
+        if act:
+            scale = torch.zeros(E.pad_to(cout, 32), device=dev)
+            shift = torch.zeros_like(scale)
+            scale[:cout] = torch.rand(cout, device=dev) + 0.5
+            shift[:cout] = torch.randn(cout, device=dev) * 0.3
+            actc = L.ACT_RELU if act == "relu" else L.ACT_PRELU
+            slope = torch.tensor([0.25], device=dev) if act == "prelu" else None
+        pad = ((kh - 1) // 2 * dil, 0)
+        outs = []
+        for no_thin in (False, True):
+            if no_thin:
+                monkeypatch.setenv("SOS_CONV_NO_THIN", "1")
+            else:
+                monkeypatch.delenv("SOS_CONV_NO_THIN", raising=False)
+            dst = E.Act(B, H, W, cs, False, dev, zero=True)
+            E.conv_to_act(x, 0, 16, w, kh, 1, cout, scale, shift, actc, dst, cout_store=cs, dil=(dil, 1), pad=pad, Ho=H, Wo=W,
+                          slope=slope, pad_mode=L.PAD_REFLECT if pmode == "reflect" else L.PAD_ZERO)
+            outs.append(dst.t.clone())
+        assert float(outs[0].float().abs().max()) > 0.1
+        assert torch.equal(outs[0], outs[1])
+        xin = x.t.float().permute(0, 3, 1, 2)
+        xp = F.pad(xin, (0, 0, pad[0], pad[0]), mode="reflect") if pmode == "reflect" else xin
+        ref = F.conv2d(xp, wt.half().float(), None, 1, (0, 0) if pmode == "reflect" else pad, (dil, 1))
+        if act:
+            ref = ref * scale[:cout].view(1, -1, 1, 1) + shift[:cout].view(1, -1, 1, 1)
+            ref = torch.relu(ref) if act == "relu" else torch.where(ref >= 0, ref, 0.25 * ref)
+        got = outs[0].float().permute(0, 3, 1, 2)
+        assert rel_err(got[:, :cout].cpu(), ref.cpu()) < 2e-3
+        if cs > cout:
+            assert float(got[:, cout:].abs().max()) == 0.0
+    finally:
+        sos_amd.set_precision("bf16")
