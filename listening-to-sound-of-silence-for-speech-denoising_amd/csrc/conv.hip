@@ -1569,7 +1569,7 @@ static void tuned_store(const ShapeKey& k, const ConvCfg& c, bool overwrite) {
 // Here a wave owns a contiguous run of pixels: the pixel operand of a 32-pixel stage is ONE 16-byte global load per lane (pixel =
 // lane & 31, channels 8 (lane >> 5) ..: the MFMA fragment as it lies in memory), the weights of all taps stay in registers, the
 // result goes through a wave-private LDS tile (no barrier) to 16-byte stores that cover the stage's contiguous output bytes.
-// The pixel operands of the next D stages are in flight while a stage is multiplied.  Epilogue y = act(acc * scale + shift) as sos_conv_desc says.
+// The pixel operands of the next two stages are in flight while a stage is multiplied.  Epilogue y = act(acc * scale + shift) as sos_conv_desc says.
 struct ThinParams {
     const bf16_t* in; const bf16_t* wgt; bf16_t* out;
     const float* scale; const float* shift; const float* slope;
@@ -1577,14 +1577,16 @@ struct ThinParams {
     int H, W, cout, cout_pad, dil, pad, reflect, act, per;
 };
 
-template <int NT, int KH, int D>
+template <int NT, int KH>
 __global__ __launch_bounds__(256) void conv_thin_kernel(ThinParams p) {
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = NT * 64, PITCH = ROWB + 16;            // bytes of an output pixel row / of its LDS image
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    char* tile = smem + wave * (32 * PITCH);
+    typedef __attribute__((address_space(3))) char lds_char;   // (explicit LDS pointers: through a generic char* the compiler fell
+    lds_char* const lds = (lds_char*)smem;                      //  back to flat loads / stores and a scratch copy of the staged pieces)
+    const int tile0 = wave * (2 * 32 * PITCH);              // two tiles per wave: one being stored, one being filled
     const int l31 = lane & 31, lhi = lane >> 5;
     const long long k0 = ((long long)blockIdx.x * 4 + wave) * p.per;
     const long long k1 = k0 + p.per < p.K ? k0 + p.per : p.K;
@@ -1601,9 +1603,12 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThinParams p) {
     const bool affine = p.scale != nullptr;
     const float slope = (p.act == SOS_ACT_PRELU && p.slope) ? p.slope[0] : 0.f;
     const float sn = p.act == SOS_ACT_RELU ? 0.f : (p.act == SOS_ACT_PRELU ? slope : 1.f);
-    float* coef = (float*)(smem + 4 * 32 * PITCH);
+    constexpr int COEF = 4 * 2 * 32 * PITCH;                // byte offset of [scale | shift]
     if (affine) {
-        for (int c = tid; c < NT * 32; c += 256) { coef[c] = p.scale[c]; coef[NT * 32 + c] = p.shift[c]; }
+        for (int c = tid; c < NT * 32; c += 256) {
+            *(__attribute__((address_space(3))) float*)(lds + COEF + c * 4) = p.scale[c];
+            *(__attribute__((address_space(3))) float*)(lds + COEF + (NT * 32 + c) * 4) = p.shift[c];
+        }
     }
     __syncthreads();                               // (the only barrier; before any wave can leave)
     if (k0 >= k1) return;
@@ -1622,8 +1627,12 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThinParams p) {
         lk += 32; lw += 32;
         while (lw >= p.W) { lw -= p.W; if (++lh == p.H) lh = 0; }
     };
-    auto stage = [&](const long long kb, const sos_u32x4 (&b)[KH]) {
-        f32x16 acc[NT];
+    // A stage is split so that its STORES get time: on gfx950 loads and stores share vmcnt and may return out of order with each
+    // other, so the compiler's wait for a stage's loads drains every store issued before it.  With [multiply, epilogue, store] per
+    // stage a wave stood ~2 us per stage behind its own previous stores (4 us per stage, 3.6 TB/s; more loads in flight did not
+    // help).  Order per step: multiply stage s + 1 (the wait for its loads drains the stores of stage s - 1, issued a whole epilogue
+    // ago), refill its load slot, STORE stage s from its LDS tile, then the epilogue of stage s + 1 into the other tile.
+    auto multiply = [&](const sos_u32x4 (&bx)[KH], f32x16 (&acc)[NT]) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -1631,7 +1640,9 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThinParams p) {
 #pragma unroll
         for (int t = 0; t < KH; ++t)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = SOS_MFMA_32x32x16(wf[t][n], __builtin_bit_cast(bf16x8, b[t]), acc[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) acc[n] = SOS_MFMA_32x32x16(wf[t][n], __builtin_bit_cast(bf16x8, bx[t]), acc[n], 0, 0, 0);
+    };
+    auto epilogue = [&](const f32x16 (&acc)[NT], const int tl) {
         // D[row][pixel l31]: four consecutive rows per register quad -> one 8-byte LDS write
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -1640,8 +1651,8 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThinParams p) {
                 float y[4];
                 float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), h4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (affine) {
-                    s4 = *(const float4*)(coef + n * 32 + 8 * q + 4 * lhi);
-                    h4 = *(const float4*)(coef + NT * 32 + n * 32 + 8 * q + 4 * lhi);
+                    s4 = *(const __attribute__((address_space(3))) float4*)(lds + COEF + (n * 32 + 8 * q + 4 * lhi) * 4);
+                    h4 = *(const __attribute__((address_space(3))) float4*)(lds + COEF + (NT * 32 + n * 32 + 8 * q + 4 * lhi) * 4);
                 }
                 const float sq[4] = {s4.x, s4.y, s4.z, s4.w}, hq[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
@@ -1652,30 +1663,48 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThinParams p) {
                     else if (p.act != SOS_ACT_NONE) v = fmaxf(v, 0.f) + sn * fminf(v, 0.f);
                     y[e] = (n * 32 + 8 * q + 4 * lhi + e < p.cout) ? v : 0.f;
                 }
-                *(uint2*)(tile + l31 * PITCH + (n * 32 + 8 * q + 4 * lhi) * 2) = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+                *(__attribute__((address_space(3))) uint2*)(lds + tl + l31 * PITCH + (n * 32 + 8 * q + 4 * lhi) * 2) =
+                    make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
             }
+    };
+    auto store = [&](const long long kb, const int tl) {
         // the stage's 32 x ROWB output bytes are contiguous in memory: 16-byte pieces, lane-contiguous
         const int npx = (int)(k1 - kb < 32 ? k1 - kb : 32);
         char* ob = (char*)p.out + kb * ROWB;
+        // (all pieces are read into their own registers before the first store: a store whose data registers are reloaded for the
+        // next piece makes the compiler wait for the PREVIOUS store to finish -- vmcnt(0) before each of the six)
+        constexpr int NP = (32 * ROWB) / 1024;
+        uint4 v[NP];
 #pragma unroll
-        for (int i = 0; i < (32 * ROWB) / 1024; ++i) {
+        for (int i = 0; i < NP; ++i) {
             const int j = i * 64 + lane, px = j / (ROWB / 16), pc = j - px * (ROWB / 16);
-            const uint4 v = *(const uint4*)(tile + px * PITCH + pc * 16);
-            if (px < npx) *(uint4*)(ob + (size_t)j * 16) = v;
+            v[i] = *(const __attribute__((address_space(3))) uint4*)(lds + tl + px * PITCH + pc * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int j = i * 64 + lane, px = j / (ROWB / 16);
+            if (px < npx) *(uint4*)(ob + (size_t)j * 16) = v[i];
         }
     };
-    // D stages of pixel operands in flight per wave; slot d is refilled for stage + D right after its stage is done.  D = 2 is
-    // enough: these layers WRITE 6 (4) KB per KB read and sit on the chip's write rate (14 -> 96: 560 MB out in 181 us; D = 8
-    // measured 213 us, 256 instead of 512 workgroups 274 us, 1 024 the same 181)
-    sos_u32x4 b[D][KH];
-#pragma unroll
-    for (int d = 0; d < D; ++d) fetch(b[d]);
-    for (long long kb = k0; kb < k1; kb += 32 * D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (kb + 32 * d < k1) stage(kb + 32 * d, b[d]);
-            fetch(b[d]);
+    sos_u32x4 b[2][KH];
+    f32x16 acc[NT];
+    fetch(b[0]);
+    fetch(b[1]);
+    multiply(b[0], acc);
+    fetch(b[0]);
+    epilogue(acc, tile0);
+    int cur = 0;
+    for (long long kb = k0; kb < k1; kb += 32) {
+        const bool more = kb + 32 < k1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            if (cur == 0) { multiply(b[1], acc); fetch(b[1]); } else { multiply(b[0], acc); fetch(b[0]); }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        store(kb, tile0 + cur * (32 * PITCH));
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) epilogue(acc, tile0 + (cur ^ 1) * (32 * PITCH));
+        cur ^= 1;
     }
 #endif
 }
@@ -1707,8 +1736,8 @@ static int thin_conv_launch(const sos_conv_desc* d, hipStream_t s) {
     per = (per + 31) / 32 * 32;
     q.per = (int)per;
     const unsigned grid = (unsigned)((q.K + per * 4 - 1) / (per * 4));
-    if (d->kh == 5) hipLaunchKernelGGL((conv_thin_kernel<2, 5, 2>), dim3(grid), dim3(256), 4 * 32 * (2 * 64 + 16) + 2 * 64 * 4, s, q);
-    else hipLaunchKernelGGL((conv_thin_kernel<3, 1, 2>), dim3(grid), dim3(256), 4 * 32 * (3 * 64 + 16) + 2 * 96 * 4, s, q);
+    if (d->kh == 5) hipLaunchKernelGGL((conv_thin_kernel<2, 5>), dim3(grid), dim3(256), 8 * 32 * (2 * 64 + 16) + 2 * 64 * 4, s, q);
+    else hipLaunchKernelGGL((conv_thin_kernel<3, 1>), dim3(grid), dim3(256), 8 * 32 * (3 * 64 + 16) + 2 * 96 * 4, s, q);
     return sos_check_launch("sos_conv2d_fwd(thin)");
 }
 
