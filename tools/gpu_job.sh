@@ -1,9 +1,10 @@
 #!/bin/bash
 # The ONE metered-GPU batch script (rewritten per call; replaces round 4's tools/gpu/g*.sh):  gpurun -- bash tools/gpu_job.sh
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/j50; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_train_ops.py -m gpu -q -x -k "thin_input_streaming or first_down_block" > $O/pytest.log 2>&1; tail -5 $O/pytest.log | cut -c1-250
-for sw in "SOS_NOP=1" "SOS_CONV_NO_THIN=1" "SOS_CONV_THIN_WGS=256" "SOS_CONV_THIN_WGS=768"; do
-  echo "== $sw"; for only in "thin 2->96 folded" "thin 2->64 folded"; do env SOS_PRECISION=fp16 $sw python tools/conv_bench.py --only "$only" 2>&1 | grep -v amdgpu; done
-done | tee $O/conv_thin.txt
-echo "== raw epilogue"; for only in "thin 2->96 folded" "thin 2->64 folded"; do env SOS_PRECISION=fp16 SOS_BENCH_EPI=raw python tools/conv_bench.py --only "$only" 2>&1 | grep -v amdgpu; done | tee -a $O/conv_thin.txt
+O=gpurun_out/j51; mkdir -p $O
+timeout 2000 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; python -c "
+import json; d=json.loads(open('$O/bench.json').read()); s=d['secondary']
+print(round(d['value'],1), d['roofline']['frac'])
+print({k:v for k,v in s.items() if k!='note' and 'roofline' not in k and 'runs' not in k})"
