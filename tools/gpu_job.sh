@@ -1,10 +1,3 @@
 #!/bin/bash
 # The ONE metered-GPU batch script (rewritten per call; replaces round 4's tools/gpu/g*.sh):  gpurun -- bash tools/gpu_job.sh
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/j51; mkdir -p $O
-timeout 2000 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; tail -3 $O/pytest.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
-timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; python -c "
-import json; d=json.loads(open('$O/bench.json').read()); s=d['secondary']
-print(round(d['value'],1), d['roofline']['frac'])
-print({k:v for k,v in s.items() if k!='note' and 'roofline' not in k and 'runs' not in k})"
+bash tools/refresh_profiles.sh r05
