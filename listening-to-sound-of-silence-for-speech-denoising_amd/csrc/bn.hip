@@ -604,8 +604,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_stream_kernel(View dy, View
 }
 
 // (The apply pass -- 2 reads + 1 write per element -- was written the same way and measured: 315-330 us against 316 us for the
-// block-interleaved kernel below at 96 channels, 157-167 against 162 at 48: it is bound by the read / write mix, not by the loads in
-// flight.  Removed.)
+// block-interleaved kernel below at 96 channels, 157-167 against 162 at 48: whatever keeps it at 5.1-5.3 TB/s (torch's add, also 2R + 1W,
+// reaches 6.0) is not the loads in flight.  Removed.)
 template <bool RELU_ONLY>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View x, const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
