@@ -665,22 +665,19 @@ extern "C" int sos_bn_bwd(const sos_view* dy, const sos_view* x, const float* sc
     hipStream_t s = (hipStream_t)stream;
     int nblk = sos_bn_stats_blocks(x->npix);
     const int C = x->C;
-    // SOS_BN_STREAM=<workgroups> (e.g. 512): the per-wave streaming reduce.  OFF by default: alone on the chip it is 17-33 % faster
-    // (96 channels 219 -> 184 us = 6.1 TB/s, 48: 120 -> 92, 128 channels at 128 x 89: 98 -> 66), but the three-stream training
-    // step did not move (555.0 -> 553.8 utt/s over three alternations; 256 / 1024 workgroups and U = 2 likewise 0.99-1.00): beside the
-    // other streams' MFMA workgroups the pass is not limited by its own loads in flight, and its 168 VGPRs co-reside less well than
-    // the 56 of the block-interleaved kernel.  The thin weight gradients (wgrad.hip) gained because they were LATENCY-bound.
-    static const int stream_wgs = [] { const char* e = getenv("SOS_BN_STREAM"); return e ? atoi(e) : 0; }();
-    const bool use_stream = stream_wgs > 0 && !x->x3 && !dy->x3 && (C + 7) / 8 <= 64 && x->npix >= 1 << 16;
+    // SOS_BN_STREAM=<workgroups> (default 512; 0 = the block-interleaved kernel everywhere): the per-wave streaming reduce for the
+    // ReLU blocks at full resolution.  Alone on the chip 17-23 % faster (96 channels 219 -> 184 us = 6.1 TB/s, 48: 120 -> 92), in the
+    // training step 25.5 -> 23.0 ms of this pass per 4 steps: 543.4 -> 545.3 utt/s concurrent, 513.0 -> 515.3 serial (four / two
+    // alternations; a second box: 558.2 -> 561.1, 521.4 -> 524.0).  A first version that also took the U-Net's PReLU layers was 0.998 of the step: see below.
+    static const int stream_wgs = [] { const char* e = getenv("SOS_BN_STREAM"); return e ? atoi(e) : 512; }();
+    // (ReLU blocks at full resolution only: on the U-Net's PReLU layers -- 64-256 channels, 0.18-0.74 M pixels -- the streaming
+    // variant took 140 us where the block-interleaved kernel takes 59-117: runs of ~100 pixels per wave are all prologue)
+    const bool use_stream = stream_wgs > 0 && act == SOS_ACT_RELU && !x->x3 && !dy->x3 && (C + 7) / 8 <= 64 && x->npix >= 1 << 20;
     if (use_stream) {
         // (the partial buffer is sized for sos_bn_stats_blocks workgroups: fewer rows are used, with their own pitch)
         if (nblk > stream_wgs) nblk = stream_wgs;
-        if (act == SOS_ACT_RELU)
-            hipLaunchKernelGGL((bn_bwd_reduce_stream_kernel<4, true>), dim3(nblk), dim3(256), 0, s, to_view(dy), to_view(x), scale, shift,
-                               mean, invstd, act, slope, partial);
-        else
-            hipLaunchKernelGGL((bn_bwd_reduce_stream_kernel<4, false>), dim3(nblk), dim3(256), 0, s, to_view(dy), to_view(x), scale, shift,
-                               mean, invstd, act, slope, partial);
+        hipLaunchKernelGGL((bn_bwd_reduce_stream_kernel<4, true>), dim3(nblk), dim3(256), 0, s, to_view(dy), to_view(x), scale, shift,
+                           mean, invstd, act, slope, partial);
     } else if (act == SOS_ACT_RELU)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, s, to_view(dy), to_view(x), scale, shift, mean,
                            invstd, act, slope, partial);
