@@ -1,7 +1,9 @@
 #!/bin/bash
 # The ONE metered-GPU batch script (rewritten per call; replaces round 4's tools/gpu/g*.sh):  gpurun -- bash tools/gpu_job.sh
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/j56; mkdir -p $O
-timeout 2000 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; tail -3 $O/pytest.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
-bash tools/refresh_profiles.sh r05 > $O/refresh.log 2>&1; tail -4 $O/refresh.log | cut -c1-200
+O=gpurun_out/j58; mkdir -p $O
+for i in 1 2 3; do for sw in "SOS_BN_STREAM=256" "SOS_BN_STREAM=512" "SOS_BN_STREAM=1024"; do
+  env $sw timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null > $O/b.json
+  python -c "
+import json; d=json.loads(open('$O/b.json').read()); print('$sw', round(d['value'],1), d['ms_per_step'])" | tee -a $O/ab.txt
+done; done
