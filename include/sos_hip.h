@@ -114,13 +114,14 @@ int sos_threshold_bits(const float* logits, int64_t n, float threshold, uint8_t*
                        sos_stream_t stream);
 /* Two-pass detector of the 'mixed' pipeline (the threshold of M1/predict.py:117-119 only depends on the SIGN of a logit):
  * logits f32 [B][n] of a 1x-cost 16-bit detector pass; clip b is MARKED (mark[b] = 1) when one of its first n_valid[b] (NULL: n)
- * frames has |logit| < band_rel * max(1, max_t |logit[b][t]|), i.e. lies inside the 16-bit pass's error band around the
- * threshold.  tabs_in / tabs_out int32 [ntab][B]: per-clip width tables of the ragged geometry (sos_conv_desc.wl_tab / wo_tab,
+ * frames has |logit| < band_rel * max(1, max_t |logit[b][t]|, max_t scale[b][t]), i.e. lies inside the 16-bit pass's error band
+ * around the threshold.  scale (ABI 10; optional f32 [B][n]): the magnitude that error is relative to -- the last layer's
+ * sum_i |w_i| |a_i| + |bias| per frame (>= |logit|), so that logits that are small by cancellation do not shrink the band.  tabs_in / tabs_out int32 [ntab][B]: per-clip width tables of the ragged geometry (sos_conv_desc.wl_tab / wo_tab,
  * the BiLSTM's lengths, ...): tabs_out = tabs_in for marked clips, 0 for the others, so that a second detector pass in the
  * parity precision computes ONLY the marked clips (tiles of a zero-width clip exit at once) without a host round trip.
  * count (optional int32 [2]) += {marked clips, clips}. */
-int sos_logit_band_mark(const float* logits, int64_t batch, int64_t n, const int32_t* n_valid, float band_rel,
-                        const int32_t* tabs_in, int32_t* tabs_out, int ntab, int32_t* mark, int32_t* count,
+int sos_logit_band_mark(const float* logits, const float* scale, int64_t batch, int64_t n, const int32_t* n_valid,
+                        float band_rel, const int32_t* tabs_in, int32_t* tabs_out, int ntab, int32_t* mark, int32_t* count,
                         sos_stream_t stream);
 
 /* ---- layout glue at the module boundary: f32 NCHW [B][C][H][W] -> bf16 NHWC

@@ -32,9 +32,14 @@ def set_precision(mode):
               noise than 'bf16' at equal cost; training keeps the activation gradients in half's exponent
               range with a power-of-two loss scale chosen on the device (engine.GradScale).
     'mixed' : the DETECTOR -- the only producer of thresholded values (M1/predict.py:117-119: the per-frame
-              silent / non-silent decisions) -- runs in 'bf16x3', everything else in 'fp16'.  The frame decisions
-              then agree with the f32 reference unless a logit lies within ~1e-5 of the threshold, at 3x the cost of
-              the detector only (11 % of the algorithmic FLOPs).
+              silent / non-silent decisions) -- decides in 'bf16x3', everything else runs in 'fp16'.  In training, and
+              in inference with SOS_MIXED_TWO_PASS=0, the whole detector runs in bf16x3 (3x its MACs, 11 % of the
+              algorithmic FLOPs): logits 1-4e-5 from the f32 reference's, decisions equal unless a logit lies within
+              that of the threshold.  The inference pipeline's default is the TWO-PASS detector (pipeline.detect): every
+              clip in fp16, and only the clips with a frame whose |logit| is below 9e-3 x max(1, max_t |logit|,
+              max_t (|W2| a_t + |b2|)) -- three times the fp16 pass's asserted error, relative to the size of what the
+              last layer sums -- again in bf16x3.  The DECISIONS are the parity detector's; the logit VALUES returned for
+              unmarked clips are the fp16 pass's (1.5-3e-3 of the logit range, not 1e-5).
     A forward pass and its backward pass must run in the same mode (the networks record the mode on their tape)."""
     global _PRECISION
     if mode not in MODES:

@@ -61,7 +61,7 @@ class WgradDesc(C.Structure):
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 ADAM_CHUNK = 16384          # SOS_ADAM_CHUNK of include/sos_hip.h
 GUARD_FLOATS = 5            # SOS_GUARD_FLOATS
-EXPECTED_ABI = 9            # sos_abi_version() of the library these argument lists were written for
+EXPECTED_ABI = 10           # sos_abi_version() of the library these argument lists were written for
 
 # name -> argtypes, exactly the prototypes of include/sos_hip.h
 SIGNATURES = {
@@ -79,7 +79,7 @@ SIGNATURES = {
     "sos_crm_target_f32": [_P, _P, _P, _L, _L, _F, _F, _P],
     "sos_bits_to_mask": [_P, _L, _L, _D, _L, _P, _P, _P, _P, _P, _P],
     "sos_threshold_bits": [_P, _L, _F, _P, _P, _P],
-    "sos_logit_band_mark": [_P, _L, _L, _P, _F, _P, _P, _I, _P, _P, _P],
+    "sos_logit_band_mark": [_P, _P, _L, _L, _P, _F, _P, _P, _I, _P, _P, _P],
     "sos_add_signals_f32": [_P, _P, _P, _L, _I, _L, _F, _P, _P, _P, _P],
     "sos_storage_dtype": [],
     "sos_pack_nchw_to_nhwc": [_P, _L, _I, _L, _L, _P, _I, _I, _P, _P],

@@ -199,10 +199,12 @@ def run_lstm(lp, feat_dims, B, T, x3, device, lengths=None):
     return h
 
 
-def linear_plan(lin, cin_store, x3):
-    w = E.pack_weight(lin.weight[:, :, None, None], cin_store, x3)
+def linear_plan(lin, cin_store, x3, absolute=False):
+    """absolute=True: |W|, |b| -- the layer that bounds the magnitude of the terms of `lin`'s dot products (pipeline.detect)."""
+    wt, bias = (lin.weight.abs(), lin.bias.abs()) if absolute else (lin.weight, lin.bias)
+    w = E.pack_weight(wt[:, :, None, None], cin_store, x3)
     return dict(w=w, scale=E.pad_vec(torch.ones(lin.out_features, device=w.device), w.shape[1], 1.0),
-                shift=E.pad_vec(lin.bias, w.shape[1]), cout=lin.out_features, cin_store=cin_store)
+                shift=E.pad_vec(bias, w.shape[1]), cout=lin.out_features, cin_store=cin_store)
 
 
 _nearest_tables = {}

@@ -1301,9 +1301,11 @@ template <int NT>
 static int launch_ks(int ks, const ConvParams& p, dim3 grid, size_t lds, hipStream_t stream) {
     if (p.in_scale) {
         // fused input BatchNorm: the 96-channel context layers' tilings only (three n-tiles, 2 or 3 k-steps per chunk, double slab)
+        // (stage_issue_bn loads in_scale / in_shift per KC-channel chunk: cin must be whole chunks, or it reads past the
+        // f32[cin] arrays -- ADVICE r5)
         if constexpr (NT == 3) {
-            if (ks == 3) return launch_one<3, 3, false, true>(p, grid, lds, stream);
-            if (ks == 2) return launch_one<3, 2, false, true>(p, grid, lds, stream);
+            if (ks == 3 && p.cin % 48 == 0) return launch_one<3, 3, false, true>(p, grid, lds, stream);
+            if (ks == 2 && p.cin % 32 == 0) return launch_one<3, 2, false, true>(p, grid, lds, stream);
         }
         sos_set_error("sos_conv2d_fwd: fused input BatchNorm (in_scale) is not built for this tiling (nt=%d ks=%d)", NT, ks);
         return SOS_EINVAL;

@@ -300,7 +300,8 @@ extern "C" int sos_threshold_bits(const float* logits, int64_t n, float threshol
 // maximum.  Marked clips keep their rows of the geometry tables (tabs_out = tabs_in), unmarked clips get width 0 in every table:
 // the second (parity-precision) detector pass then runs through the ragged per-clip geometry of the kernels and every tile of an
 // unmarked clip exits at once -- the selection never reaches the host.  count[0] += marked clips, count[1] += clips.
-__global__ void logit_band_mark_kernel(const float* __restrict__ logits, int64_t n, const int32_t* __restrict__ n_valid,
+__global__ void logit_band_mark_kernel(const float* __restrict__ logits, const float* __restrict__ scale, int64_t n,
+                                       const int32_t* __restrict__ n_valid,
                                        float band_rel, const int32_t* __restrict__ tabs_in, int32_t* __restrict__ tabs_out,
                                        int ntab, int64_t B, int32_t* __restrict__ mark, int32_t* __restrict__ count) {
     __shared__ float red[64];
@@ -309,6 +310,10 @@ __global__ void logit_band_mark_kernel(const float* __restrict__ logits, int64_t
     const float* lp = logits + b * n;
     float m = 0.f;
     for (int t = threadIdx.x; t < nv; t += 64) m = fmaxf(m, fabsf(lp[t]));
+    // scale (ABI 10, optional): the magnitude the 16-bit pass's logit error is relative to -- sum_i |w_i| |a_i| + |bias| of the
+    // last layer's dot product, >= |logit| -- so that a clip whose logits hover around 0 by CANCELLATION still gets a band as
+    // wide as its terms are large (NaN counts as a hit below: fmaxf drops it here)
+    if (scale) { const float* sp = scale + b * n; for (int t = threadIdx.x; t < nv; t += 64) m = fmaxf(m, fabsf(sp[t])); }
     red[threadIdx.x] = m;
     __syncthreads();
     for (int s = 32; s > 0; s >>= 1) {
@@ -336,15 +341,15 @@ __global__ void logit_band_mark_kernel(const float* __restrict__ logits, int64_t
     for (int k = threadIdx.x; k < ntab; k += 64) tabs_out[(int64_t)k * B + b] = mk ? tabs_in[(int64_t)k * B + b] : 0;
 }
 
-extern "C" int sos_logit_band_mark(const float* logits, int64_t batch, int64_t n, const int32_t* n_valid, float band_rel,
-                                   const int32_t* tabs_in, int32_t* tabs_out, int ntab, int32_t* mark, int32_t* count,
-                                   sos_stream_t stream) {
+extern "C" int sos_logit_band_mark(const float* logits, const float* scale, int64_t batch, int64_t n, const int32_t* n_valid,
+                                   float band_rel, const int32_t* tabs_in, int32_t* tabs_out, int ntab, int32_t* mark,
+                                   int32_t* count, sos_stream_t stream) {
     if (!logits || !mark || batch < 1 || batch > 0x7fffffff || n < 1 || !(band_rel >= 0.f) || ntab < 0 ||
         (ntab > 0 && (!tabs_in || !tabs_out))) {
         sos_set_error("sos_logit_band_mark: bad args");
         return SOS_EINVAL;
     }
-    hipLaunchKernelGGL(logit_band_mark_kernel, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, logits, n, n_valid,
+    hipLaunchKernelGGL(logit_band_mark_kernel, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, logits, scale, n, n_valid,
                        band_rel, tabs_in, tabs_out, ntab, batch, mark, count);
     return sos_check_launch("sos_logit_band_mark");
 }

@@ -20,7 +20,7 @@ int sos_check_launch(const char* what) {
     return SOS_OK;
 }
 
-extern "C" int sos_abi_version(void) { return 9; }
+extern "C" int sos_abi_version(void) { return 10; }
 // sizeof() of the descriptor structs the caller fills (0: sos_view, 1: sos_conv_desc, 2: sos_wgrad_desc): a binding whose mirror
 // of a struct has drifted from the header finds out when it loads the library, not through a corrupted launch
 extern "C" int sos_struct_size(int which) {

@@ -1159,6 +1159,12 @@ static bool wg_thin_shape(const sos_wgrad_desc* d, bool is_flat, int* m16, int* 
     const int a = (d->M + 15) / 16, b = (d->N + 15) / 16;
     if (!((a == 1 && b >= 1 && b <= 6) || (b == 1 && a >= 1 && a <= 6))) return false;
     if (a == 5 || b == 5) return false;                       // (no instance)
+    // the kernel's buffer resources and offsets are 32-bit ((unsigned)(k * cs * 2)); a descriptor that ARRIVES flat
+    // (B = Hg = 1, a huge Wg) has not been through the flatten step's range check -- and the 16-channel sub-images the kernel
+    // fetches (16 m16 / 16 n16 channels from g_off / x_off) must lie inside a pixel's channel run.  Anything else: tiled kernel.
+    const uint64_t npx = (uint64_t)d->B * d->Hg * d->Wg;
+    if (npx * (uint64_t)d->g_cs * 2 >= 0xfff00000ull || npx * (uint64_t)d->x_cs * 2 >= 0xfff00000ull) return false;
+    if (d->g_off + 16 * a > d->g_cs || d->x_off + 16 * b > d->x_cs) return false;
     *m16 = a; *n16 = b;
     return true;
 }

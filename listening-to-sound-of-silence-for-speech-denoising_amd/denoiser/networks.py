@@ -303,7 +303,7 @@ class ContextAggNet(nn.Module):
         side.wait_stream(cur)                     # the input, the packed weights and `feat` exist
         with torch.cuda.stream(side):
             CN.run_encoder(plan["enc_x"], CN.pack_encoder_input(plan["enc_x"], x, x3, rag), feat, nseg * nfeat, nfeat, 0, x3, rag=rag)
-        return dict(feat=feat, side=side, x=x, x3=x3)
+        return dict(feat=feat, side=side, x=x, x3=x3, mode=get_precision())     # the effective mode the feature matrix was written in
 
     def run(self, plan, x, n, x3, rag=None, started=None):
         """forward(x, n) of M2/networks.py:82-94 -> sigmoid mask f32 (B,2,F,T).  rag: engine.Ragged of a variable-length
@@ -567,7 +567,9 @@ class JointModel(nn.Module):
         x3 = plan["x3"]
         x = x.contiguous().float()
         n = n.contiguous().float()
-        if started is not None and (started["x"].data_ptr() != x.data_ptr() or started["x3"] != x3):
+        if started is not None and (started["x"].data_ptr() != x.data_ptr() or started["x3"] != x3 or
+                                    started.get("mode", get_precision()) != get_precision()):
+            # (the storage type matters too: a feature matrix written by the bf16 library must not be read by the fp16 one)
             raise ValueError("forward(started=): the handle belongs to another input or precision mode")
         n_pred = self.stage1.run(plan["s1"], n, x, x3, rag)
         out = self.stage2.run(plan["s2"], x, n_pred, x3, rag, started=started)

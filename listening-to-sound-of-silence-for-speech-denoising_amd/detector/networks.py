@@ -78,7 +78,8 @@ class AudioVisualNet(nn.Module):
                     vid=CN.video_plan(self.encoder_video, x3) if self.video_feat else None,
                     lstm=CN.lstm_plan(self.lstm, 8 * self.freq_bins + self.video_feat, x3),
                     fc0=CN.linear_plan(self.fc1[0], E.pad_to(200, 16), x3),
-                    fc2=CN.linear_plan(self.fc1[2], E.pad_to(100, 16), x3))
+                    fc2=CN.linear_plan(self.fc1[2], E.pad_to(100, 16), x3),
+                    fc2abs=CN.linear_plan(self.fc1[2], E.pad_to(100, 16), x3, absolute=True))
 
     # ------------------------------------------------------------------ training path
     def _build_train_plan(self):
@@ -145,7 +146,7 @@ class AudioVisualNet(nn.Module):
             TO.video_backward(plan["vid"], tape["vid"], dfeat, nseg * nfeat, nfeat, 8 * F, grads, "encoder_video", B, n, x3)
         return grads
 
-    def forward(self, s, v_num_frames=60, v=None, rag=None, before_lstm=None):
+    def forward(self, s, v_num_frames=60, v=None, rag=None, before_lstm=None, return_scale=False):
         """s (B,2,F,T) -> logits (B, v_num_frames).  Audio-visual variant: v (B,3,Tv,H,W) video frames; the audio
         features are resized to Tv frames (M1/networks.py:138) and v_num_frames is ignored.
         rag (eval only): engine.Ragged with the clips' own STFT frame counts (rag.T) and video-frame counts
@@ -162,15 +163,17 @@ class AudioVisualNet(nn.Module):
             raise ValueError("this network was built without the video branch (get_network(video=True))")
         if rag is not None and (self.training or self.video_feat):
             raise ValueError("ragged batches are an inference feature of the audio-only network")
+        if return_scale and self.training:
+            raise ValueError("return_scale is an inference feature")
         if self.training:
             return _TrainFn.apply(self, s.contiguous().float(), int(v_num_frames),
                                   v.contiguous().float() if v is not None else None, *self.parameters())
         # before_lstm (eval only): called once the encoder's convolutions are enqueued -- what follows (the recurrence over the
         # frames on 8 workgroups, the FC head) leaves the chip mostly idle, the pipeline starts the denoiser's encoder_x there
         with precision_scope(detector_precision()):
-            return self._forward_eval(s, int(v_num_frames), v, rag, before_lstm)
+            return self._forward_eval(s, int(v_num_frames), v, rag, before_lstm, return_scale)
 
-    def _forward_eval(self, s, n, v, rag, before_lstm=None):
+    def _forward_eval(self, s, n, v, rag, before_lstm=None, return_scale=False):
         plan = self._cache.get(self, self._build_plan)
         x3 = plan["x3"]
         dev = s.device
@@ -205,4 +208,10 @@ class AudioVisualNet(nn.Module):
         out = torch.empty((B, n), dtype=torch.float32, device=dev)
         E.conv(m, 0, f2["cin_store"], f2["w"], 1, 1, 1, f2["scale"], f2["shift"], L.ACT_NONE, out=out,
                out_dtype=L.DT_F32, sb=n, sh=0, sw=1, sc=1, Ho=1, Wo=n)
-        return out
+        if not return_scale:
+            return out
+        fa = plan["fc2abs"]
+        scale = torch.empty((B, n), dtype=torch.float32, device=dev)
+        E.conv(m, 0, fa["cin_store"], fa["w"], 1, 1, 1, fa["scale"], fa["shift"], L.ACT_NONE, out=scale,
+               out_dtype=L.DT_F32, sb=n, sh=0, sw=1, sc=1, Ho=1, Wo=n)
+        return out, scale

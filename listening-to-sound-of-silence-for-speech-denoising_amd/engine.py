@@ -616,15 +616,18 @@ def band_count(device):
     return _band_count[key]
 
 
-def mask_ragged(base, logits, band_rel, width_lists):
+def mask_ragged(base, logits, band_rel, width_lists, scale=None):
     """logits f32 (B, n) of a 16-bit detector pass over the geometry `base` -> (MaskedRagged, mark int32 (B,)).  width_lists:
-    the per-clip width lists whose device tables the second pass will ask for (masked by the same launch)."""
+    the per-clip width lists whose device tables the second pass will ask for (masked by the same launch).  scale: optional f32
+    (B, n), the per-frame magnitude the pass's logit error is relative to (sos_logit_band_mark)."""
     B, n = logits.shape
+    if scale is not None and (scale.shape != logits.shape or scale.dtype != torch.float32 or not scale.is_contiguous()):
+        raise ValueError("mask_ragged: scale must be a contiguous float32 tensor of the logits' shape")
     tabs_in = torch.stack([base.tab(w) for w in width_lists]).contiguous()
     tabs_out = torch.empty_like(tabs_in)
     mark = torch.empty(B, dtype=torch.int32, device=logits.device)
     nv = base.tab(base.n_vframes) if base.n_vframes is not None else None
-    L.check(L.lib().sos_logit_band_mark(L.ptr(logits), B, n, L.ptr(nv), float(band_rel), L.ptr(tabs_in), L.ptr(tabs_out),
+    L.check(L.lib().sos_logit_band_mark(L.ptr(logits), L.ptr(scale), B, n, L.ptr(nv), float(band_rel), L.ptr(tabs_in), L.ptr(tabs_out),
                                         len(width_lists), L.ptr(mark), L.ptr(band_count(logits.device)), L.stream_ptr()),
             "sos_logit_band_mark")
     tabs = {tuple(int(x) for x in w): tabs_out[k] for k, w in enumerate(width_lists)}

@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from . import get_mode, precision_scope
+from . import get_mode, get_precision, precision_scope
 from . import tools
 from . import transform
 
@@ -34,6 +34,12 @@ def n_video_frames(n_samples, sr=SR, fps=FPS):
 # clip through the parity-precision detector (rounds 3-4).  The audio-visual variant and plain modes are untouched.
 TWO_PASS = os.environ.get("SOS_MIXED_TWO_PASS", "1") != "0"
 TWO_PASS_BAND = 3 * 3e-3
+# Round 6: the band is relative to max(1, max_t |logit|, max_t scale_t) with scale_t = |W2| a_t + |b2| -- the magnitude
+# of the TERMS of the last layer's dot product (one more 100 -> 1 launch in the fp16 pass).  An fp16 pass's logit error is
+# proportional to the size of what is summed, not to the sum: a clip whose logits all hover near 0 by cancellation got a band of
+# 0.009 from its own max |logit| while its error is that of its neighbours with large logits.  scale_t >= |logit_t|, so every clip
+# the round-5 rule marked is still marked.  SOS_MIXED_BAND_SCALE=0: the round-5 rule (A/B).
+BAND_SCALE = os.environ.get("SOS_MIXED_BAND_SCALE", "1") != "0"
 _fixed_rag = {}
 
 
@@ -51,8 +57,12 @@ def detect(detector, S_mixed, n_frames, rag=None, return_mark=False, between=Non
     if get_mode() != "mixed" or not TWO_PASS or getattr(detector, "video_feat", 0):
         lo = detector(s=S_mixed, v_num_frames=n_frames, rag=rag, **hook)
         return (lo, None) if return_mark else lo
+    scale = None
     with precision_scope("fp16"):
-        lo16 = detector(s=S_mixed, v_num_frames=n_frames, rag=rag, **hook)
+        if BAND_SCALE and "return_scale" in getattr(getattr(detector.forward, "__code__", None), "co_varnames", ()):
+            lo16, scale = detector(s=S_mixed, v_num_frames=n_frames, rag=rag, return_scale=True, **hook)
+        else:
+            lo16 = detector(s=S_mixed, v_num_frames=n_frames, rag=rag, **hook)
     if between is not None:
         between()
     base = rag
@@ -63,7 +73,7 @@ def detect(detector, S_mixed, n_frames, rag=None, return_mark=False, between=Non
         if base is None:
             base = _fixed_rag[key] = E.Ragged([T] * B, S_mixed.device, n_vframes=[n_frames] * B)
             base.level(0), base.tab(base.n_vframes)
-    mrag, mark = E.mask_ragged(base, lo16, TWO_PASS_BAND, [base.widths(0), base.n_vframes])
+    mrag, mark = E.mask_ragged(base, lo16, TWO_PASS_BAND, [base.widths(0), base.n_vframes], scale=scale)
     lo3 = detector(s=S_mixed, v_num_frames=n_frames, rag=mrag)
     lo = torch.where(mark[:, None] != 0, lo3, lo16)
     return (lo, mark) if return_mark else lo
@@ -73,14 +83,15 @@ OVERLAP_X = os.environ.get("SOS_MIXED_OVERLAP_X", "1") != "0"      # A/B: encode
 EARLY_X = os.environ.get("SOS_EARLY_X", "1") != "0"                # A/B: ... from the detector's BiLSTM on (every mode), not only between the two passes
 
 
-def _begin_x(denoiser, S_mixed, rag=None):
-    """Start the denoiser's encoder_x on its branch stream if the model offers it (denoiser.networks.JointModel.begin_x)."""
+def _begin_x(denoiser, S_mixed, rag=None, mode=None):
+    """Start the denoiser's encoder_x on its branch stream if the model offers it (denoiser.networks.JointModel.begin_x).
+    mode: the EFFECTIVE precision of the pipeline call, captured by denoise() / _denoise_group_padded() at their entry
+    (get_precision(): honours an enclosing precision_scope, reads 'mixed' as 'fp16') -- the hook fires inside the detector's
+    own scope (bf16x3 for the one-pass parity detector of 'mixed'), and the denoiser(...) call that later consumes the handle runs
+    in the caller's mode: both sides of the hand-off must agree."""
     if not OVERLAP_X or not hasattr(denoiser, "begin_x"):
         return None
-    # (the hook may fire inside the detector's precision scope -- bf16x3 for the one-pass parity detector of 'mixed': the denoiser
-    # runs in the pipeline's own mode)
-    mode = get_mode()
-    with precision_scope("fp16" if mode == "mixed" else mode):
+    with precision_scope(mode if mode is not None else get_precision()):
         return denoiser.begin_x(S_mixed, rag)
 
 
@@ -99,12 +110,13 @@ def denoise(detector, denoiser, mixed, sr=SR, fps=FPS, bits=None, return_all=Fal
     """mixed f32 (B, N) on the GPU -> denoised f32 (B, hop*(T-1)).  `bits` (uint8 (B, n_frames),
     1 = non-silent) overrides the detector (M2/predict.py's `recovered_prediction` input)."""
     B, N = mixed.shape
+    mode = get_precision()            # the denoiser's mode, taken OUTSIDE the detector's precision scope
     S_mixed = transform.stft_batch(mixed)
     logits = mark = None
     started = []
     if bits is None:
         logits, mark = detect(detector, S_mixed, n_video_frames(N, sr, fps), return_mark=True,
-                              between=lambda: started.append(_begin_x(denoiser, S_mixed)))
+                              between=lambda: started.append(_begin_x(denoiser, S_mixed, mode=mode)))
         bits, _ = tools.threshold_bits(logits, SIGMOID_THRESHOLD)
     mask, noise_sig = tools.bits_to_mask_batch(bits, float(sr) / fps, N, mixed)
     S_noise = transform.stft_batch(noise_sig)
@@ -137,9 +149,10 @@ def _denoise_group_padded(detector, denoiser, wave, rag, sr, fps):
     (capturable in a hipGraph).  Returns the padded output (B, hop * (max T - 1)) and the detector's logits / bits."""
     ns, nv = rag.n_samples, rag.n_vframes
     t_ns, t_nv = rag.tab(ns), rag.tab(nv)
+    mode = get_precision()            # the denoiser's mode, taken OUTSIDE the detector's precision scope
     S_mixed = transform.stft_batch(wave, clip_samples=t_ns)
     started = []
-    logits = detect(detector, S_mixed, max(nv), rag=rag, between=lambda: started.append(_begin_x(denoiser, S_mixed, rag)))
+    logits = detect(detector, S_mixed, max(nv), rag=rag, between=lambda: started.append(_begin_x(denoiser, S_mixed, rag, mode)))
     bits, _ = tools.threshold_bits(logits, SIGMOID_THRESHOLD)
     mask, noise_sig = tools.bits_to_mask_batch(bits, float(sr) / fps, wave.shape[1], wave, clip_frames=t_nv, clip_samples=t_ns)
     S_noise = transform.stft_batch(noise_sig, clip_samples=t_ns)
@@ -209,23 +222,34 @@ class PipelinedDenoiser:
     apply, the ISTFT -- runs under the chip-filling head of batch i + 1 (STFT, the detector's convolutions).  Each call returns
     (output, event): the output is complete once `event` has been waited for (event.synchronize() on the host, or
     stream.wait_event(event) on a consumer stream); synchronize() drains both streams.  The batches themselves are computed exactly
-    as by denoise() (same kernels, same order per batch: bit-identical outputs)."""
+    as by denoise() (same kernels, same order per batch: bit-identical outputs).
+    Lifetimes: `out` is allocated from the worker stream's pool and handed to the caller's stream -- it is recorded on
+    the stream that is current at the call (out.record_stream), so its block is not reused while that stream still reads it; a
+    consumer on yet another stream must record it there itself.  The first batch builds the caches every later batch shares
+    (packed weights, geometry tables, transform tables) on streams[0]: the second batch, the first on streams[1], waits for it."""
 
     def __init__(self, detector, denoiser, sr=SR, fps=FPS):
         self.detector, self.denoiser, self.sr, self.fps = detector, denoiser, sr, fps
         self.streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         self.k = 0
+        self._first = None
 
     @torch.no_grad()
     def __call__(self, mixed):
         st = self.streams[self.k & 1]
-        self.k += 1
-        st.wait_stream(torch.cuda.current_stream())          # the input exists
+        caller = torch.cuda.current_stream()
+        st.wait_stream(caller)                                # the input exists
+        if self.k == 1 and self._first is not None:
+            st.wait_event(self._first)                        # cold start: batch 0 built the shared caches on the other stream
         with torch.cuda.stream(st):
             out = denoise(self.detector, self.denoiser, mixed, self.sr, self.fps)
             ev = torch.cuda.Event()
             ev.record(st)
+        if self.k == 0:
+            self._first = ev
+        self.k += 1
         mixed.record_stream(st)
+        out.record_stream(caller)
         return out, ev
 
     def synchronize(self):

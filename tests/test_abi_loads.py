@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(precision, storage):
     for name in declared:
         assert hasattr(h, name), f"{name} declared in sos_hip.h but not exported"
     assert set(_lib.SIGNATURES) | {"sos_last_error"} == declared
-    assert h.sos_abi_version() == _lib.EXPECTED_ABI == 9
+    assert h.sos_abi_version() == _lib.EXPECTED_ABI == 10
     assert h.sos_storage_dtype() == storage
 
 

@@ -470,6 +470,72 @@ def test_two_pass_detector_of_the_mixed_mode_equals_the_parity_detector(shift, m
     assert all(bool(torch.isfinite(y).all()) for y in ys2)
 
 
+def test_two_pass_band_follows_the_size_of_the_summed_terms(monkeypatch):
+    """an fp16 pass's logit error is relative to the magnitude of what the last layer SUMS, not to the sum.  Here the
+    head is built so that every logit is small by cancellation: fc1.0's hidden units come in identical pairs and fc1.2 weighs a
+    pair with +g and -g + delta (g = 40 x the natural weight scale), so logit = sum delta_k a_k + b (natural size) while the terms
+    are 40x larger.  The round-5 band (0.009 x max(1, max_t |logit|)) is then ~50x narrower than the fp16 pass's actual error; the
+    band relative to scale_t = |W2| a_t + |b2| (AudioVisualNet.forward(return_scale=True)) marks those clips, and the two-pass
+    detector's frame decisions equal the one-pass parity detector's."""
+    from sos_amd import pipeline, transform
+    from sos_amd.common import MyConfig
+    from sos_amd.dataset import synth_batch
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+    sd1 = onet.closed_form_state(onet.detector_spec(), seed=1)
+    sd2 = onet.closed_form_state(onet.joint_spec(), seed=2)
+    W1, b1, w2 = sd1["fc1.0.weight"].clone(), sd1["fc1.0.bias"].clone(), sd1["fc1.2.weight"].clone()
+    g = torch.Generator().manual_seed(7)
+    nat = float(w2.abs().mean())
+    for k in range(50):
+        W1[2 * k + 1] = W1[2 * k]
+        b1[2 * k + 1] = b1[2 * k]
+        big = 40.0 * nat * (0.5 + 0.5 * float(torch.rand((), generator=g))) * (1.0 if k % 2 else -1.0)
+        delta = float(w2[0, 2 * k])
+        w2[0, 2 * k], w2[0, 2 * k + 1] = big, -big + delta
+    sd1["fc1.0.weight"], sd1["fc1.0.bias"], sd1["fc1.2.weight"] = W1, b1, w2
+    raw = synth_batch(90, 6)
+    n_frames = pipeline.n_video_frames(raw["mixed"].shape[1])
+    S0 = torch.from_numpy(np.stack([ofe.fast_stft(w).transpose(2, 0, 1) for w in raw["mixed"]]).astype(np.float32))
+    with torch.no_grad():
+        lo0 = onet.detector_forward(sd1, S0, n_frames)
+        sd1["fc1.2.bias"] = sd1["fc1.2.bias"] - lo0.median()             # the threshold in the middle of the (small) logits
+        lo_ref = onet.detector_forward(sd1, S0, n_frames).numpy()
+    det = dnet.get_network(); det.load_state_dict(sd1)
+    jm = jnet.get_network(MyConfig()); jm.load_state_dict(sd2)
+    det, jm = det.cuda().eval(), jm.cuda().eval()
+    x = torch.from_numpy(raw["mixed"]).cuda()
+    sos_amd.set_precision("mixed")
+    try:
+        S = transform.stft_batch(x)
+        with sos_amd.precision_scope("fp16"):
+            lo16, scale = det(s=S, v_num_frames=n_frames, return_scale=True)
+        monkeypatch.setattr(pipeline, "TWO_PASS", False)
+        one = pipeline.denoise(det, jm, x, return_all=True)
+        monkeypatch.setattr(pipeline, "TWO_PASS", True)
+        monkeypatch.setattr(pipeline, "BAND_SCALE", False)
+        _, mark_old = pipeline.detect(det, S, n_frames, return_mark=True)
+        monkeypatch.setattr(pipeline, "BAND_SCALE", True)
+        two = pipeline.denoise(det, jm, x, return_all=True)
+    finally:
+        sos_amd.set_precision("bf16")
+    lo16, scale = lo16.cpu().numpy(), scale.cpu().numpy()
+    mark_old, mark_new = mark_old.cpu().numpy(), two["mark"].cpu().numpy()
+    err16 = np.abs(lo16 - lo_ref).max(axis=1)
+    old_band = pipeline.TWO_PASS_BAND * np.maximum(1.0, np.abs(lo16).max(axis=1))
+    print("max |logit|", np.abs(lo_ref).max(axis=1), "max scale", scale.max(axis=1), "fp16 error", err16, "round-5 band", old_band,
+          "marks old/new", mark_old.tolist(), mark_new.tolist())
+    assert (scale >= np.abs(lo16) - 1e-3 * scale.max()).all()            # |W2| a + |b2| bounds |W2 a + b2|
+    assert scale.max(axis=1).min() > 10.0 * np.abs(lo_ref).max(), "the construction must make the terms much larger than the sums"
+    assert (mark_new >= mark_old).all()                                    # every clip the round-5 rule marked is still marked
+    # the clips whose fp16 error exceeds the round-5 band are exactly the ones that rule could get wrong: the new band covers them
+    risky = err16 > old_band / 3
+    assert mark_new[risky].all()
+    assert torch.equal(one["bits"], two["bits"])
+    sure = np.abs(lo_ref) > 1e-4 * scale.max()
+    assert np.array_equal(two["bits"].cpu().numpy()[sure], (lo_ref >= 0).astype(np.uint8)[sure])
+
+
 def test_pipelined_denoiser_equals_sequential_calls():
     """pipeline.PipelinedDenoiser: consecutive batches alternate between two HIP streams (the tail of batch i under the head of batch
     i + 1); every batch's output must equal the plain denoise() call bit for bit, and be complete once its event has been waited for."""

@@ -1,9 +1,7 @@
 #!/bin/bash
-# The ONE metered-GPU batch script (rewritten per call; replaces round 4's tools/gpu/g*.sh):  gpurun -- bash tools/gpu_job.sh
+# The ONE metered-GPU batch script (rewritten per call):  gpurun -- bash tools/gpu_job.sh
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/j58; mkdir -p $O
-for i in 1 2 3; do for sw in "SOS_BN_STREAM=256" "SOS_BN_STREAM=512" "SOS_BN_STREAM=1024"; do
-  env $sw timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null > $O/b.json
-  python -c "
-import json; d=json.loads(open('$O/b.json').read()); print('$sw', round(d['value'],1), d['ms_per_step'])" | tee -a $O/ab.txt
-done; done
+O=gpurun_out/r6; mkdir -p $O
+timeout 400 tools/probe/bin/occ_probe > $O/occ_probe2.txt 2>&1
+cat $O/occ_probe2.txt
+timeout 1200 python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_frontend.py -x -q -m gpu 2>&1 | tail -15 | tee $O/pytest_pipeline.txt
