@@ -12,6 +12,9 @@ A "step" is one pass of the hot path over one batch of synthetic 2 s clips resid
                forward/backward/Adam (MSE + MSE through the mask apply) on the same B clips, 16-bit storage + f32
                accumulation, the two (independent) models on one HIP stream each;
                for N > 1 the gradients are averaged with bucketed RCCL all-reduces overlapped with backward
+  --mode train-av (BASELINE.json configs[4]: batch = 128 over 4 GPUs, i.e. --gpus 4 at the default 32 clips per GPU): one training step
+               of the AUDIO-VISUAL detector (audio branch + the video branch over 60 frames of 224 x 224 + fusion into the BiLSTM),
+               forward / backward / Adam; the same bucketed RCCL all-reduce of the gradients for N > 1
   --mode infer: STFT -> detector -> bits->mask -> STFT(noise) -> JointModel -> mask apply -> ISTFT
   --mode infer-ragged (BASELINE.json configs[3]): the same chain over --batch (default 256) clips of DIFFERENT lengths,
                U(1 s, 10 s) with seed 99, per-clip geometry inside the kernels (pipeline.denoise_ragged)
@@ -38,7 +41,8 @@ import torch         # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 N_SAMPLES = 28000             # 2 s @ 14 kHz: the reference-true geometry
 GFLOP_PER_UTT_INFER = 446.5
-DEFAULT_PRECISION = {"train": "fp16", "infer": "mixed", "infer-ragged": "mixed"}
+GFLOP_PER_CLIP_AV_FWD = 49.02 + 1471.0   # the detector's audio branch + the video branch at 60 x 224 x 224
+DEFAULT_PRECISION = {"train": "fp16", "infer": "mixed", "infer-ragged": "mixed", "train-av": "fp16"}
 # measured against the reference goldens (tests/test_gpu_nets.py, tests/test_gpu_train_nets.py); north_star bar: 1e-3
 PARITY_NOTE = {
     "fp16": "eval n_pred/mask <= 7e-4 (asserted 1e-3), logits <= 1.8e-3 (asserted 3e-3) rel vs reference goldens; SI-SDR delta <= 0.05 dB; "
@@ -149,7 +153,8 @@ def _self_launch(n):
 class Workload:
     """One (mode, precision) line: builds the resident inputs and models, exposes step()."""
 
-    def __init__(self, mode, precision, B, rank, serial=False, graph=False, frames=None, train_detector=0, pipelined=False):
+    def __init__(self, mode, precision, B, rank, serial=False, graph=False, frames=None, train_detector=0, pipelined=False,
+                 loader=0):
         import sos_amd
         from sos_amd import agent, pipeline, tools, transform
         from sos_amd.common import MyConfig
@@ -160,6 +165,20 @@ class Workload:
         self.pipeline = pipeline
         sos_amd.set_precision(precision)
         torch.manual_seed(0)
+        self.loader = None
+        if mode == "train-av":
+            # BASELINE configs[4]: the detector with its visual stream (M1/networks.py:54-77,110-118 + the fusion :135-142); synthetic
+            # frames and spectrograms of the reference shapes, resident in HBM
+            ag = agent.DetectorAgent(dnet.get_network(video=True), lr=1e-3)
+            g = torch.Generator(device="cuda").manual_seed(1000 + rank)
+            bav = {"audio": torch.randn(B, 2, 256, 178, device="cuda", generator=g),
+                   "frames": torch.rand(B, 3, 60, 224, 224, device="cuda", generator=g),
+                   "label": (torch.rand(B, 60, device="cuda", generator=g) > 0.3).float()}
+            self.agents = (ag,)
+            self.audio_seconds = B * 2.0
+            self.lens = None
+            self.step = self.eager = lambda: ag.train_func(bav)
+            return
         det = dnet.get_network().cuda().eval()
         jm = jnet.get_network(MyConfig()).cuda().eval()
         if train_detector:
@@ -219,6 +238,20 @@ class Workload:
                     serial_step()
                 else:           # the two models are independent: one HIP stream each (+ the denoiser's branch stream)
                     agent.train_concurrent([(ag_jm, batch_jm), (ag_det, batch_det)])
+            if loader:
+                # --loader N: every step draws a FRESH batch from sos_amd.dataset.get_dataloader -- N worker
+                # processes make the host draws, the producer thread uploads them from pinned memory and runs bits -> mask, the mix
+                # at the SNR, the four STFTs and the cRM target on a side stream, two batches ahead (M2/dataset.py:44-50's
+                # DataLoader(num_workers, pin_memory) + M2/dataset.py:144-320's __getitem__); the detector trains on the same clips
+                from sos_amd.dataset import get_dataloader
+                self.loader = get_dataloader("training", batch_size=B, num_workers=loader, model="denoiser", n_batches=10 ** 6,
+                                             rank=rank, world_size=1, prefetch=2)
+                it = iter(self.loader)
+
+                def step():       # noqa: F811
+                    b = next(it)
+                    agent.train_concurrent([(ag_jm, b), (ag_det, {"audio": b["mixed"], "label": b["_bits"].float()})])
+                self._loader_iter = it
             self.eager = step
             self.concurrent = not serial
         elif mode == "infer-ragged":
@@ -240,7 +273,22 @@ class Workload:
                 step = lambda: piped(mixed)   # noqa: E731  (the timed region ends with torch.cuda.synchronize(): both streams drained)
         self.step = step
 
+    def close(self):
+        """Stop the data loader's producer thread and worker processes (--loader workloads)."""
+        if getattr(self, "loader", None) is not None:
+            self._loader_iter.close()
+            self.loader.close()
+            self.loader = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def gflop_per_utt(self):
+        if self.mode == "train-av":
+            return 3.0 * GFLOP_PER_CLIP_AV_FWD
         g = GFLOP_PER_UTT_INFER * (3.0 if self.mode == "train" else 1.0)   # algorithmic (reference) FLOPs: bf16x3's 3x MACs do not count
         if self.lens is not None:                                         # FLOPs scale with the frames of a clip: 2 s = 178 frames
             g *= sum(1 + n // 158 for n in self.lens) / (178.0 * self.B)
@@ -307,6 +355,9 @@ def run_timed(wl, steps, warmup, barrier, profile=True):
     else:
         for _ in range(max(1, warmup)):
             wl.step()
+    for ag in getattr(wl, "agents", ()):            # data-parallel instrumentation: the timed steps only
+        if getattr(ag, "bucketer", None) is not None:
+            ag.bucketer.comm_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -326,8 +377,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None, help="clips per GPU per step (default 64; 256 for infer-ragged)")
-    ap.add_argument("--mode", default="train", choices=["train", "infer", "infer-ragged"])
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU per step (default 64; 256 for infer-ragged; 32 for train-av)")
+    ap.add_argument("--mode", default="train", choices=["train", "infer", "infer-ragged", "train-av"])
     ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "bf16x3", "mixed"],
                     help="16-bit storage type of activations/weights (MFMA rate is the same for bf16 and fp16); bf16x3 = "
                          "three-pass hi/lo split (3x the MACs, ~fp32 accuracy); mixed = detector in bf16x3 (frame decisions "
@@ -344,6 +395,9 @@ def main():
     ap.add_argument("--train-detector", type=int, default=0,
                     help="inference modes: train the detector for this many Adam steps on synthetic batches first (trained-like logits: "
                          "what the two-pass detector's re-run fraction depends on)")
+    ap.add_argument("--loader", type=int, default=0, metavar="WORKERS",
+                    help="train: draw a fresh batch from sos_amd.dataset.get_dataloader every step (WORKERS host processes, producer "
+                         "thread, side stream, pinned uploads) instead of re-using one resident batch")
     ap.add_argument("--force-buckets", action="store_true",
                     help="world of one: run the data-parallel gradient path anyway (bucket copies + RCCL all-reduce of every "
                          "bucket on a 1-rank group) to measure its overhead on a single GPU")
@@ -374,6 +428,7 @@ def main():
     dist = None
     n_gpus = 1
     if world > 1 or args.force_buckets:
+        os.environ.setdefault("SOS_DDP_PROFILE", "1")     # HIP-event brackets around every bucket's collective (agent.GradBucketer.comm_stats)
         import torch.distributed as dist
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -392,7 +447,7 @@ def main():
     import sos_amd
 
     if args.batch is None:
-        args.batch = 256 if args.mode == "infer-ragged" else 64
+        args.batch = 256 if args.mode == "infer-ragged" else (32 if args.mode == "train-av" else 64)
     B = args.batch
 
     def barrier():
@@ -401,9 +456,27 @@ def main():
         torch.cuda.synchronize()
 
     wl = Workload(args.mode, args.precision, B, rank, serial=args.serial, graph=args.graph, train_detector=args.train_detector,
-                  pipelined=args.pipelined)
+                  pipelined=args.pipelined, loader=args.loader if args.mode == "train" else 0)
     dt, dom, prof = run_timed(wl, args.steps, args.warmup, barrier)
+    ddp = None
     if dist is not None:
+        # what the data-parallel path did: per-rank time of the K steps (min / max over the ranks: rank skew), and
+        # per model the buckets, bytes and collective milliseconds per step -- HIP events on the stream each collective was
+        # enqueued on (SOS_DDP_COMM: inline / own / shared), maximum over the ranks
+        every = [torch.zeros(1, device="cuda", dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(every, torch.tensor([dt], device="cuda", dtype=torch.float64))
+        per_rank = [float(t.item()) for t in every]
+        ddp = {"comm_mode": os.environ.get("SOS_DDP_COMM", "inline"), "world": world,
+               "rank_step_ms_min": 1e3 * min(per_rank) / args.steps, "rank_step_ms_max": 1e3 * max(per_rank) / args.steps, "models": {}}
+        for name, ag in zip(("denoiser", "detector") if args.mode == "train" else ("detector_av",), reversed(getattr(wl, "agents", ())) if args.mode == "train" else getattr(wl, "agents", ())):
+            if getattr(ag, "bucketer", None) is None:
+                continue
+            st = ag.bucketer.comm_stats()
+            cm = torch.tensor([st["comm_ms_per_step"]], device="cuda", dtype=torch.float64)
+            dist.all_reduce(cm, op=dist.ReduceOp.MAX)
+            ddp["models"][name] = {"buckets_per_step": st["buckets_per_step"], "bytes_per_step": st["bytes_per_step"],
+                                   "comm_ms_per_step_max_over_ranks": float(cm.item()), "bucket_bytes_cap": st["bucket_bytes_cap"]}
+        ddp["comm_ms_per_step"] = sum(m["comm_ms_per_step_max_over_ranks"] for m in ddp["models"].values())
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -412,6 +485,7 @@ def main():
         value = n_gpus * B * args.steps / dt
         ach = prof["flops"] / (prof["avg_ms"] * 1e-3) / 1e12
         train = args.mode == "train"
+        train_av = args.mode == "train-av"
         from sos_amd.denoiser import networks as _jn
         branch_streams = _jn.JointModel.BRANCH_STREAMS
         gflop = wl.gflop_per_utt()
@@ -433,24 +507,30 @@ def main():
         line = {
             "metric": ("utterances/sec (variable-length clips 1-10 s), " if args.mode == "infer-ragged" else "utterances/sec (2 s clips), ") +
                       ("training step: detector + denoiser forward/backward/Adam" if train
+                       else "training step of the audio-visual detector (audio + 60 x 224 x 224 video frames): forward/backward/Adam" if train_av
                        else "inference pipeline STFT->detector->mask->denoiser->ISTFT"),
             "value": value, "unit": "utterances/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": ("training (BASELINE configs[1])" if train else
+                                    "audio-visual training (BASELINE configs[4]: batch 128 = 4 GPUs x 32)" if train_av else
                                     "inference" if args.mode == "infer" else "variable-length inference (BASELINE configs[3])") +
                                    (f", batch={B} clips/GPU of 2 s @14 kHz (28000 samples, STFT 510/158/400 -> 2x256x178), "
                                     if args.mode != "infer-ragged" else
                                     f", batch={B} clips/GPU, lengths U(1 s, 10 s) seed 99 @14 kHz ({audio_seconds:.0f} s of audio, "
                                     f"{audio_seconds / 2.0:.0f} 2-s equivalents; STFT 510/158/400 -> 2x256xT, T = 89..887), clips of "
                                     "different lengths share launches (per-clip geometry in the kernels, no padding of the data), ") +
-                                   "detector + two-stage denoiser, random-init weights (manual_seed 0)"
-                                   + (", detector BCE + denoiser 2xMSE, Adam lr 1e-3, per-rank BatchNorm" if train else ""),
+                                   ("detector with its video branch (7 Conv3d blocks + fusion into the BiLSTM), 60 frames of 224 x 224 per clip, "
+                                    "random-init weights (manual_seed 0), BCE, Adam lr 1e-3, per-rank BatchNorm" if train_av else
+                                    "detector + two-stage denoiser, random-init weights (manual_seed 0)"
+                                    + (", detector BCE + denoiser 2xMSE, Adam lr 1e-3, per-rank BatchNorm" if train else "")),
                        "clips_per_gpu": B, "n_samples": N_SAMPLES, "mode": args.mode, "precision": args.precision,
                        "parity": PARITY_NOTE[args.precision],
+                       "data_parallel": ddp,
                        "streams": (3 if branch_streams else 2) if (train and not args.serial) else 1,
                        "branch_streams": bool(train and not args.serial and branch_streams),
                        "forced_gradient_buckets": bool(args.force_buckets),
+                       "data_loader_workers": int(args.loader) if train else 0,
                        "hipgraph": bool(args.graph),
                        "realtime_factor": value * audio_seconds / B,
                        "end_to_end_tflops": value * gflop / 1e3 / n_gpus},
@@ -525,6 +605,7 @@ def main():
                 ta, tb = [], []
                 w0 = make_a()
                 run_timed(w0, 3, 8, barrier, profile=False)       # (thrown away: the first training run after the inference lines measures slow)
+                w0.close()
                 del w0
                 torch.cuda.empty_cache()
                 for _ in range(rounds):
@@ -532,6 +613,7 @@ def main():
                         wx = mk()
                         dtx, _, _ = run_timed(wx, steps, warm, barrier, profile=False)
                         acc.append(64 * steps / dtx)
+                        wx.close()
                         del wx
                         torch.cuda.empty_cache()
                 return sum(ta) / len(ta), sum(tb) / len(tb), ta, tb
@@ -560,6 +642,18 @@ def main():
             except Exception as e:
                 sec["train_fp16_branch_streams_ratio"] = None
                 sec["train_fp16_branch_streams_ratio_error"] = repr(e)[:200]
+            # the headline step fed by the asynchronous data loader (a fresh batch per step) against the resident batch
+            try:
+                nw = max(2, min(8, (os.cpu_count() or 4) // 4))
+                va, vb, la, lb = _alternate(lambda: Workload("train", "fp16", 64, rank), lambda: Workload("train", "fp16", 64, rank, loader=nw))
+                sec["train_fp16_resident_batch_utt_s"] = round(va, 1)
+                sec["train_fp16_loader_utt_s"] = round(vb, 1)
+                sec["train_fp16_loader_ratio"] = round(vb / va, 4)
+                sec["train_fp16_loader_workers"] = nw
+                sec["train_fp16_loader_runs"] = {"resident": [round(v, 1) for v in la], "loader": [round(v, 1) for v in lb]}
+            except Exception as e:
+                sec["train_fp16_loader_utt_s"] = None
+                sec["train_fp16_loader_utt_s_error"] = repr(e)[:200]
             # the audio-visual variant's per-GPU share of BASELINE configs[4] (32 clips of 60 x 224 x 224 frames + audio): one
             # training step of the detector with its video branch
             try:
@@ -635,7 +729,10 @@ def main():
                            "workload with the data-parallel gradient path forced in a world of one (1-rank RCCL groups, one per model); "
                            "train_fp16_branch_streams = the headline schedule, train_fp16_no_branch_streams = SOS_BRANCH_STREAMS=0 (the "
                            "schedule of rounds 2-4); *_ratio = mean of three runs with over mean of three runs without, timed alternately, "
-                           "every run on a freshly built workload (6 warm-up + 12 timed steps per run; *_runs lists them)")
+                           "every run on a freshly built workload (6 warm-up + 12 timed steps per run; *_runs lists them); train_fp16_loader = the "
+                           "headline step drawing a FRESH batch from sos_amd.dataset.get_dataloader every step (train_fp16_loader_workers "
+                           "host processes make the draws; pinned uploads, bits -> mask, the mix, 4 STFTs and the cRM target on a side "
+                           "stream, two batches ahead) against the resident batch of the headline, alternated the same way")
             line["secondary"] = sec
             sos_amd.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:

@@ -216,6 +216,11 @@ class GradBucketer:
         self._comm = None
         self._flush_stream = None
         self._inline_streams = set()
+        # SOS_DDP_PROFILE=1 (bench.py --gpus N / --force-buckets): every bucket's collective is bracketed with HIP events on the
+        # stream it is enqueued on (host timers around the waits for CPU tensors) -- comm_stats() reports buckets, bytes and
+        # communication milliseconds per step, so that a scaling run can explain itself
+        self.profile = os.environ.get("SOS_DDP_PROFILE") == "1"
+        self._prof, self._prof_steps, self._prof_host_s = [], 0, 0.0
         self.reset()
 
     def reset(self):
@@ -283,6 +288,8 @@ class GradBucketer:
         if not flat.is_cuda:
             if self.collective:
                 self.handles.append(dist.all_reduce(flat[:fill], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.profile:
+                    self._prof.append((None, None, fill * 4))
             return
         inline = self.COMM_MODE == "inline"
         st = self._flush_stream if inline else self._comm_stream()
@@ -292,10 +299,22 @@ class GradBucketer:
             self._inline_streams.add(self._flush_stream)
         if self.collective:
             with torch.cuda.stream(st):
+                e0 = e1 = None
+                if self.profile:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
                 if self.COMM_MODE == "own":
-                    self.handles.append(dist.all_reduce(flat[:fill], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    # (async: the collective runs on ProcessGroupNCCL's internal stream; the bracket on `st` then spans from the
+                    # enqueue to the point where `st` has waited for it)
+                    h = dist.all_reduce(flat[:fill], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self.handles.append(h)
+                    if self.profile:
+                        h.wait()
                 else:       # synchronous: enqueued on `st` itself
                     dist.all_reduce(flat[:fill], op=dist.ReduceOp.SUM, group=self.group, async_op=False)
+                if self.profile:
+                    e1.record(st)
+                    self._prof.append((e0, e1, fill * 4))
 
     def ready(self, name, g):
         """Called by the backward pass when a parameter gradient is final; returns the bucket view that
@@ -328,8 +347,16 @@ class GradBucketer:
             self._launch(self.cur, self.cur_fill)
         else:
             self._flush_pending()
+        if self.profile and self.handles and not any(e is not None for e, _, _ in self._prof[-1:]):
+            import time as _time
+            t0 = _time.perf_counter()
+            for h in self.handles:
+                h.wait()
+            self._prof_host_s += _time.perf_counter() - t0
         for h in self.handles:
             h.wait()
+        if self.profile:
+            self._prof_steps += 1
         if self._comm is not None:          # the consumer (the optimizer on the caller's stream) follows the copies and collectives
             torch.cuda.current_stream().wait_stream(self._comm)
         for st in self._inline_streams:     # "inline": they ran on the producing streams
@@ -339,6 +366,23 @@ class GradBucketer:
         for name, v in self.views.items():
             self.params[name].grad = v
         self.reset_keep_views()
+
+    def comm_reset(self):
+        """Forget the communication brackets taken so far (bench.py: after the warm-up steps)."""
+        self._prof, self._prof_steps, self._prof_host_s = [], 0, 0.0
+
+    def comm_stats(self):
+        """What the data-parallel path did per step since comm_reset() (SOS_DDP_PROFILE=1): buckets, bytes and the summed duration of
+        the buckets' collectives -- HIP events on the stream each was enqueued on (synchronises the device: call it outside a timed
+        region), or the host's time in the waits for CPU tensors (gloo)."""
+        steps = max(1, self._prof_steps)
+        ms = 1e3 * self._prof_host_s
+        if any(e0 is not None for e0, _, _ in self._prof):
+            torch.cuda.synchronize()
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self._prof if e0 is not None)
+        return {"mode": self.COMM_MODE, "world": self.world, "steps": self._prof_steps, "collective": bool(self.collective),
+                "buckets_per_step": len(self._prof) / steps, "bytes_per_step": sum(b for _, _, b in self._prof) / steps,
+                "comm_ms_per_step": ms / steps, "bucket_bytes_cap": self.bucket_bytes}
 
     def reset_keep_views(self):
         self.cur, self.cur_fill, self.handles, self.buckets, self.views = None, 0, [], [], {}

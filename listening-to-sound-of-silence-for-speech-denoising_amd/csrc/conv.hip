@@ -22,6 +22,7 @@
 #include <string.h>
 #include <unistd.h>
 #include <algorithm>
+#include <array>
 #include <map>
 #include <type_traits>
 #include <vector>
@@ -353,14 +354,26 @@ __device__ __forceinline__ void stage_issue_bn(const ConvParams& p, char* patch,
 // ---- cooperative store of the staged bf16 output tile ([256 pixels][OROW bytes] in LDS at smem, the lo
 // plane of the hi|hi|lo mode behind it): consecutive lanes write consecutive 16-byte pieces of a pixel's channel
 // run (and consecutive pixels of a tile row are adjacent in memory when dil_w == 1).  PPX = 16-byte pieces per pixel.
-template <int PPX, int OROW, int SLOTS = 256>
+// TIGHT (round 6): nothing but the staged tile in LDS -- a pixel's output offset lives in the 16-byte PAD of its own row (never read
+// as data) instead of a table behind the tile, and the statistics' partial sums go over the tile once it has been walked: 256 x 208
+// = 53 248 B for three n-tiles, which is what lets a THIRD workgroup into the CU (a third of the 160 KB at the 1 280-byte
+// allocation granule is 53 760 B; the table made it 54 272).  Single-plane (not hi|hi|lo) outputs only.
+template <int PPX, int OROW, int SLOTS = 256, bool TIGHT = false>
 __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* smem, const int tid, const int b, const int n0,
                                                   const int ho_base, const int wo_base, const int rw0, const bool x3,
                                                   const int Wo) {
     char* ost_hi = smem;
     char* ost_lo = smem + SLOTS * OROW;
     // element offset of every tile pixel inside its output image (-1: outside), SLOTS / 256 entries per thread
-    int* otab = (int*)(smem + SLOTS * OROW * (x3 ? 2 : 1));
+    int* otab_ = (int*)(smem + SLOTS * OROW * (x3 ? 2 : 1));
+    struct OTab {
+        char* smem; int* tab;
+        __device__ __forceinline__ int& operator[](const int m) const {
+            if constexpr (TIGHT) return *(int*)(smem + m * OROW + (OROW - 16));
+            else return tab[m];
+        }
+    };
+    const OTab otab{smem, otab_};
     for (int m = tid; m < SLOTS; m += 256) {
         int cls, i, j;
         tile_decode_mg(m, p, cls, i, j);
@@ -421,6 +434,9 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
         if (st) {
             // fixed-order sum over the pixel lanes (exactly the separate statistics pass's order of round 3: lanes, then tiles)
             float* red = (float*)(smem + SLOTS * OROW + SLOTS * 4);
+            // (tiles of more than 256 slots, round 6: the 16 KB of partial sums go OVER the staged tile once every thread has
+            // walked it -- one more barrier per tile instead of 16 KB that would cost the CU its second workgroup)
+            if constexpr (SLOTS > 256 || TIGHT) { __syncthreads(); red = (float*)smem; }
 #pragma unroll
             for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s[e]; red[tid * 16 + 8 + e] = q[e]; }
             __syncthreads();
@@ -531,8 +547,21 @@ __device__ __forceinline__ void store_staged_tile(const ConvParams& p, char* sme
 
 // SB: single weight-slab buffer (an extra barrier per tap, but a third workgroup fits a CU's LDS)
 // INBN: the input is a producer's RAW conv output and its BatchNorm + ReLU is applied while the patch is staged (stage_issue_bn)
-template <int NT, int KS, bool SB, bool INBN = false>
-__global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p) {
+// PT (round 6): 32-pixel column tiles per wave.  2: a wave owns 64 pixels x NT * 32 output channels (a 256-slot workgroup tile).
+// 3: 96 pixels -- a 384-slot tile.  The tap loop's per-tap barrier among four waves that share their SIMDs with another
+// workgroup costs ~11 % (profiles/r05_wreg_probe.txt), and the fragment reads another 6 %: with NT = 3 a wave now issues 6
+// ds_read_b128 per 9 MFMAs instead of 5 per 6, a tap holds 1.5x the MFMAs per barrier and per weight-slab byte, and the per-tile
+// prologue / staging / epilogue overheads spread over 1.5x the work.  tools/probe/occ_probe.hip (profiles/r06_occ_probe.txt, edge
+// waste of the tile included): 32 x 12 tile at two k-steps per chunk 0.501 of 2.5 PF against 0.471 for the production 32 x 8 /
+// three k-steps tile; 512-slot tiles (PT = 4) reach 0.54 on whole tiles but lose it on the 178-column image's edges (0.49-0.50)
+// and need 250 registers; a static issue priority per workgroup (s_setprio by HW_ID slot / TG_ID parity) and a THIRD resident
+// workgroup (two k-steps per chunk, 48 KB) both measured no gain (0.494-0.496 vs 0.497).
+// W3 (round 6): the double-slab kernel compiled for THREE workgroups per CU (<= 168 registers) with the TIGHT epilogue layout.  The
+// phase ablation of the 96 -> 96 layer (profiles/r06_pt3_ablation.txt) prices the tap loop alone at 0.99 ms and the whole kernel at
+// 1.19: with two workgroups per CU only a third of a workgroup's staging + epilogue (0.31 ms stand-alone) hides under the
+// other's MFMAs -- a lone wave per SIMD that stops at a barrier every tap leaves the matrix pipe idle.
+template <int NT, int KS, bool SB, bool INBN = false, int PT = 2, bool W3 = false>
+__global__ __launch_bounds__(256, (SB || W3) ? 3 : (PT > 2 ? 2 : 1)) void conv_mfma_kernel(ConvParams p) {
 #if __HIP_DEVICE_COMPILE__     // buffer-resource builtins exist in the device pass only; the host pass needs just the stub
     constexpr int KC = 16 * KS;                 // channels per chunk
     constexpr int PSTRIDE = KC * 2 + 16;        // bytes per patch pixel row (padded)
@@ -597,10 +626,10 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
         else lpix = ((g0 ? 0 : 1) + 2 * (rank >> 3)) * 8 + (rank & 7);              // TW = 8: a group = tile rows r and r + 2
     }
     // ---- per-lane pixel operand base addresses (tap (0,0), k-step 0)
-    int abase[2];
+    int abase[PT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int m = wave * 64 + mt * 32 + lpix;
+    for (int mt = 0; mt < PT; ++mt) {
+        const int m = wave * (32 * PT) + mt * 32 + lpix;
         int cls, i, j;
         tile_decode_mg(m, p, cls, i, j);
         if (cls >= p.NC) cls = i = j = 0;          // dead slot: reads a valid patch pixel, its column is never stored
@@ -638,8 +667,11 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
         for (int u = 0; u < WPW; ++u) {
             const int q = (wv + 4 * u) * 64 + lane;
             const int row = q / RPB, c = q - row * RPB;
-            // pad slots and the tail of the last instruction re-read a valid piece (their LDS bytes are never read)
-            wvoff[u] = (unsigned)(((n0 + min(row, rmax)) * p.ktot + min(c, CPR - 1) * 8) * 2);
+            // pad slots and the tail of the last instruction: an offset beyond the buffer resource -- the hardware writes zeros
+            // (their LDS bytes are never read) and fetches NOTHING (round 6; they used to re-read a valid piece: a fifth / a
+            // seventh of the slab stream's L2 -> LDS bytes at two / three k-steps per chunk, and the slabs are 7 of the 8 GB a
+            // launch of the 96 -> 96 layer moves by LDS-DMA)
+            wvoff[u] = (c < CPR && row < BROWS) ? (unsigned)(((n0 + min(row, rmax)) * p.ktot + c * 8) * 2) : 0xffffffffu;
         }
     }
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -654,9 +686,9 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
         }
     };
 
-    f32x16 acc[2][NT];
+    f32x16 acc[PT][NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < PT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -717,9 +749,9 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
         // fragment buffers alternate along the flat (tap, k-step) sequence; F is the buffer a tap
         // starts in -- a compile-time constant, so the rotation costs no register moves (for odd KS
         // the tap loop is unrolled by two).
-        bf16x8 af[2][2], wfr[2][NT];
-        af[0][0] = lds_frag(patch + abase[0]);
-        af[0][1] = lds_frag(patch + abase[1]);
+        bf16x8 af[2][PT], wfr[2][NT];
+#pragma unroll
+        for (int mt = 0; mt < PT; ++mt) af[0][mt] = lds_frag(patch + abase[mt]);
         const bf16_t* wtap = p.wgt + ((long long)n0 * p.ktot + (long long)cc * KC);
         auto tap_body = [&](auto ftag, const int tap) {
             constexpr int F = decltype(ftag)::value;
@@ -743,8 +775,9 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
             // patch byte offset of this tap and of the next one (lane t of tapoff; the last tap repeats itself)
             const int toff = __builtin_amdgcn_readlane(tapoff, tap);
             const int toffn = __builtin_amdgcn_readlane(tapoff, min(tap + 1, ntaps - 1));
-            const char* ap0 = patch + abase[0] + toff;
-            const char* ap1 = patch + abase[1] + toff;
+            const char* ap[PT];
+#pragma unroll
+            for (int mt = 0; mt < PT; ++mt) ap[mt] = patch + abase[mt] + toff;
             const char* bp = smem + boff0 + cur * BBYTES + bfrag_off;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wfr[F][nt] = lds_frag(bp + nt * 32 * BSTRIDE);
@@ -753,19 +786,19 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
                 constexpr int dummy = 0; (void)dummy;
                 const int cb = (F + kk) & 1, nb = cb ^ 1;
                 if (kk + 1 < KS) {
-                    af[nb][0] = lds_frag(ap0 + (kk + 1) * 32);
-                    af[nb][1] = lds_frag(ap1 + (kk + 1) * 32);
+#pragma unroll
+                    for (int mt = 0; mt < PT; ++mt) af[nb][mt] = lds_frag(ap[mt] + (kk + 1) * 32);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) wfr[nb][nt] = lds_frag(bp + nt * 32 * BSTRIDE + (kk + 1) * 32);
                 } else {
-                    af[nb][0] = lds_frag(patch + abase[0] + toffn);
-                    af[nb][1] = lds_frag(patch + abase[1] + toffn);
+#pragma unroll
+                    for (int mt = 0; mt < PT; ++mt) af[nb][mt] = lds_frag(patch + abase[mt] + toffn);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[0][nt] = SOS_MFMA_32x32x16(wfr[cb][nt], af[cb][0], acc[0][nt], 0, 0, 0);
-                    acc[1][nt] = SOS_MFMA_32x32x16(wfr[cb][nt], af[cb][1], acc[1][nt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < PT; ++mt) acc[mt][nt] = SOS_MFMA_32x32x16(wfr[cb][nt], af[cb][mt], acc[mt][nt], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -800,14 +833,15 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
     const bool staged = p.out_dtype != SOS_DT_F32 && p.sc == 1;
     const bool x3 = p.out_dtype == SOS_DT_BF16X3;
     constexpr int OROW = NT * 64 + 16;           // bytes per staged output pixel row
+    constexpr int SLOTS = 128 * PT;              // pixel slots of the workgroup's tile
     char* ost_hi = smem;
-    char* ost_lo = smem + 256 * OROW;
-    int mrow[2];
-    long long obase[2];
-    bool pix_ok[2];
+    char* ost_lo = smem + SLOTS * OROW;
+    int mrow[PT];
+    long long obase[PT];
+    bool pix_ok[PT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int m = wave * 64 + mt * 32 + lpix;
+    for (int mt = 0; mt < PT; ++mt) {
+        const int m = wave * (32 * PT) + mt * 32 + lpix;
         int cls, i, j;
         tile_decode_mg(m, p, cls, i, j);
         const int ho = ho_base + i * p.dh;
@@ -830,7 +864,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
                 const int co = n0 + col;
                 if (co >= p.cout_store) continue;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < PT; ++mt) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][g * 4 + e];
@@ -859,7 +893,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
                 const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
                 const float shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < PT; ++mt) {
                     float v[4];
                     if (relu) {
 #pragma unroll
@@ -892,7 +926,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
             const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
             const float shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < PT; ++mt) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -944,7 +978,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void conv_mfma_kernel(ConvParams p
     }
     }
     if (!staged) return;
-    store_staged_tile<NT * 4, OROW>(p, smem, tid, b, n0, ho_base, wo_base, rw0, x3, Wo);
+    store_staged_tile<NT * 4, OROW, SLOTS, W3>(p, smem, tid, b, n0, ho_base, wo_base, rw0, x3, Wo);
 #endif
 }
 
@@ -1279,10 +1313,10 @@ static const size_t LDS_LIMIT = 160 * 1024;
 
 typedef void (*conv_kernel_t)(ConvParams);
 
-template <int NT, int KS, bool SB, bool INBN = false>
+template <int NT, int KS, bool SB, bool INBN = false, int PT = 2, bool W3 = false>
 static int launch_one(const ConvParams& p, dim3 grid, size_t lds, hipStream_t stream) {
     static sos_device_once attr_once;           // one per instantiation
-    conv_kernel_t k = conv_mfma_kernel<NT, KS, SB, INBN>;
+    conv_kernel_t k = conv_mfma_kernel<NT, KS, SB, INBN, PT, W3>;
     const int arc = sos_per_device_once(attr_once, [k] {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         if (e != hipSuccess) {
@@ -1310,6 +1344,15 @@ static int launch_ks(int ks, const ConvParams& p, dim3 grid, size_t lds, hipStre
         sos_set_error("sos_conv2d_fwd: fused input BatchNorm (in_scale) is not built for this tiling (nt=%d ks=%d)", NT, ks);
         return SOS_EINVAL;
     }
+    if constexpr (NT == 3) {                    // 384-slot tiles (ks + 300): a wave owns 96 pixels x 96 output channels
+        switch (ks) {
+            case 302: return launch_one<3, 2, false, false, 3>(p, grid, lds, stream);
+            case 303: return launch_one<3, 3, false, false, 3>(p, grid, lds, stream);
+            // ks + 200: double slab, three workgroups per CU (<= 168 registers, TIGHT epilogue layout)
+            case 201: return launch_one<3, 1, false, false, 2, true>(p, grid, lds, stream);
+            case 202: return launch_one<3, 2, false, false, 2, true>(p, grid, lds, stream);
+        }
+    }
     if constexpr (NT <= 3) {
         switch (ks) {
             case 101: return launch_one<NT, 1, true>(p, grid, lds, stream);
@@ -1331,7 +1374,9 @@ static int launch_ks(int ks, const ConvParams& p, dim3 grid, size_t lds, hipStre
     return SOS_EINVAL;
 }
 
-static size_t lds_bytes(int npix, int nt, int ks) {           // ks >= 100: single slab buffer
+static size_t lds_bytes(int npix, int nt, int ks) {           // ks 100..199: single slab buffer; 200..: three per CU; 300..: 384-slot tile (double slab)
+    if (ks >= 300) ks -= 300;
+    if (ks >= 200) ks -= 200;
     const bool single = ks >= 100;
     if (single) ks -= 100;
     const size_t row = (size_t)ks * 32 + 16;
@@ -1451,6 +1496,67 @@ static std::vector<ConvCfg> enumerate_cfgs(const sos_conv_desc* d) {
         const int NC = 1 << lnc;
         if (NC > 1 && (d->stride > 1 || NC > d->dil_w)) break;
         for (int lth = 0; lth + lnc <= 8; ++lth) add_tile(NC, 1 << lth, 1 << (8 - lnc - lth));
+    }
+    // three workgroups per CU for 96-channel-wide workgroups (round 6, conv_mfma_kernel<3, ks, false, false, 2, true>; ks + 200): every
+    // 256-slot tile whose tap-loop LDS (patch + two slabs + table) AND staged output tile fit a third of the CU.
+    // SOS_CONV_NO_W3=1 removes them (A/B).
+    static const size_t LDS_THIRD = (LDS_LIMIT / 3) / 1280 * 1280;      // 53 760: LDS is allocated in 1 280-byte granules on gfx950
+    static const char* no_w3 = getenv("SOS_CONV_NO_W3");
+    if (!(no_w3 && atoi(no_w3)) && nt == 3 && nseg_eff(d) == 1 && d->out_dtype == SOS_DT_BF16 && d->out_sc == 1 && d->cout_store % 8 == 0 &&
+        !d->accumulate) {
+        const size_t base = out.size();
+        for (size_t i = 0; i < base; ++i) {
+            const ConvCfg c = out[i];
+            if (c.ks != 1 && c.ks != 2) continue;
+            const int TH = tdim(c.lth), TW = tdim(c.ltw);
+            const int PH = (TH - 1) * d->stride + d->kh, PW = (TW - 1) * d->stride + d->kw;
+            if (lds_bytes(c.NC * PH * PW, 3, c.ks) > LDS_THIRD || (size_t)256 * (3 * 64 + 16) > LDS_THIRD) continue;
+            out.push_back({c.NC, c.lth, c.ltw, c.ks + 200, c.cost * 0.93});
+        }
+    }
+    // 384-slot tiles (round 6, conv_mfma_kernel<3, ks, false, false, 3>; ks + 300): 96-channel-wide workgroups of plain 16-bit
+    // stride-1 layers.  Every (classes, height) with the widest width that fits, plus the widths / heights that cut the strided
+    // image into equal parts (178 columns: 12 x 15 instead of 16 x 12).  SOS_CONV_NO_PT3=1 removes them (A/B).
+    static const char* no_pt3 = getenv("SOS_CONV_NO_PT3");
+    if (!(no_pt3 && atoi(no_pt3)) && nt == 3 && d->stride == 1 && nseg_eff(d) == 1 && d->out_dtype == SOS_DT_BF16 && d->out_sc == 1 &&
+        !d->wl_tab && d->cout_store % 8 == 0) {
+        static const int ncs[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32}, ths[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
+        std::vector<std::array<int, 3>> seen;
+        auto add384 = [&](const int NC, const int TH, const int TW) {
+            if (NC < 1 || TH < 1 || TW < 2 || NC * TH * TW > 384 || NC * TH * TW < 300 || TH > 64 || TW > 64) return;
+            const std::array<int, 3> t = {NC, TH, TW};
+            if (std::find(seen.begin(), seen.end(), t) != seen.end()) return;
+            seen.push_back(t);
+            const int PH = TH - 1 + d->kh, PW = TW - 1 + d->kw;
+            const int npix = NC * PH * PW;
+            const long long th = (Hc + TH - 1) / TH, tw = (Wc + TW - 1) / TW, ngw = (d->dil_w + NC - 1) / NC;
+            const double blocks = (double)th * tw * ngw * d->dil_h;
+            for (int ks : {2, 3}) {
+                if (k16 % ks) continue;
+                const size_t stage = (size_t)384 * (3 * 64 + 16) + 384 * 4;
+                const size_t lds = std::max(lds_bytes(npix, 3, ks + 300), stage);
+                if (lds > LDS_LIMIT / 2) continue;           // (one workgroup per CU: never better than the 256-slot tiles)
+                const int nchunks = k16 / ks;
+                const double per_block = 0.94 * 384.0 * taps * nchunks * ks + 3.0 * npix * nchunks * ks + 40.0 * nchunks * (6 + taps);
+                out.push_back({NC, tenc(TH), tenc(TW), ks + 300, blocks * per_block});
+            }
+        };
+        for (int NC : ncs) {
+            if (NC > d->dil_w) break;
+            const int ngw = (d->dil_w + NC - 1) / NC;
+            if ((d->dil_w + ngw - 1) / ngw != NC) continue;      // a smaller class count covers the same groups
+            for (int TH : ths) {
+                if (TH > Hc && TH != ths[0]) { if (TH / 2 >= Hc) break; }
+                const int THe = std::min(TH, Hc);
+                const int TWmax = std::min(384 / (NC * THe), std::min(Wc, 64));
+                add384(NC, THe, TWmax);
+                if (TWmax >= 2) { const int parts = (Wc + TWmax - 1) / TWmax; add384(NC, THe, (Wc + parts - 1) / parts); }
+                { const int parts = (Hc + THe - 1) / THe, THb = (Hc + parts - 1) / parts;
+                  const int TWb = std::min(384 / (NC * THb), std::min(Wc, 64));
+                  add384(NC, THb, TWb);
+                  if (TWb >= 2) { const int pw = (Wc + TWb - 1) / TWb; add384(NC, THb, (Wc + pw - 1) / pw); } }
+            }
+        }
     }
     // 512-pixel workgroups of the 16-row kernel: OPT-IN (SOS_CONV16_512=1, or SOS_CONV16_FORCE512=1 of the tests).  Round 4
     // measured them slower on every 5x5 shape (48 -> 48 at B = 64: 0.396 vs 0.369 ms forced against the table's 256-pixel tile on
@@ -1861,7 +1967,8 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
     const int TH = tdim(c.lth), TW = tdim(c.ltw);
     p.NC = c.NC; p.TH = TH; p.TW = TW;
     const bool pt8 = c.ks <= -4;                          // 16-row kernel, 512-pixel workgroup
-    if (c.NC < 1 || TH < 1 || TW < 1 || c.NC * TH * TW > (pt8 ? 512 : 256)) { sos_set_error("sos_conv2d_fwd: internal: tile %d x %d x %d", c.NC, TH, TW); return SOS_EINVAL; }
+    const bool pt3 = c.ks >= 300 && c.ks < 400;           // 32-row kernel, 384-slot tile (three column tiles per wave)
+    if (c.NC < 1 || TH < 1 || TW < 1 || c.NC * TH * TW > (pt8 ? 512 : (pt3 ? 384 : 256))) { sos_set_error("sos_conv2d_fwd: internal: tile %d x %d x %d", c.NC, TH, TW); return SOS_EINVAL; }
     p.PH = (TH - 1) * d->stride + d->kh; p.PW = (TW - 1) * d->stride + d->kw;
     p.npix = p.NC * p.PH * p.PW;
     p.cps = c.ks > 0 ? d->cin / (16 * (ks_enc % 100)) : 1;
@@ -1917,17 +2024,29 @@ static int launch_cfg(const sos_conv_desc* d, const ConvCfg& c, hipStream_t s) {
         return sos_check_launch("sos_conv2d_fwd(16)");
     }
     dim3 grid((unsigned)nblk, (unsigned)nby);
-    size_t lds = lds_bytes(p.npix, nt, ks_enc);
+    int ks_run = ks_enc;
+    // fused input BatchNorm: built for the plain double-slab instances only -- a three-per-CU entry (ks + 200) runs as its plain
+    // twin (same tile, same k-steps per chunk: the same summation order, bit-identical output)
+    if (d->in_scale && ks_run >= 200 && ks_run < 300) ks_run -= 200;
+    size_t lds = lds_bytes(p.npix, nt, ks_run);
     if (d->out_dtype != SOS_DT_F32 && d->out_sc == 1) {
-        const size_t stage = (size_t)256 * (nt * 64 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + 1024 +   // + pixel offsets
-                             (d->stats ? 16384 : 0);                                                       // + statistics scratch
+        const size_t slots = pt3 ? 384 : 256;
+        const bool w3 = ks_run >= 200 && ks_run < 300;               // three per CU: TIGHT epilogue layout (nothing but the staged tile)
+        const size_t stage = w3 ? slots * (nt * 64 + 16)
+                                : slots * (nt * 64 + 16) * (d->out_dtype == SOS_DT_BF16X3 ? 2 : 1) + slots * 4 +   // + pixel offsets
+                                  ((d->stats && !pt3) ? 16384 : 0);  // + statistics scratch (384-slot tiles: over the staged tile)
         if (stage > lds) lds = stage;
+        if (w3 && (d->out_dtype == SOS_DT_BF16X3 || nt != 3 || d->accumulate || d->cout_store % 8)) { sos_set_error("sos_conv2d_fwd: internal: three-per-CU tiling for an ineligible shape"); return SOS_EINVAL; }
+        if (pt3 && (d->out_dtype == SOS_DT_BF16X3 || nt != 3)) { sos_set_error("sos_conv2d_fwd: internal: 384-slot tiling for an ineligible shape"); return SOS_EINVAL; }
     }
+#ifdef SOS_ABLATE
+    { static const char* e = getenv("SOS_CONV_LDS_PAD"); if (e) lds = std::min(lds + (size_t)atoi(e), LDS_LIMIT); }   // occupancy experiments
+#endif
     switch (nt) {
-        case 1: return launch_ks<1>(ks_enc, p, grid, lds, s);
-        case 2: return launch_ks<2>(ks_enc, p, grid, lds, s);
-        case 3: return launch_ks<3>(ks_enc, p, grid, lds, s);
-        case 4: return launch_ks<4>(ks_enc, p, grid, lds, s);
+        case 1: return launch_ks<1>(ks_run, p, grid, lds, s);
+        case 2: return launch_ks<2>(ks_run, p, grid, lds, s);
+        case 3: return launch_ks<3>(ks_run, p, grid, lds, s);
+        case 4: return launch_ks<4>(ks_run, p, grid, lds, s);
     }
     sos_set_error("sos_conv2d_fwd: internal: nt=%d", nt);
     return SOS_EINVAL;
@@ -1948,9 +2067,21 @@ static bool forced_512(const sos_conv_desc* d, ConvCfg* out) {
     return false;
 }
 
+// SOS_CONV_FORCE_PT3=1 / SOS_CONV_FORCE_W3=1 (testing / A-B): every shape that has a 384-slot candidate (ks + 300) / a
+// three-per-CU candidate (ks + 200) runs its cheapest one
+static bool forced_pt3(const sos_conv_desc* d, ConvCfg* out) {
+    static const char* f = getenv("SOS_CONV_FORCE_PT3");
+    static const char* f3 = getenv("SOS_CONV_FORCE_W3");
+    const bool pt3 = f && atoi(f), w3 = f3 && atoi(f3);
+    if (!(pt3 || w3) || d->in_scale) return false;
+    for (const ConvCfg& e : enumerate_cfgs(d))
+        if ((pt3 && e.ks >= 300 && e.ks < 400) || (w3 && e.ks >= 200 && e.ks < 300)) { *out = e; return true; }
+    return false;
+}
+
 extern "C" int64_t sos_conv2d_tile_count(const sos_conv_desc* d) {
     if (validate(d)) return -1;
-    { ConvCfg c5; if (forced_512(d, &c5)) return tiles_of(d, c5); }
+    { ConvCfg c5; if (forced_512(d, &c5) || forced_pt3(d, &c5)) return tiles_of(d, c5); }
     static const char* force = getenv("SOS_CONV_FORCE_CFG");
     if (!force) {
         ConvCfg c;
@@ -1966,7 +2097,7 @@ extern "C" int sos_conv2d_fwd(const sos_conv_desc* d, sos_stream_t stream) {
     int rc = validate(d);
     if (rc) return rc;
     if (thin_conv_shape(d)) return thin_conv_launch(d, (hipStream_t)stream);
-    { ConvCfg c5; if (forced_512(d, &c5)) return launch_cfg(d, c5, (hipStream_t)stream); }
+    { ConvCfg c5; if (forced_512(d, &c5) || forced_pt3(d, &c5)) return launch_cfg(d, c5, (hipStream_t)stream); }
     // SOS_CONV_FORCE_CFG=k (testing): use the k-th candidate tiling (mod count) instead of the tuned one
     static const char* force = getenv("SOS_CONV_FORCE_CFG");
     if (!force) {

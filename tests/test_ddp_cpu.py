@@ -38,6 +38,7 @@ def _worker(rank, world, port, q):
     torch.manual_seed(0)
     params = [("a.weight", torch.nn.Parameter(torch.zeros(7, 5))), ("a.bias", torch.nn.Parameter(torch.zeros(7))),
               ("b.weight", torch.nn.Parameter(torch.zeros(300, 40))), ("c.slope", torch.nn.Parameter(torch.zeros(1)))]
+    os.environ["SOS_DDP_PROFILE"] = "1"                   # the instrumentation bench.py --gpus N reports (comm_stats)
     bk = GradBucketer(params, bucket_bytes=4096)          # small buckets -> several all-reduces
     sink = GradSink(bk)
     # backward produces grads in reverse order; values depend on the rank
@@ -50,6 +51,12 @@ def _worker(rank, world, port, q):
         ok = ok and p.grad is not None and torch.equal(p.grad, want) and p.grad.shape == p.shape
         # the optimizer's grad_scale = 1/world turns the sum into the data-parallel AVERAGE (the kernel multiplies it in)
         ok = ok and torch.allclose(p.grad * (1.0 / bk.world), 1.5 * (1 + len(name)) * torch.ones(p.shape))
+    st = bk.comm_stats()
+    # three buckets (1 | 12000 | 7 + 35 floats), every gradient byte once, the waits timed on the host
+    ok = ok and st["world"] == 2 and st["steps"] == 1 and st["collective"] and st["buckets_per_step"] == 3
+    ok = ok and st["bytes_per_step"] == 4 * (1 + 12000 + 7 + 35) and st["comm_ms_per_step"] >= 0.0 and st["mode"] in ("inline", "own", "shared")
+    bk.comm_reset()
+    ok = ok and bk.comm_stats()["buckets_per_step"] == 0
     q.put((rank, ok, starts))
     dist.destroy_process_group()
 

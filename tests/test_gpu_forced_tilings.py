@@ -48,6 +48,33 @@ def test_network_parity_with_forced_512_pixel_16_row_workgroups():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_network_parity_with_forced_384_slot_tiles():
+    """Round 6: the 32-row conv kernel with 384-slot tiles (a wave owns 96 pixels x 96 output channels; conv_mfma_kernel<3, ks,
+    false, false, 3>) is a tiling candidate of the 96-channel stride-1 layers: the network parity tests (forward of both networks in
+    every precision mode, the exact encoder-block backward, the fused training statistics whose scratch now lies over the staged
+    tile) pass with the cheapest such candidate forced for every eligible launch (SOS_CONV_FORCE_PT3=1)."""
+    # (the fused-input-BatchNorm test compares two launches bit for bit: forcing a tile on one of them is not its subject)
+    env = dict(os.environ, SOS_CONV_FORCE_PT3="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_nets.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_train_nets.py"), os.path.join(ROOT, "tests", "test_gpu_train_ops.py"),
+                        "-k", "not fused_input_batchnorm"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_network_parity_with_forced_three_workgroups_per_cu():
+    """Round 6: conv_mfma_kernel<3, ks, false, false, 2, true> -- the 96-channel-wide double-slab kernel compiled for THREE
+    workgroups per CU (<= 168 registers) with nothing but the staged tile in the epilogue's LDS (pixel offsets in the rows' pad
+    bytes, the fused statistics' partial sums over the walked tile).  Forced for every eligible launch (SOS_CONV_FORCE_W3=1): forward
+    parity of both networks in every precision mode, the training forward's fused statistics, the block backward tests."""
+    env = dict(os.environ, SOS_CONV_FORCE_W3="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_nets.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_train_nets.py"), os.path.join(ROOT, "tests", "test_gpu_train_ops.py"),
+                        "-k", "not fused_input_batchnorm"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("env_kv", [("SOS_BN_STREAM", "0"), ("SOS_WGRAD_NO_THIN", "1")], ids=["no-bn-stream", "no-thin-wgrad"])
 def test_training_parity_with_the_alternative_round5_kernels(env_kv):
     """Round 5 left performance choices behind switches: the per-wave streaming BatchNorm backward reduce of the full-resolution ReLU

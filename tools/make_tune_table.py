@@ -31,6 +31,8 @@ RETUNE_WIDE_ALL = "--retune-wide-all" in sys.argv   # every entry of the committ
                                              # three-segment detector, the audio-visual variant)
 RETUNE_WGRAD = "--retune-wgrad" in sys.argv  # measure the weight-gradient plans of the B = 64 training step (sos_wgrad_tune, round 4) ->
                                              # gpurun_out/wgrad_table_gfx950.txt; the conv table is loaded as shipped and left alone
+RETUNE_PT3 = "--retune-pt3" in sys.argv      # keep the committed table, re-measure the B = 64 96 -> 96 stride-1 shapes, which gained the
+                                             # 384-slot tile candidates (round 6: conv_mfma_kernel<3, ks, false, false, 3>)
 OUTW = os.path.join(ROOT, "gpurun_out", "wgrad_table_gfx950.txt")
 if RETUNE_WGRAD:
     os.environ["SOS_CONV_TUNE_TABLE"] = "1"
@@ -77,6 +79,17 @@ if RETUNE_WIDE:
     os.environ.setdefault("SOS_CONV_TUNE_VERBOSE", "1")
     lines = open(SHIPPED).read().splitlines()
     keep = [lines[0]] + [ln for ln in lines[1:] if not (ln.split()[0] == "64" and ln.split()[5] == "1")]   # columns 0: B, 5: segments
+    for path in (OUT, OUT + ".f16"):
+        open(path, "w").write("\n".join(keep) + "\n")
+    print("dropped", len(lines) - len(keep), "entries to re-measure")
+
+if RETUNE_PT3:
+    os.environ.setdefault("SOS_CONV_TUNE_CANDIDATES", "400")
+    os.environ.setdefault("SOS_CONV_TUNE_VERBOSE", "1")
+    lines = open(SHIPPED).read().splitlines()
+    # columns (conv.hip, shape_key): 0 B, 4 cin, 5 segments, 6 cout_pad, 9 stride, 14 out dtype
+    keep = [lines[0]] + [ln for ln in lines[1:] if not (ln.split()[0] == "64" and ln.split()[4] == "96" and ln.split()[5] == "1" and
+                                                         ln.split()[6] == "96" and ln.split()[9] == "1" and ln.split()[14] == "0")]
     for path in (OUT, OUT + ".f16"):
         open(path, "w").write("\n".join(keep) + "\n")
     print("dropped", len(lines) - len(keep), "entries to re-measure")
@@ -182,7 +195,7 @@ def main():
         _lib.lib().sos_wgrad_tune_save(OUTW.encode())
         print("wrote", OUTW, sum(1 for _ in open(OUTW)) - 1, "entries")
         return
-    if RETUNE_WIDE:
+    if RETUNE_WIDE or RETUNE_PT3:
         sos_amd.set_precision("bf16")
         workloads(64)
         from sos_amd import _lib
