@@ -45,10 +45,16 @@ GFLOP_PER_CLIP_AV_FWD = 49.02 + 1471.0   # the detector's a
 DEFAULT_PRECISION = {"train": "fp16", "infer": "mixed", "infer-ragged": "mixed", "train-av": "fp16"}
 # measured against the reference goldens (tests/test_gpu_nets.py, tests/test_gpu_train_nets.py); north_star bar: 1e-3
 PARITY_NOTE = {
-    "fp16": "eval n_pred/mask <= 7e-4 (asserted 1e-3), logits <= 1.8e-3 (asserted 3e-3) rel vs reference goldens; SI-SDR delta <= 0.05 dB; "
-            "frame decisions of a 1x-cost 16-bit detector may flip within 3e-3 of the threshold (use 'mixed' for inference)",
-    "mixed": "detector in bf16x3 (logits <= 4e-5 rel, frame decisions equal the f32 reference's), everything else fp16: eval "
-             "n_pred/mask <= 7e-4 (asserted 1e-3); SI-SDR delta <= 0.05 dB",
+    # MEASURED values (max-abs error / max-abs reference per tensor, against the goldens generated from the imported reference);
+    # "asserted" = the bound the GPU tests check
+    "fp16": "measured vs reference goldens: eval n_pred/mask 6-7e-4 (asserted 1e-3), logits 1.5-1.8e-3 (asserted 3e-3), end-to-end "
+            "waveform 1.2-4.8e-3 (asserted 5.5e-3; 9e-3 ragged; the storage model of the format alone gives 4.2e-3 on the -40 dB clip), "
+            "SI-SDR delta <= 0.016 dB (asserted 0.05 dB); training: train-mode logits / n_pred / mask within 2x the storage-model "
+            "deviation, summed loss of 25 Adam steps within 2.2 % of the bf16x3 parity mode; does NOT meet 1e-3 on every tensor "
+            "(bf16x3 does); frame decisions of a 1x-cost 16-bit detector may flip within 3e-3 of the threshold (use 'mixed' for inference)",
+    "mixed": "frame decisions equal the f32 reference's (two-pass detector: fp16 for every clip, bf16x3 again for the clips with a logit "
+             "inside 9e-3 x max(1, max |logit|, max (|W2| a + |b2|)) of the threshold; logits of re-run clips 1-4e-5, of the others "
+             "1.5-1.8e-3), everything else fp16: eval n_pred/mask 6-7e-4 (asserted 1e-3), waveform 1.1-4.8e-3, SI-SDR delta <= 0.016 dB",
     "bf16": "eval outputs 0.5-1.9e-2 rel vs reference goldens (tests assert 6e-2): does NOT meet the 1e-3 bar",
     "bf16x3": "eval outputs 1-4e-5 rel vs reference goldens (tests assert 1e-3)",
 }
@@ -568,7 +574,6 @@ def main():
                                                  ("infer_mixed_pipelined_utt_s", "infer", "mixed", 64, 10, 3, "pipelined"),
                                                  ("ragged_mixed_clips_s", "infer-ragged", "mixed", 256, 3, 1, None),
                                                  ("ragged_mixed_hipgraph_clips_s", "infer-ragged", "mixed", 256, 3, 1, "graph"),
-                                                 ("train_bf16_utt_s", "train", "bf16", 64, 10, 3, None),
                                                  ("train_mixed_utt_s", "train", "mixed", 64, 10, 3, None),
                                                  # the ONE mode that meets the north_star's 1e-3 on every tensor (3x the MACs)
                                                  ("train_bf16x3_utt_s", "train", "bf16x3", 64, 3, 1, None),
@@ -642,6 +647,17 @@ def main():
             except Exception as e:
                 sec["train_fp16_branch_streams_ratio"] = None
                 sec["train_fp16_branch_streams_ratio_error"] = repr(e)[:200]
+            # BASELINE configs[1] names bf16; the headline runs IEEE half on the same kernels at the same MFMA rate (8x less rounding
+            # noise).  The two storage types alternated like every other ratio of this record (round 5's single
+            # un-bracketed 10-step bf16 line read 506.5 against a 566.7 headline on the driver's box, 552.7 / 551.3 on another)
+            try:
+                va, vb, la, lb = _alternate(lambda: Workload("train", "fp16", 64, rank), lambda: Workload("train", "bf16", 64, rank))
+                sec["train_bf16_utt_s"] = round(vb, 1)
+                sec["train_bf16_ratio"] = round(vb / va, 4)
+                sec["train_bf16_runs"] = {"fp16": [round(v, 1) for v in la], "bf16": [round(v, 1) for v in lb]}
+            except Exception as e:
+                sec["train_bf16_utt_s"] = None
+                sec["train_bf16_utt_s_error"] = repr(e)[:200]
             # the headline step fed by the asynchronous data loader (a fresh batch per step) against the resident batch
             try:
                 nw = max(2, min(8, (os.cpu_count() or 4) // 4))

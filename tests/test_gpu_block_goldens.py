@@ -1,0 +1,266 @@
+"""Per-block goldens: ONE block of each kind and one optimizer step, computed by the REFERENCE's own
+live classes in the build container (tests/golden/make_goldens_blocks.py -> tests/golden/blocks.npz: strided samples of the large
+tensors, everything of the small ones) and compared here with the HIP path in the parity mode (bf16x3) at the north_star's 1e-3
+(max-abs error over max-abs reference, per tensor).  Weights are closed-form and inputs hashed: both are rebuilt here."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sos_amd
+from oracle import nets as onet
+from util import hashed, rel_err, silent_gate, spec_input
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "blocks.npz"))
+STRIDE = 7
+TOL = 1e-3
+
+
+@pytest.fixture(autouse=True)
+def parity_mode():
+    sos_amd.set_precision("bf16x3")
+    try:
+        yield
+    finally:
+        sos_amd.set_precision("bf16")
+
+
+def _samples(t):
+    return t.detach().float().cpu().reshape(-1)[::STRIDE].numpy()
+
+
+def _err(got, want, scale=None):
+    want = np.asarray(want, dtype=np.float64)
+    return float(np.max(np.abs(np.asarray(got, dtype=np.float64) - want)) / (np.max(np.abs(want)) if scale is None else scale))
+
+
+def _down_like(tag, blk, spec_seed, plan_fn, fwd_fn, bwd_fn, x_idx, x_shape, out_hw, names):
+    from sos_amd import engine as E, train_ops as TO
+    from test_gpu_train_ops import _act_from_nchw, _act_to_nchw
+    x3 = True
+    blk.load_state_dict(spec_seed, strict=True)
+    blk = blk.cuda().train()
+    x = torch.from_numpy(hashed(x_idx, x_shape).astype(np.float32))
+    xa, _ = _act_from_nchw(x, x3)
+    lp = plan_fn(blk, x3)
+    cout = lp["cout"]
+    dst = E.Act(x_shape[0], out_hw[0], out_hw[1], E.pad_to(cout, 16), x3, torch.device("cuda"), zero=True)
+    t = fwd_fn(lp, xa, dst)
+    y = _act_to_nchw(dst, cout)
+    e_y = _err(_samples(y), G[f"{tag}_y"], float(G[f"{tag}_y_absmax"]))
+    g = torch.from_numpy(hashed(int(G[f"{tag}_dy_idx"]), tuple(y.shape)).astype(np.float32))
+    ga, _ = _act_from_nchw(g, x3)
+    gb = TO.GradBufs(x3)
+    gb.bufs[id(dst)] = ga
+    gb.written[id(dst)] = [(0, cout)]
+    grads = {}
+    bwd_fn(t, gb, grads)
+    dx = _act_to_nchw(gb.of(xa), x_shape[1])
+    e_dx = _err(_samples(dx), G[f"{tag}_dx"], float(G[f"{tag}_dx_absmax"]))
+    errs = {"y": e_y, "dx": e_dx}
+    for ours, theirs in names.items():
+        errs[theirs] = _err(grads[ours].detach().float().cpu().numpy(), G[f"{tag}_grad_{theirs}"])
+    sd = blk.state_dict()
+    for k in sd:
+        if "running" in k:
+            errs[k] = _err(sd[k].float().cpu().numpy(), G[f"{tag}_{k}"])
+    print(tag, {k: f"{v:.1e}" for k, v in errs.items()})
+    # the shared PReLU slope's gradient is a cancelling sum over every negative pre-activation: bounded at 5e-3 (see SLOPE_TOL of
+    # tests/test_gpu_train_nets.py), everything else at the north_star's 1e-3
+    for k, v in errs.items():
+        assert v < (5e-3 if k.endswith("block.3.weight") or k == "block.2.weight" and tag == "up" else TOL), (tag, k, v)
+
+
+def test_reflect_padded_dilation_16_block():
+    """DownConvBlock(64, 64, 3, 1, dilation=16) in training mode (M2/networks.py:97-117): output, updated running statistics,
+    every parameter gradient and the input gradient against the reference class."""
+    from sos_amd import train_ops as TO
+    from sos_amd.denoiser.networks import DownConvBlock
+    sd = {k[2:]: v for k, v in onet.closed_form_state(onet._down_spec("b", 64, 64, 3), seed=12).items()}
+    _down_like("down_d16", DownConvBlock(64, 64, 3, 1, dilation=16), sd, TO.down_train_plan,
+               lambda lp, xa, dst: TO.down_forward_train(lp, xa, 0, dst, 0, 40, 37, True),
+               lambda t, gb, grads: TO.down_backward(t, gb, grads, "b", True), 802, (2, 64, 40, 37), (40, 37),
+               {"b.block.1.weight": "block.1.weight", "b.block.2.weight": "block.2.weight", "b.block.2.bias": "block.2.bias",
+                "b.block.3.weight": "block.3.weight"})
+
+
+def test_stride_2_block():
+    """DownConvBlock(64, 128, 5, 2): the stride-2 layers of the U-Net (M2/networks.py:160-175)."""
+    from sos_amd import train_ops as TO
+    from sos_amd.denoiser.networks import DownConvBlock
+    sd = {k[2:]: v for k, v in onet.closed_form_state(onet._down_spec("b", 64, 128, 5), seed=13).items()}
+    _down_like("down_s2", DownConvBlock(64, 128, 5, 2), sd, TO.down_train_plan,
+               lambda lp, xa, dst: TO.down_forward_train(lp, xa, 0, dst, 0, 10, 14, True),
+               lambda t, gb, grads: TO.down_backward(t, gb, grads, "b", True), 803, (2, 64, 20, 27), (10, 14),
+               {"b.block.1.weight": "block.1.weight", "b.block.2.weight": "block.2.weight", "b.block.2.bias": "block.2.bias",
+                "b.block.3.weight": "block.3.weight"})
+
+
+def test_transposed_conv_block():
+    """UpConvBlock(128, 64, 3, 2): ConvTranspose2d(k3, s2, p1, output_padding=1) + BN + PReLU (M2/networks.py:120-149)."""
+    from sos_amd import train_ops as TO
+    from sos_amd.denoiser.networks import UpConvBlock
+    sd = {k[2:]: v for k, v in onet.closed_form_state(onet._up_spec("b", 128, 64, 3), seed=14).items()}
+    _down_like("up", UpConvBlock(128, 64, 3, 2), sd, TO.up_train_plan,
+               lambda lp, xa, dst: TO.up_forward_train(lp, xa, dst, 0, True),
+               lambda t, gb, grads: TO.up_backward(t, gb, grads, "b", True), 804, (2, 128, 10, 13), (20, 26),
+               {"b.block.0.weight": "block.0.weight", "b.block.1.weight": "block.1.weight", "b.block.1.bias": "block.1.bias",
+                "b.block.2.weight": "block.2.weight"})
+
+
+def test_zero_padded_dilation_32_block():
+    """ConvBlock(48, 48, (5, 5), (32, 32)) in training mode (M2/networks.py:28-51 == M1/networks.py:28-51): conv + fused statistics,
+    BatchNorm(train) + ReLU, their backward, the weight gradient and the data gradient -- the launches of one encoder block."""
+    from sos_amd import _lib as L, common_nets as CN, engine as E, train_ops as TO
+    from test_gpu_train_ops import _act_from_nchw, _act_to_nchw
+    x3, tag, C = True, "conv_d32", 48
+    spec = [("block.0.weight", (48, 48, 5, 5), "conv")] + onet._bn_spec("block.1", 48)
+    sd = onet.closed_form_state(spec, seed=11)
+    blk = CN.Conv2dBlock(48, 48, (5, 5), (32, 32))
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.cuda().train()
+    x = torch.from_numpy(hashed(801, (2, 48, 80, 70)).astype(np.float32))
+    xa, _ = _act_from_nchw(x, x3)
+    dev = torch.device("cuda")
+    lp = TO.encoder_train_plan(torch.nn.Sequential(blk), x3)[0]
+    assert "wtaps" not in lp
+    one, zero = TO.ones_zeros(lp["w"].shape[1], dev)
+    raw = E.Act(2, 80, 70, 48, x3, dev)
+    st = E.conv_to_act(xa, 0, lp["cin_store"], lp["w"], 5, 5, C, one, zero, L.ACT_NONE, raw, cout_store=48, dil=(32, 32), pad=(64, 64),
+                       Ho=80, Wo=70, stats_c=C)
+    y = E.Act(2, 80, 70, 48, x3, dev)
+    saved = E.bn_train(raw, 0, C, lp["bn"], L.ACT_RELU, None, y, 0, None, stats=st)
+    yn = _act_to_nchw(y, C)
+    errs = {"y": _err(_samples(yn), G[f"{tag}_y"], float(G[f"{tag}_y_absmax"]))}
+    g = torch.from_numpy(hashed(int(G[f"{tag}_dy_idx"]), tuple(yn.shape)).astype(np.float32))
+    ga, _ = _act_from_nchw(g, x3)
+    d_raw = E.Act(2, 80, 70, 48, x3, dev)
+    dgamma, dbeta, _ = TO.bn_bwd(ga, 0, raw, 0, C, saved, lp["bn"].weight, L.ACT_RELU, None, d_raw)
+    dw = torch.empty((C, C, 5, 5), dtype=torch.float32, device=dev)
+    E.wgrad(d_raw, 0, C, xa, 0, C, 5, 5, dw, dil=(32, 32), pad=(64, 64))
+    d_in = E.Act(2, 80, 70, 48, x3, dev)
+    o2, z2 = TO.ones_zeros(lp["wd"].shape[1], dev)
+    E.conv_to_act(d_raw, 0, d_raw.cs, lp["wd"], 5, 5, C, o2, z2, L.ACT_NONE, d_in, cout_store=48, dil=(32, 32), pad=(64, 64), Ho=80, Wo=70)
+    errs["dx"] = _err(_samples(_act_to_nchw(d_in, C)), G[f"{tag}_dx"], float(G[f"{tag}_dx_absmax"]))
+    errs["dw"] = _err(dw.cpu().numpy(), G[f"{tag}_grad_block.0.weight"])
+    errs["dgamma"] = _err(dgamma.cpu().numpy(), G[f"{tag}_grad_block.1.weight"])
+    errs["dbeta"] = _err(dbeta.cpu().numpy(), G[f"{tag}_grad_block.1.bias"])
+    errs["running_mean"] = _err(blk.block[1].running_mean.cpu().numpy(), G[f"{tag}_block.1.running_mean"])
+    errs["running_var"] = _err(blk.block[1].running_var.cpu().numpy(), G[f"{tag}_block.1.running_var"])
+    print(tag, {k: f"{v:.1e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < TOL, (k, v)
+
+
+def test_bilstm_and_fc_head():
+    """nn.LSTM(2048, 100, bidirectional) + Linear(200, 100) + ReLU + Linear(100, 1) as M1/networks.py:91-98,143-153 wires them:
+    hidden states, logits, the gradient of the feature matrix and every parameter gradient (norms + strided samples)."""
+    from sos_amd import _lib as L, engine as E, train_ops as TO
+    x3, T, B, I, H = True, 30, 2, 2048, 100
+    spec = onet._lstm_spec("lstm", I, H) + [("fc1.0.weight", (100, 200), "lin"), ("fc1.0.bias", (100,), "bias"),
+                                             ("fc1.2.weight", (1, 100), "lin"), ("fc1.2.bias", (1,), "bias")]
+    sd = onet.closed_form_state(spec, seed=15)
+    lstm = torch.nn.LSTM(input_size=I, hidden_size=H, bidirectional=True)
+    fc1 = torch.nn.Sequential(torch.nn.Linear(200, 100), torch.nn.ReLU(True), torch.nn.Linear(100, 1))
+    lstm.load_state_dict({k[5:]: v for k, v in sd.items() if k.startswith("lstm.")}, strict=True)
+    fc1.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("fc1.")}, strict=True)
+    lstm, fc1 = lstm.cuda(), fc1.cuda()
+    dev = torch.device("cuda")
+    feat = torch.from_numpy(hashed(805, (T, B, I)).astype(np.float32) * 0.5).permute(1, 0, 2).contiguous()     # (B, T, I)
+    hi = feat.to(torch.bfloat16)
+    lo = (feat - hi.float()).to(torch.bfloat16)
+    feat3 = torch.cat([hi, hi, lo], dim=2).cuda().contiguous()
+    lp = TO.lstm_train_plan(lstm, I, x3)
+    f0, f2 = TO.linear_train_plan(fc1[0], E.pad_to(200, 16), x3), TO.linear_train_plan(fc1[2], E.pad_to(100, 16), x3)
+    h, tape = TO.lstm_forward_train(lp, (feat3, B, 1, T, I, 3), B, T, x3, dev)
+    m = E.Act(B, 1, T, E.pad_to(100, 16), x3, dev, zero=True)
+    E.conv_to_act(h, 0, f0["cin_store"], f0["w"], 1, 1, 100, f0["scale"], f0["shift"], L.ACT_RELU, m, cout_store=m.cs, Ho=1, Wo=T)
+    out = torch.empty((B, T), dtype=torch.float32, device=dev)
+    E.conv(m, 0, f2["cin_store"], f2["w"], 1, 1, 1, f2["scale"], f2["shift"], L.ACT_NONE, out=out, out_dtype=L.DT_F32, sb=T, sh=0, sw=1,
+           sc=1, Ho=1, Wo=T)
+    ht = h.t.float().cpu().view(B, T, -1)
+    hv = (ht[..., :200] + ht[..., 2 * h.cs:2 * h.cs + 200]).permute(1, 0, 2)                  # (T, B, 2H)
+    errs = {"h": _err(hv.numpy(), G["lstm_h"]), "logits": _err(out.cpu().numpy(), G["lstm_logits"])}
+    g = torch.from_numpy(hashed(905, (B, T)).astype(np.float32)).cuda()
+    grads = {}
+    dz2 = E.Act(B, 1, T, 16, x3, dev, zero=True)
+    TO.pack_grad(g, None, L.ACT_NONE, B, T, 1, T, 1, 1, dz2)
+    d_m = TO.linear_backward(f2, m, dz2, grads, "fc1.2", x3, dev)
+    dz0 = E.Act(B, 1, T, m.cs, x3, dev, zero=True)
+    TO.act_bwd_from_y(d_m, m, L.ACT_RELU, dz0, 100)
+    dh = TO.linear_backward(f0, h, dz0, grads, "fc1.0", x3, dev)
+    dfeat = TO.lstm_backward(lp, tape, dh, grads, "lstm", B, T, x3, dev)
+    torch.cuda.synchronize()
+    df = dfeat.float().cpu()
+    dfv = (df[..., :I] + df[..., 2 * I:]).permute(1, 0, 2).contiguous()                          # (T, B, I)
+    errs["dfeat"] = _err(_samples(dfv), G["lstm_dfeat"], float(G["lstm_dfeat_absmax"]))
+    for k in [k for k in G.files if k.startswith("lstm_gradnorm_")]:
+        name = k[len("lstm_gradnorm_"):]
+        ours = grads[name if name.startswith("fc1.") else "lstm." + name].detach().float().cpu().reshape(-1).numpy()
+        gn = float(np.sqrt(np.sum(ours.astype(np.float64) ** 2)))
+        errs["|" + name + "|"] = abs(gn - float(G[k])) / float(G[k])
+        errs[name] = float(np.max(np.abs(ours[::101] - G["lstm_gradsamples_" + name])) / (np.max(np.abs(G["lstm_gradsamples_" + name])) + 1e-3 * float(G[k])))
+    print("lstm", {k: f"{v:.1e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < TOL, (k, v)
+
+
+@pytest.mark.parametrize("which", ["det", "jm"])
+def test_one_adam_step_of_the_reference_trainer(which):
+    """M1/agent.py:48,106-111 / M2/agent.py:101-106: zero_grad -> backward -> Adam(lr 1e-3).step() on the B = 2, T = 89 training
+    batch of networks.npz.  Adam's first update is -lr g / (|g| + eps) = -lr sign(g) wherever |g| >> 1e-8, so the parameters
+    after the step pin the SIGN of every gradient element and the optimizer's arithmetic (bias corrections, eps placement): at the
+    sampled positions whose reference gradient is decided at this precision (|g| above 1e-3 of the tensor's largest) the update
+    must equal the reference's to 1e-3 of lr; the loss to 1e-4."""
+    from sos_amd import agent
+    from sos_amd.common import MyConfig
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+    Bt, Tt, nfr = 2, 89, 30
+    x = spec_input(100 + Bt, Bt, Tt)
+    n = silent_gate(x)
+    clean = spec_input(300, Bt, Tt) * 0.5
+    full_noise = x - clean
+    label = torch.from_numpy((onet._hash_uniform(301, Bt * nfr).reshape(Bt, nfr) > 0).astype(np.float32))
+    if which == "det":
+        net = dnet.get_network()
+        net.load_state_dict(onet.closed_form_state(onet.detector_spec(), seed=1))
+        ag = agent.DetectorAgent(net, lr=1e-3)
+        batch = {"audio": x.cuda(), "label": label.cuda()}
+    else:
+        net = jnet.get_network(MyConfig())
+        net.load_state_dict(onet.closed_form_state(onet.joint_spec(), seed=2))
+        ag = agent.DenoiserAgent(net, lr=1e-3)
+        batch = {"mixed": x.cuda(), "noise": n.cuda(), "clean": clean.cuda(), "full_noise": full_noise.cuda()}
+    before = {k: p.detach().clone() for k, p in ag.net.named_parameters()}
+    _, losses = ag.train_func(batch)
+    torch.cuda.synchronize()
+    loss = sum(float(v) for v in losses.values())
+    assert abs(loss - float(G[f"adam_{which}_loss"])) < 1e-4 * abs(float(G[f"adam_{which}_loss"])), (loss, float(G[f"adam_{which}_loss"]))
+    counts = G[f"adam_{which}_sample_counts"]
+    upd, gs = G[f"adam_{which}_update_samples"], G[f"adam_{which}_grad_samples"]
+    off, worst, checked, total, flipped = 0, 0.0, 0, 0, 0
+    for (k, p), c in zip(ag.net.named_parameters(), counts):
+        d = (p.detach() - before[k]).float().cpu().reshape(-1)[::53].numpy()
+        ru, rg = upd[off:off + c], gs[off:off + c]
+        off += c
+        sure = np.abs(rg) > 1e-3 * max(float(np.max(np.abs(rg))), 1e-30)
+        total += c
+        checked += int(sure.sum())
+        if sure.any():
+            dev_ = np.abs(d[sure] - ru[sure])
+            # (an element whose update has the OPPOSITE sign is a gradient that cancels to within this precision -- the shared PReLU
+            # slopes: sums of ~1e6 signed terms with condition numbers of 2e2-2e4 -- counted, not bounded)
+            flip = dev_ > 1.5e-3
+            flipped += int(flip.sum())
+            if (~flip).any():
+                worst = max(worst, float(np.max(dev_[~flip])))
+        # no element may move by more than lr (+ rounding) whatever its gradient
+        assert float(np.max(np.abs(d))) <= 1.001e-3, k
+    print(which, "loss", loss, "checked", checked, "of", total, "sampled elements; worst |update - reference| / lr", worst / 1e-3,
+          "opposite signs", flipped)
+    assert checked > 0.8 * total
+    assert flipped <= 2e-3 * checked
+    assert worst < 1e-3 * 1e-3 + 2e-7
