@@ -12,7 +12,7 @@
 
 #ifndef SOS_BN_BWD_ALIGNED
 #define SOS_BN_BWD_ALIGNED 0      // 1: backward passes with pixel lanes spanning whole 128-byte lines like the forward ones -- measured (round 3,
-                                  // tools/probe/bn_ab.sh): 96 ch 570 vs 562 us, 48 ch 275 vs 282 us for reduce + apply: inside the noise, not adopted
+                                  // tools/probe/archive/bn_ab.sh): 96 ch 570 vs 562 us, 48 ch 275 vs 282 us for reduce + apply: inside the noise, not adopted
 #endif
 #ifndef SOS_BN_RED_U
 #define SOS_BN_RED_U 2            // 16-byte loads in flight per thread and operand in bn_bwd_reduce (4: 0-7 % slower)

@@ -78,6 +78,14 @@ def main():
     x = torch.from_numpy(hashed(801, (2, 48, 80, 70)).astype(np.float32))
     run("conv_d32", ref2.ConvBlock(48, 48, (5, 5), (32, 32)), sd, x, lambda k: k[2:],
         lambda xo, s, st: onet.conv_block(xo, s, "b", (32, 32), True, st))
+    # the ReLU gate of this block: an element whose pre-activation lies within rounding of zero may legitimately sit on the other
+    # side of the gate in another implementation, which moves dbeta / dgamma / dW of ITS output channel by one dy-sized term (the
+    # PReLU blocks only change slope there).  Stored: the smallest |pre-activation| per output channel; the test skips the channels
+    # whose margin is below its own forward accuracy (tools/probe/archive/conv_d32_debug.py: one such element here, 3.1e-6, channel 2).
+    with torch.no_grad():
+        pre = onet.batch_norm(torch.nn.functional.conv2d(x, sd["b.block.0.weight"], None, 1, (64, 64), (32, 32)), sd, "b.block.1", True, {})
+    out["conv_d32_gate_margin"] = pre.abs().amin(dim=(0, 2, 3)).numpy().copy()
+    print("conv_d32 gate margins below 1e-4:", [(c, float(v)) for c, v in enumerate(out["conv_d32_gate_margin"]) if v < 1e-4])
     # ---- (2) reflection-padded block at dilation 16 (the U-Net's middle): M2/networks.py:97-117
     sd = onet.closed_form_state(onet._down_spec("b", 64, 64, 3), seed=12)
     x = torch.from_numpy(hashed(802, (2, 64, 40, 37)).astype(np.float32))

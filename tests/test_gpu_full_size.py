@@ -85,7 +85,10 @@ def test_training_step_on_a_doubled_batch_equals_the_half_batch(which, precision
 def _doubled_batch(which, precision, agent):
     # fp16 (the timed mode: loss-scaled half gradients; the doubled batch halves the entering gradient, the power-of-two
     # loss scale doubles, nothing else changes) is bounded like bf16, 4x tighter on the losses
-    l_tol, g_tol = {"bf16x3": (2e-6, 0.1), "bf16": (2e-4, None), "fp16": (5e-5, None)}[precision]
+    # (bf16: 4e-4 since round 6 -- the B = 64 shapes of the 96-channel layers run the three-per-CU tiling with two k-steps per chunk,
+    # the B = 32 shapes their own table entries: other summation orders of the fused BatchNorm statistics, 1.8e-4 observed on the
+    # denoiser's stage-2 loss where 2e-4 was asserted)
+    l_tol, g_tol = {"bf16x3": (2e-6, 0.1), "bf16": (4e-4, None), "fp16": (5e-5, None)}[precision]
     bj, bd = _train_batches(B // 2)
     half = bd if which == "detector" else bj
     half = {k: v for k, v in half.items() if torch.is_tensor(v)}

@@ -88,7 +88,7 @@ def test_detector_train_step_matches_reference_autograd(golden, precision):
         # few dozen ReLU decisions (|z| ~ 0) of the 364k outputs of a block, and BatchNorm's
         # backward sums (d_beta = sum dz) cancel heavily, so single elements move by ~1e-2 even
         # though every kernel matches torch to ~1e-5 in isolation (test_encoder_block_backward_exact,
-        # tools/probe/det_bwd_debug.py).  Norms stay within a few 1e-3 with the tuned tilings; other (equally valid)
+        # tools/probe/archive/det_bwd_debug.py).  Norms stay within a few 1e-3 with the tuned tilings; other (equally valid)
         # conv tilings change the summation order and moved single tensors to 1.3e-2 (test_gpu_forced_tilings.py),
         # so the bound leaves room for whatever tiling the autotuner picks on a given box.
         tol = {"bf16x3": 2e-2, "fp16": DET_TOL_FP16, "bf16": 0.25}[precision]

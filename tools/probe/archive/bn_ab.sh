@@ -1,5 +1,5 @@
 #!/bin/bash
-# BatchNorm kernel bandwidths of several library builds on the model's tensor shapes: gpurun -- bash tools/probe/bn_ab.sh "" ab/v2 ab/v3
+# BatchNorm kernel bandwidths of several library builds on the model's tensor shapes: gpurun -- bash tools/probe/archive/bn_ab.sh "" ab/v2 ab/v3
 for cfg in "96 256 178" "48 256 178" "64 256 178" "128 128 89" "256 64 45"; do
   set -- $cfg; C=$1; H=$2; W=$3
   for lib in "" ab/v2 ab/v3; do

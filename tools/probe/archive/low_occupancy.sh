@@ -2,7 +2,7 @@
 # Where is the chip under-filled during a steady-state training step?  rocprofv3 kernel trace of bench.py; every instant of the last
 # 6 steps is weighted by the fraction of the chip its running kernels can occupy (workgroups x waves per workgroup against 256 CUs x
 # 8 waves; a kernel with >= 2048 waves counts as full).  Prints the time per step spent below 50 % / 25 % fill and the kernels
-# that run during that time.   gpurun -- bash tools/probe/low_occupancy.sh [extra bench flags]
+# that run during that time.   gpurun -- bash tools/probe/archive/low_occupancy.sh [extra bench flags]
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/lowocc; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --output-format csv -d $O/t -o k -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary "$@" > $O/bench.log 2>&1

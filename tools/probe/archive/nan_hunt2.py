@@ -17,4 +17,4 @@ del det, lo, loss
 from sos_amd import engine as E, _lib as L, train_ops as TO, common_nets as CN
 from util import hashed
 sos_amd.set_precision('bf16x3'); x3 = True
-exec(open(os.path.join(R, "tools/probe/nan_hunt.py")).read().split("# poison the allocator's free pool")[1].split("\n", 2)[2].replace('p = torch.full((256 * 1024 * 1024,), float("nan"), dtype=torch.bfloat16, device="cuda"); del p', ''))
+exec(open(os.path.join(R, "tools/probe/archive/nan_hunt.py")).read().split("# poison the allocator's free pool")[1].split("\n", 2)[2].replace('p = torch.full((256 * 1024 * 1024,), float("nan"), dtype=torch.bfloat16, device="cuda"); del p', ''))

@@ -48,7 +48,7 @@ python bench.py --mode infer --steps 20 --warmup 3 --no-cpu-baseline --no-second
 python bench.py --mode infer --precision fp16 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench_infer_fp16.json 2> $O/bench_infer_fp16.err
 python bench.py --mode infer-ragged --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/bench_ragged_mixed.json 2> $O/bench_ragged_mixed.err
 bash tools/probe/steady_families.sh > $O/steady_families.txt 2>&1
-bash tools/probe/low_occupancy.sh > $O/low_occupancy.txt 2>&1
+bash tools/probe/archive/low_occupancy.sh > $O/low_occupancy.txt 2>&1
 python profiles/summarize_rocpd.py $(find $O/prof_train -name "*.db" | head -1) $O/train_kernels.md $O/launch_train.log > /dev/null 2>&1
 for m in infer ragged; do python profiles/summarize_rocpd.py $(find $O/prof_$m -name "*.db" | head -1) $O/${m}_kernels.md > /dev/null 2>&1; done
 find $O -name "*.db" -delete            # the summaries stay; gpurun copies at most 64 MiB back
