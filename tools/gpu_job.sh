@@ -1,4 +1,4 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r6; mkdir -p $O
-timeout 600 python tools/probe/conv_d32_debug.py 2>&1 | grep -v amdgpu.ids | tee $O/conv_d32_debug.txt
+timeout 900 python tools/probe/torch_ops_in_step.py 2>&1 | grep -v amdgpu.ids | tail -110 > $O/torch_ops.txt; cat $O/torch_ops.txt | cut -c1-330

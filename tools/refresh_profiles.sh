@@ -5,7 +5,7 @@
 #   rocprofv3 --kernel-trace --stats summaries of the train / infer / ragged benches,
 #   the HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs) of the dominant conv kernel,
 #   the micro-benchmarks.  Every process loads the shipped tiling table: nothing is tuned here.
-R=${1:-r05}
+R=${1:-r06}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/refresh; mkdir -p $O
 python tools/conv_bench.py > $O/conv_bench.txt 2>&1
