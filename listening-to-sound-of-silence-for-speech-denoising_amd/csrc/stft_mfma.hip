@@ -475,6 +475,12 @@ extern "C" int sos_stft_f32(const float* wave, int64_t batch, int64_t n_samples,
         (void)hipFuncSetAttribute((const void*)stft_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return (int)SOS_OK;
     });
+    // (Round 6, built and removed -- profiles/r06_stft_resident.txt: a PERSISTENT workgroup with its four row tiles' matrix
+    // fragments resident in registers (25 k-steps x (hi, lo) = 200 registers per wave, one wave per SIMD) walking (clip, frame tile)
+    // items with the next item's samples prefetched through registers -- no per-tile matrix stream from L2 (157 MB per B = 64
+    // launch here).  Bit-identical, and SLOWER: 33.6 vs 25.8 us at B = 64, 110 vs 94 us at B = 256 -- one wave per SIMD exposes the
+    // dependent-MFMA latency of its two accumulators and every LDS fragment read that three co-resident workgroups hide here.  The
+    // floor of this formulation is the MFMA time of the three hi / lo passes: 7.5 us at B = 64 = 0.51 of the HBM roofline.)
     // 64 frames x all rows per workgroup would be 192 workgroups for 64 two-second clips (a quarter of the CUs idle, no
     // co-resident workgroup to cover staging / stores): the rows are split over FE_SRS workgroups that stage the same span
     dim3 grid((unsigned)((n_frames + FE_COLS - 1) / FE_COLS), (unsigned)batch, FE_SRS);

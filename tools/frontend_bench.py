@@ -24,7 +24,13 @@ def timed(fn, iters=50):
 
 
 def main():
-    B, N = 64, 28000
+    for B in (64, 256):          # BASELINE configs[1] and configs[3]'s batch
+        run(B)
+
+
+def run(B):
+    N = 28000
+    print(f"--- B = {B}")
     wave = torch.randn(B, N, device="cuda") * 0.1
     S = transform.stft_batch(wave)
     crm = torch.rand_like(S) * 0.8 + 0.1
