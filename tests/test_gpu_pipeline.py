@@ -537,6 +537,33 @@ def test_two_pass_band_follows_the_size_of_the_summed_terms(monkeypatch):
     assert np.array_equal(two["bits"].cpu().numpy()[sure], (lo_ref >= 0).astype(np.uint8)[sure])
 
 
+@pytest.mark.parametrize("glob,scope", [("bf16", "fp16"), ("fp16", "bf16"), ("bf16", "bf16x3")])
+def test_denoise_inside_a_precision_scope_equals_the_global_mode(glob, scope):
+    """the pipeline starts the denoiser's encoder_x early (JointModel.begin_x, on the branch stream) from a hook that
+    fires inside the DETECTOR's precision scope; it used to pick the GLOBAL mode there while the denoiser(...) call that consumes
+    the feature matrix honours an enclosing precision_scope -- under `with precision_scope('fp16')` and a global 'bf16' the bf16
+    library wrote what the fp16 library read.  The effective mode is now captured once at the pipeline's entry: a scoped call
+    equals the same call under the corresponding global mode bit for bit (and a bf16x3 scope no longer raises)."""
+    from sos_amd import pipeline
+    from sos_amd.common import MyConfig
+    from sos_amd.dataset import synth_batch
+    from sos_amd.denoiser import networks as jnet
+    from sos_amd.detector import networks as dnet
+    det = dnet.get_network(); det.load_state_dict(onet.closed_form_state(onet.detector_spec(), seed=1))
+    jm = jnet.get_network(MyConfig()); jm.load_state_dict(onet.closed_form_state(onet.joint_spec(), seed=2))
+    det, jm = det.cuda().eval(), jm.cuda().eval()
+    x = torch.from_numpy(synth_batch(500, 3, n_samples=14000)["mixed"]).cuda()
+    try:
+        sos_amd.set_precision(scope)
+        want = pipeline.denoise(det, jm, x, return_all=True)
+        sos_amd.set_precision(glob)
+        with sos_amd.precision_scope(scope):
+            got = pipeline.denoise(det, jm, x, return_all=True)
+    finally:
+        sos_amd.set_precision("bf16")
+    assert torch.equal(got["bits"], want["bits"]) and torch.equal(got["out"], want["out"]) and torch.isfinite(got["out"]).all()
+
+
 def test_pipelined_denoiser_equals_sequential_calls():
     """pipeline.PipelinedDenoiser: consecutive batches alternate between two HIP streams (the tail of batch i under the head of batch
     i + 1); every batch's output must equal the plain denoise() call bit for bit, and be complete once its event has been waited for."""
